@@ -1,0 +1,189 @@
+"""shiftConvPP network forward (oracle; test infrastructure only).
+
+Functional torch-CPU restatement of reference
+e2enet/network_architecture/unetpp_d.py:
+  * conv block  = depth shift -> Conv3d k(1,3,3) pad(0,1,1) stride s, bias ->
+    InstanceNorm3d(eps 1e-5, affine, instance statistics always) ->
+    LeakyReLU(0.01)                                            (:61-111)
+  * encoder stages with strided first conv ("convolutional pooling")  (:326-371)
+  * UNet++ nests loc/up/down 0..4                              (:380-389, :491-550)
+  * wiring and output order                                    (:447-488)
+Parameters are addressed by the reference's state-dict names (wire format).
+"""
+from dataclasses import dataclass, field
+from typing import Dict, List, Sequence, Tuple
+import math
+import torch
+import torch.nn.functional as F
+
+from .shift import depth_shift
+
+
+@dataclass
+class NetSpec:
+    in_channels: int
+    base_features: int
+    num_classes: int
+    pool_kernels: List[Tuple[int, int, int]]
+    convs_per_stage: int = 2
+    max_features: int = 320
+    feats: List[int] = field(default_factory=list)
+
+    @property
+    def num_pool(self):
+        return len(self.pool_kernels)
+
+
+def make_spec(in_channels, base_features, num_classes, pool_kernels=None, convs_per_stage=2,
+              max_features=320) -> NetSpec:
+    if pool_kernels is None:
+        pool_kernels = [(2, 2, 2)] * 5
+    pool_kernels = [tuple(int(v) for v in k) for k in pool_kernels]
+    if len(pool_kernels) != 5:
+        # reference forward() indexes 6 levels literally (unetpp_d.py:451-483)
+        raise ValueError("shiftConvPP needs exactly 5 pooling stages")
+    feats = []
+    f = base_features
+    for _ in range(len(pool_kernels) + 1):
+        feats.append(min(f, max_features))
+        f = int(round(f * 2))
+        f = min(f, max_features)
+    return NetSpec(in_channels, base_features, num_classes, pool_kernels, convs_per_stage,
+                   max_features, feats)
+
+
+# --------------------------------------------------------------------------- naming
+def _block_names(prefix):
+    return [prefix + ".conv.weight", prefix + ".conv.bias",
+            prefix + ".instnorm.weight", prefix + ".instnorm.bias"]
+
+
+def nest_nodes(spec: NetSpec, z: int):
+    """Nodes of nest z (= diagonal k = 5 - z) as (m, level i). m indexes loc_z/up_z/down_z."""
+    k = spec.num_pool - z
+    return [(m, k - 1 - m) for m in range(k)]
+
+
+def loc_block_prefixes(spec: NetSpec, z: int, m: int):
+    """state-dict prefixes of the conv blocks inside loc{z}[m], in execution order."""
+    n = spec.convs_per_stage
+    if z != 0:
+        return ["loc%d.%d.0.blocks.%d" % (z, m, b) for b in range(n - 1)]
+    return (["loc0.%d.0.blocks.%d" % (m, b) for b in range(n - 1)] +
+            ["loc0.%d.1.blocks.0" % m])
+
+
+def encoder_block_prefixes(spec: NetSpec, stage: int):
+    n = spec.convs_per_stage
+    if stage < spec.num_pool:
+        return ["conv_blocks_context.%d.blocks.%d" % (stage, b) for b in range(n)]
+    return (["conv_blocks_context.%d.0.blocks.%d" % (stage, b) for b in range(n - 1)] +
+            ["conv_blocks_context.%d.1.blocks.0" % stage])
+
+
+def concat_channels(spec: NetSpec, level: int) -> int:
+    f = spec.feats
+    return 2 * f[level] + (f[level - 1] if level > 0 else 0)
+
+
+def param_shapes(spec: NetSpec) -> "Dict[str, Tuple[int, ...]]":
+    """Ordered like the reference's named_parameters(): loc0..4, conv_blocks_context,
+    up0..4, seg_outputs (module registration order, unetpp_d.py:418-438)."""
+    f = spec.feats
+    shapes: Dict[str, Tuple[int, ...]] = {}
+
+    def add_block(prefix, cin, cout):
+        shapes[prefix + ".conv.weight"] = (cout, cin, 1, 3, 3)
+        shapes[prefix + ".conv.bias"] = (cout,)
+        shapes[prefix + ".instnorm.weight"] = (cout,)
+        shapes[prefix + ".instnorm.bias"] = (cout,)
+
+    for z in range(spec.num_pool):
+        for m, lvl in nest_nodes(spec, z):
+            cin = concat_channels(spec, lvl)
+            for bi, p in enumerate(loc_block_prefixes(spec, z, m)):
+                add_block(p, cin if bi == 0 else f[lvl], f[lvl])
+    for st in range(spec.num_pool + 1):
+        cin = spec.in_channels if st == 0 else f[st - 1]
+        for bi, p in enumerate(encoder_block_prefixes(spec, st)):
+            add_block(p, cin if bi == 0 else f[st], f[st])
+    for z in range(spec.num_pool):
+        for m, lvl in nest_nodes(spec, z):
+            shapes["up%d.%d.weight" % (z, m)] = (f[lvl + 1], f[lvl]) + tuple(spec.pool_kernels[lvl])
+    for h in range(4):
+        shapes["seg_outputs.%d.weight" % h] = (spec.num_classes, f[h], 1, 1, 1)
+    return shapes
+
+
+def masked_names(spec: NetSpec):
+    """Names the reference's Masking.add_module selects (core_channel.py:320-336)."""
+    out = []
+    for name in param_shapes(spec):
+        if (("loc" in name and "context" not in name) or "up" in name) and \
+                "bias" not in name and "instnorm" not in name:
+            out.append(name)
+    return out
+
+
+def init_params(spec: NetSpec, seed: int = 0, dtype=torch.float32) -> "Dict[str, torch.Tensor]":
+    """He-normal(a=0.01) conv / transposed-conv weights, zero bias, unit affine
+    (rule of unetpp_d.py:28-36).  RNG draw order is this module's own (name
+    order), NOT the reference's; parity fixtures carry explicit weights."""
+    g = torch.Generator().manual_seed(seed)
+    params = {}
+    for name, shp in param_shapes(spec).items():
+        if name.endswith("conv.weight") or name.startswith("up") or name.startswith("seg_outputs"):
+            # kaiming_normal_: fan_in = size(1) * receptive field
+            fan_in = shp[1] * int(math.prod(shp[2:]))
+            gain = math.sqrt(2.0 / (1 + 0.01 ** 2))
+            std = gain / math.sqrt(fan_in)
+            params[name] = (torch.randn(shp, generator=g, dtype=dtype) * std)
+        elif name.endswith("instnorm.weight"):
+            params[name] = torch.ones(shp, dtype=dtype)
+        else:
+            params[name] = torch.zeros(shp, dtype=dtype)
+    return params
+
+
+# --------------------------------------------------------------------------- forward
+def conv_block(x, w, b, gamma, beta, stride=(1, 1, 1)):
+    """unetpp_d.py:102-111 for kernel (1,3,3)."""
+    x = depth_shift(x)
+    y = F.conv3d(x, w, b, stride=stride, padding=(0, 1, 1))
+    y = F.instance_norm(y, weight=gamma, bias=beta, eps=1e-5)
+    return F.leaky_relu(y, 0.01)
+
+
+def _run_blocks(params, prefixes, x, first_stride=(1, 1, 1)):
+    for bi, p in enumerate(prefixes):
+        x = conv_block(x, params[p + ".conv.weight"], params[p + ".conv.bias"],
+                       params[p + ".instnorm.weight"], params[p + ".instnorm.bias"],
+                       stride=first_stride if bi == 0 else (1, 1, 1))
+    return x
+
+
+def forward(spec: NetSpec, params, x, do_ds=True, return_nodes=False):
+    """unetpp_d.py:447-488.  Returns [full, 1/2, 1/4, 1/8] logits if do_ds else full only."""
+    P = spec.num_pool
+    nodes = {}
+    cur = x
+    for st in range(P + 1):
+        stride = (1, 1, 1) if st == 0 else spec.pool_kernels[st - 1]
+        cur = _run_blocks(params, encoder_block_prefixes(spec, st), cur, stride)
+        nodes[(st, 0)] = cur
+        if st == 0:
+            continue
+        z = P - st
+        for m, lvl in nest_nodes(spec, z):
+            j = st - lvl
+            parts = [nodes[(lvl, j - 1)],
+                     F.conv_transpose3d(nodes[(lvl + 1, j - 1)], params["up%d.%d.weight" % (z, m)],
+                                        stride=spec.pool_kernels[lvl])]
+            if lvl > 0:
+                parts.append(F.max_pool3d(nodes[(lvl - 1, j - 1)], spec.pool_kernels[lvl - 1]))
+            nodes[(lvl, j)] = _run_blocks(params, loc_block_prefixes(spec, z, m), torch.cat(parts, 1))
+    outs = [F.conv3d(nodes[(h, P - h)], params["seg_outputs.%d.weight" % h]) for h in range(4)]
+    res = outs if do_ds else outs[0]
+    if return_nodes:
+        return res, nodes
+    return res

@@ -1,0 +1,391 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by importing the REFERENCE from /root/reference.
+
+Runs only in the build container (the reference never travels to the GPU box).
+Nothing from the reference is copied: this script imports it, feeds seeded /
+closed-form inputs and stores inputs' recipes + outputs as data fixtures.
+
+    python tools/make_golden.py            # all fixtures
+    python tools/make_golden.py shift net  # a subset
+"""
+import os
+import sys
+import types
+import random
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+OUT = os.path.join(ROOT, "tests", "golden")
+
+from tests.helpers import (closed_form_params, seeded_input, seeded_labels,   # noqa: E402
+                           pack_kernel_mask, sha_of)
+
+
+# ----------------------------------------------------------------------------- stubs
+def _pad_nd_image(image, new_shape=None, mode="constant", kwargs=None, return_slicer=False,
+                  shape_must_be_divisible_by=None):
+    """Restatement of batchgenerators==0.24 pad_nd_image (third party, absent here)."""
+    if kwargs is None:
+        kwargs = {'constant_values': 0}
+    old_shape = np.array(image.shape[-len(new_shape):])
+    num_axes_nopad = len(image.shape) - len(new_shape)
+    new_shape = np.array([max(new_shape[i], old_shape[i]) for i in range(len(new_shape))])
+    if shape_must_be_divisible_by is not None:
+        div = np.array(shape_must_be_divisible_by) if not isinstance(shape_must_be_divisible_by, int) \
+            else np.array([shape_must_be_divisible_by] * len(new_shape))
+        for i in range(len(new_shape)):
+            if new_shape[i] % div[i] != 0:
+                new_shape[i] += div[i] - new_shape[i] % div[i]
+    difference = new_shape - old_shape
+    pad_below = difference // 2
+    pad_above = difference // 2 + difference % 2
+    pad_list = [[0, 0]] * num_axes_nopad + list([list(i) for i in zip(pad_below, pad_above)])
+    if not (all(i == 0 for i in pad_below) and all(i == 0 for i in pad_above)):
+        res = np.pad(image, pad_list, mode, **kwargs)
+    else:
+        res = image
+    if not return_slicer:
+        return res
+    pad_list = np.array(pad_list)
+    pad_list[:, 1] = np.array(res.shape) - pad_list[:, 1]
+    return res, list(slice(*i) for i in pad_list)
+
+
+def install_stubs():
+    ut = types.ModuleType('batchgenerators.augmentations.utils')
+    ut.pad_nd_image = _pad_nd_image
+    for n, m in [('batchgenerators', types.ModuleType('batchgenerators')),
+                 ('batchgenerators.augmentations', types.ModuleType('batchgenerators.augmentations')),
+                 ('batchgenerators.augmentations.utils', ut),
+                 ('medpy', types.ModuleType('medpy')),
+                 ('medpy.metric', types.ModuleType('medpy.metric'))]:
+        sys.modules[n] = m
+    sys.modules['medpy'].metric = sys.modules['medpy.metric']
+    torch.Tensor.cuda = lambda self, *a, **k: self      # Masking calls .cuda() unconditionally
+
+
+install_stubs()
+from torch import nn                                                            # noqa: E402
+from e2enet.network_architecture.unetpp_d import (Generic_UNetPlusPlus, InitWeights_He,   # noqa: E402
+                                                  torch_shift, ConvDropoutNormNonlin)
+from e2enet.network_architecture.neural_network import SegmentationNetwork     # noqa: E402
+from e2enet.training.network_training.sparselearning.core_channel import (     # noqa: E402
+    Masking, CosineDecay)
+from e2enet.training.loss_functions.dice_loss import DC_and_CE_loss            # noqa: E402
+from e2enet.training.loss_functions.deep_supervision import MultipleOutputLoss2  # noqa: E402
+from e2enet.evaluation.metrics import dice as ref_dice                         # noqa: E402
+
+
+def build_ref_net(patch, cin, base, k, pools, max_feat=None, seed=None):
+    if seed is not None:
+        torch.manual_seed(seed)
+    return Generic_UNetPlusPlus(patch, cin, base, k, len(pools), 2, 2, nn.Conv3d, nn.InstanceNorm3d,
+                                {'eps': 1e-5, 'affine': True}, nn.Dropout3d, {'p': 0, 'inplace': True},
+                                nn.LeakyReLU, {'negative_slope': 1e-2, 'inplace': True}, True, False,
+                                lambda x: x, InitWeights_He(1e-2), pools, None, False, True, True,
+                                max_num_features=max_feat)
+
+
+def load_closed_form(net):
+    shapes = {n: tuple(p.shape) for n, p in net.named_parameters()}
+    params = closed_form_params(shapes)
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            p.copy_(params[n])
+    return shapes
+
+
+class _Args:
+    adv = False
+    fix = False
+    update_frequency = 1
+    final_density = 0.05
+
+
+def make_masking(net, density, death_rate=0.5, t_max=10, update_frequency=1, seed=0):
+    opt = torch.optim.SGD(net.parameters(), 1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)
+    args = _Args()
+    args.update_frequency = update_frequency
+    decay = CosineDecay(death_rate, t_max)
+    random.seed(seed)
+    mask = Masking(opt, death_rate=death_rate, death_mode='magnitude', death_rate_decay=decay,
+                   growth_mode='random', redistribution_mode='none', args=args)
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        mask.add_module(net, sparse_init='uniform', density=density)
+    return mask, opt
+
+
+# ----------------------------------------------------------------------------- fixtures
+def gen_shift():
+    out = {}
+    for c in (1, 2, 3, 4, 5, 7, 12, 32, 64, 160, 896):
+        d, h, w = 7, 2, 3
+        x = seeded_input((2, c, d, h, w), seed=100 + c)
+        y = torch_shift(5, 2, 3)(x)
+        out["c%d" % c] = y.numpy()
+    # a one-slice-deep volume (every shifted group reads zeros)
+    x = seeded_input((1, 10, 1, 2, 2), seed=7)
+    out["d1_c10"] = torch_shift(5, 2, 3)(x).numpy()
+    x = seeded_input((1, 10, 2, 2, 2), seed=8)
+    out["d2_c10"] = torch_shift(5, 2, 3)(x).numpy()
+    np.savez_compressed(os.path.join(OUT, "shift.npz"), **out)
+
+
+def gen_block():
+    out = {}
+    for tag, stride, cin, cout, shape in (("s1", (1, 1, 1), 8, 6, (6, 8, 8)),
+                                         ("s2", (2, 2, 2), 8, 12, (6, 8, 8)),
+                                         ("s122", (1, 2, 2), 5, 7, (5, 10, 6)),
+                                         ("odd", (1, 1, 1), 13, 9, (4, 7, 9))):
+        kw = {'kernel_size': (1, 3, 3), 'stride': stride, 'padding': (0, 1, 1), 'dilation': 1, 'bias': True}
+        blk = ConvDropoutNormNonlin(cin, cout, nn.Conv3d, kw, nn.InstanceNorm3d, {'eps': 1e-5, 'affine': True},
+                                    nn.Dropout3d, {'p': 0, 'inplace': True}, nn.LeakyReLU,
+                                    {'negative_slope': 1e-2, 'inplace': True})
+        shapes = {n: tuple(p.shape) for n, p in blk.named_parameters()}
+        params = closed_form_params(shapes)
+        with torch.no_grad():
+            for n, p in blk.named_parameters():
+                p.copy_(params[n])
+        x = seeded_input((2, cin) + shape, seed=11)
+        x.requires_grad_(True)
+        y = blk(x)
+        gy = seeded_input(tuple(y.shape), seed=12)
+        y.backward(gy)
+        out[tag + "_y"] = y.detach().numpy()
+        out[tag + "_dx"] = x.grad.numpy()
+        for n, p in blk.named_parameters():
+            out[tag + "_d_" + n] = p.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "block.npz"), **out)
+
+
+TINY = dict(patch=(16, 32, 32), cin=2, base=8, k=3, pools=[[2, 2, 2]] * 3 + [[1, 2, 2]] * 2, max_feat=32)
+
+
+def gen_net_tiny():
+    net = build_ref_net(TINY["patch"], TINY["cin"], TINY["base"], TINY["k"], TINY["pools"], TINY["max_feat"])
+    shapes = load_closed_form(net)
+    x = seeded_input((2, TINY["cin"]) + TINY["patch"], seed=21)
+    outs = net(x)
+    targets = []
+    for i, o in enumerate(outs):
+        targets.append(seeded_labels((o.shape[0], 1) + tuple(o.shape[2:]), TINY["k"], seed=30 + i))
+    w = np.array([1 / (2 ** i) for i in range(5)])
+    w[-1] = 0
+    w = w / w.sum()
+    loss_fn = MultipleOutputLoss2(DC_and_CE_loss({'batch_dice': False, 'smooth': 1e-5, 'do_bg': False}, {}), w)
+    loss = loss_fn(outs, targets)
+    loss.backward()
+    out = {"loss": np.float64(loss.item()), "ds_weights": w}
+    for i, o in enumerate(outs):
+        out["logits%d" % i] = o.detach().numpy()
+    names = list(shapes.keys())
+    out["names"] = np.array(names)
+    out["grad_l2"] = np.array([net.get_parameter(n).grad.double().norm().item() for n in names])
+    for n in ("conv_blocks_context.0.blocks.0.conv.weight", "loc0.4.1.blocks.0.conv.weight", "up2.1.weight",
+              "seg_outputs.0.weight", "loc3.0.0.blocks.0.instnorm.weight", "conv_blocks_context.5.1.blocks.0.conv.bias",
+              "loc0.0.0.blocks.0.conv.weight"):
+        out["grad::" + n] = net.get_parameter(n).grad.numpy()
+    # eval / no-deep-supervision path returns the full-res logits only
+    net.do_ds = False
+    with torch.no_grad():
+        out["logits_nods_sum"] = np.float64(net(x).double().sum().item())
+    np.savez_compressed(os.path.join(OUT, "net_tiny.npz"), **out)
+
+
+def gen_net_sparse_tiny():
+    """Tiny net with DSFF masks (density 0.3) applied: forward + one full train-step."""
+    net = build_ref_net(TINY["patch"], TINY["cin"], TINY["base"], TINY["k"], TINY["pools"], TINY["max_feat"])
+    shapes = load_closed_form(net)
+    mask, opt = make_masking(net, density=0.3, death_rate=0.5, t_max=10, update_frequency=2, seed=5)
+    out = {"names": np.array(list(mask.masks.keys()))}
+    for n, m in mask.masks.items():
+        out["mask0::" + n] = pack_kernel_mask(m)
+    x = seeded_input((2, TINY["cin"]) + TINY["patch"], seed=21)
+    w = np.array([1 / (2 ** i) for i in range(5)])
+    w[-1] = 0
+    w = w / w.sum()
+    loss_fn = MultipleOutputLoss2(DC_and_CE_loss({'batch_dice': False, 'smooth': 1e-5, 'do_bg': False}, {}), w)
+    import io, contextlib
+    losses = []
+    for it in range(2):                         # nnUNetTrainer_simple.run_iteration, non-AMP branch
+        opt.zero_grad()
+        outs = net(x)
+        targets = [seeded_labels((o.shape[0], 1) + tuple(o.shape[2:]), TINY["k"], seed=30 + i)
+                   for i, o in enumerate(outs)]
+        loss = loss_fn(outs, targets)
+        loss.backward()
+        if it == 0:
+            out["logits0_it0"] = outs[0].detach().numpy()
+            out["grad_l2_it0"] = np.array([p.grad.double().norm().item() for _, p in net.named_parameters()])
+        tn = torch.nn.utils.clip_grad_norm_(net.parameters(), 12)
+        opt.step()
+        with contextlib.redirect_stdout(io.StringIO()):
+            mask.step()
+        losses.append(loss.item())
+        out["total_norm_it%d" % it] = np.float64(tn.item())
+        out["death_rate_it%d" % it] = np.float64(mask.death_rate)
+    out["losses"] = np.array(losses)
+    for n, m in mask.masks.items():                  # after the prune/grow at step 2
+        out["mask2::" + n] = pack_kernel_mask(m)
+    sd = net.state_dict()
+    out["param_names"] = np.array(list(shapes.keys()))
+    out["param_sum_after"] = np.array([sd[n].double().sum().item() for n in shapes])
+    out["param_abs_after"] = np.array([sd[n].double().abs().sum().item() for n in shapes])
+    for n in ("loc0.4.1.blocks.0.conv.weight", "up4.0.weight", "conv_blocks_context.0.blocks.0.conv.weight"):
+        out["param_after::" + n] = sd[n].numpy()
+    np.savez_compressed(os.path.join(OUT, "net_sparse_tiny.npz"), **out)
+
+
+def gen_net64():
+    """64^3, base 32, Cin 4, K 4, DSFF density 0.2 (random.seed(0)), closed-form weights."""
+    pools = [[2, 2, 2]] * 5
+    net = build_ref_net((64, 64, 64), 4, 32, 4, pools)
+    load_closed_form(net)
+    mask, _ = make_masking(net, density=0.2, seed=0)
+    net.eval()
+    x = seeded_input((1, 4, 64, 64, 64), seed=41)
+    with torch.no_grad():
+        outs = net(x)
+    out = {}
+    for i, o in enumerate(outs):
+        o = o.double()
+        out["sum%d" % i] = np.float64(o.sum().item())
+        out["abs%d" % i] = np.float64(o.abs().sum().item())
+    out["slice_d32"] = outs[0][0, :, 32].numpy()
+    out["slice_h5"] = outs[0][0, :, :, 5].numpy()
+    out["logits1"] = outs[1].numpy()[0, :, ::4]
+    out["mask_names"] = np.array(list(mask.masks.keys()))
+    out["mask_sha"] = np.array([sha_of(pack_kernel_mask(m)) for m in mask.masks.values()])
+    out["mask_nnz"] = np.array([int(m.sum().item()) for m in mask.masks.values()])
+    np.savez_compressed(os.path.join(OUT, "net64.npz"), **out)
+
+
+def gen_masks():
+    """Initial uniform masks at the BASELINE widths + death-rate schedule + L1 association order."""
+    out = {}
+    pools = [[2, 2, 2]] * 5
+    for base in (32, 48):
+        net = build_ref_net((64, 64, 64), 4, base, 4, pools, seed=0)
+        for dens in (0.1, 0.2, 0.5):
+            mask, _ = make_masking(net, density=dens, seed=0)
+            tag = "b%d_d%s" % (base, dens)
+            out[tag + "_names"] = np.array(list(mask.masks.keys()))
+            out[tag + "_sha"] = np.array([sha_of(pack_kernel_mask(m)) for m in mask.masks.values()])
+            out[tag + "_nnz"] = np.array([int(m.sum().item()) for m in mask.masks.values()])
+            if base == 32 and dens == 0.2:
+                out[tag + "_loc4.0"] = pack_kernel_mask(mask.masks["loc4.0.0.blocks.0.conv.weight"])
+                out[tag + "_up0.0"] = pack_kernel_mask(mask.masks["up0.0.weight"])
+    decay = CosineDecay(0.5, 10)
+    seq = []
+    for _ in range(12):
+        decay.step()
+        seq.append(decay.get_dr())
+    out["death_rate_T10"] = np.array(seq, dtype=np.float64)
+    decay = CosineDecay(0.5, 250 * 1000)
+    seq = []
+    for _ in range(5):
+        decay.step()
+        seq.append(decay.get_dr())
+    out["death_rate_T250k"] = np.array(seq, dtype=np.float64)
+    # kernel L1 association order on closed-form weights (three chained sums, core_channel.py:652-655)
+    from tests.helpers import closed_form_tensor
+    for tag, shp in (("l1_133", (320, 896, 1, 3, 3)), ("l1_222", (64, 32, 2, 2, 2)), ("l1_122", (16, 24, 1, 2, 2))):
+        wt = closed_form_tensor(shp, 3, "conv")
+        s = torch.sum(torch.sum(torch.sum(torch.abs(wt), dim=-1), dim=-1), dim=-1)
+        out[tag] = s.numpy()
+    np.savez_compressed(os.path.join(OUT, "masks.npz"), **out)
+
+
+def gen_loss():
+    out = {}
+    for tag, batch_dice in (("sample", False), ("batch", True)):
+        k = 4
+        shapes = [(2, k, 8, 12, 10), (2, k, 4, 6, 5), (2, k, 2, 3, 5), (2, k, 1, 3, 5)]
+        logits = [seeded_input(s, seed=50 + i).mul(2.0).requires_grad_(True) for i, s in enumerate(shapes)]
+        targets = [seeded_labels((s[0], 1) + s[2:], k, seed=60 + i) for i, s in enumerate(shapes)]
+        w = np.array([1 / (2 ** i) for i in range(5)])
+        w[-1] = 0
+        w = w / w.sum()
+        loss_fn = MultipleOutputLoss2(DC_and_CE_loss({'batch_dice': batch_dice, 'smooth': 1e-5, 'do_bg': False}, {}), w)
+        loss = loss_fn(logits, targets)
+        loss.backward()
+        out[tag + "_loss"] = np.float64(loss.item())
+        for i, l in enumerate(logits):
+            out[tag + "_g%d" % i] = l.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "loss.npz"), **out)
+
+
+def gen_sliding():
+    out = {}
+    for ps in ((64, 64, 64), (128, 128, 128), (16, 32, 32), (40, 56, 40)):
+        g = SegmentationNetwork._get_gaussian(ps, 1. / 8)
+        tag = "g%dx%dx%d" % ps
+        c = [i // 2 for i in ps]
+        out[tag + "_line0"] = g[:, c[1], c[2]]
+        out[tag + "_line2"] = g[c[0], c[1], :]
+        out[tag + "_diag"] = np.array([g[i * ps[0] // 16, i * ps[1] // 16, i * ps[2] // 16] for i in range(16)])
+        out[tag + "_stats"] = np.array([g.min(), g.max(), g.astype(np.float64).sum()], dtype=np.float64)
+        if ps == (16, 32, 32):
+            out[tag + "_full"] = g
+    # full predict_3D on a volume that needs padding in x, several tiles in y and z, 8-fold mirroring
+    net = build_ref_net(TINY["patch"], TINY["cin"], TINY["base"], TINY["k"], TINY["pools"], TINY["max_feat"])
+    load_closed_form(net)
+    net.inference_apply_nonlin = lambda x: torch.nn.functional.softmax(x, 1)
+    net.eval()
+    net.do_ds = False
+    vol = seeded_input((TINY["cin"], 13, 50, 70), seed=71).numpy()
+    for tag, kw in (("tta", dict(do_mirroring=True, mirror_axes=(0, 1, 2))),
+                    ("notta", dict(do_mirroring=False, mirror_axes=(0, 1, 2))),
+                    ("tta01", dict(do_mirroring=True, mirror_axes=(0, 1)))):
+        seg, probs = net.predict_3D(vol, use_sliding_window=True, step_size=0.5, patch_size=TINY["patch"],
+                                    use_gaussian=True, all_in_gpu=False, verbose=False, mixed_precision=False, **kw)
+        out["pred_%s_seg" % tag] = seg.astype(np.int8)
+        out["pred_%s_probs_sum" % tag] = probs.astype(np.float64).sum(axis=(1, 2, 3))
+        out["pred_%s_probs_slice" % tag] = probs[:, 6, ::2, ::2]
+    np.savez_compressed(os.path.join(OUT, "sliding.npz"), **out)
+
+
+def gen_dice():
+    out = {}
+    rng = np.random.RandomState(3)
+    a = rng.randint(0, 4, (12, 14, 9))
+    b = rng.randint(0, 4, (12, 14, 9))
+    out["a"] = a.astype(np.int8)
+    out["b"] = b.astype(np.int8)
+    out["dice"] = np.array([ref_dice(a == l, b == l) for l in range(1, 4)])
+    out["dice_small"] = np.float64(ref_dice(np.array([0, 1, 1, 0]), np.array([0, 1, 0, 0])))
+    np.savez_compressed(os.path.join(OUT, "dice.npz"), **out)
+
+
+def gen_init():
+    """Reference He init under torch.manual_seed(1234): per-tensor checksums (RNG draw order)."""
+    out = {}
+    for tag, (patch, cin, base, k, pools, mf) in {
+            "tiny": (TINY["patch"], TINY["cin"], TINY["base"], TINY["k"], TINY["pools"], TINY["max_feat"]),
+            "b32": ((64, 64, 64), 4, 32, 4, [[2, 2, 2]] * 5, None)}.items():
+        net = build_ref_net(patch, cin, base, k, pools, mf, seed=1234)
+        sd = net.state_dict()
+        out[tag + "_names"] = np.array(list(sd.keys()))
+        out[tag + "_shapes"] = np.array([str(tuple(v.shape)) for v in sd.values()])
+        out[tag + "_sum"] = np.array([v.double().sum().item() for v in sd.values()])
+        out[tag + "_abs"] = np.array([v.double().abs().sum().item() for v in sd.values()])
+        out[tag + "_param_order"] = np.array([n for n, _ in net.named_parameters()])
+    np.savez_compressed(os.path.join(OUT, "init.npz"), **out)
+
+
+ALL = dict(shift=gen_shift, block=gen_block, net=gen_net_tiny, sparse=gen_net_sparse_tiny, net64=gen_net64,
+           masks=gen_masks, loss=gen_loss, sliding=gen_sliding, dice=gen_dice, init=gen_init)
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    os.makedirs(OUT, exist_ok=True)
+    todo = sys.argv[1:] or list(ALL)
+    for name in todo:
+        print("generating", name, flush=True)
+        ALL[name]()
+    print("done")
