@@ -1,0 +1,117 @@
+"""ctypes binding of libe2e_hip.so (the C-ABI declared in include/e2e_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C e2enet_medical_amd/csrc``.
+There is NO fallback: if the library is missing or a call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libe2e_hip.so")
+
+
+class InChan(C.Structure):
+    """e2e_in_chan_t"""
+    _fields_ = [("ptr", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
+                ("nstride", C.c_longlong), ("ab_nstride", C.c_int), ("dshift", C.c_int),
+                ("slope", C.c_float), ("reserved", C.c_int)]
+
+
+class OutChan(C.Structure):
+    """e2e_out_chan_t"""
+    _fields_ = [("ptr", C.c_void_p), ("nstride", C.c_longlong), ("dshift", C.c_int), ("accumulate", C.c_int)]
+
+
+class ParamEntry(C.Structure):
+    """e2e_param_t"""
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("momentum", C.c_void_p), ("mask", C.c_void_p),
+                ("numel", C.c_longlong)]
+
+
+assert C.sizeof(InChan) == 48 and C.sizeof(OutChan) == 24 and C.sizeof(ParamEntry) == 40
+
+P, I, F, LL = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+
+# name -> (restype, argtypes); every symbol declared in include/e2e_hip.h
+SIGNATURES = {
+    "e2e_last_error": (C.c_char_p, []),
+    "e2e_abi_version": (I, []),
+    "e2e_conv133_num_partials": (I, [I, I, I, I, I]),
+    "e2e_conv133_fwd": (I, [P, I, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "e2e_conv133_dgrad": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
+    "e2e_conv133_wgrad_ws_bytes": (LL, [I, I, I, I, I, I, I, I, I]),
+    "e2e_conv133_wgrad": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
+    "e2e_in_stats_finalize": (I, [P, I, P, P, F, P, P, P, P, I, I, P]),
+    "e2e_in_lrelu_bwd": (I, [P, P, P, P, P, P, F, P, P, P, P, I, I, LL, P]),
+    "e2e_convT_fwd": (I, [P, P, P, F, P, P, P, I, I, I, I, I, I, I, I, I, P]),
+    "e2e_convT_dgrad": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
+    "e2e_convT_wgrad_ws_bytes": (LL, [I, I, I, I, I, I, I, I, I]),
+    "e2e_convT_wgrad": (I, [P, P, P, F, P, P, P, I, I, I, I, I, I, I, I, I, P]),
+    "e2e_maxpool_fwd": (I, [P, P, P, F, P, I, I, I, I, I, I, I, I, P]),
+    "e2e_maxpool_bwd": (I, [P, P, P, F, P, P, I, I, I, I, I, I, I, I, I, P]),
+    "e2e_head1x1_fwd": (I, [P, P, P, F, P, P, I, I, I, LL, P]),
+    "e2e_head1x1_dgrad": (I, [P, P, P, I, I, I, I, LL, P]),
+    "e2e_head1x1_wgrad_ws_bytes": (LL, [I, I, I, LL]),
+    "e2e_head1x1_wgrad": (I, [P, P, P, F, P, P, P, I, I, I, LL, P]),
+    "e2e_loss_ws_bytes": (LL, [I, I]),
+    "e2e_dc_ce_reduce": (I, [P, P, P, I, I, LL, P]),
+    "e2e_dc_ce_grad": (I, [P, P, P, F, I, F, P, P, I, I, LL, P]),
+    "e2e_grad_sqnorm": (I, [P, I, P, P]),
+    "e2e_sgd_clip_mask_step": (I, [P, I, P, F, F, F, F, I, I, P]),
+    "e2e_apply_mask": (I, [P, I, P]),
+    "e2e_dsff_kernel_l1": (I, [P, P, I, I, I, I, I, P]),
+    "e2e_dsff_kth_value": (I, [P, I, I, P, P, P]),
+    "e2e_dsff_death": (I, [P, P, P, I, P]),
+    "e2e_dsff_expand": (I, [P, P, P, P, I, I, I, P]),
+    "e2e_dsff_kmask_from_weights": (I, [P, P, I, I, I, P]),
+    "e2e_flip3d": (I, [P, P, I, I, I, I, I, P]),
+    "e2e_softmax_flip_acc": (I, [P, P, F, I, I, I, I, I, I, P]),
+    "e2e_sw_accumulate": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
+    "e2e_sw_finalize_argmax": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
+}
+
+_NO_STATUS = {"e2e_last_error", "e2e_abi_version", "e2e_conv133_num_partials", "e2e_conv133_wgrad_ws_bytes",
+              "e2e_convT_wgrad_ws_bytes", "e2e_head1x1_wgrad_ws_bytes", "e2e_loss_ws_bytes"}
+
+
+class E2EError(RuntimeError):
+    pass
+
+
+class _Lib:
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise ImportError(
+                "libe2e_hip.so not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C e2enet_medical_amd/csrc`. There is no CPU fallback." % path)
+        self._dll = C.CDLL(path)
+        self.path = path
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(self._dll, name)          # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+            if name in _NO_STATUS:
+                setattr(self, name[4:], fn)
+            else:
+                setattr(self, name[4:], self._checked(name, fn))
+
+    def _checked(self, name, fn):
+        last_error = self._dll.e2e_last_error
+
+        def call(*a):
+            rc = fn(*a)
+            if rc != 0:
+                raise E2EError("%s failed (%d): %s" % (name, rc, (last_error() or b"").decode()))
+        call.__name__ = name
+        return call
+
+
+_lib = None
+
+
+def lib() -> _Lib:
+    """The loaded library (loads on first use; raises ImportError when it has not been built)."""
+    global _lib
+    if _lib is None:
+        _lib = _Lib(LIB_PATH)
+    return _lib

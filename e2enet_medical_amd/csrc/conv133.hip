@@ -1,0 +1,438 @@
+// K1 / K6a: LDS-tiled direct 1x3x3 convolution for gfx950 (forward and stride-1 data gradient).
+//
+// Reference semantics: unetpp_d.py:45-59 (depth shift), :453-478 (concat), :93/:108 (Conv3d k(1,3,3)),
+// and autograd of the same for the data gradient.
+//
+// Design (MI355X-first):
+//   * one workgroup = one (batch item, output depth slice, TH x TW spatial tile, group of OCG output planes);
+//   * the input tile of CK input planes (+1 halo) is staged through LDS once and shared by all OCG output
+//     planes; the depth shift is an index offset in the load stage (plane p is read at depth d*sd - s(p)),
+//     the concat is a per-plane pointer table, the producer's InstanceNorm+LeakyReLU is applied while staging;
+//   * one wave owns OPW output planes; a lane owns a PH x PW micro-tile of each (register accumulators);
+//   * DSFF sparsity: per (output plane, 32 input planes) liveness word; the wave walks the set bits with
+//     scalar bit ops, so dead (out,in) kernels cost nothing;
+//   * epilogue (fwd): bias, store, per-tile (count, mean, M2) partial for InstanceNorm;
+//     epilogue (dgrad): un-shift on store into the per-channel destination (scatter back through the concat).
+#include "e2e_common.h"
+
+namespace {
+
+struct ConvParams {
+  const e2e_in_chan_t* chans;   // P input planes (null: plain tensor `xin`, used by the data gradient)
+  const float* xin;             // [B, P, Di, Hi, Wi] when chans == null
+  const float* w;
+  const float* bias;            // fwd only (may be null)
+  const unsigned* live;         // [Q][live_words] or null
+  float* y;                     // fwd
+  float* part;                  // fwd, may be null
+  const e2e_out_chan_t* outs;   // dgrad
+  int P, Q;                     // input planes, output planes
+  int wq_stride, wp_stride;     // element strides of the weight tensor for (q, p)
+  int live_words;
+  int B, Di, Hi, Wi, Do, Ho, Wo, sd;
+  int tiles_x, tiles_y, tiles_per_n;   // tiles_per_n = Do * tiles_y * tiles_x
+  int groups;                          // ceil(Q / OCG)
+  int total;                           // B * tiles_per_n * groups (logical work items)
+  int padded_total;
+};
+
+template <int MODE, int SH, int SW, int TH, int TW, int LY, int LX, int OPW, int NW, int CK>
+struct Cfg {
+  static_assert(LY * LX == 64, "one wave covers the tile");
+  static constexpr int PH = TH / LY, PW = TW / LX;
+  static constexpr int IH = (TH - 1) * SH + 3, IW = (TW - 1) * SW + 3;
+  // lane column offset in floats; decides the widest aligned LDS read of a neighbourhood row
+  static constexpr int LSTEP = PW * SW;
+  static constexpr int VEC = (LSTEP % 4 == 0) ? 4 : (LSTEP % 2 == 0 ? 2 : 1);
+  // VEC 4: pitch % 16 == 8 puts the four 16-lane groups of a ds_read_b128 on disjoint bank quarters;
+  // VEC 2: pitch % 8 == 4 does the same for the two lane rows of a 32-lane ds_read_b64 group.
+  static constexpr int pitch_for(int iw) {
+    int p = iw;
+    if (VEC == 4) { while (p % 16 != 8) ++p; }
+    else if (VEC == 2) { while (p % 8 != 4) ++p; }
+    return p;
+  }
+  static constexpr int PITCH = pitch_for(IW);
+  static constexpr int CHS = IH * PITCH;
+  static constexpr int NT = NW * 64;
+  static constexpr int OCG = OPW * NW;
+  static constexpr int NR = (PH - 1) * SH + 3, NC = (PW - 1) * SW + 3;
+  static constexpr int LDS_FLOATS = CK * CHS;
+};
+
+// read NC consecutive floats starting at an address aligned to VEC floats
+template <int NC, int VEC>
+__device__ __forceinline__ void load_row(const float* __restrict__ src, float* __restrict__ dst) {
+  int c = 0;
+  if (VEC == 4) {
+#pragma unroll
+    for (; c + 4 <= NC; c += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(src + c);
+      dst[c] = v.x; dst[c + 1] = v.y; dst[c + 2] = v.z; dst[c + 3] = v.w;
+    }
+  }
+  if (VEC >= 2) {
+#pragma unroll
+    for (; c + 2 <= NC; c += 2) {
+      const float2 v = *reinterpret_cast<const float2*>(src + c);
+      dst[c] = v.x; dst[c + 1] = v.y;
+    }
+  }
+#pragma unroll
+  for (; c < NC; ++c) dst[c] = src[c];
+}
+
+template <int MODE, int SH, int SW, int TH, int TW, int LY, int LX, int OPW, int NW, int CK, int MINW>
+__global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
+  using C = Cfg<MODE, SH, SW, TH, TW, LY, LX, OPW, NW, CK>;
+  __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
+
+  const int logical = e2e::xcd_remap(blockIdx.x, p.padded_total);
+  if (logical >= p.total) return;
+  const int g = logical % p.groups;
+  int t = logical / p.groups;
+  const int n = t / p.tiles_per_n;
+  t -= n * p.tiles_per_n;
+  const int tile_in_n = t;
+  const int tx = t % p.tiles_x;
+  t /= p.tiles_x;
+  const int ty = t % p.tiles_y;
+  const int d = t / p.tiles_y;
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int lx = lane % LX, ly = lane / LX;
+
+  const int h0 = ty * TH, w0 = tx * TW;                 // output tile origin
+  const int hbase = h0 * SH - 1, wbase = w0 * SW - 1;   // input tile origin (incl. halo)
+  const long long in_plane = (long long)p.Hi * p.Wi;
+
+  float acc[OPW][C::PH][C::PW];
+#pragma unroll
+  for (int a = 0; a < OPW; ++a)
+#pragma unroll
+    for (int i = 0; i < C::PH; ++i)
+#pragma unroll
+      for (int j = 0; j < C::PW; ++j) acc[a][i][j] = 0.f;
+
+  const int qbase = g * C::OCG + wave * OPW;
+  const float* lane_tp = lds + (ly * C::PH * SH) * C::PITCH + lx * C::LSTEP;
+
+  for (int c0 = 0; c0 < p.P; c0 += CK) {
+    // ---------------- stage CK input planes (halo included, transform applied, zero padded) ---------------
+    // per-plane (wave-uniform) descriptors first, then all loads of an element batch before any use
+    gfloat_p pbase[CK];   // global address space: plain global_load (vmcnt only), not flat_load
+    float pa[CK], pb[CK], psl[CK];
+    bool pv[CK];
+#pragma unroll
+    for (int k = 0; k < CK; ++k) {
+      const int pl = c0 + k;
+      pa[k] = 1.f; pb[k] = 0.f; psl[k] = 1.f;
+      if (MODE == 0) {
+        pbase[k] = (gfloat_p)p.chans[0].ptr;
+        pv[k] = false;
+        if (pl < p.P) {
+          const e2e_in_chan_t ch = p.chans[pl];
+          const int din = d * p.sd - ch.dshift;
+          if ((unsigned)din < (unsigned)p.Di) {
+            pv[k] = true;
+            pbase[k] = (gfloat_p)(ch.ptr + (long long)n * ch.nstride + (long long)din * in_plane);
+            if (ch.scale != nullptr) {
+              pa[k] = ch.scale[(long long)n * ch.ab_nstride];
+              pb[k] = ch.shift[(long long)n * ch.ab_nstride];
+              psl[k] = ch.slope;
+            }
+          }
+        }
+      } else {
+        pv[k] = pl < p.P;
+        pbase[k] = (gfloat_p)(p.xin + (((long long)n * p.P + (pv[k] ? pl : 0)) * p.Di + d) * in_plane);
+      }
+    }
+    for (int e = tid; e < C::IH * C::IW; e += C::NT) {
+      const int r = e / C::IW, cc = e - r * C::IW;
+      const int hi = hbase + r, wi = wbase + cc;
+      const bool ok = (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi;
+      const long long off = ok ? (long long)hi * p.Wi + wi : 0;
+      float v[CK];
+#pragma unroll
+      for (int k = 0; k < CK; ++k) v[k] = pbase[k][pv[k] ? off : 0];
+#pragma unroll
+      for (int k = 0; k < CK; ++k) {
+        float x = v[k];
+        if (MODE == 0) x = e2e::in_act(x, pa[k], pb[k], psl[k]);
+        lds[k * C::CHS + r * C::PITCH + cc] = (ok && pv[k]) ? x : 0.f;
+      }
+    }
+    __syncthreads();
+
+    // ---------------- compute: each wave walks the live input planes of its OPW output planes -------------
+#pragma unroll
+    for (int a = 0; a < OPW; ++a) {
+      const int q = qbase + a;
+      if (q < p.Q) {
+        unsigned bits;
+        if (p.live != nullptr) {
+          const unsigned word = p.live[(long long)q * p.live_words + (c0 >> 5)];
+          bits = (CK == 32) ? word : ((word >> (c0 & 31)) & ((1u << (CK & 31)) - 1u));
+        } else {
+          bits = (CK == 32) ? 0xffffffffu : ((1u << (CK & 31)) - 1u);
+        }
+        const int remain = p.P - c0;
+        if (remain < CK) bits &= (1u << remain) - 1u;
+        bits = __builtin_amdgcn_readfirstlane(bits);
+        while (bits) {
+          const int cl = __builtin_ctz(bits);
+          bits &= bits - 1;
+          const float* wp = p.w + (long long)q * p.wq_stride + (long long)(c0 + cl) * p.wp_stride;
+          float wk[9];
+#pragma unroll
+          for (int k = 0; k < 9; ++k) wk[k] = wp[MODE == 1 ? 8 - k : k];
+          const float* tp = lane_tp + cl * C::CHS;
+          float nb[C::NR][C::NC];
+#pragma unroll
+          for (int r = 0; r < C::NR; ++r) load_row<C::NC, C::VEC>(tp + r * C::PITCH, nb[r]);
+#pragma unroll
+          for (int i = 0; i < C::PH; ++i)
+#pragma unroll
+            for (int j = 0; j < C::PW; ++j)
+#pragma unroll
+              for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+                  acc[a][i][j] = fmaf(wk[kh * 3 + kw], nb[i * SH + kh][j * SW + kw], acc[a][i][j]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---------------- epilogue ------------------------------------------------------------------------------
+  const int oh0 = h0 + ly * C::PH, ow0 = w0 + lx * C::PW;
+  const long long out_plane = (long long)p.Ho * p.Wo;
+#pragma unroll
+  for (int a = 0; a < OPW; ++a) {
+    const int q = qbase + a;
+    if (q >= p.Q) continue;
+    if (MODE == 0) {
+      const float bq = p.bias ? p.bias[q] : 0.f;
+      float* yp = p.y + (((long long)n * p.Q + q) * p.Do + d) * out_plane;
+      float s = 0.f;
+      int cnt = 0;
+#pragma unroll
+      for (int i = 0; i < C::PH; ++i)
+#pragma unroll
+        for (int j = 0; j < C::PW; ++j) {
+          const int oh = oh0 + i, ow = ow0 + j;
+          const float val = acc[a][i][j] + bq;
+          acc[a][i][j] = val;
+          if (oh < p.Ho && ow < p.Wo) {
+            yp[(long long)oh * p.Wo + ow] = val;
+            s += val;
+            ++cnt;
+          }
+        }
+      if (p.part != nullptr) {
+        const float tot = e2e::wave_sum(s);
+        const float tcnt = e2e::wave_sum((float)cnt);
+        const float mean = tot / tcnt;
+        float m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < C::PH; ++i)
+#pragma unroll
+          for (int j = 0; j < C::PW; ++j) {
+            const int oh = oh0 + i, ow = ow0 + j;
+            if (oh < p.Ho && ow < p.Wo) {
+              const float dlt = acc[a][i][j] - mean;
+              m2 = fmaf(dlt, dlt, m2);
+            }
+          }
+        m2 = e2e::wave_sum(m2);
+        if (lane == 0) {
+          float* pp = p.part + (((long long)n * p.Q + q) * p.tiles_per_n + tile_in_n) * 3;
+          pp[0] = tcnt;
+          pp[1] = mean;
+          pp[2] = m2;
+        }
+      }
+    } else {
+      // dgrad: gradient of virtual-concat channel q at (shifted) depth d goes to depth d - s(q) of its source
+      const e2e_out_chan_t oc = p.outs[q];
+      if (oc.ptr == nullptr) continue;
+      int dd = d - oc.dshift;
+      bool zero_fill = false;
+      if (dd < 0) {              // s > 0: slices [max(D-s,0), D) receive nothing -> this workgroup zero-fills one
+        const int lo = p.Do - oc.dshift > 0 ? p.Do - oc.dshift : 0;
+        dd = lo + d;
+        zero_fill = true;
+      } else if (dd >= p.Do) {   // s < 0: slices [0, min(-s, D)) receive nothing
+        const int lo = p.Do + oc.dshift > 0 ? p.Do + oc.dshift : 0;
+        dd = d - lo;
+        zero_fill = true;
+      }
+      if (zero_fill && oc.accumulate) continue;
+      float* xp = oc.ptr + (long long)n * oc.nstride + (long long)dd * out_plane;
+#pragma unroll
+      for (int i = 0; i < C::PH; ++i)
+#pragma unroll
+        for (int j = 0; j < C::PW; ++j) {
+          const int oh = oh0 + i, ow = ow0 + j;
+          if (oh < p.Ho && ow < p.Wo) {
+            float* dst = xp + (long long)oh * p.Wo + ow;
+            if (zero_fill) *dst = 0.f;
+            else if (oc.accumulate) *dst += acc[a][i][j];
+            else *dst = acc[a][i][j];
+          }
+        }
+    }
+  }
+}
+
+// ---- strided data gradient (encoder "convolutional pooling" convs, 5 layers, dense): gather form ------------
+// dx[c][di][hi][wi] = sum_o sum_{kh,kw : (hi+1-kh) % sh == 0, (wi+1-kw) % sw == 0} dy[o][ds][(hi+1-kh)/sh][(wi+1-kw)/sw] w[o][c][kh][kw]
+// where the shifted depth ds*sd = di + s(c).
+__global__ __launch_bounds__(256) void conv133_dgrad_strided_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                                    const e2e_out_chan_t* outs, int B, int Cin, int Cout,
+                                                                    int Di, int Hi, int Wi, int Do, int Ho, int Wo, int sd,
+                                                                    int sh, int sw) {
+  const long long plane = (long long)Hi * Wi;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.y;
+  const int n = blockIdx.z;
+  if (idx >= (long long)Di * plane) return;
+  const e2e_out_chan_t oc = outs[c];
+  if (oc.ptr == nullptr) return;
+  const int di = (int)(idx / plane);
+  const int rem = (int)(idx - (long long)di * plane);
+  const int hi = rem / Wi, wi = rem - hi * Wi;
+  const int dsft = di + oc.dshift;     // depth in the shifted tensor
+  float acc = 0.f;
+  if (dsft >= 0 && dsft < Di && dsft % sd == 0) {
+    const int dz = dsft / sd;
+    if (dz < Do) {
+      for (int kh = 0; kh < 3; ++kh) {
+        const int th = hi + 1 - kh;
+        if (th < 0 || th % sh) continue;
+        const int ho = th / sh;
+        if (ho >= Ho) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+          const int tw = wi + 1 - kw;
+          if (tw < 0 || tw % sw) continue;
+          const int wo = tw / sw;
+          if (wo >= Wo) continue;
+          const float* dyp = dy + (((long long)n * Cout) * Do + dz) * Ho * Wo + (long long)ho * Wo + wo;
+          const float* wp = w + (long long)c * 9 + kh * 3 + kw;
+          const long long ostride = (long long)Do * Ho * Wo;
+          float s = 0.f;
+          for (int o = 0; o < Cout; ++o) s = fmaf(dyp[o * ostride], wp[(long long)o * Cin * 9], s);
+          acc += s;
+        }
+      }
+    }
+  }
+  float* dst = oc.ptr + (long long)n * oc.nstride + idx;
+  if (oc.accumulate) *dst += acc;
+  else *dst = acc;
+}
+
+template <int MODE, int SH, int SW, int TH, int TW, int LY, int LX, int OPW, int NW, int CK, int MINW = 1>
+int launch_cfg(ConvParams p, hipStream_t st) {
+  using C = Cfg<MODE, SH, SW, TH, TW, LY, LX, OPW, NW, CK>;
+  p.tiles_x = e2e::cdiv(p.Wo, TW);
+  p.tiles_y = e2e::cdiv(p.Ho, TH);
+  p.tiles_per_n = p.Do * p.tiles_y * p.tiles_x;
+  p.groups = e2e::cdiv(p.Q, C::OCG);
+  p.total = p.B * p.tiles_per_n * p.groups;
+  p.padded_total = (p.total + 7) & ~7;
+  hipLaunchKernelGGL((conv133_kernel<MODE, SH, SW, TH, TW, LY, LX, OPW, NW, CK, MINW>), dim3(p.padded_total), dim3(C::NT), 0, st, p);
+  return e2e::check_launch("conv133_kernel");
+}
+
+// tile selection shared by the launcher and e2e_conv133_num_partials
+enum TileKind { T32 = 0, T16 = 1, T8 = 2, T16x32S = 3, T8S = 4 };
+inline TileKind pick_tile(int Ho, int Wo, int sh, int sw) {
+  const bool strided = (sh != 1 || sw != 1);
+  const int m = Ho < Wo ? Ho : Wo;
+  if (strided) return m > 8 ? T16x32S : T8S;
+  if (m > 16) return T32;
+  if (m > 8) return T16;
+  return T8;
+}
+inline void tile_dims(TileKind k, int& th, int& tw) {
+  switch (k) {
+    case T32: th = 32; tw = 32; break;
+    case T16: th = 16; tw = 16; break;
+    case T8: th = 8; tw = 8; break;
+    case T16x32S: th = 16; tw = 32; break;
+    default: th = 8; tw = 8; break;
+  }
+}
+
+}  // namespace
+
+extern "C" int e2e_conv133_num_partials(int Do, int Ho, int Wo, int sh, int sw) {
+  int th, tw;
+  tile_dims(pick_tile(Ho, Wo, sh, sw), th, tw);
+  return Do * e2e::cdiv(Ho, th) * e2e::cdiv(Wo, tw);
+}
+
+extern "C" int e2e_conv133_fwd(const e2e_in_chan_t* chans, int Cin, const float* w, const float* bias,
+                               const unsigned* live, float* y, float* part, int B, int Cout, int Di, int Hi, int Wi,
+                               int sd, int sh, int sw, void* stream) {
+  E2E_REQUIRE(chans && w && y, "conv133_fwd: null pointer");
+  E2E_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Di > 0 && Hi > 0 && Wi > 0, "conv133_fwd: bad dims");
+  E2E_REQUIRE((sd == 1 || sd == 2) && (sh == 1 || sh == 2) && (sw == 1 || sw == 2), "conv133_fwd: stride must be 1 or 2");
+  ConvParams p{};
+  p.chans = chans; p.xin = nullptr; p.w = w; p.bias = bias; p.live = live; p.y = y; p.part = part; p.outs = nullptr;
+  p.P = Cin; p.Q = Cout; p.wq_stride = Cin * 9; p.wp_stride = 9; p.live_words = e2e::cdiv(Cin, 32);
+  p.B = B; p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.sd = sd;
+  p.Do = (Di - 1) / sd + 1; p.Ho = (Hi - 1) / sh + 1; p.Wo = (Wi - 1) / sw + 1;
+  hipStream_t st = (hipStream_t)stream;
+  const TileKind k = pick_tile(p.Ho, p.Wo, sh, sw);
+  if (sh == 1 && sw == 1) {
+    switch (k) {
+      case T32: return launch_cfg<0, 1, 1, 32, 32, 8, 8, 4, 8, 8, 4>(p, st);
+      case T16: return launch_cfg<0, 1, 1, 16, 16, 8, 8, 4, 8, 16>(p, st);
+      default: return launch_cfg<0, 1, 1, 8, 8, 8, 8, 4, 8, 32>(p, st);
+    }
+  }
+  // strided variants are instantiated per (sh, sw)
+  if (sh == 2 && sw == 2) {
+    if (k == T16x32S) return launch_cfg<0, 2, 2, 16, 32, 4, 16, 4, 8, 8>(p, st);
+    return launch_cfg<0, 2, 2, 8, 8, 8, 8, 4, 8, 16>(p, st);
+  }
+  if (sh == 1 && sw == 2) {
+    if (k == T16x32S) return launch_cfg<0, 1, 2, 16, 32, 4, 16, 4, 8, 8>(p, st);
+    return launch_cfg<0, 1, 2, 8, 8, 8, 8, 4, 8, 16>(p, st);
+  }
+  if (k == T16x32S) return launch_cfg<0, 2, 1, 16, 32, 4, 16, 4, 8, 8>(p, st);
+  return launch_cfg<0, 2, 1, 8, 8, 8, 8, 4, 8, 16>(p, st);
+}
+
+extern "C" int e2e_conv133_dgrad(const float* dy, const float* w, const unsigned* live_t, const e2e_out_chan_t* outs,
+                                 int B, int Cin, int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw,
+                                 void* stream) {
+  E2E_REQUIRE(dy && w && outs, "conv133_dgrad: null pointer");
+  E2E_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Di > 0 && Hi > 0 && Wi > 0, "conv133_dgrad: bad dims");
+  hipStream_t st = (hipStream_t)stream;
+  const int Do = (Di - 1) / sd + 1, Ho = (Hi - 1) / sh + 1, Wo = (Wi - 1) / sw + 1;
+  if (sd != 1 || sh != 1 || sw != 1) {
+    const long long per = (long long)Di * Hi * Wi;
+    dim3 grid((unsigned)e2e::cdivll(per, 256), Cin, B);
+    hipLaunchKernelGGL(conv133_dgrad_strided_kernel, grid, dim3(256), 0, st, dy, w, outs, B, Cin, Cout, Di, Hi, Wi, Do,
+                       Ho, Wo, sd, sh, sw);
+    return e2e::check_launch("conv133_dgrad_strided_kernel");
+  }
+  // stride 1: the forward kernel with transposed, tap-reversed weights; the "input planes" are dy's channels
+  // (a plain tensor, no shift), the output planes are the virtual-concat input channels (un-shift on store).
+  ConvParams p{};
+  p.chans = nullptr; p.xin = dy; p.w = w; p.bias = nullptr; p.live = live_t; p.y = nullptr; p.part = nullptr; p.outs = outs;
+  p.P = Cout; p.Q = Cin; p.wq_stride = 9; p.wp_stride = Cin * 9; p.live_words = e2e::cdiv(Cout, 32);
+  p.B = B; p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.sd = 1; p.Do = Di; p.Ho = Hi; p.Wo = Wi;
+  switch (pick_tile(Hi, Wi, 1, 1)) {
+    case T32: return launch_cfg<1, 1, 1, 32, 32, 8, 8, 4, 8, 8, 4>(p, st);
+    case T16: return launch_cfg<1, 1, 1, 16, 16, 8, 8, 4, 8, 16>(p, st);
+    default: return launch_cfg<1, 1, 1, 8, 8, 8, 8, 4, 8, 32>(p, st);
+  }
+}

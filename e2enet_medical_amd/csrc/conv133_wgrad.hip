@@ -1,0 +1,257 @@
+// K6b: dense weight gradient of the 1x3x3 convolution on the fp32 MFMA (gfx950).
+//
+//   dW[o, c, kh, kw] = sum_{n, d, h, w} dy[n, o, d, h, w] * xs[n, c, d*sd, h*sh + kh - 1, w*sw + kw - 1]
+//   xs = depth-shifted virtual concat of the producers' lrelu(IN(.)) outputs (unetpp_d.py:45-59, :453-478)
+//
+// Why dense: the reference clips the global gradient norm over ALL parameters including DSFF-dead kernels
+// (nnUNetTrainer_simple.py:573, core_channel.py:431 masks only .data), so dead-kernel gradients are part of the
+// result.  Why MFMA: this is a true GEMM, M = Cout, N = Cin*9, K = voxels (~2M); v_mfma_f32_16x16x4_f32 is an exact
+// fp32 fma chain (bit-compatible with a plain fp32 accumulation) and keeps the whole reduction inside the matrix
+// pipe, no cross-lane reduction.
+//
+// One workgroup = (32 out channels) x (32 in channels) x 9 taps over a chunk of pixel tiles; wave (oh, ch) owns
+// the 16 x 16 sub-block for all 9 taps (36 accumulator registers).  dy and the halo'd input tile are staged in LDS
+// with channel strides == 2 (mod 32) so that the A/B fragment reads (16 channels x 4 consecutive pixels) hit 32
+// distinct banks.  Per-chunk partial sums go to a slab, reduced in fixed order by a second kernel (deterministic).
+#include "e2e_common.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+struct WgParams {
+  const e2e_in_chan_t* chans;
+  const float* dy;
+  float* slab;
+  int B, Cin, Cout, Di, Hi, Wi, Do, Ho, Wo, sd;
+  int tiles_x, tiles_y, tiles_d, tiles_per_n;
+  long long total_tiles;
+  int tiles_per_chunk;
+  int cblocks;
+};
+
+constexpr int pad_mod32_2(int v) {
+  while (v % 32 != 2) ++v;
+  return v;
+}
+
+template <int SH, int SW, int ND, int TH, int TW>
+struct WCfg {
+  static constexpr int TP = ND * TH * TW;
+  static_assert(TW % 4 == 0, "k-steps of 4 pixels stay inside a row");
+  static constexpr int IH = (TH - 1) * SH + 3, IW = (TW - 1) * SW + 3;
+  static constexpr int PITCH = IW;
+  static constexpr int CS = pad_mod32_2(ND * IH * PITCH);
+  static constexpr int OS = pad_mod32_2(TP);
+  static constexpr int LDS_FLOATS = 32 * CS + 32 * OS;
+};
+
+template <int SH, int SW, int ND, int TH, int TW>
+__global__ __launch_bounds__(256) void conv133_wgrad_kernel(WgParams p) {
+  using C = WCfg<SH, SW, ND, TH, TW>;
+  __shared__ float lds[C::LDS_FLOATS];
+  float* xs = lds;
+  float* ys = lds + 32 * C::CS;
+
+  const int chunk = blockIdx.x;
+  const int cb = blockIdx.y % p.cblocks, ob = blockIdx.y / p.cblocks;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ch = wave & 1, oh = wave >> 1;
+  const long long in_plane = (long long)p.Hi * p.Wi;
+  const long long out_plane = (long long)p.Ho * p.Wo;
+
+  f32x4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int ti = 0; ti < p.tiles_per_chunk; ++ti) {
+    const long long tile = (long long)chunk * p.tiles_per_chunk + ti;
+    if (tile >= p.total_tiles) break;
+    int t = (int)(tile % p.tiles_per_n);
+    const int n = (int)(tile / p.tiles_per_n);
+    const int tx = t % p.tiles_x;
+    t /= p.tiles_x;
+    const int ty = t % p.tiles_y;
+    const int td = t / p.tiles_y;
+    const int d0 = td * ND, h0 = ty * TH, w0 = tx * TW;
+    const int hbase = h0 * SH - 1, wbase = w0 * SW - 1;
+
+    // ---- stage the input tile: 32 channels x ND slices x IH x IW (transform on load, zero padded) ----
+    for (int cl = wave; cl < 32; cl += 4) {          // one wave per channel -> channel descriptor is wave-uniform
+      const int c = cb * 32 + cl;
+      const bool cv = c < p.Cin;
+      e2e_in_chan_t chd = p.chans[cv ? c : 0];
+      float a = 1.f, b = 0.f, sl = 1.f;
+      if (cv && chd.scale != nullptr) {
+        a = chd.scale[(long long)n * chd.ab_nstride];
+        b = chd.shift[(long long)n * chd.ab_nstride];
+        sl = chd.slope;
+      }
+      gfloat_p base = (gfloat_p)(chd.ptr + (long long)n * chd.nstride);
+      for (int e = lane; e < ND * C::IH * C::IW; e += 64) {
+        const int nd = e / (C::IH * C::IW);
+        const int rem = e - nd * (C::IH * C::IW);
+        const int r = rem / C::IW, cc = rem - r * C::IW;
+        const int hi = hbase + r, wi = wbase + cc;
+        const int dq = d0 + nd;
+        const int din = dq * p.sd - chd.dshift;
+        const bool ok = cv && dq < p.Do && (unsigned)din < (unsigned)p.Di && (unsigned)hi < (unsigned)p.Hi &&
+                        (unsigned)wi < (unsigned)p.Wi;
+        const long long off = ok ? (long long)din * in_plane + (long long)hi * p.Wi + wi : 0;
+        float v = base[off];
+        v = e2e::in_act(v, a, b, sl);
+        xs[cl * C::CS + nd * (C::IH * C::PITCH) + r * C::PITCH + cc] = ok ? v : 0.f;
+      }
+    }
+    // ---- stage dy: 32 channels x TP pixels ----
+    for (int idx = tid; idx < 32 * C::TP; idx += 256) {
+      const int ol = idx / C::TP, pi = idx - ol * C::TP;
+      const int nd = pi / (TH * TW);
+      const int rem = pi - nd * (TH * TW);
+      const int r = rem / TW, col = rem - r * TW;
+      const int o = ob * 32 + ol;
+      const int dq = d0 + nd, ho = h0 + r, wo = w0 + col;
+      float v = 0.f;
+      if (o < p.Cout && dq < p.Do && ho < p.Ho && wo < p.Wo)
+        v = p.dy[(((long long)n * p.Cout + o) * p.Do + dq) * out_plane + (long long)ho * p.Wo + wo];
+      ys[ol * C::OS + pi] = v;
+    }
+    __syncthreads();
+
+    // ---- MFMA: k = 4 consecutive pixels of a row; 9 taps share the A fragment ----
+    const int li = lane & 15, lk = lane >> 4;
+    const float* ap = ys + (oh * 16 + li) * C::OS + lk;
+    const float* bp = xs + (ch * 16 + li) * C::CS + lk * SW;
+    for (int nd = 0; nd < ND; ++nd) {
+      for (int r = 0; r < TH; ++r) {
+        const float* apr = ap + (nd * TH + r) * TW;
+        const float* bpr = bp + nd * (C::IH * C::PITCH) + (r * SH) * C::PITCH;
+#pragma unroll
+        for (int cq = 0; cq < TW / 4; ++cq) {
+          const float a = apr[cq * 4];
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+              acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bpr[kh * C::PITCH + cq * 4 * SW + kw],
+                                                                      acc[kh * 3 + kw], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // D[i = o][j = c]: col = lane & 15 -> c, row = (lane >> 4) * 4 + reg -> o
+  float* sp = p.slab + (long long)chunk * p.Cout * p.Cin * 9;
+  const int c = cb * 32 + ch * 16 + (lane & 15);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int o = ob * 32 + oh * 16 + (lane >> 4) * 4 + r;
+    if (o < p.Cout && c < p.Cin) {
+      float* dst = sp + ((long long)o * p.Cin + c) * 9;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) dst[t] = acc[t][r];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
+                                                                long long numel, int nchunks) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= numel) return;
+  float s = 0.f;
+  for (int k = 0; k < nchunks; ++k) s += slab[(long long)k * numel + i];
+  out[i] = s;
+}
+
+struct TileSel {
+  int nd, th, tw;
+};
+inline TileSel pick(int Ho, int Wo, bool strided) {
+  const int m = Ho < Wo ? Ho : Wo;
+  if (!strided) {
+    if (m > 16) return {1, 8, 32};
+    if (m > 8) return {1, 16, 16};
+    if (m > 4) return {4, 8, 8};
+    return {16, 4, 4};
+  }
+  if (m > 8) return {1, 8, 16};
+  if (m > 4) return {2, 8, 8};
+  return {8, 4, 4};
+}
+
+inline void plan(WgParams& p, TileSel ts, int pairs, int* nchunks) {
+  p.tiles_x = e2e::cdiv(p.Wo, ts.tw);
+  p.tiles_y = e2e::cdiv(p.Ho, ts.th);
+  p.tiles_d = e2e::cdiv(p.Do, ts.nd);
+  p.tiles_per_n = p.tiles_d * p.tiles_y * p.tiles_x;
+  p.total_tiles = (long long)p.tiles_per_n * p.B;
+  long long want = 1024 / (pairs > 0 ? pairs : 1);
+  if (want < 1) want = 1;
+  long long tpc = e2e::cdivll(p.total_tiles, want);
+  if (tpc < 4) tpc = 4;
+  if (tpc > p.total_tiles) tpc = p.total_tiles;
+  p.tiles_per_chunk = (int)tpc;
+  *nchunks = (int)e2e::cdivll(p.total_tiles, tpc);
+}
+
+template <int SH, int SW, int ND, int TH, int TW>
+int launch(const WgParams& p, int nchunks, int pairs, hipStream_t st) {
+  hipLaunchKernelGGL((conv133_wgrad_kernel<SH, SW, ND, TH, TW>), dim3(nchunks, pairs), dim3(256), 0, st, p);
+  return e2e::check_launch("conv133_wgrad_kernel");
+}
+
+template <int SH, int SW>
+int dispatch_strided(const WgParams& p, TileSel ts, int nchunks, int pairs, hipStream_t st) {
+  if (ts.nd == 1) return launch<SH, SW, 1, 8, 16>(p, nchunks, pairs, st);
+  if (ts.nd == 2) return launch<SH, SW, 2, 8, 8>(p, nchunks, pairs, st);
+  return launch<SH, SW, 8, 4, 4>(p, nchunks, pairs, st);
+}
+
+}  // namespace
+
+extern "C" long long e2e_conv133_wgrad_ws_bytes(int B, int Cin, int Cout, int Di, int Hi, int Wi, int sd, int sh,
+                                                int sw) {
+  WgParams p{};
+  p.B = B; p.Cin = Cin; p.Cout = Cout; p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.sd = sd;
+  p.Do = (Di - 1) / sd + 1; p.Ho = (Hi - 1) / sh + 1; p.Wo = (Wi - 1) / sw + 1;
+  const int pairs = e2e::cdiv(Cin, 32) * e2e::cdiv(Cout, 32);
+  int nchunks;
+  plan(p, pick(p.Ho, p.Wo, sh != 1 || sw != 1), pairs, &nchunks);
+  return (long long)nchunks * Cout * Cin * 9 * (long long)sizeof(float);
+}
+
+extern "C" int e2e_conv133_wgrad(const e2e_in_chan_t* chans, const float* dy, float* dw, void* ws, int B, int Cin,
+                                 int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw, void* stream) {
+  E2E_REQUIRE(chans && dy && dw && ws, "conv133_wgrad: null pointer");
+  E2E_REQUIRE((sd == 1 || sd == 2) && (sh == 1 || sh == 2) && (sw == 1 || sw == 2), "conv133_wgrad: stride must be 1 or 2");
+  hipStream_t st = (hipStream_t)stream;
+  WgParams p{};
+  p.chans = chans; p.dy = dy; p.slab = reinterpret_cast<float*>(ws);
+  p.B = B; p.Cin = Cin; p.Cout = Cout; p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.sd = sd;
+  p.Do = (Di - 1) / sd + 1; p.Ho = (Hi - 1) / sh + 1; p.Wo = (Wi - 1) / sw + 1;
+  p.cblocks = e2e::cdiv(Cin, 32);
+  const int pairs = p.cblocks * e2e::cdiv(Cout, 32);
+  const bool strided = sh != 1 || sw != 1;
+  const TileSel ts = pick(p.Ho, p.Wo, strided);
+  int nchunks;
+  plan(p, ts, pairs, &nchunks);
+  int rc;
+  if (!strided) {
+    if (ts.nd == 1 && ts.tw == 32) rc = launch<1, 1, 1, 8, 32>(p, nchunks, pairs, st);
+    else if (ts.nd == 1) rc = launch<1, 1, 1, 16, 16>(p, nchunks, pairs, st);
+    else if (ts.nd == 4) rc = launch<1, 1, 4, 8, 8>(p, nchunks, pairs, st);
+    else rc = launch<1, 1, 16, 4, 4>(p, nchunks, pairs, st);
+  } else if (sh == 2 && sw == 2) {
+    rc = dispatch_strided<2, 2>(p, ts, nchunks, pairs, st);
+  } else if (sh == 1 && sw == 2) {
+    rc = dispatch_strided<1, 2>(p, ts, nchunks, pairs, st);
+  } else {
+    rc = dispatch_strided<2, 1>(p, ts, nchunks, pairs, st);
+  }
+  if (rc != E2E_OK) return rc;
+  const long long numel = (long long)Cout * Cin * 9;
+  hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)e2e::cdivll(numel, 256)), dim3(256), 0, st, p.slab, dw, numel,
+                     nchunks);
+  return e2e::check_launch("wgrad_slab_reduce_kernel");
+}

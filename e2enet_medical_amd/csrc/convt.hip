@@ -1,0 +1,324 @@
+// K3: transposed convolution with kernel == stride (non-overlapping up-sampling), forward / data gradient /
+// weight gradient, gfx950.  Reference: nn.ConvTranspose3d(Cin, Cout, k, k, bias=False) built at
+// unetpp_d.py:521-522, DSFF-masked on (Cin, Cout) pairs (core_channel.py:324: names containing 'up').
+//
+//   y[n,o,kd*d+i,kh*h+j,kw*w+k] = sum_c z[n,c,d,h,w] * W[c,o,i,j,k],   z = lrelu(scale*x + shift)
+//
+// The op is a per-voxel [Cin] x [Cin, Cout*KT] product; its input tensor is small next to its output (1/8 of
+// the voxels), so forward and data gradient are written in gather form straight from global memory (the
+// re-reads of z / dy are L2 hits) with the weights as wave-uniform scalars and the DSFF liveness bits walked
+// with scalar bit ops.  The dense weight gradient (huge reduction over voxels) runs on the fp32 MFMA.
+#include "e2e_common.h"
+
+namespace {
+
+__device__ __forceinline__ void tap_ijk(int t, int kh, int kw, int& i, int& j, int& k) {
+  k = t % kw;
+  const int r = t / kw;
+  j = r % kh;
+  i = r / kh;
+}
+
+// ---- forward: one thread = VPL input voxels of one output channel --------------------------------------------
+template <int KT, int VPL>
+__global__ __launch_bounds__(256) void convT_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, float slope,
+                                                        const float* __restrict__ w, const unsigned* __restrict__ live,
+                                                        float* __restrict__ y, int Cin, int Cout, int D, int H, int W,
+                                                        int kd, int kh, int kw) {
+  const int o = blockIdx.y, n = blockIdx.z;
+  const long long spatial = (long long)D * H * W;
+  const long long v0 = ((long long)blockIdx.x * 256 + threadIdx.x) * VPL;   // VPL consecutive voxels (same row if W % VPL == 0)
+  float acc[VPL][KT];
+#pragma unroll
+  for (int v = 0; v < VPL; ++v)
+#pragma unroll
+    for (int t = 0; t < KT; ++t) acc[v][t] = 0.f;
+  const int words = e2e::cdiv(Cin, 32);
+  const bool vec_ok = (VPL == 1) || (spatial % VPL == 0);
+  for (int wd = 0; wd < words; ++wd) {
+    unsigned bits = live ? live[(long long)o * words + wd] : 0xffffffffu;
+    const int remain = Cin - wd * 32;
+    if (remain < 32) bits &= (1u << remain) - 1u;
+    bits = __builtin_amdgcn_readfirstlane(bits);
+    while (bits) {
+      const int c = wd * 32 + __builtin_ctz(bits);
+      bits &= bits - 1;
+      const float* wp = w + ((long long)c * Cout + o) * KT;
+      float wt[KT];
+#pragma unroll
+      for (int t = 0; t < KT; ++t) wt[t] = wp[t];
+      float a = 1.f, b = 0.f, sl = 1.f;
+      if (scale) { a = scale[(long long)n * Cin + c]; b = shift[(long long)n * Cin + c]; sl = slope; }
+      const float* xp = x + ((long long)n * Cin + c) * spatial;
+      float xv[VPL];
+      if (VPL == 4 && vec_ok && v0 + 3 < spatial) {
+        const float4 q = *reinterpret_cast<const float4*>(xp + v0);
+        xv[0] = q.x; xv[1 % VPL] = q.y; xv[2 % VPL] = q.z; xv[3 % VPL] = q.w;
+      } else {
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) xv[v] = (v0 + v < spatial) ? xp[v0 + v] : 0.f;
+      }
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        const float z = e2e::in_act(xv[v], a, b, sl);
+#pragma unroll
+        for (int t = 0; t < KT; ++t) acc[v][t] = fmaf(wt[t], z, acc[v][t]);
+      }
+    }
+  }
+  const int Ho = H * kh, Wo = W * kw;
+  float* yp = y + ((long long)n * Cout + o) * spatial * KT;
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    const long long vi = v0 + v;
+    if (vi >= spatial) continue;
+    const int wv = (int)(vi % W);
+    const long long r = vi / W;
+    const int hv = (int)(r % H), dv = (int)(r / H);
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      int i, j, k;
+      tap_ijk(t, kh, kw, i, j, k);
+      yp[((long long)(dv * kd + i) * Ho + (hv * kh + j)) * Wo + (wv * kw + k)] = acc[v][t];
+    }
+  }
+}
+
+// ---- data gradient: one thread = one input voxel of one input channel ---------------------------------------
+template <int KT>
+__global__ __launch_bounds__(256) void convT_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                          const unsigned* __restrict__ live_t, float* __restrict__ dx,
+                                                          int accumulate, int Cin, int Cout, int D, int H, int W, int kd,
+                                                          int kh, int kw) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const long long spatial = (long long)D * H * W;
+  const long long vi = (long long)blockIdx.x * 256 + threadIdx.x;
+  const bool in = vi < spatial;
+  const long long vv = in ? vi : 0;
+  const int wv = (int)(vv % W);
+  const long long r = vv / W;
+  const int hv = (int)(r % H), dv = (int)(r / H);
+  const int Ho = H * kh, Wo = W * kw;
+  long long offs[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    int i, j, k;
+    tap_ijk(t, kh, kw, i, j, k);
+    offs[t] = ((long long)(dv * kd + i) * Ho + (hv * kh + j)) * Wo + (wv * kw + k);
+  }
+  float acc = 0.f;
+  const int words = e2e::cdiv(Cout, 32);
+  for (int wd = 0; wd < words; ++wd) {
+    unsigned bits = live_t ? live_t[(long long)c * words + wd] : 0xffffffffu;
+    const int remain = Cout - wd * 32;
+    if (remain < 32) bits &= (1u << remain) - 1u;
+    bits = __builtin_amdgcn_readfirstlane(bits);
+    while (bits) {
+      const int o = wd * 32 + __builtin_ctz(bits);
+      bits &= bits - 1;
+      const float* wp = w + ((long long)c * Cout + o) * KT;
+      const float* dyp = dy + ((long long)n * Cout + o) * spatial * KT;
+#pragma unroll
+      for (int t = 0; t < KT; ++t) acc = fmaf(wp[t], dyp[offs[t]], acc);
+    }
+  }
+  if (in) {
+    float* dst = dx + ((long long)n * Cin + c) * spatial + vi;
+    if (accumulate) *dst += acc;
+    else *dst = acc;
+  }
+}
+
+// ---- weight gradient (dense) on the fp32 MFMA ------------------------------------------------------------------
+// dW[c, o, t] = sum_{n, v} z[n, c, v] * dy[n, o, out(v, t)].
+// One workgroup = (32 input channels) x (32 output channels) x all KT taps over a chunk of voxel tiles.
+// Wave (ch, oh) owns the 16 x 16 sub-block (c half, o half): KT accumulator tiles of v_mfma_f32_16x16x4_f32
+// (exact fp32 fma chain, so the sum is a plain fp32 accumulation like the reference's).  The reduction index is
+// the voxel: it lives inside the MFMA K dimension and in the loop, so no cross-lane reduction is needed.
+// Partial sums per chunk go to a slab; a second kernel adds the slabs in fixed order (deterministic).
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int WG_TPX = 64;                 // voxels staged per step
+constexpr int WG_ZS = WG_TPX + 2;          // channel stride in LDS, == 2 (mod 32): conflict-free A/B fragment reads
+
+template <int KT>
+__global__ __launch_bounds__(256) void convT_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, float slope,
+                                                          const float* __restrict__ dy, float* __restrict__ slab, int B,
+                                                          int Cin, int Cout, int D, int H, int W, int kd, int kh, int kw,
+                                                          int tiles_per_chunk, int nchunks) {
+  __shared__ float zs[32 * WG_ZS];
+  __shared__ float ds[32 * KT * WG_ZS];
+  const int chunk = blockIdx.x;
+  const int cblocks = e2e::cdiv(Cin, 32);
+  const int cb = blockIdx.y % cblocks, ob = blockIdx.y / cblocks;
+  const long long spatial = (long long)D * H * W;
+  const long long tiles_per_n = e2e::cdivll(spatial, WG_TPX);
+  const long long total_tiles = tiles_per_n * B;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ch = wave & 1, oh = wave >> 1;
+  const int Ho = H * kh, Wo = W * kw;
+
+  f32x4 acc[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int ti = 0; ti < tiles_per_chunk; ++ti) {
+    const long long tile = (long long)chunk * tiles_per_chunk + ti;
+    if (tile >= total_tiles) break;
+    const int n = (int)(tile / tiles_per_n);
+    const long long vbase = (tile - (long long)n * tiles_per_n) * WG_TPX;
+    // stage z[32 c][64 v]
+    for (int idx = tid; idx < 32 * WG_TPX; idx += 256) {
+      const int cl = idx / WG_TPX, pv = idx - cl * WG_TPX;
+      const int c = cb * 32 + cl;
+      const long long vi = vbase + pv;
+      float val = 0.f;
+      if (c < Cin && vi < spatial) {
+        val = x[((long long)n * Cin + c) * spatial + vi];
+        if (scale) val = e2e::in_act(val, scale[(long long)n * Cin + c], shift[(long long)n * Cin + c], slope);
+      }
+      zs[cl * WG_ZS + pv] = val;
+    }
+    // stage dy[32 o][KT][64 v]
+    for (int idx = tid; idx < 32 * KT * WG_TPX; idx += 256) {
+      const int pv = idx % WG_TPX;
+      const int rest = idx / WG_TPX;
+      const int t = rest % KT, ol = rest / KT;
+      const int o = ob * 32 + ol;
+      const long long vi = vbase + pv;
+      float val = 0.f;
+      if (o < Cout && vi < spatial) {
+        const int wv = (int)(vi % W);
+        const long long r = vi / W;
+        const int hv = (int)(r % H), dv = (int)(r / H);
+        int i, j, k;
+        tap_ijk(t, kh, kw, i, j, k);
+        val = dy[((long long)n * Cout + o) * spatial * KT + ((long long)(dv * kd + i) * Ho + (hv * kh + j)) * Wo + (wv * kw + k)];
+      }
+      ds[(ol * KT + t) * WG_ZS + pv] = val;
+    }
+    __syncthreads();
+    const int li = lane & 15, lk = lane >> 4;
+    const float* ap = zs + (ch * 16 + li) * WG_ZS + lk;
+    const float* bp = ds + ((oh * 16 + li) * KT) * WG_ZS + lk;
+#pragma unroll 4
+    for (int k0 = 0; k0 < WG_TPX; k0 += 4) {
+      const float a = ap[k0];
+#pragma unroll
+      for (int t = 0; t < KT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp[t * WG_ZS + k0], acc[t], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // D[i = c][j = o]: col = lane & 15 -> o, row = (lane >> 4) * 4 + reg -> c
+  float* sp = slab + (long long)chunk * Cin * Cout * KT;
+  const int o = ob * 32 + oh * 16 + (lane & 15);
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = cb * 32 + ch * 16 + (lane >> 4) * 4 + r;
+      if (c < Cin && o < Cout) sp[((long long)c * Cout + o) * KT + t] = acc[t][r];
+    }
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
+                                                          long long numel, int nchunks) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= numel) return;
+  float s = 0.f;
+  for (int k = 0; k < nchunks; ++k) s += slab[(long long)k * numel + i];
+  out[i] = s;
+}
+
+inline int wgrad_chunks(long long total_tiles, int pairs, int* tiles_per_chunk) {
+  // aim at ~1024 workgroups, but keep slabs few: at least 8 tiles per chunk
+  long long want = 1024 / (pairs > 0 ? pairs : 1);
+  if (want < 1) want = 1;
+  long long tpc = e2e::cdivll(total_tiles, want);
+  if (tpc < 8) tpc = 8;
+  if (tpc > total_tiles) tpc = total_tiles;
+  *tiles_per_chunk = (int)tpc;
+  return (int)e2e::cdivll(total_tiles, tpc);
+}
+
+}  // namespace
+
+#define DISPATCH_KT(KTV, ...)                  \
+  switch (KTV) {                               \
+    case 1: { constexpr int KT = 1; __VA_ARGS__; break; } \
+    case 2: { constexpr int KT = 2; __VA_ARGS__; break; } \
+    case 4: { constexpr int KT = 4; __VA_ARGS__; break; } \
+    case 8: { constexpr int KT = 8; __VA_ARGS__; break; } \
+    default: e2e::set_error("convT: kernel volume %d unsupported", KTV); return E2E_ERR_UNSUPPORTED; \
+  }
+
+static int check_k(int kd, int kh, int kw) {
+  return (kd == 1 || kd == 2) && (kh == 1 || kh == 2) && (kw == 1 || kw == 2);
+}
+
+extern "C" int e2e_convT_fwd(const float* x, const float* scale, const float* shift, float slope, const float* w,
+                             const unsigned* live, float* y, int B, int Cin, int Cout, int D, int H, int W, int kd,
+                             int kh, int kw, void* stream) {
+  E2E_REQUIRE(x && w && y, "convT_fwd: null pointer");
+  E2E_REQUIRE(check_k(kd, kh, kw), "convT_fwd: kernel must be in {1,2}^3");
+  E2E_REQUIRE((scale == nullptr) == (shift == nullptr), "convT_fwd: scale/shift must both be given");
+  hipStream_t st = (hipStream_t)stream;
+  const long long spatial = (long long)D * H * W;
+  const int kt = kd * kh * kw;
+  if (spatial >= 4096 && kt <= 4) {
+    dim3 grid((unsigned)e2e::cdivll(spatial, 256 * 4), Cout, B);
+    DISPATCH_KT(kt, hipLaunchKernelGGL((convT_fwd_kernel<KT, 4>), grid, dim3(256), 0, st, x, scale, shift, slope, w, live, y,
+                                       Cin, Cout, D, H, W, kd, kh, kw));
+  } else if (spatial >= 4096) {
+    dim3 grid((unsigned)e2e::cdivll(spatial, 256 * 2), Cout, B);
+    DISPATCH_KT(kt, hipLaunchKernelGGL((convT_fwd_kernel<KT, 2>), grid, dim3(256), 0, st, x, scale, shift, slope, w, live, y,
+                                       Cin, Cout, D, H, W, kd, kh, kw));
+  } else {
+    dim3 grid((unsigned)e2e::cdivll(spatial, 256), Cout, B);
+    DISPATCH_KT(kt, hipLaunchKernelGGL((convT_fwd_kernel<KT, 1>), grid, dim3(256), 0, st, x, scale, shift, slope, w, live, y,
+                                       Cin, Cout, D, H, W, kd, kh, kw));
+  }
+  return e2e::check_launch("convT_fwd_kernel");
+}
+
+extern "C" int e2e_convT_dgrad(const float* dy, const float* w, const unsigned* live_t, float* dx, int accumulate,
+                               int B, int Cin, int Cout, int D, int H, int W, int kd, int kh, int kw, void* stream) {
+  E2E_REQUIRE(dy && w && dx, "convT_dgrad: null pointer");
+  E2E_REQUIRE(check_k(kd, kh, kw), "convT_dgrad: kernel must be in {1,2}^3");
+  hipStream_t st = (hipStream_t)stream;
+  const long long spatial = (long long)D * H * W;
+  dim3 grid((unsigned)e2e::cdivll(spatial, 256), Cin, B);
+  DISPATCH_KT(kd * kh * kw, hipLaunchKernelGGL((convT_dgrad_kernel<KT>), grid, dim3(256), 0, st, dy, w, live_t, dx, accumulate,
+                                               Cin, Cout, D, H, W, kd, kh, kw));
+  return e2e::check_launch("convT_dgrad_kernel");
+}
+
+extern "C" long long e2e_convT_wgrad_ws_bytes(int B, int Cin, int Cout, int D, int H, int W, int kd, int kh, int kw) {
+  const long long total_tiles = e2e::cdivll((long long)D * H * W, WG_TPX) * B;
+  int tpc;
+  const int pairs = e2e::cdiv(Cin, 32) * e2e::cdiv(Cout, 32);
+  const int nchunks = wgrad_chunks(total_tiles, pairs, &tpc);
+  return (long long)nchunks * Cin * Cout * kd * kh * kw * (long long)sizeof(float);
+}
+
+extern "C" int e2e_convT_wgrad(const float* x, const float* scale, const float* shift, float slope, const float* dy,
+                               float* dw, void* ws, int B, int Cin, int Cout, int D, int H, int W, int kd, int kh,
+                               int kw, void* stream) {
+  E2E_REQUIRE(x && dy && dw && ws, "convT_wgrad: null pointer");
+  E2E_REQUIRE(check_k(kd, kh, kw), "convT_wgrad: kernel must be in {1,2}^3");
+  hipStream_t st = (hipStream_t)stream;
+  const long long total_tiles = e2e::cdivll((long long)D * H * W, WG_TPX) * B;
+  int tpc;
+  const int pairs = e2e::cdiv(Cin, 32) * e2e::cdiv(Cout, 32);
+  const int nchunks = wgrad_chunks(total_tiles, pairs, &tpc);
+  const int kt = kd * kh * kw;
+  float* slab = reinterpret_cast<float*>(ws);
+  dim3 grid(nchunks, pairs);
+  DISPATCH_KT(kt, hipLaunchKernelGGL((convT_wgrad_kernel<KT>), grid, dim3(256), 0, st, x, scale, shift, slope, dy, slab, B,
+                                     Cin, Cout, D, H, W, kd, kh, kw, tpc, nchunks));
+  const long long numel = (long long)Cin * Cout * kt;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)e2e::cdivll(numel, 256)), dim3(256), 0, st, slab, dw, numel, nchunks);
+  return e2e::check_launch("convT_wgrad");
+}

@@ -1,0 +1,60 @@
+// Shared helpers for the gfx950 kernels of libe2e_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdarg>
+#include "e2e_hip.h"
+
+typedef const float __attribute__((address_space(1)))* gfloat_p;
+
+namespace e2e {
+
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return E2E_ERR_LAUNCH;
+  }
+  return E2E_OK;
+}
+
+#define E2E_REQUIRE(cond, ...)          \
+  do {                                  \
+    if (!(cond)) {                      \
+      e2e::set_error(__VA_ARGS__);      \
+      return E2E_ERR_ARG;               \
+    }                                   \
+  } while (0)
+
+__host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ inline long long cdivll(long long a, long long b) { return (a + b - 1) / b; }
+
+// normalise-on-load: lrelu(a*v + b)
+__device__ __forceinline__ float in_act(float v, float a, float b, float slope) {
+  float u = fmaf(v, a, b);
+  return u > 0.f ? u : u * slope;
+}
+
+// full-wave (64 lane) sum, result valid in every lane
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// XCD-aware remap of a linear workgroup id (MI355X deals consecutive ids round-robin over the 8 XCDs):
+// ids that share id % 8 run on one XCD (one L2), so hand each XCD a contiguous run of logical work items.
+// Returns the logical index for `id` in a grid padded to a multiple of 8; callers bounds-check it.
+__device__ __forceinline__ int xcd_remap(int id, int padded_total) {
+  int per = padded_total >> 3;
+  return (id & 7) * per + (id >> 3);
+}
+
+}  // namespace e2e

@@ -1,0 +1,230 @@
+// K2 / K7: InstanceNorm statistics finalize and InstanceNorm + LeakyReLU backward (gfx950).
+// Reference semantics: nn.InstanceNorm3d(eps=1e-5, affine=True, instance statistics in train and eval) followed
+// by nn.LeakyReLU(0.01) (unetpp_d.py:99-100,111); backward = autograd of the same.
+#include "e2e_common.h"
+
+namespace {
+
+// Chan et al. pairwise combination of (count, mean, M2)
+struct Stat {
+  double n, mean, m2;
+};
+__device__ __forceinline__ Stat combine(const Stat a, const Stat b) {
+  if (b.n == 0.0) return a;
+  if (a.n == 0.0) return b;
+  Stat r;
+  r.n = a.n + b.n;
+  const double delta = b.mean - a.mean;
+  r.mean = a.mean + delta * (b.n / r.n);
+  r.m2 = a.m2 + b.m2 + delta * delta * (a.n * b.n / r.n);
+  return r;
+}
+
+__global__ __launch_bounds__(256) void in_finalize_kernel(const float* __restrict__ part, int np,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps,
+                                                          float* __restrict__ scale, float* __restrict__ shift,
+                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                          int C) {
+  const int nc = blockIdx.x;
+  const int c = nc % C;
+  const float* pp = part + (long long)nc * np * 3;
+  Stat s{0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < np; i += 256) {
+    Stat t{(double)pp[i * 3], (double)pp[i * 3 + 1], (double)pp[i * 3 + 2]};
+    s = combine(s, t);
+  }
+  __shared__ double sh[3][256];
+  sh[0][threadIdx.x] = s.n;
+  sh[1][threadIdx.x] = s.mean;
+  sh[2][threadIdx.x] = s.m2;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) {
+      Stat a{sh[0][threadIdx.x], sh[1][threadIdx.x], sh[2][threadIdx.x]};
+      Stat b{sh[0][threadIdx.x + off], sh[1][threadIdx.x + off], sh[2][threadIdx.x + off]};
+      a = combine(a, b);
+      sh[0][threadIdx.x] = a.n;
+      sh[1][threadIdx.x] = a.mean;
+      sh[2][threadIdx.x] = a.m2;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double var = sh[2][0] / sh[0][0];   // biased variance
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const double g = gamma[c], b = beta[c];
+    scale[nc] = (float)(g * rstd);
+    shift[nc] = (float)(b - sh[1][0] * g * rstd);
+    mean_out[nc] = (float)sh[1][0];
+    rstd_out[nc] = (float)rstd;
+  }
+}
+
+// ---- backward ---------------------------------------------------------------------------------------------------
+// pass 1: s1 = sum du, s2 = sum du * xhat   per (n, c), fp64 accumulation
+__global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const float* __restrict__ dz, const float* __restrict__ y,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float slope,
+                                                            double* __restrict__ sums, int C, long long spatial) {
+  const int nc = blockIdx.y;
+  const int c = nc % C;
+  const float mu = mean[nc], rs = rstd[nc], g = gamma[c], b = beta[c];
+  const float* dzp = dz + (long long)nc * spatial;
+  const float* yp = y + (long long)nc * spatial;
+  float s1 = 0.f, s2 = 0.f;
+  double d1 = 0.0, d2 = 0.0;
+  const long long stride = (long long)gridDim.x * 256 * 4;
+  const bool vec = (spatial % 4) == 0;
+  int it = 0;
+  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < spatial; i += stride) {
+    float dv[4], yv[4];
+    if (vec) {
+      const float4 a = *reinterpret_cast<const float4*>(dzp + i);
+      const float4 q = *reinterpret_cast<const float4*>(yp + i);
+      dv[0] = a.x; dv[1] = a.y; dv[2] = a.z; dv[3] = a.w;
+      yv[0] = q.x; yv[1] = q.y; yv[2] = q.z; yv[3] = q.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool in = i + k < spatial;
+        dv[k] = in ? dzp[i + k] : 0.f;
+        yv[k] = in ? yp[i + k] : mu;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float xh = (yv[k] - mu) * rs;
+      const float u = fmaf(g, xh, b);
+      const float du = u > 0.f ? dv[k] : dv[k] * slope;
+      s1 += du;
+      s2 = fmaf(du, xh, s2);
+    }
+    if ((++it & 15) == 0) {   // flush the fp32 running sums into fp64 every 64 elements
+      d1 += s1; d2 += s2; s1 = 0.f; s2 = 0.f;
+    }
+  }
+  d1 += s1; d2 += s2;
+  d1 = e2e::wave_sum_d(d1);
+  d2 = e2e::wave_sum_d(d2);
+  __shared__ double sh[2][4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { sh[0][wave] = d1; sh[1][wave] = d2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&sums[(long long)nc * 3 + 0], sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]);
+    atomicAdd(&sums[(long long)nc * 3 + 1], sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
+  }
+}
+
+// pass 2: dy = gamma * rstd * (du - s1/N - xhat * s2/N), in place; s3 = sum dy (bias gradient)
+__global__ __launch_bounds__(256) void in_bwd_apply_kernel(float* __restrict__ dz, const float* __restrict__ y,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float slope,
+                                                           double* __restrict__ sums, int C, long long spatial) {
+  const int nc = blockIdx.y;
+  const int c = nc % C;
+  const float mu = mean[nc], rs = rstd[nc], g = gamma[c], b = beta[c];
+  const double inv_n = 1.0 / (double)spatial;
+  const float m1 = (float)(sums[(long long)nc * 3 + 0] * inv_n);
+  const float m2 = (float)(sums[(long long)nc * 3 + 1] * inv_n);
+  const float grs = g * rs;
+  float* dzp = dz + (long long)nc * spatial;
+  const float* yp = y + (long long)nc * spatial;
+  double acc = 0.0;
+  const long long stride = (long long)gridDim.x * 256 * 4;
+  const bool vec = (spatial % 4) == 0;
+  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < spatial; i += stride) {
+    float dv[4], yv[4], o[4];
+    if (vec) {
+      const float4 a = *reinterpret_cast<const float4*>(dzp + i);
+      const float4 q = *reinterpret_cast<const float4*>(yp + i);
+      dv[0] = a.x; dv[1] = a.y; dv[2] = a.z; dv[3] = a.w;
+      yv[0] = q.x; yv[1] = q.y; yv[2] = q.z; yv[3] = q.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool in = i + k < spatial;
+        dv[k] = in ? dzp[i + k] : 0.f;
+        yv[k] = in ? yp[i + k] : mu;
+      }
+    }
+    float part = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float xh = (yv[k] - mu) * rs;
+      const float u = fmaf(g, xh, b);
+      const float du = u > 0.f ? dv[k] : dv[k] * slope;
+      o[k] = grs * (du - m1 - xh * m2);
+      if (vec || i + k < spatial) part += o[k];
+    }
+    acc += part;
+    if (vec) {
+      *reinterpret_cast<float4*>(dzp + i) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (i + k < spatial) dzp[i + k] = o[k];
+    }
+  }
+  acc = e2e::wave_sum_d(acc);
+  __shared__ double sh[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) sh[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&sums[(long long)nc * 3 + 2], sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+__global__ void in_bwd_params_kernel(const double* __restrict__ sums, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta, float* __restrict__ dbias, int B, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  for (int n = 0; n < B; ++n) {
+    s1 += sums[((long long)n * C + c) * 3 + 0];
+    s2 += sums[((long long)n * C + c) * 3 + 1];
+    s3 += sums[((long long)n * C + c) * 3 + 2];
+  }
+  dbeta[c] = (float)s1;
+  dgamma[c] = (float)s2;
+  if (dbias) dbias[c] = (float)s3;
+}
+
+}  // namespace
+
+extern "C" int e2e_in_stats_finalize(const float* part, int np, const float* gamma, const float* beta, float eps,
+                                     float* scale, float* shift, float* mean, float* rstd, int B, int C,
+                                     void* stream) {
+  E2E_REQUIRE(part && gamma && beta && scale && shift && mean && rstd, "in_stats_finalize: null pointer");
+  E2E_REQUIRE(np > 0 && B > 0 && C > 0, "in_stats_finalize: bad dims");
+  hipLaunchKernelGGL(in_finalize_kernel, dim3(B * C), dim3(256), 0, (hipStream_t)stream, part, np, gamma, beta, eps,
+                     scale, shift, mean, rstd, C);
+  return e2e::check_launch("in_finalize_kernel");
+}
+
+extern "C" int e2e_in_lrelu_bwd(float* dz_dy, const float* y, const float* mean, const float* rstd,
+                                const float* gamma, const float* beta, float slope, float* dgamma, float* dbeta,
+                                float* dbias, float* sums, int B, int C, long long spatial, void* stream) {
+  E2E_REQUIRE(dz_dy && y && mean && rstd && gamma && beta && dgamma && dbeta && sums, "in_lrelu_bwd: null pointer");
+  E2E_REQUIRE(B > 0 && C > 0 && spatial > 0, "in_lrelu_bwd: bad dims");
+  hipStream_t st = (hipStream_t)stream;
+  double* ds = reinterpret_cast<double*>(sums);
+  if (hipMemsetAsync(ds, 0, (size_t)B * C * 3 * sizeof(double), st) != hipSuccess) {
+    e2e::set_error("in_lrelu_bwd: memset failed");
+    return E2E_ERR_LAUNCH;
+  }
+  long long blocks = e2e::cdivll(spatial, 256 * 4 * 4);
+  if (blocks > 256) blocks = 256;
+  if (blocks < 1) blocks = 1;
+  dim3 grid((unsigned)blocks, B * C);
+  hipLaunchKernelGGL(in_bwd_reduce_kernel, grid, dim3(256), 0, st, dz_dy, y, mean, rstd, gamma, beta, slope, ds, C,
+                     spatial);
+  hipLaunchKernelGGL(in_bwd_apply_kernel, grid, dim3(256), 0, st, dz_dy, y, mean, rstd, gamma, beta, slope, ds, C,
+                     spatial);
+  hipLaunchKernelGGL(in_bwd_params_kernel, dim3(e2e::cdiv(C, 64)), dim3(64), 0, st, ds, dgamma, dbeta, dbias, B, C);
+  return e2e::check_launch("in_lrelu_bwd");
+}

@@ -1,0 +1,87 @@
+// K10: clip_grad_norm_ + SGD (momentum, Nesterov, weight decay) + DSFF mask as multi-tensor kernels (gfx950).
+// Reference: torch.nn.utils.clip_grad_norm_(params, 12) and torch.optim.SGD(lr, weight_decay=3e-5, momentum=0.99,
+// nesterov=True).step() (nnUNetTrainer_simple.py:573-574, :369-370) followed by Masking.apply_mask
+// (core_channel.py:427-434: weight *= mask, momentum_buffer *= mask).
+#include "e2e_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sqnorm_kernel(const e2e_param_t* __restrict__ table, double* __restrict__ out) {
+  const e2e_param_t t = table[blockIdx.y];
+  float s = 0.f;
+  double d = 0.0;
+  int it = 0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < t.numel; i += (long long)gridDim.x * 256) {
+    const float g = t.grad[i];
+    s = fmaf(g, g, s);
+    if ((++it & 63) == 0) { d += s; s = 0.f; }
+  }
+  d = e2e::wave_sum_d(d + (double)s);
+  __shared__ double sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double tot = sh[0] + sh[1] + sh[2] + sh[3];
+    if (tot != 0.0) atomicAdd(out, tot);
+  }
+}
+
+__global__ __launch_bounds__(256) void sgd_kernel(const e2e_param_t* __restrict__ table, const double* __restrict__ sq,
+                                                  float max_norm, float lr, float wd, float mom, int nesterov, int first) {
+  const e2e_param_t t = table[blockIdx.y];
+  // clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped to 1, always multiplied in (fp32 like torch)
+  const float total = (float)sqrt(*sq);
+  float coef = max_norm / (total + 1e-6f);
+  coef = coef > 1.f ? 1.f : coef;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < t.numel; i += (long long)gridDim.x * 256) {
+    float p = t.param[i];
+    float g = t.grad[i] * coef;
+    g = g + wd * p;
+    float buf = first ? g : t.momentum[i] * mom + g;
+    const float step = nesterov ? g + mom * buf : buf;
+    p = p - lr * step;
+    if (t.mask) {
+      const float m = t.mask[i];
+      p *= m;
+      buf *= m;
+    }
+    t.param[i] = p;
+    t.momentum[i] = buf;
+  }
+}
+
+__global__ __launch_bounds__(256) void apply_mask_kernel(const e2e_param_t* __restrict__ table) {
+  const e2e_param_t t = table[blockIdx.y];
+  if (!t.mask) return;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < t.numel; i += (long long)gridDim.x * 256) {
+    const float m = t.mask[i];
+    t.param[i] *= m;
+    if (t.momentum) t.momentum[i] *= m;
+  }
+}
+}  // namespace
+
+extern "C" int e2e_grad_sqnorm(const e2e_param_t* table, int n, double* sq_out, void* stream) {
+  E2E_REQUIRE(table && sq_out && n > 0, "grad_sqnorm: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(sq_out, 0, sizeof(double), st) != hipSuccess) {
+    e2e::set_error("grad_sqnorm: memset failed");
+    return E2E_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(16, n), dim3(256), 0, st, table, sq_out);
+  return e2e::check_launch("sqnorm_kernel");
+}
+
+extern "C" int e2e_sgd_clip_mask_step(const e2e_param_t* table, int n, const double* sq_norm, float max_norm, float lr,
+                                      float weight_decay, float momentum, int nesterov, int first_step, void* stream) {
+  E2E_REQUIRE(table && sq_norm && n > 0, "sgd_clip_mask_step: bad arguments");
+  hipLaunchKernelGGL(sgd_kernel, dim3(32, n), dim3(256), 0, (hipStream_t)stream, table, sq_norm, max_norm, lr, weight_decay,
+                     momentum, nesterov, first_step);
+  return e2e::check_launch("sgd_kernel");
+}
+
+extern "C" int e2e_apply_mask(const e2e_param_t* table, int n, void* stream) {
+  E2E_REQUIRE(table && n > 0, "apply_mask: bad arguments");
+  hipLaunchKernelGGL(apply_mask_kernel, dim3(32, n), dim3(256), 0, (hipStream_t)stream, table);
+  return e2e::check_launch("apply_mask_kernel");
+}

@@ -1,0 +1,251 @@
+// K4 / K5: max pooling (kernel == stride) and the 1x1x1 segmentation heads, gfx950.
+// Reference: nn.MaxPool3d(k) built at unetpp_d.py:523-524 ("down" fusion branch) and
+// nn.Conv3d(C, K, 1, bias=False) at unetpp_d.py:394-401 (used :480-483).  Both read a conv block's pre-norm
+// output and apply its InstanceNorm affine + LeakyReLU on load (z = lrelu(scale * x + shift)).
+// Both are HBM-streaming ops: one coalesced pass over the input, nothing staged.
+#include "e2e_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ max pool
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, float slope,
+                                                          float* __restrict__ y, int D, int H, int W, int kd, int kh, int kw,
+                                                          int Do, int Ho, int Wo) {
+  const int nc = blockIdx.y;
+  const long long ospatial = (long long)Do * Ho * Wo;
+  const long long oi = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (oi >= ospatial) return;
+  const int wo = (int)(oi % Wo);
+  const long long r = oi / Wo;
+  const int ho = (int)(r % Ho), dq = (int)(r / Ho);
+  float a = 1.f, b = 0.f, sl = 1.f;
+  if (scale) { a = scale[nc]; b = shift[nc]; sl = slope; }
+  const float* xp = x + (long long)nc * D * H * W;
+  float m = -INFINITY;
+  for (int i = 0; i < kd; ++i)
+    for (int j = 0; j < kh; ++j)
+      for (int k = 0; k < kw; ++k) {
+        const float v = e2e::in_act(xp[((long long)(dq * kd + i) * H + (ho * kh + j)) * W + (wo * kw + k)], a, b, sl);
+        m = (v > m || v != v) ? v : m;    // ATen: NaN propagates, first maximum wins
+      }
+  y[(long long)nc * ospatial + oi] = m;
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, float slope,
+                                                          const float* __restrict__ dy, float* __restrict__ dx,
+                                                          int accumulate, int D, int H, int W, int kd, int kh, int kw, int Do,
+                                                          int Ho, int Wo) {
+  const int nc = blockIdx.y;
+  const long long ospatial = (long long)Do * Ho * Wo;
+  const long long oi = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (oi >= ospatial) return;
+  const int wo = (int)(oi % Wo);
+  const long long r = oi / Wo;
+  const int ho = (int)(r % Ho), dq = (int)(r / Ho);
+  float a = 1.f, b = 0.f, sl = 1.f;
+  if (scale) { a = scale[nc]; b = shift[nc]; sl = slope; }
+  const float* xp = x + (long long)nc * D * H * W;
+  float* dxp = dx + (long long)nc * D * H * W;
+  float m = -INFINITY;
+  int best = 0;
+  for (int i = 0; i < kd; ++i)
+    for (int j = 0; j < kh; ++j)
+      for (int k = 0; k < kw; ++k) {
+        const float v = e2e::in_act(xp[((long long)(dq * kd + i) * H + (ho * kh + j)) * W + (wo * kw + k)], a, b, sl);
+        if (v > m || v != v) { m = v; best = (i * kh + j) * kw + k; }
+      }
+  const float g = dy[(long long)nc * ospatial + oi];
+  for (int i = 0; i < kd; ++i)
+    for (int j = 0; j < kh; ++j)
+      for (int k = 0; k < kw; ++k) {
+        const float val = ((i * kh + j) * kw + k) == best ? g : 0.f;
+        float* dst = dxp + ((long long)(dq * kd + i) * H + (ho * kh + j)) * W + (wo * kw + k);
+        if (accumulate) *dst += val;
+        else *dst = val;
+      }
+}
+
+// ------------------------------------------------------------------------------------------------ 1x1x1 head
+// logits[n,k,v] = sum_c W[k,c] z[n,c,v]; KB classes per pass kept in registers, weights are wave-uniform scalars.
+template <int KB>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, float slope,
+                                                       const float* __restrict__ w, float* __restrict__ logits, int C, int K,
+                                                       long long spatial) {
+  const int n = blockIdx.y;
+  const long long v = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (v >= spatial) return;
+  for (int k0 = 0; k0 < K; k0 += KB) {
+    float acc[KB];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) acc[k] = 0.f;
+    for (int c = 0; c < C; ++c) {
+      float a = 1.f, b = 0.f, sl = 1.f;
+      if (scale) { a = scale[(long long)n * C + c]; b = shift[(long long)n * C + c]; sl = slope; }
+      const float z = e2e::in_act(x[((long long)n * C + c) * spatial + v], a, b, sl);
+#pragma unroll
+      for (int k = 0; k < KB; ++k)
+        if (k0 + k < K) acc[k] = fmaf(w[(long long)(k0 + k) * C + c], z, acc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < KB; ++k)
+      if (k0 + k < K) logits[((long long)n * K + k0 + k) * spatial + v] = acc[k];
+  }
+}
+
+// dx[n,c,v] (+)= sum_k W[k,c] dlogits[n,k,v]
+template <int KB>
+__global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict__ dl, const float* __restrict__ w,
+                                                         float* __restrict__ dx, int accumulate, int C, int K,
+                                                         long long spatial) {
+  const int n = blockIdx.y;
+  const long long v = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (v >= spatial) return;
+  for (int k0 = 0; k0 < K; k0 += KB) {
+    float g[KB];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) g[k] = (k0 + k < K) ? dl[((long long)n * K + k0 + k) * spatial + v] : 0.f;
+    for (int c = 0; c < C; ++c) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < KB; ++k)
+        if (k0 + k < K) s = fmaf(w[(long long)(k0 + k) * C + c], g[k], s);
+      float* dst = dx + ((long long)n * C + c) * spatial + v;
+      if (accumulate || k0 > 0) *dst += s;
+      else *dst = s;
+    }
+  }
+}
+
+// dW[k,c] = sum_{n,v} dlogits[n,k,v] z[n,c,v]: block = (voxel chunk, channel c); fp64 atomics into ws[K*C]
+template <int KB>
+__global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, float slope,
+                                                         const float* __restrict__ dl, double* __restrict__ acc_out, int C,
+                                                         int K, long long spatial, int B) {
+  const int c = blockIdx.y;
+  __shared__ double sh[4][KB];
+  for (int k0 = 0; k0 < K; k0 += KB) {
+    float acc[KB];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) acc[k] = 0.f;
+    double dacc[KB];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) dacc[k] = 0.0;
+    for (int n = 0; n < B; ++n) {
+      float a = 1.f, b = 0.f, sl = 1.f;
+      if (scale) { a = scale[(long long)n * C + c]; b = shift[(long long)n * C + c]; sl = slope; }
+      const float* xp = x + ((long long)n * C + c) * spatial;
+      int it = 0;
+      for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < spatial; v += (long long)gridDim.x * 256) {
+        const float z = e2e::in_act(xp[v], a, b, sl);
+#pragma unroll
+        for (int k = 0; k < KB; ++k)
+          if (k0 + k < K) acc[k] = fmaf(dl[((long long)n * K + k0 + k) * spatial + v], z, acc[k]);
+        if ((++it & 63) == 0) {
+#pragma unroll
+          for (int k = 0; k < KB; ++k) { dacc[k] += acc[k]; acc[k] = 0.f; }
+        }
+      }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      const double t = e2e::wave_sum_d(dacc[k] + (double)acc[k]);
+      if (lane == 0) sh[wave][k] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < KB && k0 + threadIdx.x < K)
+      atomicAdd(&acc_out[(long long)(k0 + threadIdx.x) * C + c],
+                sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    __syncthreads();
+  }
+}
+
+__global__ void d2f_kernel(const double* __restrict__ src, float* __restrict__ dst, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (float)src[i];
+}
+
+}  // namespace
+
+extern "C" int e2e_maxpool_fwd(const float* x, const float* scale, const float* shift, float slope, float* y, int B,
+                               int C, int D, int H, int W, int kd, int kh, int kw, void* stream) {
+  E2E_REQUIRE(x && y, "maxpool_fwd: null pointer");
+  E2E_REQUIRE(kd >= 1 && kh >= 1 && kw >= 1 && D >= kd && H >= kh && W >= kw, "maxpool_fwd: bad dims");
+  const int Do = D / kd, Ho = H / kh, Wo = W / kw;
+  dim3 grid((unsigned)e2e::cdivll((long long)Do * Ho * Wo, 256), B * C);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, scale, shift, slope, y, D, H, W, kd, kh,
+                     kw, Do, Ho, Wo);
+  return e2e::check_launch("maxpool_fwd_kernel");
+}
+
+extern "C" int e2e_maxpool_bwd(const float* x, const float* scale, const float* shift, float slope, const float* dy,
+                               float* dx, int accumulate, int B, int C, int D, int H, int W, int kd, int kh, int kw,
+                               void* stream) {
+  E2E_REQUIRE(x && dy && dx, "maxpool_bwd: null pointer");
+  E2E_REQUIRE(kd >= 1 && kh >= 1 && kw >= 1 && D >= kd && H >= kh && W >= kw, "maxpool_bwd: bad dims");
+  hipStream_t st = (hipStream_t)stream;
+  const int Do = D / kd, Ho = H / kh, Wo = W / kw;
+  if (!accumulate && (D % kd || H % kh || W % kw)) {   // cells outside every window receive no gradient
+    if (hipMemsetAsync(dx, 0, (size_t)B * C * D * H * W * sizeof(float), st) != hipSuccess) {
+      e2e::set_error("maxpool_bwd: memset failed");
+      return E2E_ERR_LAUNCH;
+    }
+  }
+  dim3 grid((unsigned)e2e::cdivll((long long)Do * Ho * Wo, 256), B * C);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, grid, dim3(256), 0, st, x, scale, shift, slope, dy, dx, accumulate, D, H, W, kd, kh,
+                     kw, Do, Ho, Wo);
+  return e2e::check_launch("maxpool_bwd_kernel");
+}
+
+#define DISPATCH_KB(K, ...)                                   \
+  if ((K) <= 4) { constexpr int KB = 4; __VA_ARGS__; }        \
+  else if ((K) <= 8) { constexpr int KB = 8; __VA_ARGS__; }   \
+  else { constexpr int KB = 16; __VA_ARGS__; }
+
+extern "C" int e2e_head1x1_fwd(const float* x, const float* scale, const float* shift, float slope, const float* w,
+                               float* logits, int B, int C, int K, long long spatial, void* stream) {
+  E2E_REQUIRE(x && w && logits, "head1x1_fwd: null pointer");
+  E2E_REQUIRE(B > 0 && C > 0 && K > 0 && spatial > 0, "head1x1_fwd: bad dims");
+  dim3 grid((unsigned)e2e::cdivll(spatial, 256), B);
+  DISPATCH_KB(K, hipLaunchKernelGGL((head_fwd_kernel<KB>), grid, dim3(256), 0, (hipStream_t)stream, x, scale, shift, slope, w,
+                                    logits, C, K, spatial));
+  return e2e::check_launch("head_fwd_kernel");
+}
+
+extern "C" int e2e_head1x1_dgrad(const float* dlogits, const float* w, float* dx, int accumulate, int B, int C, int K,
+                                 long long spatial, void* stream) {
+  E2E_REQUIRE(dlogits && w && dx, "head1x1_dgrad: null pointer");
+  dim3 grid((unsigned)e2e::cdivll(spatial, 256), B);
+  DISPATCH_KB(K, hipLaunchKernelGGL((head_dgrad_kernel<KB>), grid, dim3(256), 0, (hipStream_t)stream, dlogits, w, dx,
+                                    accumulate, C, K, spatial));
+  return e2e::check_launch("head_dgrad_kernel");
+}
+
+extern "C" long long e2e_head1x1_wgrad_ws_bytes(int B, int C, int K, long long spatial) {
+  (void)B; (void)spatial;
+  return (long long)C * K * (long long)sizeof(double);
+}
+
+extern "C" int e2e_head1x1_wgrad(const float* x, const float* scale, const float* shift, float slope,
+                                 const float* dlogits, float* dw, void* ws, int B, int C, int K, long long spatial,
+                                 void* stream) {
+  E2E_REQUIRE(x && dlogits && dw && ws, "head1x1_wgrad: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  double* acc = reinterpret_cast<double*>(ws);
+  if (hipMemsetAsync(acc, 0, (size_t)C * K * sizeof(double), st) != hipSuccess) {
+    e2e::set_error("head1x1_wgrad: memset failed");
+    return E2E_ERR_LAUNCH;
+  }
+  long long blocks = e2e::cdivll(spatial, 256 * 16);
+  if (blocks > 128) blocks = 128;
+  if (blocks < 1) blocks = 1;
+  dim3 grid((unsigned)blocks, C);
+  DISPATCH_KB(K, hipLaunchKernelGGL((head_wgrad_kernel<KB>), grid, dim3(256), 0, st, x, scale, shift, slope, dlogits, acc, C, K,
+                                    spatial, B));
+  hipLaunchKernelGGL(d2f_kernel, dim3((unsigned)e2e::cdivll((long long)C * K, 256)), dim3(256), 0, st, acc, dw, (long long)C * K);
+  return e2e::check_launch("head1x1_wgrad");
+}

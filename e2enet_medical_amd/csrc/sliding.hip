@@ -1,0 +1,126 @@
+// K11: sliding-window inference aggregation on device (gfx950).
+// Reference: _internal_maybe_mirror_and_pred_3D (neural_network.py:500-565: result += flip(softmax(net(flip(x)))) / n,
+// result *= gaussian) and _internal_predict_3D_3Dconv_tiled (neural_network.py:383-407: overlap-add, count map,
+// divide, argmax).  The reference moves every tile to the host and adds in numpy; here everything stays in HBM.
+#include "e2e_common.h"
+
+namespace {
+
+__device__ __forceinline__ long long flipped_index(int x, int y, int z, int X, int Y, int Z, int axes) {
+  const int fx = (axes & 1) ? X - 1 - x : x;
+  const int fy = (axes & 2) ? Y - 1 - y : y;
+  const int fz = (axes & 4) ? Z - 1 - z : z;
+  return ((long long)fx * Y + fy) * Z + fz;
+}
+
+__global__ __launch_bounds__(256) void flip3d_kernel(const float* __restrict__ src, float* __restrict__ dst, int X, int Y, int Z,
+                                                     int axes) {
+  const long long spatial = (long long)X * Y * Z;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= spatial) return;
+  const int z = (int)(i % Z);
+  const long long r = i / Z;
+  const int y = (int)(r % Y), x = (int)(r / Y);
+  dst[(long long)blockIdx.y * spatial + i] = src[(long long)blockIdx.y * spatial + flipped_index(x, y, z, X, Y, Z, axes)];
+}
+
+template <int KB>
+__global__ __launch_bounds__(256) void softmax_flip_acc_kernel(const float* __restrict__ logits, float* __restrict__ result,
+                                                               float w, int first, int K, int X, int Y, int Z, int axes) {
+  const long long spatial = (long long)X * Y * Z;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;   // index in the flipped (network) frame
+  if (i >= spatial) return;
+  const int z = (int)(i % Z);
+  const long long r = i / Z;
+  const int y = (int)(r % Y), x = (int)(r / Y);
+  const long long o = flipped_index(x, y, z, X, Y, Z, axes);
+  for (int k0 = 0; k0 < K; k0 += KB) {
+    // softmax needs all classes: first pass max / sum over all K, then emit this block
+    float m = -INFINITY;
+    for (int k = 0; k < K; ++k) m = fmaxf(m, logits[(long long)k * spatial + i]);
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += expf(logits[(long long)k * spatial + i] - m);
+    const float inv = 1.f / s;
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      if (k0 + k >= K) break;
+      const float p = expf(logits[(long long)(k0 + k) * spatial + i] - m) * inv;
+      float* dst = result + (long long)(k0 + k) * spatial + o;
+      if (first) *dst = w * p;
+      else *dst += w * p;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void sw_accumulate_kernel(const float* __restrict__ patch, const float* __restrict__ gauss,
+                                                            float* __restrict__ agg, float* __restrict__ cnt, int K, int X, int Y,
+                                                            int Z, int px, int py, int pz, int x0, int y0, int z0) {
+  const long long ps = (long long)px * py * pz;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= ps) return;
+  const int z = (int)(i % pz);
+  const long long r = i / pz;
+  const int y = (int)(r % py), x = (int)(r / py);
+  const long long o = ((long long)(x0 + x) * Y + (y0 + y)) * Z + (z0 + z);
+  const float g = gauss ? gauss[i] : 1.f;
+  const long long vs = (long long)X * Y * Z;
+  for (int k = 0; k < K; ++k) {
+    agg[(long long)k * vs + o] += patch[(long long)k * ps + i] * g;
+    cnt[(long long)k * vs + o] += g;
+  }
+}
+
+__global__ __launch_bounds__(256) void sw_finalize_kernel(const float* __restrict__ agg, const float* __restrict__ cnt,
+                                                          float* __restrict__ probs, long long* __restrict__ seg, int K, int X, int Y,
+                                                          int Z, int cx0, int cy0, int cz0, int CX, int CY, int CZ) {
+  const long long cs = (long long)CX * CY * CZ;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= cs) return;
+  const int z = (int)(i % CZ);
+  const long long r = i / CZ;
+  const int y = (int)(r % CY), x = (int)(r / CY);
+  const long long o = ((long long)(cx0 + x) * Y + (cy0 + y)) * Z + (cz0 + z);
+  const long long vs = (long long)X * Y * Z;
+  float best = -INFINITY;
+  int arg = 0;
+  for (int k = 0; k < K; ++k) {
+    const float p = agg[(long long)k * vs + o] / cnt[(long long)k * vs + o];
+    probs[(long long)k * cs + i] = p;
+    if (p > best || (p != p && best == best)) { best = p; arg = k; }   // first maximum; NaN counts as maximal (numpy)
+  }
+  seg[i] = arg;
+}
+}  // namespace
+
+extern "C" int e2e_flip3d(const float* src, float* dst, int NC, int X, int Y, int Z, int axes, void* stream) {
+  E2E_REQUIRE(src && dst && src != dst && NC > 0 && X > 0 && Y > 0 && Z > 0, "flip3d: bad arguments");
+  dim3 grid((unsigned)e2e::cdivll((long long)X * Y * Z, 256), NC);
+  hipLaunchKernelGGL(flip3d_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, X, Y, Z, axes);
+  return e2e::check_launch("flip3d_kernel");
+}
+
+extern "C" int e2e_softmax_flip_acc(const float* logits, float* result, float w, int first, int K, int X, int Y, int Z,
+                                    int axes, void* stream) {
+  E2E_REQUIRE(logits && result && K > 0, "softmax_flip_acc: bad arguments");
+  dim3 grid((unsigned)e2e::cdivll((long long)X * Y * Z, 256));
+  hipLaunchKernelGGL((softmax_flip_acc_kernel<32>), grid, dim3(256), 0, (hipStream_t)stream, logits, result, w, first, K, X, Y, Z, axes);
+  return e2e::check_launch("softmax_flip_acc_kernel");
+}
+
+extern "C" int e2e_sw_accumulate(const float* patch, const float* gauss, float* agg, float* cnt, int K, int X, int Y,
+                                 int Z, int px, int py, int pz, int x0, int y0, int z0, void* stream) {
+  E2E_REQUIRE(patch && agg && cnt && K > 0, "sw_accumulate: bad arguments");
+  E2E_REQUIRE(x0 >= 0 && y0 >= 0 && z0 >= 0 && x0 + px <= X && y0 + py <= Y && z0 + pz <= Z, "sw_accumulate: tile outside volume");
+  dim3 grid((unsigned)e2e::cdivll((long long)px * py * pz, 256));
+  hipLaunchKernelGGL(sw_accumulate_kernel, grid, dim3(256), 0, (hipStream_t)stream, patch, gauss, agg, cnt, K, X, Y, Z, px, py, pz, x0, y0, z0);
+  return e2e::check_launch("sw_accumulate_kernel");
+}
+
+extern "C" int e2e_sw_finalize_argmax(const float* agg, const float* cnt, float* probs, long long* seg, int K, int X,
+                                      int Y, int Z, int cx0, int cy0, int cz0, int CX, int CY, int CZ, void* stream) {
+  E2E_REQUIRE(agg && cnt && probs && seg && K > 0, "sw_finalize_argmax: bad arguments");
+  E2E_REQUIRE(cx0 >= 0 && cy0 >= 0 && cz0 >= 0 && cx0 + CX <= X && cy0 + CY <= Y && cz0 + CZ <= Z, "sw_finalize_argmax: crop outside volume");
+  dim3 grid((unsigned)e2e::cdivll((long long)CX * CY * CZ, 256));
+  hipLaunchKernelGGL(sw_finalize_kernel, grid, dim3(256), 0, (hipStream_t)stream, agg, cnt, probs, seg, K, X, Y, Z, cx0, cy0, cz0, CX, CY, CZ);
+  return e2e::check_launch("sw_finalize_kernel");
+}

@@ -1,0 +1,489 @@
+"""Execution plan of the shiftConvPP network on the HIP kernels.
+
+Mirrors the wiring of reference ``Generic_UNetPlusPlus.forward`` (unetpp_d.py:447-488) and ``create_nest``
+(:491-550) as a static list of ops over pre-allocated HBM buffers.  PyTorch supplies device memory and streams
+only; every arithmetic op is a call through the C ABI of libe2e_hip.so (``_lib``).
+
+Design notes:
+  * a conv block stores its *pre-norm* output y plus per-(n,c) InstanceNorm scale/shift; consumers apply
+    ``lrelu(scale*y+shift)`` on load, so normalisation costs no extra pass over HBM;
+  * ``torch.cat`` and the depth shift never materialise: a conv reads through a per-channel plane table;
+  * backward is the reverse op list; gradients w.r.t. a tensor are accumulated in one buffer whose first writer
+    (in backward order) overwrites and later writers add -- decided statically when the plan is built.
+"""
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from ._lib import lib, InChan, OutChan, ParamEntry
+
+LRELU_SLOPE = 0.01
+IN_EPS = 1e-5
+
+
+def shift_amounts(num_channels: int, shift_size: int = 5):
+    """s(c) of the restricted depth shift (reference unetpp_d.py:45-59: torch.chunk into ceil(C/5)-sized groups,
+    group i rolled by i-2)."""
+    group = math.ceil(num_channels / shift_size)
+    pad = shift_size // 2
+    return [c // group - pad for c in range(num_channels)]
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def _upload_structs(structs, device) -> torch.Tensor:
+    raw = b"".join(bytes(s) for s in structs)
+    return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+
+
+class Act:
+    """An activation tensor in HBM.  ``normed`` tensors hold the pre-norm conv output together with the
+    InstanceNorm scale/shift that consumers apply on load."""
+
+    def __init__(self, name, shape, normed, device):
+        self.name = name
+        self.shape = tuple(int(v) for v in shape)          # (B, C, D, H, W)
+        self.normed = normed
+        self.data = torch.empty(self.shape, dtype=torch.float32, device=device)
+        b, c = self.shape[:2]
+        if normed:
+            self.scale = torch.empty(b * c, dtype=torch.float32, device=device)
+            self.shift = torch.empty(b * c, dtype=torch.float32, device=device)
+            self.mean = torch.empty(b * c, dtype=torch.float32, device=device)
+            self.rstd = torch.empty(b * c, dtype=torch.float32, device=device)
+        else:
+            self.scale = self.shift = self.mean = self.rstd = None
+        self.grad: Optional[torch.Tensor] = None
+        self.needs_grad = True
+        self._grad_written = False                          # plan-time bookkeeping
+
+    @property
+    def spatial(self):
+        return self.shape[2] * self.shape[3] * self.shape[4]
+
+    def alloc_grad(self):
+        if self.grad is None and self.needs_grad:
+            self.grad = torch.empty(self.shape, dtype=torch.float32, device=self.data.device)
+
+    def claim_grad_write(self) -> int:
+        """Plan-time: returns the accumulate flag for the next writer (in backward order)."""
+        acc = 1 if self._grad_written else 0
+        self._grad_written = True
+        return acc
+
+
+class ConvOp:
+    """depth shift + concat + Conv3d(1,3,3) + InstanceNorm statistics (reference ConvDropoutNormNonlin,
+    unetpp_d.py:61-111; LeakyReLU/affine are applied by the consumers)."""
+
+    def __init__(self, eng, prefix, sources: Sequence[Act], cout, stride):
+        self.eng, self.prefix, self.sources, self.stride = eng, prefix, list(sources), tuple(stride)
+        b, _, di, hi, wi = sources[0].shape
+        for s in sources:
+            assert s.shape[0] == b and s.shape[2:] == sources[0].shape[2:], "concat sources must agree spatially"
+        self.cin = sum(s.shape[1] for s in sources)
+        self.cout = cout
+        self.in_dims = (di, hi, wi)
+        sd, sh, sw = self.stride
+        self.out_dims = ((di - 1) // sd + 1, (hi - 1) // sh + 1, (wi - 1) // sw + 1)
+        self.out = Act(prefix, (b, cout) + self.out_dims, True, eng.device)
+        self.np = lib().conv133_num_partials(*self.out_dims, sh, sw)
+        self.part = torch.empty(b * cout * self.np * 3, dtype=torch.float32, device=eng.device)
+        self.w_name = prefix + ".conv.weight"
+        self.live = None        # [Cout, ceil(Cin/32)] int32
+        self.live_t = None      # [Cin, ceil(Cout/32)] int32
+        # per input channel plane table
+        shifts = shift_amounts(self.cin)
+        structs = []
+        c = 0
+        for s in sources:
+            cs = s.shape[1]
+            plane = s.spatial
+            for k in range(cs):
+                structs.append(InChan(s.data.data_ptr() + 4 * k * plane,
+                                      (s.scale.data_ptr() + 4 * k) if s.normed else None,
+                                      (s.shift.data_ptr() + 4 * k) if s.normed else None,
+                                      cs * plane, cs, shifts[c], LRELU_SLOPE if s.normed else 1.0, 0))
+                c += 1
+        self.chans = _upload_structs(structs, eng.device)
+        self.shifts = shifts
+        self.outs = None
+        self.do_dgrad = any(s.needs_grad for s in sources)
+
+    def plan_backward(self):
+        if not self.do_dgrad:
+            return
+        structs = []
+        c = 0
+        for s in self.sources:
+            cs = s.shape[1]
+            plane = s.spatial
+            if s.needs_grad:
+                s.alloc_grad()
+                acc = s.claim_grad_write()
+            for k in range(cs):
+                if s.needs_grad:
+                    structs.append(OutChan(s.grad.data_ptr() + 4 * k * plane, cs * plane, self.shifts[c], acc))
+                else:
+                    structs.append(OutChan(None, 0, 0, 0))
+                c += 1
+        self.outs = _upload_structs(structs, self.eng.device)
+
+    def forward(self):
+        e = self.eng
+        p = e.params
+        b = self.out.shape[0]
+        di, hi, wi = self.in_dims
+        sd, sh, sw = self.stride
+        L = lib()
+        L.conv133_fwd(self.chans.data_ptr(), self.cin, p[self.w_name].data_ptr(), p[self.prefix + ".conv.bias"].data_ptr(),
+                      _ptr(self.live), self.out.data.data_ptr(), self.part.data_ptr(), b, self.cout, di, hi, wi,
+                      sd, sh, sw, _stream())
+        L.in_stats_finalize(self.part.data_ptr(), self.np, p[self.prefix + ".instnorm.weight"].data_ptr(),
+                            p[self.prefix + ".instnorm.bias"].data_ptr(), IN_EPS, self.out.scale.data_ptr(),
+                            self.out.shift.data_ptr(), self.out.mean.data_ptr(), self.out.rstd.data_ptr(), b,
+                            self.cout, _stream())
+
+    def backward(self):
+        e = self.eng
+        p, g = e.params, e.grads
+        o = self.out
+        b = o.shape[0]
+        di, hi, wi = self.in_dims
+        sd, sh, sw = self.stride
+        L = lib()
+        # dz (w.r.t. the post-activation output) -> dy (w.r.t. the pre-norm conv output), in place
+        L.in_lrelu_bwd(o.grad.data_ptr(), o.data.data_ptr(), o.mean.data_ptr(), o.rstd.data_ptr(),
+                       p[self.prefix + ".instnorm.weight"].data_ptr(), p[self.prefix + ".instnorm.bias"].data_ptr(),
+                       LRELU_SLOPE, g[self.prefix + ".instnorm.weight"].data_ptr(),
+                       g[self.prefix + ".instnorm.bias"].data_ptr(), g[self.prefix + ".conv.bias"].data_ptr(),
+                       e.in_sums.data_ptr(), b, self.cout, o.spatial, _stream())
+        L.conv133_wgrad(self.chans.data_ptr(), o.grad.data_ptr(), g[self.w_name].data_ptr(), e.wgrad_ws.data_ptr(),
+                        b, self.cin, self.cout, di, hi, wi, sd, sh, sw, _stream())
+        if self.do_dgrad:
+            L.conv133_dgrad(o.grad.data_ptr(), p[self.w_name].data_ptr(), _ptr(self.live_t), self.outs.data_ptr(),
+                            b, self.cin, self.cout, di, hi, wi, sd, sh, sw, _stream())
+
+    def wgrad_ws_bytes(self):
+        di, hi, wi = self.in_dims
+        return lib().conv133_wgrad_ws_bytes(self.out.shape[0], self.cin, self.cout, di, hi, wi, *self.stride)
+
+
+class UpOp:
+    """nn.ConvTranspose3d(Cin, Cout, k, k, bias=False) (unetpp_d.py:521-522)."""
+
+    def __init__(self, eng, w_name, src: Act, cout, kernel):
+        self.eng, self.w_name, self.src, self.cout, self.kernel = eng, w_name, src, cout, tuple(kernel)
+        b, cin, d, h, w = src.shape
+        self.cin = cin
+        kd, kh, kw = self.kernel
+        self.out = Act(w_name, (b, cout, d * kd, h * kh, w * kw), False, eng.device)
+        self.live = None      # [Cout, ceil(Cin/32)]
+        self.live_t = None    # [Cin, ceil(Cout/32)]
+        self.acc = 0
+
+    def plan_backward(self):
+        self.src.alloc_grad()
+        self.acc = self.src.claim_grad_write()
+
+    def forward(self):
+        s = self.src
+        b, cin, d, h, w = s.shape
+        lib().convT_fwd(s.data.data_ptr(), _ptr(s.scale), _ptr(s.shift), LRELU_SLOPE, self.eng.params[self.w_name].data_ptr(),
+                        _ptr(self.live), self.out.data.data_ptr(), b, cin, self.cout, d, h, w, *self.kernel, _stream())
+
+    def backward(self):
+        s, e = self.src, self.eng
+        b, cin, d, h, w = s.shape
+        L = lib()
+        L.convT_wgrad(s.data.data_ptr(), _ptr(s.scale), _ptr(s.shift), LRELU_SLOPE, self.out.grad.data_ptr(),
+                      e.grads[self.w_name].data_ptr(), e.wgrad_ws.data_ptr(), b, cin, self.cout, d, h, w, *self.kernel,
+                      _stream())
+        L.convT_dgrad(self.out.grad.data_ptr(), e.params[self.w_name].data_ptr(), _ptr(self.live_t), s.grad.data_ptr(),
+                      self.acc, b, cin, self.cout, d, h, w, *self.kernel, _stream())
+
+    def wgrad_ws_bytes(self):
+        b, cin, d, h, w = self.src.shape
+        return lib().convT_wgrad_ws_bytes(b, cin, self.cout, d, h, w, *self.kernel)
+
+
+class PoolOp:
+    """nn.MaxPool3d(k) of the down-fusion branch (unetpp_d.py:523-524)."""
+
+    def __init__(self, eng, name, src: Act, kernel):
+        self.eng, self.src, self.kernel = eng, src, tuple(kernel)
+        b, c, d, h, w = src.shape
+        kd, kh, kw = self.kernel
+        self.out = Act(name, (b, c, d // kd, h // kh, w // kw), False, eng.device)
+        self.acc = 0
+
+    def plan_backward(self):
+        self.src.alloc_grad()
+        self.acc = self.src.claim_grad_write()
+
+    def forward(self):
+        s = self.src
+        b, c, d, h, w = s.shape
+        lib().maxpool_fwd(s.data.data_ptr(), _ptr(s.scale), _ptr(s.shift), LRELU_SLOPE, self.out.data.data_ptr(),
+                          b, c, d, h, w, *self.kernel, _stream())
+
+    def backward(self):
+        s = self.src
+        b, c, d, h, w = s.shape
+        lib().maxpool_bwd(s.data.data_ptr(), _ptr(s.scale), _ptr(s.shift), LRELU_SLOPE, self.out.grad.data_ptr(),
+                          s.grad.data_ptr(), self.acc, b, c, d, h, w, *self.kernel, _stream())
+
+
+class HeadOp:
+    """nn.Conv3d(C, K, 1, bias=False) segmentation head (unetpp_d.py:394-401, :480-483)."""
+
+    def __init__(self, eng, w_name, src: Act, num_classes):
+        self.eng, self.w_name, self.src, self.k = eng, w_name, src, num_classes
+        b, c = src.shape[:2]
+        self.out = Act(w_name, (b, num_classes) + src.shape[2:], False, eng.device)
+        self.acc = 0
+        self.active = True           # deep supervision off: only head 0 runs
+
+    def plan_backward(self):
+        self.src.alloc_grad()
+        self.acc = self.src.claim_grad_write()
+
+    def forward(self):
+        s = self.src
+        b, c = s.shape[:2]
+        lib().head1x1_fwd(s.data.data_ptr(), _ptr(s.scale), _ptr(s.shift), LRELU_SLOPE,
+                          self.eng.params[self.w_name].data_ptr(), self.out.data.data_ptr(), b, c, self.k, s.spatial,
+                          _stream())
+
+    def backward(self):
+        s, e = self.src, self.eng
+        b, c = s.shape[:2]
+        L = lib()
+        L.head1x1_wgrad(s.data.data_ptr(), _ptr(s.scale), _ptr(s.shift), LRELU_SLOPE, self.out.grad.data_ptr(),
+                        e.grads[self.w_name].data_ptr(), e.wgrad_ws.data_ptr(), b, c, self.k, s.spatial, _stream())
+        L.head1x1_dgrad(self.out.grad.data_ptr(), e.params[self.w_name].data_ptr(), s.grad.data_ptr(), self.acc, b, c,
+                        self.k, s.spatial, _stream())
+
+
+class NetConfig:
+    """Static description of a shiftConvPP network (what reference Generic_UNetPlusPlus.__init__ derives,
+    unetpp_d.py:227-445)."""
+
+    def __init__(self, in_channels, base_features, num_classes, pool_kernels, convs_per_stage=2, max_features=320):
+        if len(pool_kernels) != 5:
+            # reference forward() indexes six levels literally (unetpp_d.py:451-483)
+            raise ValueError("shiftConvPP needs exactly 5 pooling stages, got %d" % len(pool_kernels))
+        self.in_channels, self.base_features, self.num_classes = in_channels, base_features, num_classes
+        self.pool_kernels = [tuple(int(v) for v in k) for k in pool_kernels]
+        self.convs_per_stage, self.max_features = convs_per_stage, max_features
+        feats, f = [], base_features
+        for _ in range(6):
+            feats.append(min(f, max_features))
+            f = min(int(round(f * 2)), max_features)
+        self.feats = feats
+
+    @property
+    def num_pool(self):
+        return len(self.pool_kernels)
+
+    def nest_nodes(self, z):
+        k = self.num_pool - z
+        return [(m, k - 1 - m) for m in range(k)]
+
+    def loc_prefixes(self, z, m):
+        n = self.convs_per_stage
+        if z != 0:
+            return ["loc%d.%d.0.blocks.%d" % (z, m, b) for b in range(n - 1)]
+        return ["loc0.%d.0.blocks.%d" % (m, b) for b in range(n - 1)] + ["loc0.%d.1.blocks.0" % m]
+
+    def encoder_prefixes(self, stage):
+        n = self.convs_per_stage
+        if stage < self.num_pool:
+            return ["conv_blocks_context.%d.blocks.%d" % (stage, b) for b in range(n)]
+        return (["conv_blocks_context.%d.0.blocks.%d" % (stage, b) for b in range(n - 1)] +
+                ["conv_blocks_context.%d.1.blocks.0" % stage])
+
+
+class Engine:
+    """Plan + executor for one (batch, patch) shape."""
+
+    def __init__(self, cfg: NetConfig, params: Dict[str, torch.Tensor], batch: int, patch: Tuple[int, int, int],
+                 device, training: bool = True):
+        lib()                                    # fail loudly if the HIP library is missing
+        self.cfg, self.params, self.device, self.training = cfg, params, device, training
+        self.batch, self.patch = batch, tuple(patch)
+        P = cfg.num_pool
+        self.ops: List = []
+        self.conv_ops: Dict[str, ConvOp] = {}
+        self.up_ops: Dict[str, UpOp] = {}
+        self.input = Act("input", (batch, cfg.in_channels) + self.patch, False, device)
+        self.input.needs_grad = False
+        nodes = {}
+        cur = self.input
+        for st in range(P + 1):
+            stride = (1, 1, 1) if st == 0 else cfg.pool_kernels[st - 1]
+            for bi, prefix in enumerate(cfg.encoder_prefixes(st)):
+                op = self._add_conv(prefix, [cur], cfg.feats[st], stride if bi == 0 else (1, 1, 1))
+                cur = op.out
+            nodes[(st, 0)] = cur
+            if st == 0:
+                continue
+            z = P - st
+            for m, lvl in cfg.nest_nodes(z):
+                j = st - lvl
+                up = UpOp(self, "up%d.%d.weight" % (z, m), nodes[(lvl + 1, j - 1)], cfg.feats[lvl], cfg.pool_kernels[lvl])
+                self.ops.append(up)
+                self.up_ops[up.w_name] = up
+                srcs = [nodes[(lvl, j - 1)], up.out]
+                if lvl > 0:
+                    pool = PoolOp(self, "down%d.%d" % (z, m), nodes[(lvl - 1, j - 1)], cfg.pool_kernels[lvl - 1])
+                    self.ops.append(pool)
+                    srcs.append(pool.out)
+                t = None
+                for prefix in cfg.loc_prefixes(z, m):
+                    op = self._add_conv(prefix, srcs if t is None else [t], cfg.feats[lvl], (1, 1, 1))
+                    t = op.out
+                nodes[(lvl, j)] = t
+        self.nodes = nodes
+        self.heads: List[HeadOp] = []
+        for h in range(4):
+            head = HeadOp(self, "seg_outputs.%d.weight" % h, nodes[(h, P - h)], cfg.num_classes)
+            self.heads.append(head)
+            self.ops.append(head)
+        self.grads: Dict[str, torch.Tensor] = {}
+        self._backward_ready = False
+        self.loss_ws = None
+        self.loss_val = None
+
+    def _add_conv(self, prefix, sources, cout, stride):
+        op = ConvOp(self, prefix, sources, cout, stride)
+        self.ops.append(op)
+        self.conv_ops[op.w_name] = op
+        return op
+
+    # ------------------------------------------------------------------------------------------ sparsity
+    def set_kernel_masks(self, kmasks: Dict[str, torch.Tensor]):
+        """kmasks: weight name -> uint8 [dim0, dim1] kernel map (1 = alive).  Builds the liveness bit tables the
+        kernels walk.  Names absent from the dict are treated as dense."""
+        L = lib()
+        for name, op in list(self.conv_ops.items()) + list(self.up_ops.items()):
+            km = kmasks.get(name)
+            if km is None:
+                op.live = op.live_t = None
+                continue
+            r, cc = km.shape
+            km = km.to(device=self.device, dtype=torch.uint8).contiguous()
+            rows = torch.empty(r * ((cc + 31) // 32), dtype=torch.int32, device=self.device)
+            cols = torch.empty(cc * ((r + 31) // 32), dtype=torch.int32, device=self.device)
+            L.dsff_expand(km.data_ptr(), None, rows.data_ptr(), cols.data_ptr(), r, cc, 1, _stream())
+            if isinstance(op, ConvOp):         # weight [Cout, Cin, ...]: rows index out channels
+                op.live, op.live_t = rows, cols
+            else:                              # weight [Cin, Cout, ...]: rows index in channels
+                op.live, op.live_t = cols, rows
+
+    def kernel_masks_from_weights(self, names=None):
+        """Inference: a kernel is alive iff any tap is non-zero (pruned kernels are exact zeros in checkpoints)."""
+        L = lib()
+        out = {}
+        for name, op in list(self.conv_ops.items()) + list(self.up_ops.items()):
+            if names is not None and name not in names:
+                continue
+            w = self.params[name]
+            r, cc = w.shape[0], w.shape[1]
+            ks = w[0, 0].numel()
+            km = torch.empty((r, cc), dtype=torch.uint8, device=self.device)
+            L.dsff_kmask_from_weights(w.data_ptr(), km.data_ptr(), r, cc, ks, _stream())
+            out[name] = km
+        return out
+
+    # ------------------------------------------------------------------------------------------ forward
+    def forward(self, x: torch.Tensor, deep_supervision: bool = True):
+        assert x.is_cuda and x.dtype == torch.float32, "engine input must be a float32 GPU tensor"
+        assert tuple(x.shape) == self.input.shape, "engine built for %s, got %s" % (self.input.shape, tuple(x.shape))
+        self.input.data.copy_(x)
+        for op in self.ops:
+            if isinstance(op, HeadOp):
+                op.active = deep_supervision or op is self.heads[0]
+                if not op.active:
+                    continue
+            op.forward()
+        outs = [h.out.data for h in self.heads]
+        return outs if deep_supervision else outs[0]
+
+    # ------------------------------------------------------------------------------------------ backward
+    def prepare_backward(self):
+        if self._backward_ready:
+            return
+        for op in reversed(self.ops):          # backward order: first writer of a gradient buffer overwrites
+            op.out.alloc_grad()
+            op.plan_backward()
+        for name, p in self.params.items():
+            self.grads[name] = torch.zeros_like(p, device=self.device)
+        ws = max([op.wgrad_ws_bytes() for op in self.ops if hasattr(op, "wgrad_ws_bytes")] +
+                 [lib().head1x1_wgrad_ws_bytes(self.batch, h.src.shape[1], h.k, h.src.spatial) for h in self.heads])
+        self.wgrad_ws = torch.empty((ws + 3) // 4, dtype=torch.float32, device=self.device)
+        cmax = max(op.cout for op in self.conv_ops.values())
+        self.in_sums = torch.empty(self.batch * cmax * 3, dtype=torch.float64, device=self.device)
+        self.loss_ws = torch.empty(lib().loss_ws_bytes(self.batch, self.cfg.num_classes) // 8, dtype=torch.float64,
+                                   device=self.device)
+        self.loss_val = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._backward_ready = True
+
+    def backward(self, dlogits: Optional[Sequence[Optional[torch.Tensor]]] = None):
+        """dlogits: gradients w.r.t. the 4 logits (None entries = zero).  When omitted the heads' grad buffers are
+        expected to be filled already (loss_backward)."""
+        self.prepare_backward()
+        if dlogits is not None:
+            for h, g in zip(self.heads, dlogits):
+                if g is None:
+                    h.out.grad.zero_()
+                else:
+                    h.out.grad.copy_(g)
+        for op in reversed(self.ops):
+            if isinstance(op, HeadOp) and not op.active:
+                # inactive head (no deep supervision): its source still needs a defined gradient
+                if op.acc == 0:
+                    op.src.grad.zero_()
+                self.grads[op.w_name].zero_()
+                continue
+            op.backward()
+        return self.grads
+
+    def loss_backward(self, targets: Sequence[torch.Tensor], weights: Sequence[float], batch_dice=False, smooth=1e-5):
+        """Deep-supervision Dice+CE loss (reference MultipleOutputLoss2(DC_and_CE_loss), deep_supervision.py:31-43)
+        and the full backward pass.  targets[i]: [B,1,...] float labels at scale i.  Returns the device loss scalar."""
+        self.prepare_backward()
+        L = lib()
+        self.loss_val.zero_()
+        k = self.cfg.num_classes
+        for i, h in enumerate(self.heads):
+            wgt = float(weights[i]) if i < len(weights) else 0.0
+            if wgt == 0.0:
+                h.out.grad.zero_()
+                continue
+            t = targets[i]
+            assert t.is_cuda and t.dtype == torch.float32 and t.numel() == self.batch * h.src.spatial
+            L.dc_ce_reduce(h.out.data.data_ptr(), t.data_ptr(), self.loss_ws.data_ptr(), self.batch, k, h.src.spatial,
+                           _stream())
+            L.dc_ce_grad(h.out.data.data_ptr(), t.data_ptr(), self.loss_ws.data_ptr(), wgt, 1 if batch_dice else 0,
+                         smooth, h.out.grad.data_ptr(), self.loss_val.data_ptr(), self.batch, k, h.src.spatial, _stream())
+        self.backward(None)
+        return self.loss_val
+
+    # ------------------------------------------------------------------------------------------ accounting
+    def activation_bytes(self):
+        seen, total = set(), 0
+        for op in self.ops:
+            for a in [op.out]:
+                if id(a) not in seen:
+                    seen.add(id(a))
+                    total += a.data.numel() * 4 + (a.grad.numel() * 4 if a.grad is not None else 0)
+        return total

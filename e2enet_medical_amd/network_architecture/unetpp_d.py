@@ -1,0 +1,320 @@
+"""shiftConvPP network (``Generic_UNetPlusPlus``) on the MI355X engine.
+
+Drop-in for reference e2enet/network_architecture/unetpp_d.py: same constructor signature (:227-236), same
+attributes read by the trainer / inference code, same module tree and therefore the same ``state_dict`` names
+(the checkpoint wire format), same parameter registration order (:418-438) and the same RNG draw order, so
+``torch.manual_seed(s); Generic_UNetPlusPlus(...)`` yields bit-identical initial weights.
+
+The nn modules below are parameter containers only.  ``forward`` runs the HIP engine (``engine.Engine``): depth
+shift, concat, conv, InstanceNorm, LeakyReLU, transposed conv, pooling and heads are hand-written gfx950
+kernels behind the C ABI of libe2e_hip.so.  There is no CPU / eager fallback: a CPU tensor raises.
+"""
+from copy import deepcopy
+
+import numpy as np
+import torch
+from torch import nn
+
+from .initialization import InitWeights_He          # noqa: F401  (re-exported like the reference module)
+from .neural_network import SegmentationNetwork
+from ..utilities.nd_softmax import softmax_helper
+from ..engine import Engine, NetConfig
+
+
+class torch_shift(nn.Module):
+    """Restricted depth shift (reference unetpp_d.py:38-59).  On the engine the shift is an index offset in the
+    conv load stage and is never materialised; the module exists for structural parity only."""
+
+    def __init__(self, shift_size, dim, dim_num):
+        super().__init__()
+        self.shift_size, self.dim, self.dim_num = shift_size, dim, dim_num
+
+    def forward(self, x):
+        raise RuntimeError("torch_shift is fused into the convolution load stage of the HIP engine; "
+                           "run the enclosing Generic_UNetPlusPlus instead")
+
+
+class ConvDropoutNormNonlin(nn.Module):
+    """Parameter container for shift -> conv(1,3,3) -> [dropout] -> InstanceNorm -> LeakyReLU
+    (reference unetpp_d.py:61-111)."""
+
+    def __init__(self, input_channels, output_channels, conv_op=nn.Conv3d, conv_kwargs=None, norm_op=nn.InstanceNorm3d,
+                 norm_op_kwargs=None, dropout_op=nn.Dropout3d, dropout_op_kwargs=None, nonlin=nn.LeakyReLU,
+                 nonlin_kwargs=None, shift_size=5):
+        super().__init__()
+        if nonlin_kwargs is None:
+            nonlin_kwargs = {'negative_slope': 1e-2, 'inplace': True}
+        if dropout_op_kwargs is None:
+            dropout_op_kwargs = {'p': 0.5, 'inplace': True}
+        if norm_op_kwargs is None:
+            norm_op_kwargs = {'eps': 1e-5, 'affine': True, 'momentum': 0.1}
+        if conv_kwargs is None:
+            conv_kwargs = {'kernel_size': 3, 'stride': 1, 'padding': 1, 'dilation': 1, 'bias': True}
+        self.nonlin_kwargs, self.nonlin = nonlin_kwargs, nonlin
+        self.dropout_op, self.dropout_op_kwargs = dropout_op, dropout_op_kwargs
+        self.norm_op_kwargs, self.conv_kwargs = norm_op_kwargs, conv_kwargs
+        self.conv_op, self.norm_op = conv_op, norm_op
+        self.shift_size = 5
+        self.shift_D = torch_shift(self.shift_size, 2, 3)
+        self.conv = self.conv_op(input_channels, output_channels, **self.conv_kwargs)
+        if self.dropout_op is not None and self.dropout_op_kwargs['p'] is not None and self.dropout_op_kwargs['p'] > 0:
+            self.dropout = self.dropout_op(**self.dropout_op_kwargs)
+        else:
+            self.dropout = None
+        self.instnorm = self.norm_op(output_channels, **self.norm_op_kwargs)
+        self.lrelu = self.nonlin(**self.nonlin_kwargs)
+
+    def forward(self, x):
+        raise RuntimeError("ConvDropoutNormNonlin blocks execute inside the HIP engine of Generic_UNetPlusPlus")
+
+
+class StackedConvLayers(nn.Module):
+    """reference unetpp_d.py:122-185"""
+
+    def __init__(self, input_feature_channels, output_feature_channels, num_convs, conv_op=nn.Conv3d, conv_kwargs=None,
+                 norm_op=nn.InstanceNorm3d, norm_op_kwargs=None, dropout_op=nn.Dropout3d, dropout_op_kwargs=None,
+                 nonlin=nn.LeakyReLU, nonlin_kwargs=None, first_stride=None, basic_block=ConvDropoutNormNonlin):
+        self.input_channels = input_feature_channels
+        self.output_channels = output_feature_channels
+        if conv_kwargs is None:
+            conv_kwargs = {'kernel_size': 3, 'stride': 1, 'padding': 1, 'dilation': 1, 'bias': True}
+        self.conv_kwargs = conv_kwargs
+        if first_stride is not None:
+            self.conv_kwargs_first_conv = deepcopy(conv_kwargs)
+            self.conv_kwargs_first_conv['stride'] = first_stride
+        else:
+            self.conv_kwargs_first_conv = conv_kwargs
+        super().__init__()
+        common = (norm_op, norm_op_kwargs, dropout_op, dropout_op_kwargs, nonlin, nonlin_kwargs)
+        blocks = [basic_block(input_feature_channels, output_feature_channels, conv_op, self.conv_kwargs_first_conv, *common)]
+        blocks += [basic_block(output_feature_channels, output_feature_channels, conv_op, self.conv_kwargs, *common)
+                   for _ in range(num_convs - 1)]
+        self.blocks = nn.Sequential(*blocks)
+
+    def forward(self, x):
+        return self.blocks(x)
+
+
+class _EngineFunction(torch.autograd.Function):
+    """One autograd node for the whole network: forward/backward are the engine's op lists."""
+
+    @staticmethod
+    def forward(ctx, net, x, deep_supervision, *params):
+        eng = net._engine_for(x)
+        ctx.net, ctx.eng, ctx.ds = net, eng, deep_supervision
+        outs = eng.forward(x, deep_supervision)
+        outs = outs if isinstance(outs, list) else [outs]
+        return tuple(o.clone() for o in outs)
+
+    @staticmethod
+    def backward(ctx, *grad_outputs):
+        eng = ctx.eng
+        dl = list(grad_outputs) + [None] * (4 - len(grad_outputs))
+        dl = [g.contiguous() if g is not None else None for g in dl]
+        grads = eng.backward(dl)
+        names = ctx.net._param_names
+        return (None, None, None) + tuple(grads[n] for n in names)
+
+
+class Generic_UNetPlusPlus(SegmentationNetwork):
+    DEFAULT_BATCH_SIZE_3D = 2
+    DEFAULT_PATCH_SIZE_3D = (64, 192, 160)
+    SPACING_FACTOR_BETWEEN_STAGES = 2
+    BASE_NUM_FEATURES_3D = 30
+    MAX_NUMPOOL_3D = 999
+    MAX_NUM_FILTERS_3D = 320
+
+    def __init__(self, img_size, input_channels, base_num_features, num_classes, num_pool, num_conv_per_stage=2,
+                 feat_map_mul_on_downscale=2, conv_op=nn.Conv3d, norm_op=nn.InstanceNorm3d, norm_op_kwargs=None,
+                 dropout_op=nn.Dropout3d, dropout_op_kwargs=None, nonlin=nn.LeakyReLU, nonlin_kwargs=None,
+                 deep_supervision=True, dropout_in_localization=False, final_nonlin=softmax_helper,
+                 weightInitializer=InitWeights_He(1e-2), pool_op_kernel_sizes=None, conv_kernel_sizes=None,
+                 upscale_logits=False, convolutional_pooling=False, convolutional_upsampling=False,
+                 max_num_features=None, basic_block=ConvDropoutNormNonlin, seg_output_use_bias=False):
+        super().__init__()
+        # ---- what the engine supports: exactly the configuration nnUNetTrainer_simple builds (:292-301) ----
+        if conv_op != nn.Conv3d:
+            raise ValueError("the MI355X engine implements the 3D shiftConvPP network only (conv_op=nn.Conv3d)")
+        if norm_op != nn.InstanceNorm3d or nonlin != nn.LeakyReLU:
+            raise ValueError("engine supports InstanceNorm3d + LeakyReLU blocks (nnUNetTrainer_simple.py:276-279)")
+        if not (convolutional_pooling and convolutional_upsampling):
+            raise ValueError("shiftConvPP is built with convolutional_pooling=convolutional_upsampling=True "
+                             "(nnUNetTrainer_simple.py:300-301)")
+        if upscale_logits or seg_output_use_bias or feat_map_mul_on_downscale != 2:
+            raise ValueError("unsupported: upscale_logits / seg_output_use_bias / feat_map_mul_on_downscale != 2")
+        if num_pool != 5:
+            # the reference's forward() indexes six levels literally and fails otherwise (unetpp_d.py:451-483)
+            raise ValueError("shiftConvPP needs exactly 5 pooling stages")
+        if nonlin_kwargs is None:
+            nonlin_kwargs = {'negative_slope': 1e-2, 'inplace': True}
+        if dropout_op_kwargs is None:
+            dropout_op_kwargs = {'p': 0.5, 'inplace': True}
+        if norm_op_kwargs is None:
+            norm_op_kwargs = {'eps': 1e-5, 'affine': True, 'momentum': 0.1}
+        if dropout_op_kwargs.get('p') not in (None, 0, 0.0):
+            raise ValueError("dropout p > 0 is not supported by the engine (trainer uses p=0, nnUNetTrainer_simple.py:277)")
+        if abs(nonlin_kwargs.get('negative_slope', 1e-2) - 1e-2) > 0 or abs(norm_op_kwargs.get('eps', 1e-5) - 1e-5) > 0 \
+                or not norm_op_kwargs.get('affine', True):
+            raise ValueError("engine is specialised for LeakyReLU(0.01) and InstanceNorm(eps=1e-5, affine=True)")
+        self.convolutional_upsampling = convolutional_upsampling
+        self.convolutional_pooling = convolutional_pooling
+        self.upscale_logits = upscale_logits
+        self.conv_kwargs = {'stride': 1, 'dilation': 1, 'bias': True}
+        self.nonlin, self.nonlin_kwargs = nonlin, nonlin_kwargs
+        self.dropout_op_kwargs, self.norm_op_kwargs = dropout_op_kwargs, norm_op_kwargs
+        self.weightInitializer = weightInitializer
+        self.conv_op, self.norm_op, self.dropout_op = conv_op, norm_op, dropout_op
+        self.num_classes = num_classes
+        self.final_nonlin = final_nonlin
+        self._deep_supervision = deep_supervision
+        self.do_ds = deep_supervision
+
+        if pool_op_kernel_sizes is None:
+            pool_op_kernel_sizes = [(2, 2, 2)] * num_pool
+        conv_kernel_sizes = [(1, 3, 3)] * (num_pool + 1)          # forced, reference :286-287
+        self.input_shape_must_be_divisible_by = np.prod(pool_op_kernel_sizes, 0, dtype=np.int64)
+        self.pool_op_kernel_sizes = pool_op_kernel_sizes
+        self.conv_kernel_sizes = conv_kernel_sizes
+        self.conv_pad_sizes = [[1 if i == 3 else 0 for i in k] for k in conv_kernel_sizes]
+        self.max_num_features = self.MAX_NUM_FILTERS_3D if max_num_features is None else max_num_features
+
+        blk = (self.conv_op, None, self.norm_op, self.norm_op_kwargs, self.dropout_op, self.dropout_op_kwargs,
+               self.nonlin, self.nonlin_kwargs)
+
+        def stacked(cin, cout, n, first_stride=None):
+            kw = dict(self.conv_kwargs)
+            kw['kernel_size'] = (1, 3, 3)
+            kw['padding'] = [0, 1, 1]
+            return StackedConvLayers(cin, cout, n, blk[0], kw, *blk[2:], first_stride, basic_block=basic_block)
+
+        # ---- construction order == reference (RNG parity): encoder, bottleneck, nests 0..4, heads ----
+        context = []
+        out_f, in_f = base_num_features, input_channels
+        for d in range(num_pool):
+            first_stride = pool_op_kernel_sizes[d - 1] if d != 0 else None
+            context.append(stacked(in_f, out_f, num_conv_per_stage, first_stride))
+            in_f = out_f
+            out_f = min(int(np.round(out_f * feat_map_mul_on_downscale)), self.max_num_features)
+        final_num_features = out_f
+        context.append(nn.Sequential(stacked(in_f, out_f, num_conv_per_stage - 1, pool_op_kernel_sizes[-1]),
+                                     stacked(out_f, final_num_features, 1)))
+        self._context_out = [c.output_channels for c in context[:-1]] + [final_num_features]
+
+        locs, ups, downs = [], [], []
+        enc_feat = final_num_features
+        for z in range(5):
+            loc, up, enc_feat, down = self._create_nest(z, num_pool, enc_feat, num_conv_per_stage, stacked)
+            locs.append(loc)
+            ups.append(up)
+            downs.append(down)
+        heads = [conv_op(self._context_out[h], num_classes, 1, 1, 0, 1, 1, seg_output_use_bias) for h in range(4)]
+
+        # ---- registration order == reference (:418-438): parameter order, Masking draw order ----
+        for z in range(5):
+            setattr(self, "loc%d" % z, nn.ModuleList(locs[z]))
+        self.conv_blocks_context = nn.ModuleList(context)
+        self.td = nn.ModuleList([])
+        for z in range(5):
+            setattr(self, "up%d" % z, nn.ModuleList(ups[z]))
+        for z in range(5):
+            setattr(self, "down%d" % z, nn.ModuleList(downs[z]))
+        self.seg_outputs = nn.ModuleList(heads)
+        self.upscale_logits_ops = [lambda x: x for _ in range(num_pool - 1)]
+
+        if self.weightInitializer is not None:
+            self.apply(self.weightInitializer)
+
+        self._cfg = NetConfig(input_channels, base_num_features, num_classes, pool_op_kernel_sizes, num_conv_per_stage,
+                              self.max_num_features)
+        self._engines = {}
+        self._kernel_masks = None            # name -> uint8 [dim0, dim1]; None = dense
+        self._auto_sparsity = False          # derive liveness from zero kernels (inference on DSFF checkpoints)
+        self._param_names = [n for n, _ in self.named_parameters()]
+        self.register_load_state_dict_post_hook(lambda module, keys: module._invalidate_sparsity())
+
+    def _create_nest(self, z, num_pool, final_num_features, n_conv, stacked):
+        """reference create_nest (:491-550) for convolutional_upsampling=True."""
+        loc, tu, tdown = [], [], []
+        unet_final = None
+        for u in range(z, num_pool):
+            from_down = final_num_features
+            from_skip = self._context_out[-(2 + u)]
+            concat = from_skip * 2 + (self._context_out[-(3 + u)] if u != num_pool - 1 else 0)
+            if unet_final is None:
+                unet_final = from_skip
+            final_num_features = from_skip
+            tu.append(nn.ConvTranspose3d(from_down, from_skip, self.pool_op_kernel_sizes[-(u + 1)],
+                                         self.pool_op_kernel_sizes[-(u + 1)], bias=False))
+            if u + 2 <= len(self.pool_op_kernel_sizes):
+                tdown.append(nn.MaxPool3d(self.pool_op_kernel_sizes[-(u + 2)]))
+            if z != 0:
+                loc.append(nn.Sequential(stacked(concat, final_num_features, n_conv - 1)))
+            else:
+                loc.append(nn.Sequential(stacked(concat, from_skip, n_conv - 1), stacked(from_skip, final_num_features, 1)))
+        return loc, tu, unet_final, tdown
+
+    # ------------------------------------------------------------------------------------------ engine plumbing
+    def _live_params(self):
+        return dict(self.named_parameters())
+
+    def _engine_for(self, x: torch.Tensor) -> Engine:
+        key = (tuple(x.shape), x.device.index)
+        eng = self._engines.get(key)
+        if eng is None:
+            for k in x.shape[2:]:
+                pass
+            div = self.input_shape_must_be_divisible_by
+            if any(int(s) % int(d) for s, d in zip(x.shape[2:], div)):
+                raise ValueError("input spatial shape %s must be divisible by %s" % (tuple(x.shape[2:]), tuple(div)))
+            eng = Engine(self._cfg, self._live_params(), x.shape[0], tuple(x.shape[2:]), x.device)
+            self._engines = {key: eng}                      # one live plan at a time (activations are large)
+            eng._sparsity_version = -1
+        eng.params = self._live_params()
+        self._sync_sparsity(eng)
+        return eng
+
+    def _invalidate_sparsity(self):
+        self._sparsity_version = getattr(self, "_sparsity_version", 0) + 1
+
+    def set_kernel_masks(self, kmasks):
+        """DSFF: name -> uint8 [dim0, dim1] kernel liveness map (from ``Masking``).  None = dense."""
+        self._kernel_masks = kmasks
+        self._auto_sparsity = False
+        self._invalidate_sparsity()
+
+    def enable_auto_sparsity(self, flag=True):
+        """Inference on a DSFF checkpoint: pruned kernels are exact zeros, skip them."""
+        self._auto_sparsity = flag
+        self._invalidate_sparsity()
+
+    def _sync_sparsity(self, eng):
+        ver = getattr(self, "_sparsity_version", 0)
+        if eng._sparsity_version == ver:
+            return
+        if self._kernel_masks is not None:
+            eng.set_kernel_masks(self._kernel_masks)
+        elif self._auto_sparsity:
+            eng.set_kernel_masks(eng.kernel_masks_from_weights())
+        else:
+            eng.set_kernel_masks({})
+        eng._sparsity_version = ver
+
+    # ------------------------------------------------------------------------------------------ forward
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("Generic_UNetPlusPlus (MI355X engine) needs a GPU tensor: there is no CPU fallback")
+        x = x.contiguous().float()
+        ds = bool(self._deep_supervision and self.do_ds)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            params = [p for _, p in self.named_parameters()]
+            outs = list(_EngineFunction.apply(self, x, ds, *params))
+        else:
+            eng = self._engine_for(x)
+            o = eng.forward(x, ds)
+            outs = [t.clone() for t in (o if isinstance(o, list) else [o])]
+        outs = [self.final_nonlin(o) for o in outs]
+        return outs if ds else outs[0]
+
+    def engine(self, x):
+        """The execution plan for inputs shaped like ``x`` (fast path used by the trainer and the benchmark)."""
+        return self._engine_for(x)

@@ -1,0 +1,262 @@
+"""Dynamic Sparse Feature Fusion masks (``Masking``) with the statistics on the GPU.
+
+Drop-in for reference e2enet/training/network_training/sparselearning/core_channel.py (``add_sparse_args`` :17-31,
+``CosineDecay`` :32-41, ``Masking`` :59-).  Behaviour kept bit for bit where the reference defines it:
+  * tensor selection by name (:324), uniform kernel-granular init with Python ``random.sample`` (:141-169, incl.
+    the ``shape[0] == 48`` density quirk), ``apply_mask`` on weights and momentum (:427-434),
+  * ``step`` = apply_mask -> cosine death-rate decay -> every ``update_frequency`` steps ``truncate_weights``
+    (:290-317, :556-611): kernel-L1 magnitude death (:647-666) then random growth (:721-739).
+Mechanism: the per-kernel L1 sums (same association order as the three chained ``torch.sum``), the exact k-th order
+statistic (radix select instead of a full sort) and the death comparison run as HIP kernels; the index draws stay
+on the host with Python's ``random`` so that the mask indices are bit-identical to the reference for the same seed.
+Only death_mode='magnitude' with growth_mode='random' (the CLI defaults, :24-25) are implemented.
+"""
+from __future__ import print_function
+
+import math
+import random
+
+import numpy as np
+import torch
+import torch.optim as optim
+
+from ...._lib import lib, ParamEntry
+
+
+def str2bool(s):
+    return True if s.lower() == 'true' else False
+
+
+def add_sparse_args(parser):
+    parser.add_argument('--sparse', type=str2bool, default=True, help='Enable sparse mode. Default: True.')
+    parser.add_argument('--adv', type=bool, default=False, help='adv sparse mode. Default: True.')
+    parser.add_argument('--init-prune-epoch', type=int, default=0, help='The pruning rate / death rate.')
+    parser.add_argument('--final-prune-epoch', type=int, default=1000, help='The density of the overall sparse network.')
+    parser.add_argument('--fix', type=bool, default=False, help='Fix sparse connectivity during training. Default: True.')
+    parser.add_argument('--sparse_init', type=str, default='uniform', help='sparse initialization: ERK, snip, Grasp')
+    parser.add_argument('--growth', type=str, default='random', help='Growth mode. Choose from: momentum, random, random_unfired, and gradient.')
+    parser.add_argument('--death', type=str, default='magnitude', help='Death mode / pruning mode. Choose from: magnitude, SET, threshold.')
+    parser.add_argument('--redistribution', type=str, default='none', help='Redistribution mode. Choose from: momentum, magnitude, nonzeros, or none.')
+    parser.add_argument('--death-rate', type=float, default=0.50, help='The pruning rate / death rate.')
+    parser.add_argument('--density', type=float, default=0.3, help='The density of the overall sparse network.')
+    parser.add_argument('--final_density', type=float, default=0.05, help='The density of the overall sparse network.')
+    parser.add_argument('--update_frequency', type=int, default=5, metavar='N', help='how many iterations to train between parameter exploration')
+    parser.add_argument('--decay-schedule', type=str, default='cosine', help='The decay schedule for the pruning rate. Default: cosine. Choose from: cosine, linear.')
+
+
+class CosineDecay(object):
+    """Death-rate schedule: torch CosineAnnealingLR on a dummy SGD (reference :32-41; the recursive form is kept
+    because it differs from the closed form in the last ulp)."""
+
+    def __init__(self, death_rate, T_max, eta_min=0.001, last_epoch=-1):
+        self.sgd = optim.SGD(torch.nn.ParameterList([torch.nn.Parameter(torch.zeros(1))]), lr=death_rate)
+        self.cosine_stepper = torch.optim.lr_scheduler.CosineAnnealingLR(self.sgd, T_max, eta_min, last_epoch)
+
+    def step(self):
+        self.cosine_stepper.step()
+
+    def get_dr(self):
+        return self.sgd.param_groups[0]['lr']
+
+
+class LinearDecay(object):
+    def __init__(self, death_rate, factor=0.99, frequency=600):
+        self.factor, self.steps, self.frequency = factor, 0, frequency
+
+    def step(self):
+        self.steps += 1
+
+    def get_dr(self, death_rate):
+        if self.steps > 0 and self.steps % self.frequency == 0:
+            return death_rate * self.factor
+        return death_rate
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Masking(object):
+    def __init__(self, optimizer, death_rate=0.3, growth_death_ratio=1.0, death_rate_decay=None, death_mode='magnitude',
+                 growth_mode='momentum', redistribution_mode='momentum', threshold=0.001, train_loader=None, T_max=0.,
+                 args=None, verbose=False):
+        if death_mode != 'magnitude' or growth_mode != 'random':
+            raise NotImplementedError("MI355X Masking implements death_mode='magnitude' with growth_mode='random' "
+                                      "(the reference CLI defaults, core_channel.py:24-25); got %s/%s"
+                                      % (death_mode, growth_mode))
+        self.args = args
+        self.device = torch.device("cuda")
+        self.growth_mode, self.death_mode = growth_mode, death_mode
+        self.growth_death_ratio = growth_death_ratio
+        self.redistribution_mode = redistribution_mode
+        self.death_rate_decay = death_rate_decay
+        self.verbose = verbose
+        self.masks = {}            # name -> float32 element mask (API parity with the reference)
+        self.kmasks = {}           # name -> uint8 [dim0, dim1] kernel map on the device (authoritative)
+        self._kmask_host = {}      # host mirror (numpy uint8), used for the index draws
+        self.modules, self.names = [], []
+        self.optimizer = optimizer
+        self.name2zeros, self.num_remove, self.num_death, self.name2nonzeros = {}, {}, {}, {}
+        self.death_rate = death_rate
+        self.baseline_nonzero = None
+        self.steps = 0
+        self.explore_step = 0
+        self.decay_flag = True
+        self.total_nozeros = self.total_weights = 0
+        self.loader = train_loader
+        self.adv = getattr(args, 'adv', False)
+        self.curr_density = 0.0
+        self.T_max = T_max
+        self.prune_every_k_steps = None if getattr(args, 'fix', False) else getattr(args, 'update_frequency', None)
+        self._table = None
+        self._table_keys = None
+
+    # ------------------------------------------------------------------------------------------ setup
+    def add_module(self, module, density, sparse_init='ER'):
+        self.modules.append(module)
+        self.module = module
+        self._params = {}
+        for name, tensor in module.named_parameters():
+            if ('loc' in name and 'context' not in name) or 'up' in name:        # reference :324
+                if 'bias' in name or 'instnorm' in name:                          # remove_weight_partial_name :329-331
+                    continue
+                self.names.append(name)
+                self._params[name] = tensor
+        self.init(mode=sparse_init, density=density)
+
+    def init(self, mode='ERK', density=0.05, erk_power_scale=1.0):
+        self.density = density
+        if mode != 'uniform':
+            raise NotImplementedError("only sparse_init='uniform' (the CLI default, core_channel.py:23) is implemented")
+        self.baseline_nonzero = 0
+        for name in self.names:                                   # named_parameters order == random draw order
+            w = self._params[name]
+            shp = tuple(w.shape)
+            density_n = 0.2 if shp[0] == 48 else density          # reference quirk :147-151
+            k_size = np.prod(shp[-3:])
+            nonzeros = w.numel() * density_n
+            kernel_num = round(nonzeros / k_size)
+            idx_rand = random.sample(list(range(0, shp[0] * shp[1])), kernel_num)
+            km = np.zeros(shp[0] * shp[1], dtype=np.uint8)
+            km[np.asarray(idx_rand, dtype=np.int64)] = 1
+            self._set_kmask(name, km.reshape(shp[0], shp[1]))
+            self.baseline_nonzero += int(km.sum()) * int(k_size)
+            if self.verbose:
+                print("layer: %s, shape: %s, density: %f" % (name, shp, km.mean()))
+        self._push_liveness()
+        self.apply_mask()
+        total = sum(m.numel() for m in self.masks.values())
+        sparse = sum(int(self._kmask_host[n].sum()) * int(np.prod(self._params[n].shape[-3:])) for n in self.names)
+        print('Total Model parameters:', total)
+        print('Total parameters under sparsity level of {0}: {1}'.format(self.density, sparse / total))
+
+    def _set_kmask(self, name, km_host: np.ndarray):
+        w = self._params[name]
+        dev = w.device
+        self._kmask_host[name] = km_host
+        km = torch.from_numpy(km_host).to(dev)
+        self.kmasks[name] = km
+        mask = self.masks.get(name)
+        if mask is None or mask.device != dev:
+            mask = torch.empty(w.shape, dtype=torch.float32, device=dev)
+            self.masks[name] = mask
+        r, cc = km_host.shape
+        ks = int(np.prod(w.shape[-3:]))
+        lib().dsff_expand(km.data_ptr(), mask.data_ptr(), None, None, r, cc, ks, _stream())
+        self._table = None
+
+    def _push_liveness(self):
+        for m in self.modules:
+            if hasattr(m, "set_kernel_masks"):
+                m.set_kernel_masks(dict(self.kmasks))
+
+    # ------------------------------------------------------------------------------------------ per-step
+    def _build_table(self):
+        entries, keep = [], []
+        for name in self.names:
+            w = self._params[name]
+            st = self.optimizer.state.get(w, {}) if self.optimizer is not None else {}
+            buf = st.get('momentum_buffer')
+            entries.append(ParamEntry(w.data_ptr(), None, buf.data_ptr() if buf is not None else None,
+                                      self.masks[name].data_ptr(), w.numel()))
+            keep.append((w.data_ptr(), buf.data_ptr() if buf is not None else 0))
+        raw = b"".join(bytes(e) for e in entries)
+        dev = self._params[self.names[0]].device
+        self._table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        self._table_keys = keep
+
+    def apply_mask(self):
+        """weight *= mask; momentum_buffer *= mask (reference :427-434), one multi-tensor HIP launch."""
+        if not self.names:
+            return
+        keys = []
+        for name in self.names:
+            w = self._params[name]
+            st = self.optimizer.state.get(w, {}) if self.optimizer is not None else {}
+            buf = st.get('momentum_buffer')
+            keys.append((w.data_ptr(), buf.data_ptr() if buf is not None else 0))
+        if self._table is None or keys != self._table_keys:
+            self._build_table()
+        lib().apply_mask(self._table.data_ptr(), len(self.names), _stream())
+
+    def step(self, masks_already_applied=False):
+        """reference :290-317.  ``masks_already_applied``: the fused optimizer kernel already multiplied weights and
+        momentum by the masks this iteration."""
+        if not masks_already_applied:
+            self.apply_mask()
+        if self.decay_flag:
+            self.death_rate_decay.step()
+            self.death_rate = self.death_rate_decay.get_dr()
+        else:
+            self.death_rate = 0.001
+            self.adv = False
+        self.steps += 1
+        if self.prune_every_k_steps is not None and self.steps % self.prune_every_k_steps == 0:
+            self.explore_step += 1
+            self.truncate_weights()
+            self.cal_nonzero_counts()
+            self.curr_density = self.total_nozeros / self.total_weights
+            print('curr_density: {0:.4f}, final_density:{1:.4f}'.format(self.curr_density,
+                                                                         getattr(self.args, 'final_density', 0.0)))
+            return True
+        return False
+
+    def cal_nonzero_counts(self):
+        self.total_nozeros = self.total_weights = 0
+        for name in self.names:
+            ks = int(np.prod(self._params[name].shape[-3:]))
+            self.total_nozeros += int(self._kmask_host[name].sum()) * ks
+            self.total_weights += self._params[name].numel()
+
+    # ------------------------------------------------------------------------------------------ prune / grow
+    def truncate_weights(self):
+        L = lib()
+        dev = self._params[self.names[0]].device
+        nmax = max(self._kmask_host[n].size for n in self.names)
+        l1 = torch.empty(nmax, dtype=torch.float32, device=dev)
+        thr = torch.empty(1, dtype=torch.float32, device=dev)
+        for name in self.names:                                    # death pass (reference :558-581)
+            w = self._params[name]
+            km_h = self._kmask_host[name]
+            r, cc = km_h.shape
+            kd, kh, kw = (int(v) for v in w.shape[-3:])
+            k_size = kd * kh * kw
+            nonzeros = float(int(km_h.sum()) * k_size)             # mask.sum().item()
+            zeros = w.numel() - nonzeros
+            self.name2nonzeros[name], self.name2zeros[name] = nonzeros, zeros
+            prune_num = math.ceil(self.death_rate * nonzeros / k_size)
+            num_zeros = math.ceil(zeros / k_size)
+            L.dsff_kernel_l1(w.data_ptr(), l1.data_ptr(), r, cc, kd, kh, kw, _stream())
+            L.dsff_kth_value(l1.data_ptr(), r * cc, num_zeros + prune_num - 1, thr.data_ptr(), None, _stream())
+            L.dsff_death(l1.data_ptr(), thr.data_ptr(), self.kmasks[name].data_ptr(), r * cc, _stream())
+            self.num_death[name] = prune_num
+        for name in self.names:                                    # growth pass (reference :583-609)
+            km = self.kmasks[name].cpu().numpy().copy()
+            self.num_remove[name] = int(self._kmask_host[name].sum()) - int(km.sum())
+            cand = np.flatnonzero(km.reshape(-1) < 1)              # row-major (dim0, dim1), reference :732
+            idx_rand = random.sample(list(range(0, cand.shape[0])), self.num_death[name])
+            flat = km.reshape(-1)
+            flat[cand[np.asarray(idx_rand, dtype=np.int64)]] = 1
+            self._set_kmask(name, flat.reshape(km.shape))
+        self._push_liveness()
+        self.apply_mask()

@@ -1,0 +1,213 @@
+/*
+ * e2e_hip.h -- C ABI of libe2e_hip.so: the MI355X (gfx950) kernels of the E2ENet
+ * shiftConvPP + DSFF hot path.
+ *
+ * The reference (boqian333/E2ENet-Medical) has no FFI: its hot path bottoms out in
+ * PyTorch operators.  Every entry point below names the reference call site(s) whose
+ * arithmetic it replaces (paths relative to the reference repo root).  Conventions:
+ *   - all pointers are DEVICE pointers unless marked host; fp32 NCDHW activations;
+ *   - no ownership transfer: the caller (PyTorch-ROCm tensors) owns every buffer,
+ *     workspaces are passed in; nothing is allocated or synchronised inside;
+ *   - `stream` is a hipStream_t passed as void*; calls are asynchronous on it and
+ *     graph-capturable;
+ *   - return 0 on success, negative E2E_ERR_* otherwise; e2e_last_error() returns a
+ *     thread-local message.
+ */
+#ifndef E2E_HIP_H
+#define E2E_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define E2E_OK 0
+#define E2E_ERR_ARG (-1)
+#define E2E_ERR_LAUNCH (-2)
+#define E2E_ERR_UNSUPPORTED (-3)
+
+const char* e2e_last_error(void);
+int e2e_abi_version(void);
+
+/* One input plane (channel) of a convolution whose input is the *virtual* concatenation
+ * [skip, up, down] (unetpp_d.py:453-478) followed by the restricted depth shift
+ * (unetpp_d.py:45-59).  Neither the concat nor the shift is ever materialised: the load
+ * stage reads plane `ptr` at depth d - dshift and applies the producer's InstanceNorm
+ * affine + LeakyReLU on the fly (unetpp_d.py:111).                                      */
+typedef struct {
+  const float* ptr;     /* element [n=0, this channel, 0,0,0] of the source tensor        */
+  const float* scale;   /* IN scale for (n=0, channel); NULL => raw source (no transform)  */
+  const float* shift;   /* IN shift, same indexing                                        */
+  long long nstride;    /* elements between batch items of the source tensor              */
+  int ab_nstride;       /* elements between batch items of scale/shift (= source C)       */
+  int dshift;           /* s(c): shifted[d] = x[d - s], zero outside                      */
+  float slope;          /* LeakyReLU negative slope applied after the affine (1 = none)   */
+  int reserved;
+} e2e_in_chan_t;
+
+/* One output plane of a scatter epilogue (conv dgrad): the gradient of virtual-concat
+ * channel c computed at depth d is stored at depth d - dshift of `ptr` (un-shift on
+ * store), `accumulate` != 0 adds to what is there.                                      */
+typedef struct {
+  float* ptr;
+  long long nstride;
+  int dshift;
+  int accumulate;
+} e2e_out_chan_t;
+
+/* ---- K1: 1x3x3 convolution, forward ------------------------------------------------
+ * Replaces: torch_shift.forward (unetpp_d.py:45-59) + torch.cat (unetpp_d.py:453-478) +
+ * nn.Conv3d k(1,3,3) pad(0,1,1) stride (sd,sh,sw) bias (unetpp_d.py:93,108) and the
+ * statistics pass of nn.InstanceNorm3d (unetpp_d.py:99,111).
+ *   chans   [Cin]            device table (see e2e_in_chan_t)
+ *   w       [Cout,Cin,1,3,3] (DSFF-masked weights; dead kernels are exact zeros)
+ *   live    [Cout, ceil(Cin/32)] bit c%32 of word c/32 set <=> kernel (o,c) is alive;
+ *           NULL => dense
+ *   y       [B,Cout,Do,Ho,Wo] pre-norm output, Do=(Di-1)/sd+1, Ho=(Hi-1)/sh+1, ...
+ *   part    [B,Cout,np,3] per-tile (count, mean, M2) partials, np =
+ *           e2e_conv133_num_partials(Do,Ho,Wo,sh,sw); NULL => no statistics
+ */
+int e2e_conv133_num_partials(int Do, int Ho, int Wo, int sh, int sw);
+int e2e_conv133_fwd(const e2e_in_chan_t* chans, int Cin, const float* w, const float* bias,
+                    const unsigned* live, float* y, float* part, int B, int Cout, int Di, int Hi,
+                    int Wi, int sd, int sh, int sw, void* stream);
+
+/* ---- K6a: 1x3x3 convolution, data gradient ------------------------------------------
+ * Replaces: autograd of the Conv3d + cat + torch_shift chain w.r.t. its inputs
+ * (nnUNetTrainer_simple.py:572 l.backward()).
+ *   dy    [B,Cout,Do,Ho,Wo] gradient w.r.t. the pre-norm conv output
+ *   outs  [Cin] destinations, one per virtual-concat input channel (un-shift on store)
+ *   live_t [Cin, ceil(Cout/32)] transposed liveness bits; NULL => dense
+ */
+int e2e_conv133_dgrad(const float* dy, const float* w, const unsigned* live_t, const e2e_out_chan_t* outs,
+                      int B, int Cin, int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw, void* stream);
+
+/* ---- K6b: 1x3x3 convolution, weight gradient (dense: also for dead kernels, because the
+ * reference's clip_grad_norm_ runs over all gradients, nnUNetTrainer_simple.py:573) ----
+ *   dw   [Cout,Cin,1,3,3] (overwritten)
+ *   ws   workspace of e2e_conv133_wgrad_ws_bytes(...) bytes
+ */
+long long e2e_conv133_wgrad_ws_bytes(int B, int Cin, int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw);
+int e2e_conv133_wgrad(const e2e_in_chan_t* chans, const float* dy, float* dw, void* ws, int B, int Cin,
+                      int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw, void* stream);
+
+/* ---- K2: InstanceNorm statistics finalize --------------------------------------------
+ * Replaces: nn.InstanceNorm3d(eps, affine, instance statistics) (unetpp_d.py:99,111):
+ * combines the per-tile partials (Chan) in fp64 and emits per-(n,c)
+ *   scale = gamma * rstd, shift = beta - mean * gamma * rstd   (consumed on load), mean, rstd.
+ */
+int e2e_in_stats_finalize(const float* part, int np, const float* gamma, const float* beta, float eps,
+                          float* scale, float* shift, float* mean, float* rstd, int B, int C, void* stream);
+
+/* ---- K7: InstanceNorm + LeakyReLU backward -------------------------------------------
+ * Given dz = dL/d(lrelu(IN(y))) and the saved pre-norm y, overwrite dz with dy = dL/dy and
+ * produce dgamma, dbeta (accumulated over the batch) and dbias = sum(dy).
+ *   sums  workspace [B,C,2] floats
+ */
+int e2e_in_lrelu_bwd(float* dz_dy, const float* y, const float* mean, const float* rstd, const float* gamma,
+                     const float* beta, float slope, float* dgamma, float* dbeta, float* dbias, float* sums,
+                     int B, int C, long long spatial, void* stream);
+
+/* ---- K3: transposed convolution, kernel == stride in {1,2}^3, no bias ------------------
+ * Replaces: nn.ConvTranspose3d(Cin,Cout,k,k,bias=False) (unetpp_d.py:521-522).
+ *   x   [B,Cin,D,H,W] pre-norm producer output + (scale,shift) [B,Cin] (NULL => raw), slope
+ *   w   [Cin,Cout,kd,kh,kw];  live [Cout, ceil(Cin/32)] bits or NULL
+ *   y   [B,Cout,D*kd,H*kh,W*kw]
+ */
+int e2e_convT_fwd(const float* x, const float* scale, const float* shift, float slope, const float* w,
+                  const unsigned* live, float* y, int B, int Cin, int Cout, int D, int H, int W, int kd,
+                  int kh, int kw, void* stream);
+/* dgrad: dx (gradient w.r.t. the *post-activation* input) [B,Cin,D,H,W]; accumulate != 0 adds.
+ * live_t [Cin, ceil(Cout/32)] or NULL. */
+int e2e_convT_dgrad(const float* dy, const float* w, const unsigned* live_t, float* dx, int accumulate, int B,
+                    int Cin, int Cout, int D, int H, int W, int kd, int kh, int kw, void* stream);
+/* wgrad (dense): dw [Cin,Cout,kd,kh,kw] overwritten; ws of e2e_convT_wgrad_ws_bytes bytes. */
+long long e2e_convT_wgrad_ws_bytes(int B, int Cin, int Cout, int D, int H, int W, int kd, int kh, int kw);
+int e2e_convT_wgrad(const float* x, const float* scale, const float* shift, float slope, const float* dy,
+                    float* dw, void* ws, int B, int Cin, int Cout, int D, int H, int W, int kd, int kh, int kw,
+                    void* stream);
+
+/* ---- K4: max pooling, kernel == stride ------------------------------------------------
+ * Replaces: nn.MaxPool3d(k) (unetpp_d.py:523-524) on a normalise-on-load source. */
+int e2e_maxpool_fwd(const float* x, const float* scale, const float* shift, float slope, float* y, int B, int C,
+                    int D, int H, int W, int kd, int kh, int kw, void* stream);
+/* dx [B,C,D,H,W] (w.r.t. the post-activation input; first maximum in scan order wins, as ATen). */
+int e2e_maxpool_bwd(const float* x, const float* scale, const float* shift, float slope, const float* dy,
+                    float* dx, int accumulate, int B, int C, int D, int H, int W, int kd, int kh, int kw,
+                    void* stream);
+
+/* ---- K5: 1x1x1 segmentation head, no bias ----------------------------------------------
+ * Replaces: nn.Conv3d(C,K,1,bias=False) (unetpp_d.py:394-401, used :480-483). */
+int e2e_head1x1_fwd(const float* x, const float* scale, const float* shift, float slope, const float* w,
+                    float* logits, int B, int C, int K, long long spatial, void* stream);
+int e2e_head1x1_dgrad(const float* dlogits, const float* w, float* dx, int accumulate, int B, int C, int K,
+                      long long spatial, void* stream);
+long long e2e_head1x1_wgrad_ws_bytes(int B, int C, int K, long long spatial);
+int e2e_head1x1_wgrad(const float* x, const float* scale, const float* shift, float slope,
+                      const float* dlogits, float* dw, void* ws, int B, int C, int K, long long spatial,
+                      void* stream);
+
+/* ---- K8: softmax + soft-Dice + cross-entropy, forward and gradient ----------------------
+ * Replaces: DC_and_CE_loss (dice_loss.py:302-359, :156-192, :100-153, crossentropy.py:4-12) for one
+ * deep-supervision scale; MultipleOutputLoss2 weights (deep_supervision.py:31-43) enter as `weight`.
+ *   target  [B,1,spatial] float labels;  acc [B,K,3]+[1] fp64 workspace (tp,fp,fn ; ce sum) zeroed by caller
+ *   loss_out: *loss_out += weight * (ce + dice)   (device scalar, fp32)
+ *   dlogits [B,K,spatial] = weight * dL/dlogits
+ */
+long long e2e_loss_ws_bytes(int B, int K);
+int e2e_dc_ce_reduce(const float* logits, const float* target, void* acc, int B, int K, long long spatial,
+                     void* stream);
+int e2e_dc_ce_grad(const float* logits, const float* target, const void* acc, float weight, int batch_dice,
+                   float smooth, float* dlogits, float* loss_out, int B, int K, long long spatial, void* stream);
+
+/* ---- K10: clip_grad_norm_ + SGD(nesterov) + DSFF mask, multi-tensor ---------------------
+ * Replaces: torch.nn.utils.clip_grad_norm_(params, 12) + torch.optim.SGD.step (nnUNetTrainer_simple.py:573-574,
+ * :369-370) + Masking.apply_mask (core_channel.py:427-434).
+ *   table: device array of n entries {param, grad, momentum, mask-or-NULL, numel} */
+typedef struct {
+  float* param;
+  const float* grad;
+  float* momentum;
+  const float* mask;
+  long long numel;
+} e2e_param_t;
+int e2e_grad_sqnorm(const e2e_param_t* table, int n, double* sq_out /* device, zeroed by callee */, void* stream);
+int e2e_sgd_clip_mask_step(const e2e_param_t* table, int n, const double* sq_norm, float max_norm, float lr,
+                           float weight_decay, float momentum, int nesterov, int first_step, void* stream);
+int e2e_apply_mask(const e2e_param_t* table, int n, void* stream);
+
+/* ---- K9: DSFF kernel statistics ---------------------------------------------------------
+ * Replaces: the three chained torch.sum(|w|, dim=-1) of kernel_death (core_channel.py:652-655; the association
+ * order is reproduced bit for bit), torch.sort + threshold (:658-661) as an exact k-th order statistic
+ * (radix select), and the liveness bit tables consumed by K1/K3/K6.
+ *   w [R, Cc, kd,kh,kw] -> l1 [R*Cc] */
+int e2e_dsff_kernel_l1(const float* w, float* l1, int R, int Cc, int kd, int kh, int kw, void* stream);
+/* kth: value of the k-th smallest (0-based) of n non-negative floats; ws >= 4096 bytes */
+int e2e_dsff_kth_value(const float* v, int n, int k, float* out, void* ws, void* stream);
+/* kmask [R*Cc] u8: kmask &= !(l1 <= *thr) */
+int e2e_dsff_death(const float* l1, const float* thr, unsigned char* kmask, int n, void* stream);
+/* expand a kernel-granular u8 map to the fp32 element mask [R,Cc,ks] and to liveness bit tables:
+ * bits_rows [R, ceil(Cc/32)] and bits_cols [Cc, ceil(R/32)] (either may be NULL) */
+int e2e_dsff_expand(const unsigned char* kmask, float* mask, unsigned* bits_rows, unsigned* bits_cols, int R,
+                    int Cc, int ks, void* stream);
+/* kernel map from weights (inference: live <=> any nonzero tap) */
+int e2e_dsff_kmask_from_weights(const float* w, unsigned char* kmask, int R, int Cc, int ks, void* stream);
+
+/* ---- K11: sliding-window aggregation ------------------------------------------------------
+ * Replaces: _internal_maybe_mirror_and_pred_3D accumulation (neural_network.py:529-563) and the overlap-add /
+ * normalise / argmax of _internal_predict_3D_3Dconv_tiled (neural_network.py:383-407).            */
+/* dst[n,c,flip(x)] = src  (torch.flip over the set bits of `axes`: bit0=X(dim2), bit1=Y, bit2=Z)   */
+int e2e_flip3d(const float* src, float* dst, int NC, int X, int Y, int Z, int axes, void* stream);
+/* result (+)= w * flip(softmax_c(logits));  first != 0 overwrites */
+int e2e_softmax_flip_acc(const float* logits, float* result, float w, int first, int K, int X, int Y, int Z,
+                         int axes, void* stream);
+/* agg[:, x0:x0+px, ...] += patch * gauss (gauss NULL => 1); cnt[x..] += gauss (or 1) */
+int e2e_sw_accumulate(const float* patch, const float* gauss, float* agg, float* cnt, int K, int X, int Y, int Z,
+                      int px, int py, int pz, int x0, int y0, int z0, void* stream);
+/* probs = agg[crop]/cnt[crop]; seg = argmax_k (first max), int64 */
+int e2e_sw_finalize_argmax(const float* agg, const float* cnt, float* probs, long long* seg, int K, int X, int Y,
+                           int Z, int cx0, int cy0, int cz0, int CX, int CY, int CZ, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* E2E_HIP_H */

@@ -1,0 +1,259 @@
+"""Whole-network parity of the MI355X engine: against the reference's golden vectors (tests/golden, produced by
+tools/make_golden.py from the reference itself) and against the CPU oracle on the same seeded inputs.
+Bars (BASELINE.json north_star): |dlogit| <= 1e-4, Dice >= 1 - 1e-3, DSFF mask indices bit exact."""
+import random
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+import oracle
+from oracle import network as onet
+from tests.helpers import (golden, closed_form_params, seeded_input, seeded_labels, pack_kernel_mask, sha_of)
+
+pytestmark = pytest.mark.gpu
+
+TINY = dict(patch=(16, 32, 32), cin=2, base=8, k=3, pools=[(2, 2, 2)] * 3 + [(1, 2, 2)] * 2, max_feat=32)
+
+
+def build_net(patch, cin, base, k, pools, max_feat=None):
+    from e2enet_medical_amd.network_architecture.unetpp_d import Generic_UNetPlusPlus
+    from e2enet_medical_amd.network_architecture.initialization import InitWeights_He
+    net = Generic_UNetPlusPlus(patch, cin, base, k, 5, 2, 2, nn.Conv3d, nn.InstanceNorm3d, {'eps': 1e-5, 'affine': True},
+                               nn.Dropout3d, {'p': 0, 'inplace': True}, nn.LeakyReLU,
+                               {'negative_slope': 1e-2, 'inplace': True}, True, False, lambda x: x, InitWeights_He(1e-2),
+                               pools, None, False, True, True, max_num_features=max_feat)
+    return net.cuda()
+
+
+def load_closed_form(net):
+    shapes = {n: tuple(p.shape) for n, p in net.named_parameters()}
+    params = closed_form_params(shapes)
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            p.copy_(params[n])
+    return shapes, params
+
+
+def tiny_net():
+    net = build_net(TINY["patch"], TINY["cin"], TINY["base"], TINY["k"], TINY["pools"], TINY["max_feat"])
+    shapes, params = load_closed_form(net)
+    return net, shapes, params
+
+
+def test_native_library_is_loaded():
+    from e2enet_medical_amd._lib import lib, LIB_PATH
+    assert lib().abi_version() == 1
+    with open("/proc/self/maps") as f:
+        assert any(LIB_PATH in line for line in f), "libe2e_hip.so is not mapped into this process"
+
+
+def test_cpu_input_fails_loudly():
+    net, _, _ = tiny_net()
+    with pytest.raises(RuntimeError):
+        net(torch.zeros((1, TINY["cin"]) + TINY["patch"]))
+
+
+def test_tiny_forward_backward_vs_reference_golden():
+    g = golden("net_tiny.npz")
+    net, shapes, _ = tiny_net()
+    x = seeded_input((2, TINY["cin"]) + TINY["patch"], seed=21).cuda()
+    outs = net(x)                                          # autograd path (one node for the whole net)
+    assert len(outs) == 4
+    for i, o in enumerate(outs):
+        err = np.abs(o.detach().cpu().numpy() - g["logits%d" % i]).max()
+        assert err <= 1e-4, "logits%d: %g" % (i, err)
+    from e2enet_medical_amd.training.loss_functions.dice_loss import DC_and_CE_loss
+    from e2enet_medical_amd.training.loss_functions.deep_supervision import MultipleOutputLoss2
+    targets = [seeded_labels((o.shape[0], 1) + tuple(o.shape[2:]), TINY["k"], seed=30 + i).cuda() for i, o in enumerate(outs)]
+    loss_fn = MultipleOutputLoss2(DC_and_CE_loss({'batch_dice': False, 'smooth': 1e-5, 'do_bg': False}, {}), g["ds_weights"])
+    loss = loss_fn(outs, targets)
+    assert abs(loss.item() - float(g["loss"])) < 2e-5
+    loss.backward()
+    names = [str(s) for s in g["names"]]
+    got_l2 = np.array([net.get_parameter(n).grad.double().norm().item() for n in names])
+    np.testing.assert_allclose(got_l2, g["grad_l2"], rtol=5e-3, atol=2e-6)
+    for key in g.files:
+        if key.startswith("grad::"):
+            ref = g[key]
+            got = net.get_parameter(key[6:]).grad.cpu().numpy()
+            assert np.abs(got - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max()), key
+    net.do_ds = False
+    with torch.no_grad():
+        full = net(x)
+    assert full.shape == outs[0].shape
+    assert abs(full.double().sum().item() - float(g["logits_nods_sum"])) < 5e-2
+
+
+def test_tiny_engine_fastpath_matches_oracle_all_grads():
+    """Engine fast path (fused loss kernels + backward) against the oracle's autograd for every parameter."""
+    net, shapes, params = tiny_net()
+    spec = oracle.make_spec(TINY["cin"], TINY["base"], TINY["k"], TINY["pools"], 2, TINY["max_feat"])
+    x = seeded_input((2, TINY["cin"]) + TINY["patch"], seed=77)
+    eng = net.engine(x.cuda())
+    outs = eng.forward(x.cuda(), True)
+    targets = [seeded_labels((o.shape[0], 1) + tuple(o.shape[2:]), TINY["k"], seed=80 + i) for i, o in enumerate(outs)]
+    w = oracle.ds_weights(5)
+    for bd in (False, True):
+        loss = eng.loss_backward([t.cuda() for t in targets], w, batch_dice=bd)
+        leaves = {n: p.clone().requires_grad_(True) for n, p in params.items()}
+        ref = oracle.forward(spec, leaves, x)
+        ref_loss = oracle.deep_supervision_loss(ref, targets, w, bd)
+        ref_loss.backward()
+        assert abs(loss.item() - ref_loss.item()) < 2e-5
+        for o, r in zip(outs, ref):
+            assert (o.cpu() - r.detach()).abs().max() <= 1e-4
+        for n in shapes:
+            rg = leaves[n].grad
+            err = (eng.grads[n].cpu() - rg).abs().max().item()
+            assert err <= 2e-4 * max(1.0, rg.abs().max().item()) + 1e-6, (n, err)
+
+
+def test_net64_sparse_forward_vs_reference_golden():
+    """64^3, base 32, Cin 4, K 4, DSFF density 0.2 (SURVEY golden #4): masks bit exact, logits within 1e-4."""
+    from e2enet_medical_amd.training.network_training.sparselearning.core_channel import Masking, CosineDecay
+    g = golden("net64.npz")
+    net = build_net((64, 64, 64), 4, 32, 4, [(2, 2, 2)] * 5)
+    load_closed_form(net)
+    opt = torch.optim.SGD(net.parameters(), 1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)
+
+    class A:
+        adv = False
+        fix = False
+        update_frequency = 1
+        final_density = 0.05
+    random.seed(0)
+    mask = Masking(opt, death_rate=0.5, death_mode='magnitude', death_rate_decay=CosineDecay(0.5, 10), growth_mode='random',
+                   redistribution_mode='none', args=A())
+    mask.add_module(net, sparse_init='uniform', density=0.2)
+    assert list(mask.masks.keys()) == [str(s) for s in g["mask_names"]]
+    assert [sha_of(pack_kernel_mask(m.cpu())) for m in mask.masks.values()] == [str(s) for s in g["mask_sha"]]
+    assert [int(m.sum().item()) for m in mask.masks.values()] == list(g["mask_nnz"])
+    net.eval()
+    x = seeded_input((1, 4, 64, 64, 64), seed=41).cuda()
+    with torch.no_grad():
+        outs = net(x)
+    assert np.abs(outs[0][0, :, 32].cpu().numpy() - g["slice_d32"]).max() <= 1e-4
+    assert np.abs(outs[0][0, :, :, 5].cpu().numpy() - g["slice_h5"]).max() <= 1e-4
+    assert np.abs(outs[1].cpu().numpy()[0, :, ::4] - g["logits1"]).max() <= 1e-4
+    for i, o in enumerate(outs):
+        assert abs(o.double().abs().sum().item() - float(g["abs%d" % i])) <= 2e-5 * float(g["abs%d" % i])
+    # dense execution of the same masked weights gives the same logits (liveness bits only skip exact zeros)
+    net.set_kernel_masks(None)
+    with torch.no_grad():
+        dense = net(x)
+    assert (dense[0] - outs[0]).abs().max().item() <= 2e-5
+    # inference-style liveness derived from the zero kernels of the weights
+    net.enable_auto_sparsity(True)
+    with torch.no_grad():
+        auto = net(x)
+    assert torch.equal(auto[0], outs[0])
+
+
+def test_sparse_training_two_steps_vs_reference_golden():
+    """Two reference training iterations (run_iteration, non-AMP) on the tiny net with DSFF, prune/grow at step 2:
+    losses, clip norm, death rate, updated weights within tolerance; mask indices bit exact."""
+    from e2enet_medical_amd.training.network_training.sparselearning.core_channel import Masking, CosineDecay
+    from e2enet_medical_amd.training.fused_optim import FusedClipSGD
+    g = golden("net_sparse_tiny.npz")
+    net, shapes, _ = tiny_net()
+    opt = torch.optim.SGD(net.parameters(), 1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)
+
+    class A:
+        adv = False
+        fix = False
+        update_frequency = 2
+        final_density = 0.05
+    random.seed(5)
+    mask = Masking(opt, death_rate=0.5, death_mode='magnitude', death_rate_decay=CosineDecay(0.5, 10), growth_mode='random',
+                   redistribution_mode='none', args=A())
+    mask.add_module(net, sparse_init='uniform', density=0.3)
+    names = [str(s) for s in g["names"]]
+    assert list(mask.masks.keys()) == names
+    for n in names:
+        assert np.array_equal(pack_kernel_mask(mask.masks[n].cpu()), g["mask0::" + n]), n
+    x = seeded_input((2, TINY["cin"]) + TINY["patch"], seed=21).cuda()
+    w = oracle.ds_weights(5)
+    fused = FusedClipSGD(opt, list(net.named_parameters()), 12.0)
+    eng = net.engine(x)
+    losses = []
+    for it in range(2):
+        outs = eng.forward(x, True)
+        targets = [seeded_labels((o.shape[0], 1) + tuple(o.shape[2:]), TINY["k"], seed=30 + i).cuda() for i, o in enumerate(outs)]
+        if it == 0:
+            assert np.abs(outs[0].cpu().numpy() - g["logits0_it0"]).max() <= 1e-4
+        loss = eng.loss_backward(targets, w, batch_dice=False)
+        if it == 0:
+            l2 = np.array([eng.grads[n].double().norm().item() for n in shapes])
+            np.testing.assert_allclose(l2, g["grad_l2_it0"], rtol=5e-3, atol=2e-6)
+        fused.step(eng.grads, mask.masks)
+        tn = fused.total_norm()
+        assert abs(tn - float(g["total_norm_it%d" % it])) <= 2e-3 * float(g["total_norm_it%d" % it])
+        mask.step(masks_already_applied=True)
+        assert mask.death_rate == float(g["death_rate_it%d" % it])
+        losses.append(loss.item())
+    np.testing.assert_allclose(losses, g["losses"], rtol=0, atol=5e-5)
+    for n in names:                                             # after magnitude death + random growth
+        assert np.array_equal(pack_kernel_mask(mask.masks[n].cpu()), g["mask2::" + n]), n
+    sd = net.state_dict()
+    for key in g.files:
+        if key.startswith("param_after::"):
+            assert np.abs(sd[key[13:]].cpu().numpy() - g[key]).max() <= 5e-5, key
+    got_abs = np.array([sd[n].double().abs().sum().item() for n in shapes])
+    np.testing.assert_allclose(got_abs, g["param_abs_after"], rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("tag,kw", [("tta", dict(do_mirroring=True, mirror_axes=(0, 1, 2))),
+                                    ("notta", dict(do_mirroring=False, mirror_axes=(0, 1, 2))),
+                                    ("tta01", dict(do_mirroring=True, mirror_axes=(0, 1)))])
+def test_predict_3d_vs_reference_golden(tag, kw):
+    from e2enet_medical_amd.utilities.nd_softmax import softmax_helper
+    g = golden("sliding.npz")
+    net, _, _ = tiny_net()
+    net.inference_apply_nonlin = softmax_helper
+    net.eval()
+    net.do_ds = False
+    vol = seeded_input((TINY["cin"], 13, 50, 70), seed=71).numpy()
+    seg, probs = net.predict_3D(vol, use_sliding_window=True, step_size=0.5, patch_size=TINY["patch"], use_gaussian=True,
+                                all_in_gpu=False, verbose=False, mixed_precision=False, **kw)
+    assert seg.shape == (13, 50, 70) and seg.dtype == np.int64 and probs.dtype == np.float32
+    ref_seg = g["pred_%s_seg" % tag].astype(np.int64)
+    for label in range(1, TINY["k"]):
+        assert oracle.hard_dice(seg, ref_seg, label) >= 1 - 1e-3
+    assert (seg != ref_seg).mean() < 1e-3
+    assert np.abs(probs[:, 6, ::2, ::2] - g["pred_%s_probs_slice" % tag]).max() <= 2e-5
+    np.testing.assert_allclose(probs.astype(np.float64).sum(axis=(1, 2, 3)), g["pred_%s_probs_sum" % tag], rtol=1e-5)
+
+
+def test_trainer_surface_runs_iterations():
+    """nnUNetTrainer_simple surface: plans dict -> initialize -> run_iteration with Masking; loss finite, masks kept."""
+    from e2enet_medical_amd.training.network_training.nnUNetTrainer_simple import nnUNetTrainer_simple
+    from e2enet_medical_amd.training.network_training.sparselearning.core_channel import Masking, CosineDecay
+    plans = {'plans_per_stage': {0: {'batch_size': 2, 'patch_size': [16, 32, 32], 'num_pool_per_axis': [3, 5, 5],
+                                     'pool_op_kernel_sizes': [[2, 2, 2]] * 3 + [[1, 2, 2]] * 2,
+                                     'conv_kernel_sizes': [[3, 3, 3]] * 6, 'do_dummy_2D_data_aug': False}},
+             'base_num_features': 32, 'num_modalities': 1, 'num_classes': 2, 'all_classes': [1, 2],
+             'transpose_forward': [0, 1, 2], 'transpose_backward': [0, 1, 2], 'conv_per_stage': 2}
+    tr = nnUNetTrainer_simple(plans, 0, output_folder=None, batch_dice=False, Tconv='shiftConvPP', max_num_epochs=2,
+                              num_batches_per_epoch=2)
+    tr.base_num_features_override = 8
+    torch.manual_seed(0)
+    net, opt = tr.initialize(True)
+
+    class A:
+        adv = False
+        fix = False
+        update_frequency = 2
+        final_density = 0.05
+    random.seed(0)
+    mask = Masking(opt, death_rate=0.5, death_mode='magnitude', death_rate_decay=CosineDecay(0.5, 4), growth_mode='random',
+                   redistribution_mode='none', args=A())
+    mask.add_module(net, sparse_init='uniform', density=0.2)
+    nnz0 = {n: int(m.sum().item()) for n, m in mask.masks.items()}
+    losses = [float(tr.run_iteration(tr.tr_gen, True, mask=mask)) for _ in range(3)]
+    assert all(np.isfinite(losses))
+    assert {n: int(m.sum().item()) for n, m in mask.masks.items()} == nnz0        # prune/grow conserves the kernel count
+    for n, m in mask.masks.items():                                               # dead kernels stay exactly zero
+        assert float((net.get_parameter(n).detach() * (1 - m)).abs().max()) == 0.0
+    v = float(tr.run_iteration(tr.val_gen, False))
+    assert np.isfinite(v)

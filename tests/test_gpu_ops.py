@@ -1,0 +1,387 @@
+"""Op-level parity of the HIP kernels (through the C ABI) against the CPU oracle on seeded inputs.
+Tolerances: fp32 paths compare at 1e-4-ish absolute on O(1) data; index / mask / integer results are bit exact."""
+import math
+import random
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle
+from tests.helpers import seeded_input, golden, closed_form_tensor
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _eng_stub(params):
+    """Minimal stand-in for engine.Engine used to drive single ops."""
+    class E:
+        pass
+    e = E()
+    e.device = _dev()
+    e.params = {k: v.to(e.device) for k, v in params.items()}
+    e.grads = {k: torch.zeros_like(v) for k, v in e.params.items()}
+    e.wgrad_ws = torch.empty(64 << 20, dtype=torch.float32, device=e.device)   # 256 MiB
+    e.in_sums = torch.empty(4096 * 3, dtype=torch.float64, device=e.device)
+    e.batch = 1
+    return e
+
+
+def _make_act(shape, normed, seed):
+    from e2enet_medical_amd.engine import Act
+    a = Act("t", shape, normed, _dev())
+    a.data.copy_(seeded_input(shape, seed=seed))
+    if normed:
+        n = shape[0] * shape[1]
+        a.scale.copy_(0.5 + torch.rand(n, generator=torch.Generator().manual_seed(seed + 1)))
+        a.scale[::3] *= -1.0                                  # negative gamma happens in trained nets
+        a.shift.copy_(seeded_input((n,), seed=seed + 2) * 0.3)
+    return a
+
+
+def _act_value(a):
+    """what consumers see: lrelu(scale*x+shift) for normed tensors, x otherwise (CPU tensor)."""
+    x = a.data.cpu()
+    if not a.normed:
+        return x
+    b, c = x.shape[:2]
+    s = a.scale.cpu().view(b, c, 1, 1, 1)
+    t = a.shift.cpu().view(b, c, 1, 1, 1)
+    return F.leaky_relu(x * s + t, 0.01)
+
+
+CONV_CASES = [
+    # (B, sources [(C, normed)], Cout, (D,H,W), stride, density)
+    (1, [(4, False)], 8, (5, 12, 20), (1, 1, 1), 1.0),
+    (2, [(7, True), (6, False)], 9, (4, 9, 11), (1, 1, 1), 1.0),            # odd sizes, ragged channel counts
+    (1, [(16, True), (16, False), (8, False)], 40, (6, 33, 35), (1, 1, 1), 0.3),   # 3-source concat, DSFF bits
+    (1, [(1, False)], 5, (6, 8, 8), (1, 1, 1), 1.0),                         # single group, s = -2
+    (1, [(12, True)], 20, (8, 16, 16), (2, 2, 2), 1.0),                      # strided ("convolutional pooling")
+    (2, [(10, True)], 12, (5, 18, 10), (1, 2, 2), 1.0),
+    (1, [(33, True)], 34, (3, 40, 64), (1, 1, 1), 0.2),
+    (1, [(70, True), (30, False)], 64, (2, 8, 8), (1, 1, 1), 0.5),           # small planes (8x8 tile kernel)
+    (1, [(40, True)], 33, (4, 4, 4), (2, 2, 2), 1.0),
+    (1, [(9, True)], 7, (1, 6, 5), (1, 1, 1), 1.0),                          # one-slice volume: all shifted groups vanish
+]
+
+
+def _ref_conv(srcs, w, b, stride):
+    x = torch.cat([_act_value(a) for a in srcs], 1)
+    return F.conv3d(oracle.depth_shift(x), w, b, stride=stride, padding=(0, 1, 1))
+
+
+def _kmask(cout, cin, density, seed):
+    if density >= 1.0:
+        return None
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand((cout, cin), generator=g) < density).to(torch.uint8)
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv133_fwd_bwd(case):
+    from e2enet_medical_amd.engine import ConvOp, shift_amounts
+    from e2enet_medical_amd._lib import lib
+    B, src_desc, cout, dims, stride, density = case
+    srcs = [_make_act((B, c) + dims, normed, 10 + i) for i, (c, normed) in enumerate(src_desc)]
+    cin = sum(c for c, _ in src_desc)
+    assert shift_amounts(cin) == oracle.shift_amounts(cin)
+    w = seeded_input((cout, cin, 1, 3, 3), seed=3) * (1.0 / math.sqrt(cin * 9))
+    km = _kmask(cout, cin, density, 5)
+    if km is not None:
+        w = w * km.view(cout, cin, 1, 1, 1)
+    params = {"blk.conv.weight": w, "blk.conv.bias": seeded_input((cout,), seed=4) * 0.1,
+              "blk.instnorm.weight": 1 + 0.2 * seeded_input((cout,), seed=6),
+              "blk.instnorm.bias": 0.2 * seeded_input((cout,), seed=7)}
+    e = _eng_stub(params)
+    e.batch = B
+    op = ConvOp(e, "blk", srcs, cout, stride)
+    if km is not None:
+        rows = torch.empty(cout * ((cin + 31) // 32), dtype=torch.int32, device=e.device)
+        cols = torch.empty(cin * ((cout + 31) // 32), dtype=torch.int32, device=e.device)
+        kmd = km.to(e.device)
+        lib().dsff_expand(kmd.data_ptr(), None, rows.data_ptr(), cols.data_ptr(), cout, cin, 1, 0)
+        op.live, op.live_t = rows, cols
+    op.forward()
+    torch.cuda.synchronize()
+    # ---- forward: pre-norm output and the normalise-on-load coefficients
+    leaf_srcs = [_act_value(a).requires_grad_(True) for a in srcs]
+    wl = params["blk.conv.weight"].clone().requires_grad_(True)
+    bl = params["blk.conv.bias"].clone().requires_grad_(True)
+    gl = params["blk.instnorm.weight"].clone().requires_grad_(True)
+    tl = params["blk.instnorm.bias"].clone().requires_grad_(True)
+    y = F.conv3d(oracle.depth_shift(torch.cat(leaf_srcs, 1)), wl, bl, stride=stride, padding=(0, 1, 1))
+    got_y = op.out.data.cpu()
+    assert got_y.shape == y.shape
+    assert (got_y - y.detach()).abs().max() < 2e-5, "conv output"
+    z = F.leaky_relu(F.instance_norm(y, weight=gl, bias=tl, eps=1e-5), 0.01)
+    z_got = _act_value(op.out)
+    assert (z_got - z.detach()).abs().max() < 1e-4, "normalised output"
+    # ---- backward
+    dz = seeded_input(tuple(z.shape), seed=8)
+    z.backward(dz)
+    for s in srcs:
+        s._grad_written = False
+    op.out.alloc_grad()
+    op.plan_backward()
+    op.out.grad.copy_(dz)
+    for s in srcs:
+        s.grad.fill_(float("nan"))           # first writer must overwrite
+    op.backward()
+    torch.cuda.synchronize()
+    scale_w = max(1.0, float(wl.grad.abs().max()))
+    assert (e.grads["blk.conv.weight"].cpu() - wl.grad).abs().max() < 2e-4 * scale_w, "wgrad"
+    assert (e.grads["blk.instnorm.weight"].cpu() - gl.grad).abs().max() < 2e-4 * max(1.0, float(gl.grad.abs().max()))
+    assert (e.grads["blk.instnorm.bias"].cpu() - tl.grad).abs().max() < 2e-4 * max(1.0, float(tl.grad.abs().max()))
+    assert (e.grads["blk.conv.bias"].cpu() - bl.grad).abs().max() < 1e-3 * max(1.0, float(dz.abs().sum()) * 1e-3)
+    for s, leaf in zip(srcs, leaf_srcs):
+        got = s.grad.cpu()
+        assert torch.isfinite(got).all(), "dgrad left unwritten cells"
+        assert (got - leaf.grad).abs().max() < 2e-4 * max(1.0, float(leaf.grad.abs().max())), "dgrad"
+    # accumulate mode: a second backward with accumulate flags set adds on top
+    for s in srcs:
+        s._grad_written = True
+    op.plan_backward()
+    op.out.grad.copy_(dz)
+    op.backward()
+    torch.cuda.synchronize()
+    for s, leaf in zip(srcs, leaf_srcs):
+        assert (s.grad.cpu() - 2 * leaf.grad).abs().max() < 4e-4 * max(1.0, float(leaf.grad.abs().max())), "dgrad accumulate"
+
+
+@pytest.mark.parametrize("B,cin,cout,dims,kernel,density,normed", [
+    (1, 16, 8, (4, 6, 10), (2, 2, 2), 1.0, True),
+    (2, 40, 33, (3, 5, 7), (2, 2, 2), 0.3, True),
+    (1, 9, 5, (2, 9, 8), (1, 2, 2), 1.0, True),
+    (1, 70, 64, (1, 4, 4), (1, 1, 1), 0.5, False),
+    (1, 64, 32, (16, 16, 16), (2, 2, 2), 0.2, True),
+])
+def test_convT_fwd_bwd(B, cin, cout, dims, kernel, density, normed):
+    from e2enet_medical_amd.engine import UpOp
+    from e2enet_medical_amd._lib import lib
+    src = _make_act((B, cin) + dims, normed, 21)
+    w = seeded_input((cin, cout) + kernel, seed=22) * (1.0 / math.sqrt(cin))
+    km = _kmask(cin, cout, density, 23)
+    if km is not None:
+        w = w * km.view(cin, cout, 1, 1, 1)
+    e = _eng_stub({"up.weight": w})
+    op = UpOp(e, "up.weight", src, cout, kernel)
+    if km is not None:
+        rows = torch.empty(cin * ((cout + 31) // 32), dtype=torch.int32, device=e.device)
+        cols = torch.empty(cout * ((cin + 31) // 32), dtype=torch.int32, device=e.device)
+        lib().dsff_expand(km.to(e.device).data_ptr(), None, rows.data_ptr(), cols.data_ptr(), cin, cout, 1, 0)
+        op.live, op.live_t = cols, rows
+    op.forward()
+    xl = _act_value(src).requires_grad_(True)
+    wl = w.clone().requires_grad_(True)
+    y = F.conv_transpose3d(xl, wl, stride=kernel)
+    assert (op.out.data.cpu() - y.detach()).abs().max() < 2e-5
+    dy = seeded_input(tuple(y.shape), seed=24)
+    y.backward(dy)
+    op.out.alloc_grad()
+    op.plan_backward()
+    op.out.grad.copy_(dy)
+    src.grad.fill_(float("nan"))
+    op.backward()
+    torch.cuda.synchronize()
+    assert (e.grads["up.weight"].cpu() - wl.grad).abs().max() < 2e-4 * max(1.0, float(wl.grad.abs().max())), "wgrad"
+    assert (src.grad.cpu() - xl.grad).abs().max() < 2e-4 * max(1.0, float(xl.grad.abs().max())), "dgrad"
+
+
+@pytest.mark.parametrize("B,c,dims,kernel", [(2, 5, (4, 6, 8), (2, 2, 2)), (1, 3, (3, 10, 6), (1, 2, 2)),
+                                             (1, 4, (5, 7, 9), (2, 2, 2))])
+def test_maxpool_fwd_bwd(B, c, dims, kernel):
+    from e2enet_medical_amd.engine import PoolOp
+    src = _make_act((B, c) + dims, True, 31)
+    op = PoolOp(_eng_stub({}), "down", src, kernel)
+    op.forward()
+    xl = _act_value(src).requires_grad_(True)
+    y = F.max_pool3d(xl, kernel)
+    assert torch.equal(op.out.data.cpu(), y.detach())
+    dy = seeded_input(tuple(y.shape), seed=32)
+    y.backward(dy)
+    op.out.alloc_grad()
+    op.plan_backward()
+    op.out.grad.copy_(dy)
+    src.grad.fill_(float("nan"))
+    op.backward()
+    assert torch.equal(src.grad.cpu(), xl.grad)
+
+
+@pytest.mark.parametrize("B,c,k,dims", [(2, 8, 3, (4, 6, 8)), (1, 32, 4, (8, 16, 16)), (1, 20, 14, (3, 5, 7)),
+                                        (1, 12, 16, (2, 4, 6))])
+def test_head_fwd_bwd(B, c, k, dims):
+    from e2enet_medical_amd.engine import HeadOp
+    src = _make_act((B, c) + dims, True, 41)
+    w = seeded_input((k, c, 1, 1, 1), seed=42) * 0.3
+    e = _eng_stub({"seg.weight": w})
+    op = HeadOp(e, "seg.weight", src, k)
+    op.forward()
+    xl = _act_value(src).requires_grad_(True)
+    wl = w.clone().requires_grad_(True)
+    y = F.conv3d(xl, wl)
+    assert (op.out.data.cpu() - y.detach()).abs().max() < 1e-5
+    dy = seeded_input(tuple(y.shape), seed=43)
+    y.backward(dy)
+    op.out.alloc_grad()
+    op.plan_backward()
+    op.out.grad.copy_(dy)
+    src.grad.fill_(float("nan"))
+    op.backward()
+    torch.cuda.synchronize()
+    assert (e.grads["seg.weight"].cpu() - wl.grad).abs().max() < 2e-4 * max(1.0, float(wl.grad.abs().max()))
+    assert (src.grad.cpu() - xl.grad).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("batch_dice", [False, True])
+@pytest.mark.parametrize("k", [3, 4, 14])
+def test_loss_kernels(k, batch_dice):
+    from e2enet_medical_amd.training.loss_functions.dice_loss import DC_and_CE_loss
+    shape = (2, k, 6, 10, 9)
+    logits = (seeded_input(shape, seed=51) * 2).requires_grad_(True)
+    g = torch.Generator().manual_seed(52)
+    target = torch.randint(0, k, (2, 1, 6, 10, 9), generator=g).float()
+    ref = oracle.dc_ce_loss(logits, target, batch_dice)
+    ref.backward()
+    lg = logits.detach().cuda().requires_grad_(True)
+    loss = DC_and_CE_loss({'batch_dice': batch_dice, 'smooth': 1e-5, 'do_bg': False}, {})(lg, target.cuda())
+    loss.backward()
+    assert abs(loss.item() - ref.item()) < 2e-6
+    assert (lg.grad.cpu() - logits.grad).abs().max() < 2e-8 + 1e-4 * float(logits.grad.abs().max())
+
+
+def test_loss_golden():
+    """Same fixture as the oracle test: MultipleOutputLoss2(DC_and_CE_loss) value + gradients from the reference."""
+    from e2enet_medical_amd.training.loss_functions.dice_loss import DC_and_CE_loss
+    from e2enet_medical_amd.training.loss_functions.deep_supervision import MultipleOutputLoss2
+    from tests.helpers import seeded_labels
+    g = golden("loss.npz")
+    for tag, bd in (("sample", False), ("batch", True)):
+        k = 4
+        shapes = [(2, k, 8, 12, 10), (2, k, 4, 6, 5), (2, k, 2, 3, 5), (2, k, 1, 3, 5)]
+        logits = [seeded_input(s, seed=50 + i).mul(2.0).cuda().requires_grad_(True) for i, s in enumerate(shapes)]
+        targets = [seeded_labels((s[0], 1) + s[2:], k, seed=60 + i).cuda() for i, s in enumerate(shapes)]
+        fn = MultipleOutputLoss2(DC_and_CE_loss({'batch_dice': bd, 'smooth': 1e-5, 'do_bg': False}, {}), oracle.ds_weights(5))
+        loss = fn(logits, targets)
+        loss.backward()
+        assert abs(loss.item() - float(g[tag + "_loss"])) < 2e-6
+        for i, l in enumerate(logits):
+            np.testing.assert_allclose(l.grad.cpu().numpy(), g[tag + "_g%d" % i], rtol=0, atol=2e-7)
+
+
+def test_fused_clip_sgd_matches_torch():
+    from e2enet_medical_amd.training.fused_optim import FusedClipSGD
+    torch.manual_seed(0)
+    shapes = [(7, 5, 1, 3, 3), (11,), (4, 6, 2, 2, 2)]
+    cpu = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    gpu = [torch.nn.Parameter(p.detach().clone().cuda()) for p in cpu]
+    opt_c = torch.optim.SGD(cpu, 1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)
+    opt_g = torch.optim.SGD(gpu, 1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)
+    names = ["a", "b", "c"]
+    fused = FusedClipSGD(opt_g, list(zip(names, gpu)), 12.0)
+    mask = (torch.rand(shapes[0]) < 0.5).float()
+    for step in range(4):
+        grads = [torch.randn(s) * (40.0 if step == 1 else 0.2) for s in shapes]
+        for p, gr in zip(cpu, grads):
+            p.grad = gr.clone()
+        tn = torch.nn.utils.clip_grad_norm_(cpu, 12)
+        opt_c.step()
+        with torch.no_grad():                                   # Masking.apply_mask on tensor "a"
+            cpu[0].mul_(mask)
+            opt_c.state[cpu[0]]['momentum_buffer'].mul_(mask)
+        fused.step({n: gr.cuda() for n, gr in zip(names, grads)}, {"a": mask.cuda()})
+        assert abs(fused.total_norm() - tn.item()) < 1e-4 * max(1.0, tn.item())
+        for p, q in zip(cpu, gpu):
+            assert (p.detach() - q.detach().cpu()).abs().max() < 2e-6
+            assert (opt_c.state[p]['momentum_buffer'] - opt_g.state[q]['momentum_buffer'].cpu()).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("tag,shp", [("l1_133", (320, 896, 1, 3, 3)), ("l1_222", (64, 32, 2, 2, 2)),
+                                     ("l1_122", (16, 24, 1, 2, 2))])
+def test_dsff_kernel_l1_bit_exact(tag, shp):
+    """Golden from the reference's three chained torch.sum (core_channel.py:652-655): bit identical."""
+    from e2enet_medical_amd._lib import lib
+    w = closed_form_tensor(shp, 3, "conv").cuda()
+    out = torch.empty(shp[0] * shp[1], dtype=torch.float32, device="cuda")
+    lib().dsff_kernel_l1(w.data_ptr(), out.data_ptr(), shp[0], shp[1], shp[2], shp[3], shp[4], 0)
+    assert np.array_equal(out.cpu().numpy().reshape(shp[0], shp[1]), golden("masks.npz")[tag])
+
+
+@pytest.mark.parametrize("n", [1, 7, 1000, 286720])
+def test_dsff_kth_value_exact(n):
+    from e2enet_medical_amd._lib import lib
+    g = torch.Generator().manual_seed(n)
+    v = torch.rand(n, generator=g)
+    v[::5] = 0.0                                # dead kernels have sum exactly 0, many ties
+    if n > 10:
+        v[3] = v[9]                             # a tie among live values
+    srt, _ = torch.sort(v)
+    vd = v.cuda()
+    out = torch.empty(1, dtype=torch.float32, device="cuda")
+    for k in sorted({0, n // 5, n // 2, max(0, n - 2), n - 1}):
+        lib().dsff_kth_value(vd.data_ptr(), n, k, out.data_ptr(), None, 0)
+        assert out.item() == srt[k].item(), (n, k)
+
+
+def test_dsff_death_and_expand():
+    from e2enet_medical_amd._lib import lib
+    r, c = 37, 70
+    km = (torch.rand((r, c), generator=torch.Generator().manual_seed(1)) < 0.4).to(torch.uint8)
+    kmd = km.cuda()
+    mask = torch.empty((r, c, 1, 3, 3), dtype=torch.float32, device="cuda")
+    rows = torch.empty(r * 3, dtype=torch.int32, device="cuda")
+    cols = torch.empty(c * 2, dtype=torch.int32, device="cuda")
+    lib().dsff_expand(kmd.data_ptr(), mask.data_ptr(), rows.data_ptr(), cols.data_ptr(), r, c, 9, 0)
+    assert torch.equal(mask.cpu(), km.float().view(r, c, 1, 1, 1).expand(r, c, 1, 3, 3))
+    rows_h = rows.cpu().numpy().view(np.uint32).reshape(r, 3)
+    cols_h = cols.cpu().numpy().view(np.uint32).reshape(c, 2)
+    for i in range(r):
+        for j in range(c):
+            assert ((rows_h[i, j // 32] >> (j % 32)) & 1) == km[i, j].item()
+            assert ((cols_h[j, i // 32] >> (i % 32)) & 1) == km[i, j].item()
+    l1 = torch.rand(r * c, generator=torch.Generator().manual_seed(2))
+    thr = torch.tensor([0.3])
+    lib().dsff_death(l1.cuda().data_ptr(), thr.cuda().data_ptr(), kmd.data_ptr(), r * c, 0)
+    assert torch.equal(kmd.cpu().view(-1), km.view(-1) * (l1 > 0.3).to(torch.uint8))
+    w = seeded_input((r, c, 1, 3, 3), seed=3) * km.view(r, c, 1, 1, 1)
+    out = torch.empty((r, c), dtype=torch.uint8, device="cuda")
+    lib().dsff_kmask_from_weights(w.cuda().data_ptr(), out.data_ptr(), r, c, 9, 0)
+    assert torch.equal(out.cpu(), km)
+
+
+def test_sliding_window_kernels():
+    from e2enet_medical_amd._lib import lib
+    L = lib()
+    c, X, Y, Z = 3, 5, 6, 7
+    x = seeded_input((c, X, Y, Z), seed=61)
+    xd = x.cuda()
+    for bits in range(8):
+        dims = [d + 1 for d in range(3) if bits & (1 << d)]
+        out = torch.empty_like(xd)
+        L.flip3d(xd.data_ptr(), out.data_ptr(), c, X, Y, Z, bits, 0)
+        assert torch.equal(out.cpu(), torch.flip(x, dims) if dims else x)
+        res = torch.full((c, X, Y, Z), 0.25, device="cuda")
+        L.softmax_flip_acc(xd.data_ptr(), res.data_ptr(), 0.125, 0, c, X, Y, Z, bits, 0)
+        p = torch.softmax(x, 0)
+        ref = 0.25 + 0.125 * (torch.flip(p, dims) if dims else p)
+        assert (res.cpu() - ref).abs().max() < 1e-6
+    K, VX, VY, VZ = 3, 9, 10, 11
+    agg = torch.zeros((K, VX, VY, VZ), device="cuda")
+    cnt = torch.zeros_like(agg)
+    patch = torch.rand((K, 5, 6, 7), generator=torch.Generator().manual_seed(5))
+    gs = torch.rand((5, 6, 7), generator=torch.Generator().manual_seed(6)) + 0.1
+    ra, rc = torch.zeros((K, VX, VY, VZ)), torch.zeros((K, VX, VY, VZ))
+    for (x0, y0, z0) in [(0, 0, 0), (4, 4, 4), (2, 1, 3)]:
+        L.sw_accumulate(patch.cuda().data_ptr(), gs.cuda().data_ptr(), agg.data_ptr(), cnt.data_ptr(), K, VX, VY, VZ, 5, 6, 7,
+                        x0, y0, z0, 0)
+        ra[:, x0:x0 + 5, y0:y0 + 6, z0:z0 + 7] += patch * gs
+        rc[:, x0:x0 + 5, y0:y0 + 6, z0:z0 + 7] += gs
+    assert torch.equal(agg.cpu(), ra) and torch.equal(cnt.cpu(), rc)
+    probs = torch.empty((K, 5, 6, 7), device="cuda")
+    seg = torch.empty((5, 6, 7), dtype=torch.int64, device="cuda")
+    L.sw_finalize_argmax(agg.data_ptr(), cnt.data_ptr(), probs.data_ptr(), seg.data_ptr(), K, VX, VY, VZ, 2, 1, 3, 5, 6, 7, 0)
+    rp = (ra / rc)[:, 2:7, 1:7, 3:10]
+    assert torch.equal(probs.cpu(), rp) and torch.equal(seg.cpu(), rp.argmax(0))

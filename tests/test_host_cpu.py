@@ -1,0 +1,193 @@
+"""CPU-side tests: the C-ABI library loads and exports every symbol include/e2e_hip.h declares (no compute calls),
+host logic of the drop-in surface, init RNG parity with the reference, and the N>1 exchange paths on gloo."""
+import os
+import re
+import sys
+import subprocess
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from tests.helpers import golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from e2enet_medical_amd._lib import lib, SIGNATURES, LIB_PATH
+    hdr = open(os.path.join(ROOT, "include", "e2e_hip.h")).read()
+    declared = set(re.findall(r"\b(e2e_[a-zA-Z0-9_]+)\s*\(", hdr))
+    assert declared == set(SIGNATURES.keys()), declared ^ set(SIGNATURES.keys())
+    handle = lib()                                   # dlopen + getattr on every symbol
+    assert os.path.samefile(handle.path, LIB_PATH)
+    assert handle.abi_version() == 1
+    assert handle.conv133_num_partials(128, 128, 128, 1, 1) == 128 * 4 * 4
+    assert handle.loss_ws_bytes(2, 4) == (2 * 4 * 3 + 1) * 8
+
+
+def _build(patch, cin, base, k, pools, mf, seed=None):
+    from e2enet_medical_amd.network_architecture.unetpp_d import Generic_UNetPlusPlus
+    from e2enet_medical_amd.network_architecture.initialization import InitWeights_He
+    if seed is not None:
+        torch.manual_seed(seed)
+    return Generic_UNetPlusPlus(patch, cin, base, k, 5, 2, 2, nn.Conv3d, nn.InstanceNorm3d, {'eps': 1e-5, 'affine': True},
+                                nn.Dropout3d, {'p': 0, 'inplace': True}, nn.LeakyReLU,
+                                {'negative_slope': 1e-2, 'inplace': True}, True, False, lambda x: x, InitWeights_He(1e-2),
+                                pools, None, False, True, True, max_num_features=mf)
+
+
+@pytest.mark.parametrize("tag,args", [("tiny", ((16, 32, 32), 2, 8, 3, [[2, 2, 2]] * 3 + [[1, 2, 2]] * 2, 32)),
+                                      ("b32", ((64, 64, 64), 4, 32, 4, [[2, 2, 2]] * 5, None))])
+def test_module_tree_and_init_match_reference_bit_for_bit(tag, args):
+    """state_dict names/shapes (checkpoint wire format), named_parameters order (Masking draw order) and the
+    He-normal initial weights under torch.manual_seed(1234) equal the reference's."""
+    g = golden("init.npz")
+    net = _build(*args, seed=1234)
+    sd = net.state_dict()
+    assert list(sd.keys()) == [str(s) for s in g[tag + "_names"]]
+    assert [str(tuple(v.shape)) for v in sd.values()] == [str(s) for s in g[tag + "_shapes"]]
+    assert [n for n, _ in net.named_parameters()] == [str(s) for s in g[tag + "_param_order"]]
+    assert np.array_equal(np.array([v.double().sum().item() for v in sd.values()]), g[tag + "_sum"])
+    assert np.array_equal(np.array([v.double().abs().sum().item() for v in sd.values()]), g[tag + "_abs"])
+
+
+def test_network_attributes_and_errors():
+    net = _build((16, 32, 32), 2, 8, 3, [[2, 2, 2]] * 3 + [[1, 2, 2]] * 2, 32)
+    assert net.conv_op == nn.Conv3d and net.num_classes == 3 and net.do_ds and net._deep_supervision
+    assert list(net.input_shape_must_be_divisible_by) == [8, 32, 32]
+    assert len(net.td) == 0 and len(net.down0) == 4 and len(net.up0) == 5 and len(net.loc4) == 1
+    with pytest.raises(RuntimeError):                       # product path never computes on the CPU
+        net(torch.zeros(1, 2, 16, 32, 32))
+    with pytest.raises(ValueError):                         # reference forward() needs exactly 6 levels
+        from e2enet_medical_amd.network_architecture.unetpp_d import Generic_UNetPlusPlus
+        Generic_UNetPlusPlus((40, 56, 40), 1, 8, 3, 3, conv_op=nn.Conv3d, norm_op=nn.InstanceNorm3d,
+                             dropout_op_kwargs={'p': 0}, convolutional_pooling=True, convolutional_upsampling=True)
+    from e2enet_medical_amd.engine import shift_amounts
+    import oracle
+    for c in (1, 4, 12, 32, 64, 160, 896):
+        assert shift_amounts(c) == oracle.shift_amounts(c)
+
+
+def test_sliding_window_host_logic_matches_reference_vectors():
+    from e2enet_medical_amd.network_architecture.neural_network import SegmentationNetwork, pad_nd_image
+    cs = SegmentationNetwork._compute_steps_for_sliding_window
+    assert cs((128, 128, 128), (146, 176, 148), 0.5) == [[0, 18], [0, 48], [0, 20]]
+    assert cs((128, 128, 128), (424, 456, 456), 0.5) == [[0, 59, 118, 178, 237, 296], [0, 55, 109, 164, 219, 273, 328],
+                                                         [0, 55, 109, 164, 219, 273, 328]]
+    assert cs((64, 192, 192), (94, 308, 308), 0.5) == [[0, 30], [0, 58, 116], [0, 58, 116]]
+    assert cs((40, 56, 40), (40, 56, 40), 0.5) == [[0], [0], [0]]
+    g = golden("sliding.npz")
+    m = SegmentationNetwork._get_gaussian((16, 32, 32))
+    assert np.array_equal(m, g["g16x32x32_full"])
+    x = np.arange(2 * 13 * 5 * 40, dtype=np.float32).reshape(2, 13, 5, 40)
+    padded, slicer = pad_nd_image(x, (16, 32, 32), "constant", {'constant_values': 0}, True, None)
+    assert padded.shape == (2, 16, 32, 40)
+    assert [(s.start, s.stop) for s in slicer] == [(0, 2), (1, 14), (13, 18), (0, 40)]
+    assert np.array_equal(padded[tuple(slicer)], x)
+
+
+def test_trainer_and_masking_fail_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from e2enet_medical_amd.training.network_training.nnUNetTrainer_simple import nnUNetTrainer_simple
+    plans = {'plans_per_stage': {0: {'batch_size': 1, 'patch_size': [16, 32, 32], 'num_pool_per_axis': [3, 5, 5],
+                                     'pool_op_kernel_sizes': [[2, 2, 2]] * 3 + [[1, 2, 2]] * 2,
+                                     'conv_kernel_sizes': [[3, 3, 3]] * 6, 'do_dummy_2D_data_aug': False}},
+             'base_num_features': 32, 'num_modalities': 1, 'num_classes': 2, 'all_classes': [1, 2], 'conv_per_stage': 2}
+    tr = nnUNetTrainer_simple(plans, 0, batch_dice=False, Tconv='shiftConvPP')
+    tr.base_num_features_override = 8
+    tr.initialize(True)
+    assert tr.ds_loss_weights.tolist() == pytest.approx([8 / 15, 4 / 15, 2 / 15, 1 / 15, 0])
+    assert tr.deep_supervision_scales[:3] == [[1, 1, 1], [0.5, 0.5, 0.5], [0.25, 0.25, 0.25]]
+    with pytest.raises(RuntimeError):
+        tr.run_iteration(tr.tr_gen, True)
+    from e2enet_medical_amd.training.loss_functions.dice_loss import DC_and_CE_loss
+    with pytest.raises(RuntimeError):
+        DC_and_CE_loss({'batch_dice': False, 'smooth': 1e-5, 'do_bg': False}, {})(torch.zeros(1, 3, 2, 2, 2), torch.zeros(1, 1, 2, 2, 2))
+
+
+def test_missing_library_is_an_import_error(tmp_path):
+    code = ("import sys; sys.path.insert(0, %r); import e2enet_medical_amd._lib as L; L.LIB_PATH = %r;\n"
+            "try:\n    L.lib()\nexcept ImportError as e:\n    print('IMPORT_ERROR')\n" % (ROOT, str(tmp_path / "nope.so")))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "IMPORT_ERROR" in out.stdout, out.stderr
+
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+import oracle
+from oracle import network as onet
+from tests.helpers import closed_form_params, seeded_input
+from e2enet_medical_amd import parallel
+from e2enet_medical_amd.network_architecture.neural_network import SegmentationNetwork, pad_nd_image
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.set_num_threads(2)
+pools = [(2, 2, 2)] * 3 + [(1, 2, 2)] * 2
+spec = oracle.make_spec(2, 8, 3, pools, 2, 32)
+params = closed_form_params(onet.param_shapes(spec))
+patch = (16, 32, 32)
+vol = seeded_input((2, 13, 40, 50), seed=71).numpy()
+
+def net_fn(t):
+    with torch.no_grad():
+        return torch.softmax(oracle.forward(spec, params, t, do_ds=False), 1)
+
+# single-process reference (oracle), no mirroring to keep the test short
+seg_ref, probs_ref = oracle.predict_tiled(net_fn, vol, 3, patch, 0.5, do_mirroring=False, use_gaussian=True)
+
+# sharded: the product's partition / exchange / ordered overlap-add, with the oracle standing in for the GPU forward
+data, slicer = pad_nd_image(vol, patch, "constant", {'constant_values': 0}, True, None)
+steps = SegmentationNetwork._compute_steps_for_sliding_window(patch, data.shape[1:], 0.5)
+tiles = [(a, b, c) for a in steps[0] for b in steps[1] for c in steps[2]]
+g = SegmentationNetwork._get_gaussian(patch)
+per = parallel.slots_per_rank(len(tiles), world)
+mine = torch.zeros((per, 3) + patch)
+for slot, ti in enumerate(parallel.partition_tiles(len(tiles), rank, world)):
+    sx, sy, sz = tiles[ti]
+    t = torch.from_numpy(np.ascontiguousarray(data[None, :, sx:sx + 16, sy:sy + 32, sz:sz + 32]))
+    mine[slot] = net_fn(t)[0]
+gathered = parallel.gather_patches(mine, world)
+agg = np.zeros((3,) + data.shape[1:], np.float32); cnt = np.zeros_like(agg)
+for ti, (sx, sy, sz) in enumerate(tiles):
+    o, s = parallel.tile_slot(ti, world)
+    agg[:, sx:sx + 16, sy:sy + 32, sz:sz + 32] += gathered[o, s].numpy() * g
+    cnt[:, sx:sx + 16, sy:sy + 32, sz:sz + 32] += g
+sl = tuple([slice(0, 3)] + slicer[1:])
+probs = agg[sl] / cnt[sl]
+assert np.array_equal(probs, probs_ref), "sharded overlap-add must be bit identical to the single-process order"
+assert np.array_equal(probs.argmax(0), seg_ref)
+
+# data-parallel gradient averaging + DSFF mask broadcast
+grads = {"a": torch.full((5, 3), float(rank + 1)), "b": torch.arange(4, dtype=torch.float32) * (rank + 1)}
+parallel.allreduce_mean_gradients(grads, ["a", "b"])
+assert torch.allclose(grads["a"], torch.full((5, 3), (1 + world) / 2.0))
+assert torch.allclose(grads["b"], torch.arange(4, dtype=torch.float32) * (1 + world) / 2.0)
+km = {"k": (torch.arange(12).reshape(3, 4) %% (rank + 2) == 0).to(torch.uint8)}
+want = (torch.arange(12).reshape(3, 4) %% 2 == 0).to(torch.uint8)
+parallel.broadcast_kernel_masks(km, src=0)
+assert torch.equal(km["k"], want)
+dist.barrier()
+if rank == 0:
+    print("WORKER_OK")
+dist.destroy_process_group()
+'''
+
+
+def test_world_size_2_tile_sharding_and_dp_exchange_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29553", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    assert "WORKER_OK" in outs[0][0]
