@@ -113,5 +113,8 @@ def lib() -> _Lib:
     """The loaded library (loads on first use; raises ImportError when it has not been built)."""
     global _lib
     if _lib is None:
+        # torch first: libe2e_hip.so must bind to the HIP runtime PyTorch-ROCm has loaded (one runtime per process,
+        # so that torch's streams and device pointers are valid in our launches)
+        import torch  # noqa: F401
         _lib = _Lib(LIB_PATH)
     return _lib

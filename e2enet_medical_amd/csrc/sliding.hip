@@ -46,8 +46,10 @@ __global__ __launch_bounds__(256) void softmax_flip_acc_kernel(const float* __re
       if (k0 + k >= K) break;
       const float p = expf(logits[(long long)(k0 + k) * spatial + i] - m) * inv;
       float* dst = result + (long long)(k0 + k) * spatial + o;
-      if (first) *dst = w * p;
-      else *dst += w * p;
+      // reference: result += (1 / n) * pred -- multiply, round, then add (no fma contraction)
+      const float wp = __fmul_rn(w, p);
+      if (first) *dst = wp;
+      else *dst = __fadd_rn(*dst, wp);
     }
   }
 }
@@ -65,8 +67,10 @@ __global__ __launch_bounds__(256) void sw_accumulate_kernel(const float* __restr
   const float g = gauss ? gauss[i] : 1.f;
   const long long vs = (long long)X * Y * Z;
   for (int k = 0; k < K; ++k) {
-    agg[(long long)k * vs + o] += patch[(long long)k * ps + i] * g;
-    cnt[(long long)k * vs + o] += g;
+    // reference: patch *= gaussian (rounded), then aggregated += patch (neural_network.py:562-563, :392-393)
+    const float pg = __fmul_rn(patch[(long long)k * ps + i], g);
+    agg[(long long)k * vs + o] = __fadd_rn(agg[(long long)k * vs + o], pg);
+    cnt[(long long)k * vs + o] = __fadd_rn(cnt[(long long)k * vs + o], g);
   }
 }
 
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(256) void sw_finalize_kernel(const float* __restric
   float best = -INFINITY;
   int arg = 0;
   for (int k = 0; k < K; ++k) {
-    const float p = agg[(long long)k * vs + o] / cnt[(long long)k * vs + o];
+    const float p = __fdiv_rn(agg[(long long)k * vs + o], cnt[(long long)k * vs + o]);
     probs[(long long)k * cs + i] = p;
     if (p > best || (p != p && best == best)) { best = p; arg = k; }   // first maximum; NaN counts as maximal (numpy)
   }

@@ -172,7 +172,8 @@ def test_convT_fwd_bwd(B, cin, cout, dims, kernel, density, normed):
     if km is not None:
         rows = torch.empty(cin * ((cout + 31) // 32), dtype=torch.int32, device=e.device)
         cols = torch.empty(cout * ((cin + 31) // 32), dtype=torch.int32, device=e.device)
-        lib().dsff_expand(km.to(e.device).data_ptr(), None, rows.data_ptr(), cols.data_ptr(), cin, cout, 1, 0)
+        kmd = km.to(e.device)
+        lib().dsff_expand(kmd.data_ptr(), None, rows.data_ptr(), cols.data_ptr(), cin, cout, 1, 0)
         op.live, op.live_t = cols, rows
     op.forward()
     xl = _act_value(src).requires_grad_(True)
@@ -200,7 +201,7 @@ def test_maxpool_fwd_bwd(B, c, dims, kernel):
     op.forward()
     xl = _act_value(src).requires_grad_(True)
     y = F.max_pool3d(xl, kernel)
-    assert torch.equal(op.out.data.cpu(), y.detach())
+    assert (op.out.data.cpu() - y.detach()).abs().max() < 1e-6     # fma vs mul+add in the on-load affine
     dy = seeded_input(tuple(y.shape), seed=32)
     y.backward(dy)
     op.out.alloc_grad()
@@ -208,7 +209,7 @@ def test_maxpool_fwd_bwd(B, c, dims, kernel):
     op.out.grad.copy_(dy)
     src.grad.fill_(float("nan"))
     op.backward()
-    assert torch.equal(src.grad.cpu(), xl.grad)
+    assert torch.equal(src.grad.cpu(), xl.grad)                    # gradient routing (arg max) is exact
 
 
 @pytest.mark.parametrize("B,c,k,dims", [(2, 8, 3, (4, 6, 8)), (1, 32, 4, (8, 16, 16)), (1, 20, 14, (3, 5, 7)),
@@ -344,11 +345,13 @@ def test_dsff_death_and_expand():
             assert ((cols_h[j, i // 32] >> (i % 32)) & 1) == km[i, j].item()
     l1 = torch.rand(r * c, generator=torch.Generator().manual_seed(2))
     thr = torch.tensor([0.3])
-    lib().dsff_death(l1.cuda().data_ptr(), thr.cuda().data_ptr(), kmd.data_ptr(), r * c, 0)
+    l1d, thrd = l1.cuda(), thr.cuda()                      # keep device buffers alive across the async launch
+    lib().dsff_death(l1d.data_ptr(), thrd.data_ptr(), kmd.data_ptr(), r * c, 0)
     assert torch.equal(kmd.cpu().view(-1), km.view(-1) * (l1 > 0.3).to(torch.uint8))
     w = seeded_input((r, c, 1, 3, 3), seed=3) * km.view(r, c, 1, 1, 1)
     out = torch.empty((r, c), dtype=torch.uint8, device="cuda")
-    lib().dsff_kmask_from_weights(w.cuda().data_ptr(), out.data_ptr(), r, c, 9, 0)
+    wd = w.cuda()
+    lib().dsff_kmask_from_weights(wd.data_ptr(), out.data_ptr(), r, c, 9, 0)
     assert torch.equal(out.cpu(), km)
 
 
@@ -374,9 +377,9 @@ def test_sliding_window_kernels():
     patch = torch.rand((K, 5, 6, 7), generator=torch.Generator().manual_seed(5))
     gs = torch.rand((5, 6, 7), generator=torch.Generator().manual_seed(6)) + 0.1
     ra, rc = torch.zeros((K, VX, VY, VZ)), torch.zeros((K, VX, VY, VZ))
+    pd, gd = patch.cuda(), gs.cuda()
     for (x0, y0, z0) in [(0, 0, 0), (4, 4, 4), (2, 1, 3)]:
-        L.sw_accumulate(patch.cuda().data_ptr(), gs.cuda().data_ptr(), agg.data_ptr(), cnt.data_ptr(), K, VX, VY, VZ, 5, 6, 7,
-                        x0, y0, z0, 0)
+        L.sw_accumulate(pd.data_ptr(), gd.data_ptr(), agg.data_ptr(), cnt.data_ptr(), K, VX, VY, VZ, 5, 6, 7, x0, y0, z0, 0)
         ra[:, x0:x0 + 5, y0:y0 + 6, z0:z0 + 7] += patch * gs
         rc[:, x0:x0 + 5, y0:y0 + 6, z0:z0 + 7] += gs
     assert torch.equal(agg.cpu(), ra) and torch.equal(cnt.cpu(), rc)

@@ -224,6 +224,11 @@ def gen_net_sparse_tiny():
             out["grad_l2_it0"] = np.array([p.grad.double().norm().item() for _, p in net.named_parameters()])
         tn = torch.nn.utils.clip_grad_norm_(net.parameters(), 12)
         opt.step()
+        if it == 1:
+            # weights (after the optimizer step, before Masking.step) that the prune/grow decision is taken on,
+            # and the momentum buffers it masks: lets the GPU test replay exactly this update
+            for n in mask.masks:
+                out["pre_prune::" + n] = net.get_parameter(n).detach().numpy().copy()
         with contextlib.redirect_stdout(io.StringIO()):
             mask.step()
         losses.append(loss.item())
