@@ -14,12 +14,13 @@
 //   * epilogue (fwd): bias, store, per-tile (count, mean, M2) partial for InstanceNorm;
 //     epilogue (dgrad): un-shift on store into the per-channel destination (scatter back through the concat).
 #include "e2e_common.h"
+#include <cstdlib>
 
 namespace {
 
 struct ConvParams {
   const e2e_in_chan_t* chans;   // P input planes (null: plain tensor `xin`, used by the data gradient)
-  const float* xin;             // [B, P, Di, Hi, Wi] when chans == null
+  const float* xin;             // [B, P, Ds, Hs, Ws] when chans == null
   const float* w;
   const float* bias;            // fwd only (may be null)
   const unsigned* live;         // [Q][live_words] or null
@@ -30,15 +31,24 @@ struct ConvParams {
   int wq_stride, wp_stride;     // element strides of the weight tensor for (q, p)
   int live_words;
   int B, Di, Hi, Wi, Do, Ho, Wo, sd;
+  int Ds, Hs, Ws;               // dgrad: dims of the dy tensor (== Di.. when not dilated)
   int tiles_x, tiles_y, tiles_per_n;   // tiles_per_n = Do * tiles_y * tiles_x
   int groups;                          // ceil(Q / OCG)
   int total;                           // B * tiles_per_n * groups (logical work items)
   int padded_total;
 };
 
-template <int MODE, int SH, int SW, int TH, int TW, int LY, int LX, int OPW, int NW, int CK>
+// wave-uniform description of one staged input plane, kept in LDS (double buffered per chunk)
+struct PlaneDesc {
+  gfloat_p base;      // plane origin for this (n, depth); always dereferenceable
+  float a, b, slope;  // normalise-on-load coefficients
+  int valid;
+};
+
+template <int MODE, int SH, int SW, int DH, int DW, int TH, int TW, int LY, int LX, int OPW, int NW, int CK, int STG>
 struct Cfg {
   static_assert(LY * LX == 64, "one wave covers the tile");
+  static_assert(MODE == 1 || (DH == 1 && DW == 1), "dilation is a data-gradient feature");
   static constexpr int PH = TH / LY, PW = TW / LX;
   static constexpr int IH = (TH - 1) * SH + 3, IW = (TW - 1) * SW + 3;
   // lane column offset in floats; decides the widest aligned LDS read of a neighbourhood row
@@ -58,6 +68,11 @@ struct Cfg {
   static constexpr int OCG = OPW * NW;
   static constexpr int NR = (PH - 1) * SH + 3, NC = (PW - 1) * SW + 3;
   static constexpr int LDS_FLOATS = CK * CHS;
+  // staging units: STG 1 = aligned float4 groups of a tile row (tile column origin is a multiple of 4, so the
+  // group starting 4 columns left of it covers the halo), STG 0 = single elements
+  static constexpr int NQ = (IW + 3 + 3) / 4;
+  static constexpr int UNITS = STG ? CK * IH * NQ : CK * IH * IW;
+  static constexpr int NU = (UNITS + NT - 1) / NT;
 };
 
 // read NC consecutive floats starting at an address aligned to VEC floats
@@ -82,10 +97,15 @@ __device__ __forceinline__ void load_row(const float* __restrict__ src, float* _
   for (; c < NC; ++c) dst[c] = src[c];
 }
 
-template <int MODE, int SH, int SW, int TH, int TW, int LY, int LX, int OPW, int NW, int CK, int MINW>
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef const f32x4_t __attribute__((address_space(1)))* gfloat4_p;
+
+template <int MODE, int SH, int SW, int DH, int DW, int TH, int TW, int LY, int LX, int OPW, int NW, int CK, int STG, int MINW>
 __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
-  using C = Cfg<MODE, SH, SW, TH, TW, LY, LX, OPW, NW, CK>;
+  using C = Cfg<MODE, SH, SW, DH, DW, TH, TW, LY, LX, OPW, NW, CK, STG>;
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+  PlaneDesc* tab = reinterpret_cast<PlaneDesc*>(dyn_lds);      // [P]: built once per workgroup
 
   const int logical = e2e::xcd_remap(blockIdx.x, p.padded_total);
   if (logical >= p.total) return;
@@ -107,6 +127,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
   const int h0 = ty * TH, w0 = tx * TW;                 // output tile origin
   const int hbase = h0 * SH - 1, wbase = w0 * SW - 1;   // input tile origin (incl. halo)
   const long long in_plane = (long long)p.Hi * p.Wi;
+  const long long src_plane = (long long)p.Hs * p.Ws;
 
   float acc[OPW][C::PH][C::PW];
 #pragma unroll
@@ -119,53 +140,129 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
   const int qbase = g * C::OCG + wave * OPW;
   const float* lane_tp = lds + (ly * C::PH * SH) * C::PITCH + lx * C::LSTEP;
 
-  for (int c0 = 0; c0 < p.P; c0 += CK) {
-    // ---------------- stage CK input planes (halo included, transform applied, zero padded) ---------------
-    // per-plane (wave-uniform) descriptors first, then all loads of an element batch before any use
-    gfloat_p pbase[CK];   // global address space: plain global_load (vmcnt only), not flat_load
-    float pa[CK], pb[CK], psl[CK];
-    bool pv[CK];
+  // data gradient of a depth-strided conv: only every sd-th slice of the (shifted) input received anything
+  const bool dead_slice = (MODE == 1) && (d % p.sd != 0);
+  const int nchunks = dead_slice ? 0 : (p.P + CK - 1) / CK;
+
+  // ---- descriptor of plane `pl` for this workgroup's (n, d) -------------------------------------------------
+  auto make_desc = [&](int pl) {
+    PlaneDesc ds;
+    ds.a = 1.f; ds.b = 0.f; ds.slope = 1.f; ds.valid = 0;
+    if (MODE == 0) {
+      ds.base = (gfloat_p)p.chans[0].ptr;
+      if (pl < p.P) {
+        const e2e_in_chan_t ch = p.chans[pl];
+        const int din = d * p.sd - ch.dshift;
+        if ((unsigned)din < (unsigned)p.Di) {
+          ds.valid = 1;
+          ds.base = (gfloat_p)(ch.ptr + (long long)n * ch.nstride + (long long)din * in_plane);
+          if (ch.scale != nullptr) {
+            ds.a = ch.scale[(long long)n * ch.ab_nstride];
+            ds.b = ch.shift[(long long)n * ch.ab_nstride];
+            ds.slope = ch.slope;
+          }
+        }
+      }
+    } else {
+      ds.valid = pl < p.P;
+      ds.base = (gfloat_p)(p.xin + (((long long)n * p.P + (ds.valid ? pl : 0)) * p.Ds + d / p.sd) * src_plane);
+    }
+    return ds;
+  };
+
+  // ---- staging: issue the global loads of one chunk into registers (prefetch), commit them to LDS later -----
+  f32x4_t v4[STG ? C::NU : 1];
+  float v1[STG ? 1 : C::NU];
+  auto prefetch = [&](int c0) {
 #pragma unroll
-    for (int k = 0; k < CK; ++k) {
-      const int pl = c0 + k;
-      pa[k] = 1.f; pb[k] = 0.f; psl[k] = 1.f;
-      if (MODE == 0) {
-        pbase[k] = (gfloat_p)p.chans[0].ptr;
-        pv[k] = false;
-        if (pl < p.P) {
-          const e2e_in_chan_t ch = p.chans[pl];
-          const int din = d * p.sd - ch.dshift;
-          if ((unsigned)din < (unsigned)p.Di) {
-            pv[k] = true;
-            pbase[k] = (gfloat_p)(ch.ptr + (long long)n * ch.nstride + (long long)din * in_plane);
-            if (ch.scale != nullptr) {
-              pa[k] = ch.scale[(long long)n * ch.ab_nstride];
-              pb[k] = ch.shift[(long long)n * ch.ab_nstride];
-              psl[k] = ch.slope;
-            }
+    for (int i = 0; i < C::NU; ++i) {
+      const int u = tid + i * C::NT;
+      if (STG) {
+        int k = u / (C::IH * C::NQ);
+        const int rem = u - k * (C::IH * C::NQ);
+        const int r = rem / C::NQ, q = rem - r * C::NQ;
+        const int pl = (c0 + k < p.P) ? c0 + k : p.P - 1;
+        const PlaneDesc ds = tab[pl];
+        const int hi = hbase + r, gc = w0 * SW - 4 + 4 * q;
+        const bool ok = ds.valid && u < C::UNITS && c0 + k < p.P && (unsigned)hi < (unsigned)p.Hi && gc >= 0 && gc + 3 < p.Wi;
+        const long long off = ok ? (long long)hi * p.Wi + gc : 0;
+        v4[i] = *reinterpret_cast<gfloat4_p>(ds.base + off);
+      } else {
+        int k = u / (C::IH * C::IW);
+        const int rem = u - k * (C::IH * C::IW);
+        const int r = rem / C::IW, cc = rem - r * C::IW;
+        const int pl = (c0 + k < p.P) ? c0 + k : p.P - 1;
+        const PlaneDesc ds = tab[pl];
+        const int hi = hbase + r, wi = wbase + cc;
+        bool ok = ds.valid && u < C::UNITS && c0 + k < p.P && hi >= 0 && wi >= 0;
+        long long off = 0;
+        if (DH == 1 && DW == 1) {
+          ok = ok && hi < p.Hi && wi < p.Wi;
+          off = (long long)hi * p.Wi + wi;
+        } else {   // dilated source: only positions that are multiples of the stride carry a value
+          const int hs = hi / DH, wsrc = wi / DW;
+          ok = ok && (hi - hs * DH) == 0 && (wi - wsrc * DW) == 0 && hs < p.Hs && wsrc < p.Ws;
+          off = (long long)hs * p.Ws + wsrc;
+        }
+        v1[i] = ds.base[ok ? off : 0];
+      }
+    }
+  };
+  auto commit = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < C::NU; ++i) {
+      const int u = tid + i * C::NT;
+      if (u >= C::UNITS) continue;
+      if (STG) {
+        const int k = u / (C::IH * C::NQ);
+        const int rem = u - k * (C::IH * C::NQ);
+        const int r = rem / C::NQ, q = rem - r * C::NQ;
+        const bool pin = c0 + k < p.P;
+        const PlaneDesc ds = tab[pin ? c0 + k : p.P - 1];
+        const int hi = hbase + r, gc = w0 * SW - 4 + 4 * q;
+        const bool ok = pin && ds.valid && (unsigned)hi < (unsigned)p.Hi && gc >= 0 && gc + 3 < p.Wi;
+        const float x[4] = {v4[i][0], v4[i][1], v4[i][2], v4[i][3]};
+        float* row = lds + k * C::CHS + r * C::PITCH;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int lc = 4 * q + j - 3;
+          if ((unsigned)lc < (unsigned)C::IW) {
+            float val = x[j];
+            if (MODE == 0) val = e2e::in_act(val, ds.a, ds.b, ds.slope);
+            row[lc] = ok ? val : 0.f;
           }
         }
       } else {
-        pv[k] = pl < p.P;
-        pbase[k] = (gfloat_p)(p.xin + (((long long)n * p.P + (pv[k] ? pl : 0)) * p.Di + d) * in_plane);
+        const int k = u / (C::IH * C::IW);
+        const int rem = u - k * (C::IH * C::IW);
+        const int r = rem / C::IW, cc = rem - r * C::IW;
+        const bool pin = c0 + k < p.P;
+        const PlaneDesc ds = tab[pin ? c0 + k : p.P - 1];
+        const int hi = hbase + r, wi = wbase + cc;
+        bool ok = pin && ds.valid && hi >= 0 && wi >= 0;
+        if (DH == 1 && DW == 1) {
+          ok = ok && hi < p.Hi && wi < p.Wi;
+        } else {
+          const int hs = hi / DH, wsrc = wi / DW;
+          ok = ok && (hi - hs * DH) == 0 && (wi - wsrc * DW) == 0 && hs < p.Hs && wsrc < p.Ws;
+        }
+        float val = v1[i];
+        if (MODE == 0) val = e2e::in_act(val, ds.a, ds.b, ds.slope);
+        lds[k * C::CHS + r * C::PITCH + cc] = ok ? val : 0.f;
       }
     }
-    for (int e = tid; e < C::IH * C::IW; e += C::NT) {
-      const int r = e / C::IW, cc = e - r * C::IW;
-      const int hi = hbase + r, wi = wbase + cc;
-      const bool ok = (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi;
-      const long long off = ok ? (long long)hi * p.Wi + wi : 0;
-      float v[CK];
-#pragma unroll
-      for (int k = 0; k < CK; ++k) v[k] = pbase[k][pv[k] ? off : 0];
-#pragma unroll
-      for (int k = 0; k < CK; ++k) {
-        float x = v[k];
-        if (MODE == 0) x = e2e::in_act(x, pa[k], pb[k], psl[k]);
-        lds[k * C::CHS + r * C::PITCH + cc] = (ok && pv[k]) ? x : 0.f;
-      }
-    }
+  };
+
+  if (nchunks > 0) {
+    for (int pl = tid; pl < p.P; pl += C::NT) tab[pl] = make_desc(pl);
     __syncthreads();
+    prefetch(0);
+  }
+  for (int ci = 0; ci < nchunks; ++ci) {
+    const int c0 = ci * CK;
+    commit(c0);
+    __syncthreads();
+    if (ci + 1 < nchunks) prefetch(c0 + CK);   // in flight while this chunk is computed
 
     // ---------------- compute: each wave walks the live input planes of its OPW output planes -------------
 #pragma unroll
@@ -220,19 +317,25 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
       float* yp = p.y + (((long long)n * p.Q + q) * p.Do + d) * out_plane;
       float s = 0.f;
       int cnt = 0;
+      const bool vec_store = (C::PW == 4) && (p.Wo % 4 == 0);      // lane rows are 16-byte aligned
 #pragma unroll
-      for (int i = 0; i < C::PH; ++i)
+      for (int i = 0; i < C::PH; ++i) {
+        const int oh = oh0 + i;
 #pragma unroll
         for (int j = 0; j < C::PW; ++j) {
-          const int oh = oh0 + i, ow = ow0 + j;
+          const int ow = ow0 + j;
           const float val = acc[a][i][j] + bq;
           acc[a][i][j] = val;
           if (oh < p.Ho && ow < p.Wo) {
-            yp[(long long)oh * p.Wo + ow] = val;
+            if (!vec_store) yp[(long long)oh * p.Wo + ow] = val;
             s += val;
             ++cnt;
           }
         }
+        if (vec_store && oh < p.Ho && ow0 < p.Wo)
+          *reinterpret_cast<float4*>(yp + (long long)oh * p.Wo + ow0) =
+              make_float4(acc[a][i][0], acc[a][i][1 % C::PW], acc[a][i][2 % C::PW], acc[a][i][3 % C::PW]);
+      }
       if (p.part != nullptr) {
         const float tot = e2e::wave_sum(s);
         const float tcnt = e2e::wave_sum((float)cnt);
@@ -273,11 +376,23 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
       }
       if (zero_fill && oc.accumulate) continue;
       float* xp = oc.ptr + (long long)n * oc.nstride + (long long)dd * out_plane;
+      const bool vec_store = (C::PW == 4) && (p.Wo % 4 == 0);
 #pragma unroll
-      for (int i = 0; i < C::PH; ++i)
+      for (int i = 0; i < C::PH; ++i) {
+        const int oh = oh0 + i;
+        if (vec_store) {
+          if (oh < p.Ho && ow0 < p.Wo) {
+            float4* dst = reinterpret_cast<float4*>(xp + (long long)oh * p.Wo + ow0);
+            float4 val = make_float4(acc[a][i][0], acc[a][i][1 % C::PW], acc[a][i][2 % C::PW], acc[a][i][3 % C::PW]);
+            if (zero_fill) val = make_float4(0.f, 0.f, 0.f, 0.f);
+            else if (oc.accumulate) { const float4 o = *dst; val.x += o.x; val.y += o.y; val.z += o.z; val.w += o.w; }
+            *dst = val;
+          }
+          continue;
+        }
 #pragma unroll
         for (int j = 0; j < C::PW; ++j) {
-          const int oh = oh0 + i, ow = ow0 + j;
+          const int ow = ow0 + j;
           if (oh < p.Ho && ow < p.Wo) {
             float* dst = xp + (long long)oh * p.Wo + ow;
             if (zero_fill) *dst = 0.f;
@@ -285,6 +400,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
             else *dst = acc[a][i][j];
           }
         }
+      }
     }
   }
 }
@@ -336,17 +452,44 @@ __global__ __launch_bounds__(256) void conv133_dgrad_strided_kernel(const float*
   else *dst = acc;
 }
 
-template <int MODE, int SH, int SW, int TH, int TW, int LY, int LX, int OPW, int NW, int CK, int MINW = 1>
+template <int MODE, int SH, int SW, int DH, int DW, int TH, int TW, int LY, int LX, int OPW, int NW, int CK, int STG, int MINW = 1>
 int launch_cfg(ConvParams p, hipStream_t st) {
-  using C = Cfg<MODE, SH, SW, TH, TW, LY, LX, OPW, NW, CK>;
+  using C = Cfg<MODE, SH, SW, DH, DW, TH, TW, LY, LX, OPW, NW, CK, STG>;
   p.tiles_x = e2e::cdiv(p.Wo, TW);
   p.tiles_y = e2e::cdiv(p.Ho, TH);
   p.tiles_per_n = p.Do * p.tiles_y * p.tiles_x;
   p.groups = e2e::cdiv(p.Q, C::OCG);
   p.total = p.B * p.tiles_per_n * p.groups;
   p.padded_total = (p.total + 7) & ~7;
-  hipLaunchKernelGGL((conv133_kernel<MODE, SH, SW, TH, TW, LY, LX, OPW, NW, CK, MINW>), dim3(p.padded_total), dim3(C::NT), 0, st, p);
+  hipLaunchKernelGGL((conv133_kernel<MODE, SH, SW, DH, DW, TH, TW, LY, LX, OPW, NW, CK, STG, MINW>), dim3(p.padded_total),
+                     dim3(C::NT), (size_t)p.P * sizeof(PlaneDesc), st, p);
   return e2e::check_launch("conv133_kernel");
+}
+
+inline int t32_variant_knob() {     // tuning knob for the large-plane tile (0/1: 32x32, 2: 16x32)
+  static const int v = getenv("E2E_CONV_T32") ? atoi(getenv("E2E_CONV_T32")) : 2;
+  return v;
+}
+
+// stride-1 tiles; STG = 1 (aligned float4 staging) needs rows that are multiples of 4 floats
+template <int MODE, int DH, int DW>
+int launch_s1(const ConvParams& p, int kind, hipStream_t st) {
+  const bool vec = (DH == 1 && DW == 1) && (p.Wi % 4 == 0);
+  const int t32_variant = t32_variant_knob();
+  switch (kind) {
+    case 0:
+      if (t32_variant == 2)
+        return vec ? launch_cfg<MODE, 1, 1, 1, 1, 16, 32, 8, 8, 4, 8, 8, 1, 4>(p, st)
+                   : launch_cfg<MODE, 1, 1, DH, DW, 16, 32, 8, 8, 4, 8, 8, 0, 4>(p, st);
+      return vec ? launch_cfg<MODE, 1, 1, 1, 1, 32, 32, 8, 8, 4, 8, 8, 1, 2>(p, st)
+                 : launch_cfg<MODE, 1, 1, DH, DW, 32, 32, 8, 8, 4, 8, 8, 0, 2>(p, st);
+    case 1:
+      return vec ? launch_cfg<MODE, 1, 1, 1, 1, 16, 16, 8, 8, 4, 8, 16, 1>(p, st)
+                 : launch_cfg<MODE, 1, 1, DH, DW, 16, 16, 8, 8, 4, 8, 16, 0>(p, st);
+    default:
+      return vec ? launch_cfg<MODE, 1, 1, 1, 1, 8, 8, 8, 8, 4, 8, 32, 1>(p, st)
+                 : launch_cfg<MODE, 1, 1, DH, DW, 8, 8, 8, 8, 4, 8, 32, 0>(p, st);
+  }
 }
 
 // tile selection shared by the launcher and e2e_conv133_num_partials
@@ -361,7 +504,7 @@ inline TileKind pick_tile(int Ho, int Wo, int sh, int sw) {
 }
 inline void tile_dims(TileKind k, int& th, int& tw) {
   switch (k) {
-    case T32: th = 32; tw = 32; break;
+    case T32: th = t32_variant_knob() == 2 ? 16 : 32; tw = 32; break;
     case T16: th = 16; tw = 16; break;
     case T8: th = 8; tw = 8; break;
     case T16x32S: th = 16; tw = 32; break;
@@ -388,26 +531,21 @@ extern "C" int e2e_conv133_fwd(const e2e_in_chan_t* chans, int Cin, const float*
   p.P = Cin; p.Q = Cout; p.wq_stride = Cin * 9; p.wp_stride = 9; p.live_words = e2e::cdiv(Cin, 32);
   p.B = B; p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.sd = sd;
   p.Do = (Di - 1) / sd + 1; p.Ho = (Hi - 1) / sh + 1; p.Wo = (Wi - 1) / sw + 1;
+  p.Ds = Di; p.Hs = Hi; p.Ws = Wi;
   hipStream_t st = (hipStream_t)stream;
   const TileKind k = pick_tile(p.Ho, p.Wo, sh, sw);
-  if (sh == 1 && sw == 1) {
-    switch (k) {
-      case T32: return launch_cfg<0, 1, 1, 32, 32, 8, 8, 4, 8, 8, 4>(p, st);
-      case T16: return launch_cfg<0, 1, 1, 16, 16, 8, 8, 4, 8, 16>(p, st);
-      default: return launch_cfg<0, 1, 1, 8, 8, 8, 8, 4, 8, 32>(p, st);
-    }
-  }
-  // strided variants are instantiated per (sh, sw)
+  if (sh == 1 && sw == 1) return launch_s1<0, 1, 1>(p, k == T32 ? 0 : (k == T16 ? 1 : 2), st);
+  // strided variants ("convolutional pooling", 5 layers): element staging with register prefetch
   if (sh == 2 && sw == 2) {
-    if (k == T16x32S) return launch_cfg<0, 2, 2, 16, 32, 4, 16, 4, 8, 8>(p, st);
-    return launch_cfg<0, 2, 2, 8, 8, 8, 8, 4, 8, 16>(p, st);
+    if (k == T16x32S) return launch_cfg<0, 2, 2, 1, 1, 16, 32, 4, 16, 4, 8, 8, 0>(p, st);
+    return launch_cfg<0, 2, 2, 1, 1, 8, 8, 8, 8, 4, 8, 16, 0>(p, st);
   }
   if (sh == 1 && sw == 2) {
-    if (k == T16x32S) return launch_cfg<0, 1, 2, 16, 32, 4, 16, 4, 8, 8>(p, st);
-    return launch_cfg<0, 1, 2, 8, 8, 8, 8, 4, 8, 16>(p, st);
+    if (k == T16x32S) return launch_cfg<0, 1, 2, 1, 1, 16, 32, 4, 16, 4, 8, 8, 0>(p, st);
+    return launch_cfg<0, 1, 2, 1, 1, 8, 8, 8, 8, 4, 8, 16, 0>(p, st);
   }
-  if (k == T16x32S) return launch_cfg<0, 2, 1, 16, 32, 4, 16, 4, 8, 8>(p, st);
-  return launch_cfg<0, 2, 1, 8, 8, 8, 8, 4, 8, 16>(p, st);
+  if (k == T16x32S) return launch_cfg<0, 2, 1, 1, 1, 16, 32, 4, 16, 4, 8, 8, 0>(p, st);
+  return launch_cfg<0, 2, 1, 1, 1, 8, 8, 8, 8, 4, 8, 16, 0>(p, st);
 }
 
 extern "C" int e2e_conv133_dgrad(const float* dy, const float* w, const unsigned* live_t, const e2e_out_chan_t* outs,
@@ -417,22 +555,25 @@ extern "C" int e2e_conv133_dgrad(const float* dy, const float* w, const unsigned
   E2E_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Di > 0 && Hi > 0 && Wi > 0, "conv133_dgrad: bad dims");
   hipStream_t st = (hipStream_t)stream;
   const int Do = (Di - 1) / sd + 1, Ho = (Hi - 1) / sh + 1, Wo = (Wi - 1) / sw + 1;
-  if (sd != 1 || sh != 1 || sw != 1) {
+  const bool tiled = (sh == 1 && sw == 1) || (sh == 2 && sw == 2);
+  if (!tiled) {     // in-plane anisotropic strides: rare, plain gather kernel
     const long long per = (long long)Di * Hi * Wi;
     dim3 grid((unsigned)e2e::cdivll(per, 256), Cin, B);
     hipLaunchKernelGGL(conv133_dgrad_strided_kernel, grid, dim3(256), 0, st, dy, w, outs, B, Cin, Cout, Di, Hi, Wi, Do,
                        Ho, Wo, sd, sh, sw);
     return e2e::check_launch("conv133_dgrad_strided_kernel");
   }
-  // stride 1: the forward kernel with transposed, tap-reversed weights; the "input planes" are dy's channels
-  // (a plain tensor, no shift), the output planes are the virtual-concat input channels (un-shift on store).
+  // The forward kernel with transposed, tap-reversed weights.  Its "input planes" are dy's channels (a plain tensor,
+  // no shift; for a strided conv dy is read zero-dilated: only positions that are multiples of the stride carry a
+  // value, and only every sd-th depth slice is non-zero), its output planes are the virtual-concat input channels
+  // (un-shift on store).
   ConvParams p{};
   p.chans = nullptr; p.xin = dy; p.w = w; p.bias = nullptr; p.live = live_t; p.y = nullptr; p.part = nullptr; p.outs = outs;
   p.P = Cout; p.Q = Cin; p.wq_stride = 9; p.wp_stride = Cin * 9; p.live_words = e2e::cdiv(Cout, 32);
-  p.B = B; p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.sd = 1; p.Do = Di; p.Ho = Hi; p.Wo = Wi;
-  switch (pick_tile(Hi, Wi, 1, 1)) {
-    case T32: return launch_cfg<1, 1, 1, 32, 32, 8, 8, 4, 8, 8, 4>(p, st);
-    case T16: return launch_cfg<1, 1, 1, 16, 16, 8, 8, 4, 8, 16>(p, st);
-    default: return launch_cfg<1, 1, 1, 8, 8, 8, 8, 4, 8, 32>(p, st);
-  }
+  p.B = B; p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.sd = sd; p.Do = Di; p.Ho = Hi; p.Wo = Wi;
+  p.Ds = Do; p.Hs = Ho; p.Ws = Wo;
+  const TileKind k = pick_tile(Hi, Wi, 1, 1);
+  const int kind = k == T32 ? 0 : (k == T16 ? 1 : 2);
+  if (sh == 1) return launch_s1<1, 1, 1>(p, kind, st);
+  return launch_s1<1, 2, 2>(p, kind, st);
 }

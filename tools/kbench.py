@@ -1,0 +1,103 @@
+#!/usr/bin/env python
+"""Kernel micro-benchmarks on the GPU (diagnostic): times single C-ABI entry points on BASELINE layer shapes and
+prints achieved HBM GB/s (algorithmic bytes) and TFLOP/s.   python tools/kbench.py [conv|wgrad|convt|all]"""
+import math
+import os
+import sys
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from e2enet_medical_amd._lib import lib          # noqa: E402
+from e2enet_medical_amd.engine import Act, ConvOp, UpOp   # noqa: E402
+
+
+class Stub:
+    pass
+
+
+def time_ms(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def conv_case(B, srcs, cout, dims, stride, density, tag):
+    dev = torch.device("cuda")
+    acts = []
+    for i, (c, normed) in enumerate(srcs):
+        a = Act("s%d" % i, (B, c) + dims, normed, dev)
+        a.data.normal_()
+        if normed:
+            a.scale.fill_(1.0)
+            a.shift.fill_(0.0)
+        acts.append(a)
+    cin = sum(c for c, _ in srcs)
+    w = torch.randn(cout, cin, 1, 3, 3, device=dev) / math.sqrt(cin * 9)
+    e = Stub()
+    e.device = dev
+    e.params = {"b.conv.weight": w, "b.conv.bias": torch.zeros(cout, device=dev),
+                "b.instnorm.weight": torch.ones(cout, device=dev), "b.instnorm.bias": torch.zeros(cout, device=dev)}
+    e.grads = {k: torch.zeros_like(v) for k, v in e.params.items()}
+    op = ConvOp(e, "b", acts, cout, stride)
+    e.wgrad_ws = torch.empty(max(op.wgrad_ws_bytes() // 4, 1), dtype=torch.float32, device=dev)
+    e.in_sums = torch.empty(B * cout * 3, dtype=torch.float64, device=dev)
+    if density < 1.0:
+        km = (torch.rand(cout, cin, device=dev) < density).to(torch.uint8)
+        w.mul_(km.view(cout, cin, 1, 1, 1))
+        rows = torch.empty(cout * ((cin + 31) // 32), dtype=torch.int32, device=dev)
+        cols = torch.empty(cin * ((cout + 31) // 32), dtype=torch.int32, device=dev)
+        lib().dsff_expand(km.data_ptr(), None, rows.data_ptr(), cols.data_ptr(), cout, cin, 1, 0)
+        op.live, op.live_t = rows, cols
+    op.out.alloc_grad()
+    op.plan_backward()
+    op.out.grad.normal_()
+    vin = B * cin * dims[0] * dims[1] * dims[2]
+    vout = op.out.data.numel()
+    L = lib()
+    di, hi, wi = dims
+    p = e.params
+
+    def fwd():
+        L.conv133_fwd(op.chans.data_ptr(), cin, w.data_ptr(), p["b.conv.bias"].data_ptr(), op.live.data_ptr() if op.live is not None else None,
+                      op.out.data.data_ptr(), op.part.data_ptr(), B, cout, di, hi, wi, *stride, 0)
+
+    def dgrad():
+        L.conv133_dgrad(op.out.grad.data_ptr(), w.data_ptr(), op.live_t.data_ptr() if op.live_t is not None else None,
+                        op.outs.data_ptr(), B, cin, cout, di, hi, wi, *stride, 0)
+
+    def wgrad():
+        L.conv133_wgrad(op.chans.data_ptr(), op.out.grad.data_ptr(), e.grads["b.conv.weight"].data_ptr(), e.wgrad_ws.data_ptr(),
+                        B, cin, cout, di, hi, wi, *stride, 0)
+    dense = 2.0 * 9 * cin * cout * (vout / cout)
+    res = {}
+    for name, fn, flops in (("fwd", fwd, dense * density), ("dgrad", dgrad, dense * density), ("wgrad", wgrad, dense)):
+        ms = time_ms(fn)
+        gbs = (vin + vout) * 4 / ms / 1e6
+        res[name] = ms
+        print("%-26s %-6s %8.3f ms  %7.1f GB/s(alg)  %6.1f TFLOP/s" % (tag, name, ms, gbs, flops / ms / 1e9))
+    return res
+
+
+CASES = {
+    "L0_64x32": (2, [(32, True), (32, False)], 32, (128, 128, 128), (1, 1, 1), 0.2),
+    "L0_32x32d": (2, [(32, True)], 32, (128, 128, 128), (1, 1, 1), 1.0),
+    "L0_4x32d": (2, [(4, False)], 32, (128, 128, 128), (1, 1, 1), 1.0),
+    "L1_160x64": (2, [(64, True), (64, False), (32, False)], 64, (64, 64, 64), (1, 1, 1), 0.2),
+    "L1_s2_32x64d": (2, [(32, True)], 64, (128, 128, 128), (2, 2, 2), 1.0),
+    "L2_320x128": (2, [(128, True), (128, False), (64, False)], 128, (32, 32, 32), (1, 1, 1), 0.2),
+    "L3_640x256": (2, [(256, True), (256, False), (128, False)], 256, (16, 16, 16), (1, 1, 1), 0.2),
+    "L4_896x320": (2, [(320, True), (320, False), (256, False)], 320, (8, 8, 8), (1, 1, 1), 0.2),
+}
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or list(CASES)
+    for k in which:
+        conv_case(*CASES[k], k)
