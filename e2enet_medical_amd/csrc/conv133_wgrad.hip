@@ -155,6 +155,217 @@ __global__ __launch_bounds__(256) void conv133_wgrad_kernel(WgParams p) {
   }
 }
 
+// ---- v2: stride-1, rows that are multiples of 4 floats ---------------------------------------------------------
+// Same math and MFMA schedule as above, but the load stage is software pipelined: the global loads of tile t+1
+// (aligned float4 groups of the halo'd input rows and of the dy rows) are issued into registers right after the
+// barrier that publishes tile t, so they are in flight during the whole MFMA phase of tile t (7-8 us), and are
+// committed to LDS (normalise-on-load applied) when that phase is over.  One workgroup covers NCB blocks of 32 input
+// channels so that the dy tile is staged once for all of them (NCB * 4 waves).  Each wave stages 8 input channels
+// and 32 / (4 NCB) dy channels; the channel descriptors are wave-uniform and live in scalar registers for as long
+// as the batch item does not change.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef const f32x4_t __attribute__((address_space(1)))* gf4_p;
+
+template <int ND, int TH, int TW, int NCB>
+struct W2Cfg {
+  static constexpr int TP = ND * TH * TW;
+  static_assert(TP == 256, "one dy channel = 64 float4 groups = one wave-instruction");
+  static constexpr int IH = TH + 2, IW = TW + 2;
+  static constexpr int PITCH = IW;
+  static constexpr int CS = pad_mod32_2(ND * IH * PITCH);
+  static constexpr int OS = pad_mod32_2(TP);
+  static constexpr int NT = 256 * NCB;
+  static constexpr int NQ = TW / 4 + 2;                       // float4 groups per input row (starts 4 left of the tile)
+  static constexpr int GPC = ND * IH * NQ;                    // groups per input channel
+  static constexpr int ITX = (GPC + 63) / 64;                 // wave iterations per input channel
+  static constexpr int XCW = 8;                               // input channels staged per wave
+  static constexpr int YCW = 32 / (4 * NCB);                  // dy channels staged per wave
+  static constexpr int LDS_FLOATS = NCB * 32 * CS + 32 * OS;
+};
+
+template <int ND, int TH, int TW, int NCB>
+__global__ __launch_bounds__(256 * NCB) void conv133_wgrad_v2_kernel(WgParams p) {
+  using C = W2Cfg<ND, TH, TW, NCB>;
+  __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
+  float* xs = lds;
+  float* ys = lds + NCB * 32 * C::CS;
+
+  const int chunk = blockIdx.x;
+  const int cgroups = p.cblocks;                      // groups of NCB * 32 input channels
+  const int cg = blockIdx.y % cgroups, ob = blockIdx.y / cgroups;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cbl = wave >> 2, ch = wave & 1, oh = (wave >> 1) & 1;
+  const long long in_plane = (long long)p.Hi * p.Wi;
+  const long long out_plane = (long long)p.Ho * p.Wo;
+  const int cbase = cg * NCB * 32;
+
+  f32x4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const long long tile_lo = (long long)chunk * p.tiles_per_chunk;
+  long long tile_hi = tile_lo + p.tiles_per_chunk;
+  if (tile_hi > p.total_tiles) tile_hi = p.total_tiles;
+
+  auto decode = [&](long long tile, int& n, int& d0, int& h0, int& w0) {
+    int t = (int)(tile % p.tiles_per_n);
+    n = (int)(tile / p.tiles_per_n);
+    const int tx = t % p.tiles_x;
+    t /= p.tiles_x;
+    const int ty = t % p.tiles_y;
+    d0 = (t / p.tiles_y) * ND;
+    h0 = ty * TH;
+    w0 = tx * TW;
+  };
+
+  // ---- wave-uniform descriptors of this wave's 8 input channels (scalar registers) ----
+  gfloat_p xbase[C::XCW];
+  float xa[C::XCW], xb[C::XCW], xsl[C::XCW];
+  int xdsh[C::XCW];
+  bool xval[C::XCW];
+  auto load_desc = [&](int n) {
+#pragma unroll
+    for (int k = 0; k < C::XCW; ++k) {
+      const int c = cbase + wave * C::XCW + k;
+      xval[k] = c < p.Cin;
+      const e2e_in_chan_t chd = p.chans[xval[k] ? c : 0];
+      xdsh[k] = chd.dshift;
+      xbase[k] = (gfloat_p)(chd.ptr + (long long)n * chd.nstride);
+      xa[k] = 1.f; xb[k] = 0.f; xsl[k] = 1.f;
+      if (xval[k] && chd.scale != nullptr) {
+        xa[k] = chd.scale[(long long)n * chd.ab_nstride];
+        xb[k] = chd.shift[(long long)n * chd.ab_nstride];
+        xsl[k] = chd.slope;
+      }
+    }
+  };
+
+  // ---- per-lane geometry of the float4 groups (independent of the channel) ----
+  int g_lrow[C::ITX], g_q[C::ITX], g_nd[C::ITX], g_r[C::ITX];
+#pragma unroll
+  for (int it = 0; it < C::ITX; ++it) {
+    int g = lane + 64 * it;
+    if (g >= C::GPC) g = C::GPC - 1;
+    const int nd = g / (C::IH * C::NQ);
+    const int rem = g - nd * (C::IH * C::NQ);
+    const int r = rem / C::NQ;
+    g_nd[it] = nd; g_r[it] = r; g_q[it] = rem - r * C::NQ; g_lrow[it] = nd * C::IH + r;
+  }
+  // dy: lane -> float4 group of the 256-pixel tile
+  const int y_pi = lane * 4;
+  const int y_nd = y_pi / (TH * TW);
+  const int y_rem = y_pi - y_nd * (TH * TW);
+  const int y_r = y_rem / TW, y_col = y_rem - y_r * TW;
+
+  f32x4_t vx[C::XCW][C::ITX], vy[C::YCW];
+  auto prefetch = [&](int n, int d0, int h0, int w0) {
+#pragma unroll
+    for (int it = 0; it < C::ITX; ++it) {
+      const int hi = h0 - 1 + g_r[it], gc = w0 - 4 + 4 * g_q[it];
+      const int dq = d0 + g_nd[it];
+      const bool lane_ok = lane + 64 * it < C::GPC && dq < p.Do && (unsigned)hi < (unsigned)p.Hi && gc >= 0 && gc + 3 < p.Wi;
+      const long long lane_off = (long long)hi * p.Wi + gc;
+#pragma unroll
+      for (int k = 0; k < C::XCW; ++k) {
+        const int din = dq * p.sd - xdsh[k];
+        const bool ok = lane_ok && xval[k] && (unsigned)din < (unsigned)p.Di;
+        vx[k][it] = *reinterpret_cast<gf4_p>(xbase[k] + (ok ? (long long)din * in_plane + lane_off : 0));
+      }
+    }
+    const int dq = d0 + y_nd, ho = h0 + y_r, wo = w0 + y_col;
+    const bool lane_ok = dq < p.Do && ho < p.Ho && wo + 3 < p.Wo;
+#pragma unroll
+    for (int k = 0; k < C::YCW; ++k) {
+      const int o = ob * 32 + wave * C::YCW + k;
+      const bool ok = lane_ok && o < p.Cout;
+      const long long off = ok ? (((long long)n * p.Cout + o) * p.Do + dq) * out_plane + (long long)ho * p.Wo + wo : 0;
+      vy[k] = *reinterpret_cast<gf4_p>((gfloat_p)p.dy + off);
+    }
+  };
+  auto commit = [&](int d0, int h0, int w0) {
+#pragma unroll
+    for (int it = 0; it < C::ITX; ++it) {
+      if (lane + 64 * it >= C::GPC) continue;
+      const int hi = h0 - 1 + g_r[it], gc = w0 - 4 + 4 * g_q[it];
+      const int dq = d0 + g_nd[it];
+      const bool lane_ok = dq < p.Do && (unsigned)hi < (unsigned)p.Hi && gc >= 0 && gc + 3 < p.Wi;
+#pragma unroll
+      for (int k = 0; k < C::XCW; ++k) {
+        const int din = dq * p.sd - xdsh[k];
+        const bool ok = lane_ok && xval[k] && (unsigned)din < (unsigned)p.Di;
+        float* row = xs + (wave * C::XCW + k) * C::CS + g_lrow[it] * C::PITCH;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int lc = 4 * g_q[it] + j - 3;
+          if ((unsigned)lc < (unsigned)C::IW) row[lc] = ok ? e2e::in_act(vx[k][it][j], xa[k], xb[k], xsl[k]) : 0.f;
+        }
+      }
+    }
+    const int dq = d0 + y_nd, ho = h0 + y_r, wo = w0 + y_col;
+    const bool lane_ok = dq < p.Do && ho < p.Ho && wo + 3 < p.Wo;
+#pragma unroll
+    for (int k = 0; k < C::YCW; ++k) {
+      const int ol = wave * C::YCW + k;
+      const bool ok = lane_ok && ob * 32 + ol < p.Cout;
+      float2* dst = reinterpret_cast<float2*>(ys + ol * C::OS + y_pi);       // OS is even: 8-byte aligned
+      dst[0] = ok ? make_float2(vy[k][0], vy[k][1]) : make_float2(0.f, 0.f);
+      dst[1] = ok ? make_float2(vy[k][2], vy[k][3]) : make_float2(0.f, 0.f);
+    }
+  };
+
+  if (tile_lo < tile_hi) {
+    int n, d0, h0, w0;
+    decode(tile_lo, n, d0, h0, w0);
+    load_desc(n);
+    prefetch(n, d0, h0, w0);
+    for (long long tile = tile_lo; tile < tile_hi; ++tile) {
+      commit(d0, h0, w0);
+      int nn = n, nd0 = d0, nh0 = h0, nw0 = w0;
+      const bool more = tile + 1 < tile_hi;
+      if (more) {
+        decode(tile + 1, nn, nd0, nh0, nw0);
+        if (nn != n) load_desc(nn);                       // rare: the chunk crosses a batch item
+      }
+      __syncthreads();
+      if (more) prefetch(nn, nd0, nh0, nw0);              // in flight during the MFMA phase below
+
+      const int li = lane & 15, lk = lane >> 4;
+      const float* ap = ys + (oh * 16 + li) * C::OS + lk;
+      const float* bp = xs + (cbl * 32 + ch * 16 + li) * C::CS + lk;
+      for (int nd = 0; nd < ND; ++nd) {
+        for (int r = 0; r < TH; ++r) {
+          const float* apr = ap + (nd * TH + r) * TW;
+          const float* bpr = bp + nd * (C::IH * C::PITCH) + r * C::PITCH;
+#pragma unroll 2
+          for (int cq = 0; cq < TW / 4; ++cq) {
+            const float a = apr[cq * 4];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+              for (int kw = 0; kw < 3; ++kw)
+                acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bpr[kh * C::PITCH + cq * 4 + kw], acc[kh * 3 + kw], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();
+      n = nn; d0 = nd0; h0 = nh0; w0 = nw0;
+    }
+  }
+
+  float* sp = p.slab + (long long)chunk * p.Cout * p.Cin * 9;
+  const int c = cbase + cbl * 32 + ch * 16 + (lane & 15);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int o = ob * 32 + oh * 16 + (lane >> 4) * 4 + r;
+    if (o < p.Cout && c < p.Cin) {
+      float* dst = sp + ((long long)o * p.Cin + c) * 9;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) dst[t] = acc[t][r];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
                                                                 long long numel, int nchunks) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -180,13 +391,13 @@ inline TileSel pick(int Ho, int Wo, bool strided) {
   return {8, 4, 4};
 }
 
-inline void plan(WgParams& p, TileSel ts, int pairs, int* nchunks) {
+inline void plan(WgParams& p, TileSel ts, int pairs, int* nchunks, int target_wgs = 1024) {
   p.tiles_x = e2e::cdiv(p.Wo, ts.tw);
   p.tiles_y = e2e::cdiv(p.Ho, ts.th);
   p.tiles_d = e2e::cdiv(p.Do, ts.nd);
   p.tiles_per_n = p.tiles_d * p.tiles_y * p.tiles_x;
   p.total_tiles = (long long)p.tiles_per_n * p.B;
-  long long want = 1024 / (pairs > 0 ? pairs : 1);
+  long long want = target_wgs / (pairs > 0 ? pairs : 1);
   if (want < 1) want = 1;
   long long tpc = e2e::cdivll(p.total_tiles, want);
   if (tpc < 4) tpc = 4;
@@ -200,6 +411,16 @@ int launch(const WgParams& p, int nchunks, int pairs, hipStream_t st) {
   hipLaunchKernelGGL((conv133_wgrad_kernel<SH, SW, ND, TH, TW>), dim3(nchunks, pairs), dim3(256), 0, st, p);
   return e2e::check_launch("conv133_wgrad_kernel");
 }
+
+template <int ND, int TH, int TW, int NCB>
+int launch_v2(const WgParams& p, int nchunks, int pairs, hipStream_t st) {
+  hipLaunchKernelGGL((conv133_wgrad_v2_kernel<ND, TH, TW, NCB>), dim3(nchunks, pairs), dim3(256 * NCB), 0, st, p);
+  return e2e::check_launch("conv133_wgrad_v2_kernel");
+}
+
+// v2 applies to stride-1 (in plane) convs whose rows are multiples of 4 floats
+inline bool use_v2(int Wi, int sh, int sw) { return sh == 1 && sw == 1 && (Wi % 4) == 0 && Wi > 4; }   // 4x4 planes: v1
+inline int v2_ncb(int Cin) { return Cin > 32 ? 2 : 1; }
 
 template <int SH, int SW>
 int dispatch_strided(const WgParams& p, TileSel ts, int nchunks, int pairs, hipStream_t st) {
@@ -215,9 +436,14 @@ extern "C" long long e2e_conv133_wgrad_ws_bytes(int B, int Cin, int Cout, int Di
   WgParams p{};
   p.B = B; p.Cin = Cin; p.Cout = Cout; p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.sd = sd;
   p.Do = (Di - 1) / sd + 1; p.Ho = (Hi - 1) / sh + 1; p.Wo = (Wi - 1) / sw + 1;
-  const int pairs = e2e::cdiv(Cin, 32) * e2e::cdiv(Cout, 32);
   int nchunks;
-  plan(p, pick(p.Ho, p.Wo, sh != 1 || sw != 1), pairs, &nchunks);
+  if (use_v2(Wi, sh, sw)) {
+    const int pairs = e2e::cdiv(Cin, 32 * v2_ncb(Cin)) * e2e::cdiv(Cout, 32);
+    plan(p, pick(p.Ho, p.Wo, false), pairs, &nchunks, 512);
+  } else {
+    const int pairs = e2e::cdiv(Cin, 32) * e2e::cdiv(Cout, 32);
+    plan(p, pick(p.Ho, p.Wo, sh != 1 || sw != 1), pairs, &nchunks);
+  }
   return (long long)nchunks * Cout * Cin * 9 * (long long)sizeof(float);
 }
 
@@ -230,13 +456,27 @@ extern "C" int e2e_conv133_wgrad(const e2e_in_chan_t* chans, const float* dy, fl
   p.chans = chans; p.dy = dy; p.slab = reinterpret_cast<float*>(ws);
   p.B = B; p.Cin = Cin; p.Cout = Cout; p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.sd = sd;
   p.Do = (Di - 1) / sd + 1; p.Ho = (Hi - 1) / sh + 1; p.Wo = (Wi - 1) / sw + 1;
-  p.cblocks = e2e::cdiv(Cin, 32);
-  const int pairs = p.cblocks * e2e::cdiv(Cout, 32);
   const bool strided = sh != 1 || sw != 1;
   const TileSel ts = pick(p.Ho, p.Wo, strided);
   int nchunks;
-  plan(p, ts, pairs, &nchunks);
   int rc;
+  const long long numel = (long long)Cout * Cin * 9;
+  if (use_v2(Wi, sh, sw)) {
+    const int ncb = v2_ncb(Cin);
+    p.cblocks = e2e::cdiv(Cin, 32 * ncb);
+    const int pairs = p.cblocks * e2e::cdiv(Cout, 32);
+    plan(p, ts, pairs, &nchunks, 512);
+    if (ts.nd == 1 && ts.tw == 32) rc = ncb == 2 ? launch_v2<1, 8, 32, 2>(p, nchunks, pairs, st) : launch_v2<1, 8, 32, 1>(p, nchunks, pairs, st);
+    else if (ts.nd == 1) rc = ncb == 2 ? launch_v2<1, 16, 16, 2>(p, nchunks, pairs, st) : launch_v2<1, 16, 16, 1>(p, nchunks, pairs, st);
+    else rc = ncb == 2 ? launch_v2<4, 8, 8, 2>(p, nchunks, pairs, st) : launch_v2<4, 8, 8, 1>(p, nchunks, pairs, st);
+    if (rc != E2E_OK) return rc;
+    hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)e2e::cdivll(numel, 256)), dim3(256), 0, st, p.slab, dw, numel,
+                       nchunks);
+    return e2e::check_launch("wgrad_slab_reduce_kernel");
+  }
+  p.cblocks = e2e::cdiv(Cin, 32);
+  const int pairs = p.cblocks * e2e::cdiv(Cout, 32);
+  plan(p, ts, pairs, &nchunks);
   if (!strided) {
     if (ts.nd == 1 && ts.tw == 32) rc = launch<1, 1, 1, 8, 32>(p, nchunks, pairs, st);
     else if (ts.nd == 1) rc = launch<1, 1, 1, 16, 16>(p, nchunks, pairs, st);
@@ -250,7 +490,6 @@ extern "C" int e2e_conv133_wgrad(const e2e_in_chan_t* chans, const float* dy, fl
     rc = dispatch_strided<2, 1>(p, ts, nchunks, pairs, st);
   }
   if (rc != E2E_OK) return rc;
-  const long long numel = (long long)Cout * Cin * 9;
   hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)e2e::cdivll(numel, 256)), dim3(256), 0, st, p.slab, dw, numel,
                      nchunks);
   return e2e::check_launch("wgrad_slab_reduce_kernel");

@@ -223,6 +223,154 @@ __global__ __launch_bounds__(256) void convT_wgrad_kernel(const float* __restric
     }
 }
 
+// ---- v2 (kw == 2, even W): software-pipelined staging ---------------------------------------------------------------
+// The op is HBM-bound when every byte is read once (25.6 FLOP/B at 64 -> 32 channels), so the workgroup covers NCB
+// blocks of 32 input channels against one block of 32 output channels and stages the dy tile once for all of them.
+// A tile = 64 consecutive input voxels.  dy arrives as aligned float4 = (k=0,1) x (voxel pair) of one output row and
+// is scattered to an LDS image [tap][o][voxel] whose channel stride == 2 (mod 32): conflict-free B fragments.  Loads
+// of tile t+1 are issued into registers before the MFMA phase of tile t and committed after it.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef const f32x4_t __attribute__((address_space(1)))* gf4_p;
+
+template <int KDH, int NCB>     // KDH = kd * kh (output rows per input voxel row), KT = 2 * KDH
+__global__ __launch_bounds__(256 * NCB) void convT_wgrad_v2_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift, float slope,
+                                                                   const float* __restrict__ dy, float* __restrict__ slab,
+                                                                   int B, int Cin, int Cout, int D, int H, int W, int kd, int kh,
+                                                                   int tiles_per_chunk, int cgroups) {
+  constexpr int KT = 2 * KDH;
+  constexpr int TS = WG_TPX + 2;                       // 66 == 2 (mod 32)
+  constexpr int YCW = 32 / (4 * NCB);                  // dy channels staged per wave
+  constexpr int YIT = KDH * 32 / 64;                   // wave iterations per dy channel (KDH rows x 32 voxel pairs)
+  static_assert(KDH == 2 || KDH == 4, "kd*kh in {2,4}");
+  __shared__ __attribute__((aligned(16))) float zs[NCB * 32 * TS];
+  __shared__ __attribute__((aligned(16))) float ds[KT * 32 * TS];
+
+  const int chunk = blockIdx.x;
+  const int cg = blockIdx.y % cgroups, ob = blockIdx.y / cgroups;
+  const long long spatial = (long long)D * H * W;
+  const long long tiles_per_n = e2e::cdivll(spatial, WG_TPX);
+  const long long total_tiles = tiles_per_n * B;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cbl = wave >> 2, ch = wave & 1, oh = (wave >> 1) & 1;
+  const int Ho = H * kh, Wo = W * 2;
+  const long long ospatial = spatial * KT;
+  const int cbase = cg * NCB * 32;
+
+  f32x4 acc[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const long long tile_lo = (long long)chunk * tiles_per_chunk;
+  long long tile_hi = tile_lo + tiles_per_chunk;
+  if (tile_hi > total_tiles) tile_hi = total_tiles;
+
+  // z: each wave stages 8 channels x 64 voxels = 128 float4 -> 2 iterations; lane -> (channel k = g / 16, group g % 16)
+  f32x4_t vz[2], vy[YCW][YIT];
+  float za[2], zb[2];
+  auto prefetch = [&](long long tile) {
+    const int n = (int)(tile / tiles_per_n);
+    const long long vbase = (tile - (long long)n * tiles_per_n) * WG_TPX;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int g = lane + 64 * it;
+      const int c = cbase + wave * 8 + (g >> 4);
+      const long long vi = vbase + (g & 15) * 4;
+      const bool ok = c < Cin && vi + 3 < spatial;
+      const long long off = ok ? ((long long)n * Cin + c) * spatial + vi : 0;
+      vz[it] = *reinterpret_cast<gf4_p>((gfloat_p)x + off);
+      za[it] = 1.f; zb[it] = 0.f;
+      if (scale != nullptr && c < Cin) { za[it] = scale[(long long)n * Cin + c]; zb[it] = shift[(long long)n * Cin + c]; }
+    }
+#pragma unroll
+    for (int k = 0; k < YCW; ++k) {
+      const int o = ob * 32 + wave * YCW + k;
+#pragma unroll
+      for (int it = 0; it < YIT; ++it) {
+        const int g = lane + 64 * it;                 // (row rr = g / 32, voxel pair vp = g % 32)
+        const int rr = g >> 5, vp = g & 31;
+        const long long vi = vbase + 2 * vp;
+        const bool ok = o < Cout && vi + 1 < spatial;
+        long long off = 0;
+        if (ok) {
+          const int wv = (int)(vi % W);
+          const long long r = vi / W;
+          const int hv = (int)(r % H), dv = (int)(r / H);
+          const int i = rr / kh, j = rr - i * kh;
+          off = ((long long)n * Cout + o) * ospatial + ((long long)(dv * kd + i) * Ho + (hv * kh + j)) * Wo + 2 * wv;
+        }
+        vy[k][it] = *reinterpret_cast<gf4_p>((gfloat_p)dy + off);
+      }
+    }
+  };
+  auto commit = [&](long long tile) {
+    const int n = (int)(tile / tiles_per_n);
+    const long long vbase = (tile - (long long)n * tiles_per_n) * WG_TPX;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int g = lane + 64 * it;
+      const int cl = wave * 8 + (g >> 4);
+      const long long vi = vbase + (g & 15) * 4;
+      const bool ok = cbase + cl < Cin && vi + 3 < spatial;
+      float2* dst = reinterpret_cast<float2*>(zs + cl * TS + (g & 15) * 4);
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float t = vz[it][j];
+        if (scale != nullptr) t = e2e::in_act(t, za[it], zb[it], slope);
+        v[j] = ok ? t : 0.f;
+      }
+      dst[0] = make_float2(v[0], v[1]);
+      dst[1] = make_float2(v[2], v[3]);
+    }
+#pragma unroll
+    for (int k = 0; k < YCW; ++k) {
+      const int ol = wave * YCW + k;
+#pragma unroll
+      for (int it = 0; it < YIT; ++it) {
+        const int g = lane + 64 * it;
+        const int rr = g >> 5, vp = g & 31;
+        const bool ok = ob * 32 + ol < Cout && vbase + 2 * vp + 1 < spatial;
+        const f32x4_t q = vy[k][it];                  // (k=0,v) (k=1,v) (k=0,v+1) (k=1,v+1)
+        float2* d0 = reinterpret_cast<float2*>(ds + ((rr * 2 + 0) * 32 + ol) * TS + 2 * vp);
+        float2* d1 = reinterpret_cast<float2*>(ds + ((rr * 2 + 1) * 32 + ol) * TS + 2 * vp);
+        *d0 = ok ? make_float2(q[0], q[2]) : make_float2(0.f, 0.f);
+        *d1 = ok ? make_float2(q[1], q[3]) : make_float2(0.f, 0.f);
+      }
+    }
+  };
+
+  if (tile_lo < tile_hi) {
+    prefetch(tile_lo);
+    for (long long tile = tile_lo; tile < tile_hi; ++tile) {
+      commit(tile);
+      __syncthreads();
+      if (tile + 1 < tile_hi) prefetch(tile + 1);
+      const int li = lane & 15, lk = lane >> 4;
+      const float* ap = zs + (cbl * 32 + ch * 16 + li) * TS + lk;
+      const float* bp = ds + (oh * 16 + li) * TS + lk;
+#pragma unroll 4
+      for (int k0 = 0; k0 < WG_TPX; k0 += 4) {
+        const float a = ap[k0];
+#pragma unroll
+        for (int t = 0; t < KT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp[t * 32 * TS + k0], acc[t], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  }
+  // D[i = c][j = o]: col = lane & 15 -> o, row = (lane >> 4) * 4 + reg -> c
+  float* sp = slab + (long long)chunk * Cin * Cout * KT;
+  const int o = ob * 32 + oh * 16 + (lane & 15);
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = cbase + cbl * 32 + ch * 16 + (lane >> 4) * 4 + r;
+      if (c < Cin && o < Cout) sp[((long long)c * Cout + o) * KT + t] = acc[t][r];
+    }
+}
+
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
                                                           long long numel, int nchunks) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -295,10 +443,16 @@ extern "C" int e2e_convT_dgrad(const float* dy, const float* w, const unsigned* 
   return e2e::check_launch("convT_dgrad_kernel");
 }
 
+static bool convT_use_v2(int D, int H, int W, int kd, int kh, int kw) {
+  return kw == 2 && (kd * kh == 2 || kd * kh == 4) && (W % 2) == 0 && ((long long)D * H * W) % 4 == 0;
+}
+static int convT_v2_ncb(int Cin) { return Cin > 32 ? 2 : 1; }
+
 extern "C" long long e2e_convT_wgrad_ws_bytes(int B, int Cin, int Cout, int D, int H, int W, int kd, int kh, int kw) {
   const long long total_tiles = e2e::cdivll((long long)D * H * W, WG_TPX) * B;
   int tpc;
-  const int pairs = e2e::cdiv(Cin, 32) * e2e::cdiv(Cout, 32);
+  int pairs = e2e::cdiv(Cin, 32) * e2e::cdiv(Cout, 32);
+  if (convT_use_v2(D, H, W, kd, kh, kw)) pairs = e2e::cdiv(Cin, 32 * convT_v2_ncb(Cin)) * e2e::cdiv(Cout, 32);
   const int nchunks = wgrad_chunks(total_tiles, pairs, &tpc);
   return (long long)nchunks * Cin * Cout * kd * kh * kw * (long long)sizeof(float);
 }
@@ -311,10 +465,26 @@ extern "C" int e2e_convT_wgrad(const float* x, const float* scale, const float* 
   hipStream_t st = (hipStream_t)stream;
   const long long total_tiles = e2e::cdivll((long long)D * H * W, WG_TPX) * B;
   int tpc;
-  const int pairs = e2e::cdiv(Cin, 32) * e2e::cdiv(Cout, 32);
-  const int nchunks = wgrad_chunks(total_tiles, pairs, &tpc);
   const int kt = kd * kh * kw;
   float* slab = reinterpret_cast<float*>(ws);
+  const long long numel_all = (long long)Cin * Cout * kt;
+  if (convT_use_v2(D, H, W, kd, kh, kw)) {
+    const int ncb = convT_v2_ncb(Cin);
+    const int cgroups = e2e::cdiv(Cin, 32 * ncb);
+    const int pairs2 = cgroups * e2e::cdiv(Cout, 32);
+    const int nch = wgrad_chunks(total_tiles, pairs2, &tpc);
+    dim3 grid2(nch, pairs2);
+    const int kdh = kd * kh;
+#define LAUNCH_V2(KDH, NCB) hipLaunchKernelGGL((convT_wgrad_v2_kernel<KDH, NCB>), grid2, dim3(256 * NCB), 0, st, x, scale, shift, \
+                                               slope, dy, slab, B, Cin, Cout, D, H, W, kd, kh, tpc, cgroups)
+    if (kdh == 4) { if (ncb == 2) LAUNCH_V2(4, 2); else LAUNCH_V2(4, 1); }
+    else { if (ncb == 2) LAUNCH_V2(2, 2); else LAUNCH_V2(2, 1); }
+#undef LAUNCH_V2
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)e2e::cdivll(numel_all, 256)), dim3(256), 0, st, slab, dw, numel_all, nch);
+    return e2e::check_launch("convT_wgrad_v2");
+  }
+  const int pairs = e2e::cdiv(Cin, 32) * e2e::cdiv(Cout, 32);
+  const int nchunks = wgrad_chunks(total_tiles, pairs, &tpc);
   dim3 grid(nchunks, pairs);
   DISPATCH_KT(kt, hipLaunchKernelGGL((convT_wgrad_kernel<KT>), grid, dim3(256), 0, st, x, scale, shift, slope, dy, slab, B,
                                      Cin, Cout, D, H, W, kd, kh, kw, tpc, nchunks));

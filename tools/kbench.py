@@ -98,6 +98,42 @@ CASES = {
 }
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or list(CASES)
+    which = [a for a in sys.argv[1:] if a in CASES] or ([] if sys.argv[1:] else list(CASES))
     for k in which:
         conv_case(*CASES[k], k)
+
+
+def convt_case(B, cin, cout, dims, kernel, density, tag):
+    dev = torch.device("cuda")
+    src = Act("s", (B, cin) + dims, True, dev)
+    src.data.normal_(); src.scale.fill_(1.0); src.shift.fill_(0.0)
+    w = torch.randn((cin, cout) + kernel, device=dev) / math.sqrt(cin)
+    e = Stub(); e.device = dev; e.params = {"up.weight": w}; e.grads = {"up.weight": torch.zeros_like(w)}
+    op = UpOp(e, "up.weight", src, cout, kernel)
+    e.wgrad_ws = torch.empty(max(op.wgrad_ws_bytes() // 4, 1), dtype=torch.float32, device=dev)
+    if density < 1.0:
+        km = (torch.rand(cin, cout, device=dev) < density).to(torch.uint8)
+        w.mul_(km.view(cin, cout, 1, 1, 1))
+        rows = torch.empty(cin * ((cout + 31) // 32), dtype=torch.int32, device=dev)
+        cols = torch.empty(cout * ((cin + 31) // 32), dtype=torch.int32, device=dev)
+        lib().dsff_expand(km.data_ptr(), None, rows.data_ptr(), cols.data_ptr(), cin, cout, 1, 0)
+        op.live, op.live_t = cols, rows
+    op.out.alloc_grad(); op.plan_backward(); op.out.grad.normal_()
+    vin, vout = src.data.numel(), op.out.data.numel()
+    kt = kernel[0] * kernel[1] * kernel[2]
+    dense = 2.0 * cin * cout * kt * (vin / cin)
+    for name, fn, fl in (("fwd", op.forward, dense * density), ("bwd(w+d)", op.backward, dense * (1 + density))):
+        ms = time_ms(fn)
+        print("%-26s %-8s %8.3f ms  %7.1f GB/s(alg)  %6.1f TFLOP/s" % (tag, name, ms, (vin + vout) * 4 / ms / 1e6, fl / ms / 1e9))
+
+
+CT_CASES = {
+    "up_L0_64x32": (2, 64, 32, (64, 64, 64), (2, 2, 2), 0.2),
+    "up_L1_128x64": (2, 128, 64, (32, 32, 32), (2, 2, 2), 0.2),
+    "up_L2_256x128": (2, 256, 128, (16, 16, 16), (2, 2, 2), 0.2),
+    "up_L3_320x256": (2, 320, 256, (8, 8, 8), (2, 2, 2), 0.2),
+}
+if __name__ == "__main__" and any(a.startswith("up") or a == "convt" for a in sys.argv[1:]):
+    for k, v in CT_CASES.items():
+        if "convt" in sys.argv[1:] or k in sys.argv[1:]:
+            convt_case(*v, k)
