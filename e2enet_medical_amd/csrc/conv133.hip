@@ -54,12 +54,13 @@ struct Cfg {
   // lane column offset in floats; decides the widest aligned LDS read of a neighbourhood row
   static constexpr int LSTEP = PW * SW;
   static constexpr int VEC = (LSTEP % 4 == 0) ? 4 : (LSTEP % 2 == 0 ? 2 : 1);
-  // VEC 4: pitch % 16 == 8 puts the four 16-lane groups of a ds_read_b128 on disjoint bank quarters;
-  // VEC 2: pitch % 8 == 4 does the same for the two lane rows of a 32-lane ds_read_b64 group.
-  static constexpr int pitch_for(int iw) {
-    int p = iw;
-    if (VEC == 4) { while (p % 16 != 8) ++p; }
-    else if (VEC == 2) { while (p % 8 != 4) ++p; }
+    static constexpr int pitch_for(int iw) {
+    int p = (iw + 3) & ~3;
+    // VEC 4: consecutive lane rows are PH*SH tile rows apart; (PH*SH*pitch) % 64 == 32 puts the four 16-lane groups
+    // of a ds_read_b128 on disjoint bank quarters.  VEC 2: the same idea for the two lane rows of a ds_read_b64 group.
+    if (VEC == 4) { while ((PH * SH * p) % 64 != 32 && p < iw + 64) p += 4; }
+    else if (VEC == 2) { p = iw; while (p % 8 != 4) ++p; }
+    else p = iw;
     return p;
   }
   static constexpr int PITCH = pitch_for(IW);
@@ -100,10 +101,14 @@ __device__ __forceinline__ void load_row(const float* __restrict__ src, float* _
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef const f32x4_t __attribute__((address_space(1)))* gfloat4_p;
 
-template <int MODE, int SH, int SW, int DH, int DW, int TH, int TW, int LY, int LX, int OPW, int NW, int CK, int STG, int MINW>
+template <int MODE, int SH, int SW, int DH, int DW, int TH, int TW, int LY, int LX, int OPW, int NW, int CK, int STG, int MINW, int PIPE>
 __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
   using C = Cfg<MODE, SH, SW, DH, DW, TH, TW, LY, LX, OPW, NW, CK, STG>;
+  constexpr int WPAD = 12;                                     // 9 taps padded to 3 x 16 bytes
+  constexpr int WUNITS = C::OCG * CK * 9;                      // weights of one chunk for this workgroup's planes
+  constexpr int NUW = (WUNITS + C::NT - 1) / C::NT;
   __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
+  __shared__ __attribute__((aligned(16))) float wl[C::OCG * CK * WPAD];
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
   PlaneDesc* tab = reinterpret_cast<PlaneDesc*>(dyn_lds);      // [P]: built once per workgroup
 
@@ -137,7 +142,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
 #pragma unroll
       for (int j = 0; j < C::PW; ++j) acc[a][i][j] = 0.f;
 
-  const int qbase = g * C::OCG + wave * OPW;
+  const int qgroup = g * C::OCG;
+  const int qbase = qgroup + wave * OPW;
   const float* lane_tp = lds + (ly * C::PH * SH) * C::PITCH + lx * C::LSTEP;
 
   // data gradient of a depth-strided conv: only every sd-th slice of the (shifted) input received anything
@@ -150,107 +156,155 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
     ds.a = 1.f; ds.b = 0.f; ds.slope = 1.f; ds.valid = 0;
     if (MODE == 0) {
       ds.base = (gfloat_p)p.chans[0].ptr;
-      if (pl < p.P) {
-        const e2e_in_chan_t ch = p.chans[pl];
-        const int din = d * p.sd - ch.dshift;
-        if ((unsigned)din < (unsigned)p.Di) {
-          ds.valid = 1;
-          ds.base = (gfloat_p)(ch.ptr + (long long)n * ch.nstride + (long long)din * in_plane);
-          if (ch.scale != nullptr) {
-            ds.a = ch.scale[(long long)n * ch.ab_nstride];
-            ds.b = ch.shift[(long long)n * ch.ab_nstride];
-            ds.slope = ch.slope;
-          }
+      const e2e_in_chan_t ch = p.chans[pl];
+      const int din = d * p.sd - ch.dshift;
+      if ((unsigned)din < (unsigned)p.Di) {
+        ds.valid = 1;
+        ds.base = (gfloat_p)(ch.ptr + (long long)n * ch.nstride + (long long)din * in_plane);
+        if (ch.scale != nullptr) {
+          ds.a = ch.scale[(long long)n * ch.ab_nstride];
+          ds.b = ch.shift[(long long)n * ch.ab_nstride];
+          ds.slope = ch.slope;
         }
       }
     } else {
-      ds.valid = pl < p.P;
-      ds.base = (gfloat_p)(p.xin + (((long long)n * p.P + (ds.valid ? pl : 0)) * p.Ds + d / p.sd) * src_plane);
+      ds.valid = 1;
+      ds.base = (gfloat_p)(p.xin + (((long long)n * p.P + pl) * p.Ds + d / p.sd) * src_plane);
     }
     return ds;
   };
 
+  // ---- per-thread staging geometry: constant over the chunks, decoded once ----------------------------------
+  int su_k[C::NU], su_lds[C::NU], su_goff[C::NU], su_mask[C::NU];      // mask: which of the unit's elements land in the tile
+#pragma unroll
+  for (int i = 0; i < C::NU; ++i) {
+    const int u = tid + i * C::NT;
+    if (STG) {
+      int k = u / (C::IH * C::NQ);
+      const int rem = u - k * (C::IH * C::NQ);
+      const int r = rem / C::NQ, q = rem - r * C::NQ;
+      const int hi = hbase + r, gc = w0 * SW - 4 + 4 * q;
+      const bool ok = u < C::UNITS && (unsigned)hi < (unsigned)p.Hi && gc >= 0 && gc + 3 < p.Wi;
+      int m = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if ((unsigned)(4 * q + j - 3) < (unsigned)C::IW) m |= 1 << j;
+      if (u >= C::UNITS) { m = 0; k = 0; }
+      su_k[i] = k;
+      su_lds[i] = k * C::CHS + r * C::PITCH + 4 * q - 3;
+      su_goff[i] = ok ? hi * p.Wi + gc : -1;
+      su_mask[i] = m;
+    } else {
+      int k = u / (C::IH * C::IW);
+      const int rem = u - k * (C::IH * C::IW);
+      const int r = rem / C::IW, cc = rem - r * C::IW;
+      const int hi = hbase + r, wi = wbase + cc;
+      bool ok = u < C::UNITS && hi >= 0 && wi >= 0;
+      int off = 0;
+      if (DH == 1 && DW == 1) {
+        ok = ok && hi < p.Hi && wi < p.Wi;
+        off = hi * p.Wi + wi;
+      } else {   // dilated source: only positions that are multiples of the stride carry a value
+        const int hs = hi / DH, wsrc = wi / DW;
+        ok = ok && (hi - hs * DH) == 0 && (wi - wsrc * DW) == 0 && hs < p.Hs && wsrc < p.Ws;
+        off = hs * p.Ws + wsrc;
+      }
+      if (u >= C::UNITS) k = 0;
+      su_k[i] = k;
+      su_lds[i] = k * C::CHS + r * C::PITCH + cc;
+      su_goff[i] = ok ? off : -1;
+      su_mask[i] = u < C::UNITS ? 1 : 0;
+    }
+  }
+  // weights of a chunk: element (ql, cl, tap) of this workgroup's OCG output planes
+  int wu_goff[NUW], wu_lds[NUW];
+#pragma unroll
+  for (int i = 0; i < NUW; ++i) {
+    const int u = tid + i * C::NT;
+    const int ql = u / (CK * 9);
+    const int rem = u - ql * (CK * 9);
+    const int cl = rem / 9, kk = rem - cl * 9;
+    const bool ok = u < WUNITS && qgroup + ql < p.Q;
+    wu_goff[i] = ok ? (qgroup + ql) * p.wq_stride + cl * p.wp_stride + (MODE == 1 ? 8 - kk : kk) : -1;
+    wu_lds[i] = ok ? (ql * CK + cl) * WPAD + kk : -1;
+    if (u >= WUNITS) wu_lds[i] = -1;
+    else if (!ok) wu_lds[i] = (ql * CK + cl) * WPAD + kk;      // planes beyond Q: stage zeros
+  }
+
   // ---- staging: issue the global loads of one chunk into registers (prefetch), commit them to LDS later -----
   f32x4_t v4[STG ? C::NU : 1];
   float v1[STG ? 1 : C::NU];
+  float vw[NUW];
   auto prefetch = [&](int c0) {
 #pragma unroll
     for (int i = 0; i < C::NU; ++i) {
-      const int u = tid + i * C::NT;
-      if (STG) {
-        int k = u / (C::IH * C::NQ);
-        const int rem = u - k * (C::IH * C::NQ);
-        const int r = rem / C::NQ, q = rem - r * C::NQ;
-        const int pl = (c0 + k < p.P) ? c0 + k : p.P - 1;
-        const PlaneDesc ds = tab[pl];
-        const int hi = hbase + r, gc = w0 * SW - 4 + 4 * q;
-        const bool ok = ds.valid && u < C::UNITS && c0 + k < p.P && (unsigned)hi < (unsigned)p.Hi && gc >= 0 && gc + 3 < p.Wi;
-        const long long off = ok ? (long long)hi * p.Wi + gc : 0;
-        v4[i] = *reinterpret_cast<gfloat4_p>(ds.base + off);
-      } else {
-        int k = u / (C::IH * C::IW);
-        const int rem = u - k * (C::IH * C::IW);
-        const int r = rem / C::IW, cc = rem - r * C::IW;
-        const int pl = (c0 + k < p.P) ? c0 + k : p.P - 1;
-        const PlaneDesc ds = tab[pl];
-        const int hi = hbase + r, wi = wbase + cc;
-        bool ok = ds.valid && u < C::UNITS && c0 + k < p.P && hi >= 0 && wi >= 0;
-        long long off = 0;
-        if (DH == 1 && DW == 1) {
-          ok = ok && hi < p.Hi && wi < p.Wi;
-          off = (long long)hi * p.Wi + wi;
-        } else {   // dilated source: only positions that are multiples of the stride carry a value
-          const int hs = hi / DH, wsrc = wi / DW;
-          ok = ok && (hi - hs * DH) == 0 && (wi - wsrc * DW) == 0 && hs < p.Hs && wsrc < p.Ws;
-          off = (long long)hs * p.Ws + wsrc;
-        }
-        v1[i] = ds.base[ok ? off : 0];
-      }
+      const int pl = c0 + su_k[i];
+      const PlaneDesc ds = tab[pl < p.P ? pl : p.P - 1];
+      const bool ok = su_goff[i] >= 0 && pl < p.P && ds.valid;
+      if (STG) v4[i] = *reinterpret_cast<gfloat4_p>(ds.base + (ok ? su_goff[i] : 0));
+      else v1[i] = ds.base[ok ? su_goff[i] : 0];
+    }
+    const int remain = p.P - c0;
+#pragma unroll
+    for (int i = 0; i < NUW; ++i) {
+      const int cl = (wu_lds[i] / WPAD) % CK;
+      const bool ok = wu_goff[i] >= 0 && cl < remain;
+      vw[i] = ((gfloat_p)p.w)[ok ? wu_goff[i] + c0 * p.wp_stride : 0];
     }
   };
   auto commit = [&](int c0) {
 #pragma unroll
     for (int i = 0; i < C::NU; ++i) {
-      const int u = tid + i * C::NT;
-      if (u >= C::UNITS) continue;
+      if (su_mask[i] == 0) continue;
+      const int pl = c0 + su_k[i];
+      const PlaneDesc ds = tab[pl < p.P ? pl : p.P - 1];
+      const bool ok = su_goff[i] >= 0 && pl < p.P && ds.valid;
       if (STG) {
-        const int k = u / (C::IH * C::NQ);
-        const int rem = u - k * (C::IH * C::NQ);
-        const int r = rem / C::NQ, q = rem - r * C::NQ;
-        const bool pin = c0 + k < p.P;
-        const PlaneDesc ds = tab[pin ? c0 + k : p.P - 1];
-        const int hi = hbase + r, gc = w0 * SW - 4 + 4 * q;
-        const bool ok = pin && ds.valid && (unsigned)hi < (unsigned)p.Hi && gc >= 0 && gc + 3 < p.Wi;
-        const float x[4] = {v4[i][0], v4[i][1], v4[i][2], v4[i][3]};
-        float* row = lds + k * C::CHS + r * C::PITCH;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int lc = 4 * q + j - 3;
-          if ((unsigned)lc < (unsigned)C::IW) {
-            float val = x[j];
+          if (su_mask[i] & (1 << j)) {
+            float val = v4[i][j];
             if (MODE == 0) val = e2e::in_act(val, ds.a, ds.b, ds.slope);
-            row[lc] = ok ? val : 0.f;
+            lds[su_lds[i] + j] = ok ? val : 0.f;
           }
         }
       } else {
-        const int k = u / (C::IH * C::IW);
-        const int rem = u - k * (C::IH * C::IW);
-        const int r = rem / C::IW, cc = rem - r * C::IW;
-        const bool pin = c0 + k < p.P;
-        const PlaneDesc ds = tab[pin ? c0 + k : p.P - 1];
-        const int hi = hbase + r, wi = wbase + cc;
-        bool ok = pin && ds.valid && hi >= 0 && wi >= 0;
-        if (DH == 1 && DW == 1) {
-          ok = ok && hi < p.Hi && wi < p.Wi;
-        } else {
-          const int hs = hi / DH, wsrc = wi / DW;
-          ok = ok && (hi - hs * DH) == 0 && (wi - wsrc * DW) == 0 && hs < p.Hs && wsrc < p.Ws;
-        }
         float val = v1[i];
         if (MODE == 0) val = e2e::in_act(val, ds.a, ds.b, ds.slope);
-        lds[k * C::CHS + r * C::PITCH + cc] = ok ? val : 0.f;
+        lds[su_lds[i]] = ok ? val : 0.f;
       }
     }
+    const int remain = p.P - c0;
+#pragma unroll
+    for (int i = 0; i < NUW; ++i) {
+      if (wu_lds[i] < 0) continue;
+      const int cl = (wu_lds[i] / WPAD) % CK;
+      wl[wu_lds[i]] = (wu_goff[i] >= 0 && cl < remain) ? vw[i] : 0.f;
+    }
+  };
+
+  // ---- one live (output plane a, input plane cl) kernel: LDS reads (issue) and the 9 x PH x PW FMAs (apply) ----
+  auto issue = [&](int a, int cl, float (&nb)[C::NR][C::NC], float (&wk)[WPAD]) {
+    const float* wp = wl + ((wave * OPW + a) * CK + cl) * WPAD;
+    const float4 w0v = *reinterpret_cast<const float4*>(wp);
+    const float4 w1v = *reinterpret_cast<const float4*>(wp + 4);
+    wk[0] = w0v.x; wk[1] = w0v.y; wk[2] = w0v.z; wk[3] = w0v.w;
+    wk[4] = w1v.x; wk[5] = w1v.y; wk[6] = w1v.z; wk[7] = w1v.w;
+    wk[8] = wp[8];
+    const float* tp = lane_tp + cl * C::CHS;
+#pragma unroll
+    for (int r = 0; r < C::NR; ++r) load_row<C::NC, C::VEC>(tp + r * C::PITCH, nb[r]);
+  };
+  auto apply = [&](float (&ac)[C::PH][C::PW], const float (&nb)[C::NR][C::NC], const float (&wk)[WPAD]) {
+#pragma unroll
+    for (int i = 0; i < C::PH; ++i)
+#pragma unroll
+      for (int j = 0; j < C::PW; ++j)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw)
+            ac[i][j] = fmaf(wk[kh * 3 + kw], nb[i * SH + kh][j * SW + kw], ac[i][j]);
   };
 
   if (nchunks > 0) {
@@ -264,7 +318,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
     __syncthreads();
     if (ci + 1 < nchunks) prefetch(c0 + CK);   // in flight while this chunk is computed
 
-    // ---------------- compute: each wave walks the live input planes of its OPW output planes -------------
+    // ---------------- compute: each wave walks the live input planes of its OPW output planes; the LDS reads of
+    // the next live kernel are issued before the FMAs of the current one (two register sets) ----------------
 #pragma unroll
     for (int a = 0; a < OPW; ++a) {
       const int q = qbase + a;
@@ -279,26 +334,33 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
         const int remain = p.P - c0;
         if (remain < CK) bits &= (1u << remain) - 1u;
         bits = __builtin_amdgcn_readfirstlane(bits);
-        while (bits) {
-          const int cl = __builtin_ctz(bits);
+        if (!PIPE) {
+          while (bits) {
+            const int cl = __builtin_ctz(bits);
+            bits &= bits - 1;
+            float nb[C::NR][C::NC];
+            float wk[WPAD];
+            issue(a, cl, nb, wk);
+            apply(acc[a], nb, wk);
+          }
+        } else if (bits) {
+          float nbA[C::NR][C::NC], nbB[C::NR][C::NC];
+          float wkA[WPAD], wkB[WPAD];
+          int cl = __builtin_ctz(bits);
           bits &= bits - 1;
-          const float* wp = p.w + (long long)q * p.wq_stride + (long long)(c0 + cl) * p.wp_stride;
-          float wk[9];
-#pragma unroll
-          for (int k = 0; k < 9; ++k) wk[k] = wp[MODE == 1 ? 8 - k : k];
-          const float* tp = lane_tp + cl * C::CHS;
-          float nb[C::NR][C::NC];
-#pragma unroll
-          for (int r = 0; r < C::NR; ++r) load_row<C::NC, C::VEC>(tp + r * C::PITCH, nb[r]);
-#pragma unroll
-          for (int i = 0; i < C::PH; ++i)
-#pragma unroll
-            for (int j = 0; j < C::PW; ++j)
-#pragma unroll
-              for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw)
-                  acc[a][i][j] = fmaf(wk[kh * 3 + kw], nb[i * SH + kh][j * SW + kw], acc[a][i][j]);
+          issue(a, cl, nbA, wkA);
+          while (true) {
+            if (!bits) { apply(acc[a], nbA, wkA); break; }
+            cl = __builtin_ctz(bits);
+            bits &= bits - 1;
+            issue(a, cl, nbB, wkB);
+            apply(acc[a], nbA, wkA);
+            if (!bits) { apply(acc[a], nbB, wkB); break; }
+            cl = __builtin_ctz(bits);
+            bits &= bits - 1;
+            issue(a, cl, nbA, wkA);
+            apply(acc[a], nbB, wkB);
+          }
         }
       }
     }
@@ -452,7 +514,7 @@ __global__ __launch_bounds__(256) void conv133_dgrad_strided_kernel(const float*
   else *dst = acc;
 }
 
-template <int MODE, int SH, int SW, int DH, int DW, int TH, int TW, int LY, int LX, int OPW, int NW, int CK, int STG, int MINW = 1>
+template <int MODE, int SH, int SW, int DH, int DW, int TH, int TW, int LY, int LX, int OPW, int NW, int CK, int STG, int MINW = 1, int PIPE = 0>
 int launch_cfg(ConvParams p, hipStream_t st) {
   using C = Cfg<MODE, SH, SW, DH, DW, TH, TW, LY, LX, OPW, NW, CK, STG>;
   p.tiles_x = e2e::cdiv(p.Wo, TW);
@@ -461,7 +523,7 @@ int launch_cfg(ConvParams p, hipStream_t st) {
   p.groups = e2e::cdiv(p.Q, C::OCG);
   p.total = p.B * p.tiles_per_n * p.groups;
   p.padded_total = (p.total + 7) & ~7;
-  hipLaunchKernelGGL((conv133_kernel<MODE, SH, SW, DH, DW, TH, TW, LY, LX, OPW, NW, CK, STG, MINW>), dim3(p.padded_total),
+  hipLaunchKernelGGL((conv133_kernel<MODE, SH, SW, DH, DW, TH, TW, LY, LX, OPW, NW, CK, STG, MINW, PIPE>), dim3(p.padded_total),
                      dim3(C::NT), (size_t)p.P * sizeof(PlaneDesc), st, p);
   return e2e::check_launch("conv133_kernel");
 }
@@ -478,11 +540,11 @@ int launch_s1(const ConvParams& p, int kind, hipStream_t st) {
   const int t32_variant = t32_variant_knob();
   switch (kind) {
     case 0:
-      if (t32_variant == 2)
-        return vec ? launch_cfg<MODE, 1, 1, 1, 1, 16, 32, 8, 8, 4, 8, 8, 1, 4>(p, st)
-                   : launch_cfg<MODE, 1, 1, DH, DW, 16, 32, 8, 8, 4, 8, 8, 0, 4>(p, st);
-      return vec ? launch_cfg<MODE, 1, 1, 1, 1, 32, 32, 8, 8, 4, 8, 8, 1, 2>(p, st)
-                 : launch_cfg<MODE, 1, 1, DH, DW, 32, 32, 8, 8, 4, 8, 8, 0, 2>(p, st);
+      // 16x32 tile, 118 VGPRs -> two 512-thread workgroups per CU (measured best; the 32x32 tile and the double
+      // register set variant of the live-kernel loop both lose to it because they halve the occupancy or spill)
+      (void)t32_variant;
+      return vec ? launch_cfg<MODE, 1, 1, 1, 1, 16, 32, 8, 8, 4, 8, 8, 1, 4, 0>(p, st)
+                 : launch_cfg<MODE, 1, 1, DH, DW, 16, 32, 8, 8, 4, 8, 8, 0, 4, 0>(p, st);
     case 1:
       return vec ? launch_cfg<MODE, 1, 1, 1, 1, 16, 16, 8, 8, 4, 8, 16, 1>(p, st)
                  : launch_cfg<MODE, 1, 1, DH, DW, 16, 16, 8, 8, 4, 8, 16, 0>(p, st);
@@ -504,7 +566,7 @@ inline TileKind pick_tile(int Ho, int Wo, int sh, int sw) {
 }
 inline void tile_dims(TileKind k, int& th, int& tw) {
   switch (k) {
-    case T32: th = t32_variant_knob() == 2 ? 16 : 32; tw = 32; break;
+    case T32: th = 16; tw = 32; break;
     case T16: th = 16; tw = 16; break;
     case T8: th = 8; tw = 8; break;
     case T16x32S: th = 16; tw = 32; break;
