@@ -101,7 +101,7 @@ int e2e_in_stats_finalize(const float* part, int np, const float* gamma, const f
 /* ---- K7: InstanceNorm + LeakyReLU backward -------------------------------------------
  * Given dz = dL/d(lrelu(IN(y))) and the saved pre-norm y, overwrite dz with dy = dL/dy and
  * produce dgamma, dbeta (accumulated over the batch) and dbias = sum(dy).
- *   sums  workspace [B,C,2] floats
+ *   sums  workspace of B*C*3 doubles (s1 = sum du, s2 = sum du*xhat, s3 = sum dy)
  */
 int e2e_in_lrelu_bwd(float* dz_dy, const float* y, const float* mean, const float* rstd, const float* gamma,
                      const float* beta, float slope, float* dgamma, float* dbeta, float* dbias, float* sums,
