@@ -12,6 +12,9 @@
 
 namespace {
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef const f32x4_t __attribute__((address_space(1)))* gf4_p;
+
 __device__ __forceinline__ void tap_ijk(int t, int kh, int kw, int& i, int& j, int& k) {
   k = t % kw;
   const int r = t / kw;
@@ -229,8 +232,6 @@ __global__ __launch_bounds__(256) void convT_wgrad_kernel(const float* __restric
 // A tile = 64 consecutive input voxels.  dy arrives as aligned float4 = (k=0,1) x (voxel pair) of one output row and
 // is scattered to an LDS image [tap][o][voxel] whose channel stride == 2 (mod 32): conflict-free B fragments.  Loads
 // of tile t+1 are issued into registers before the MFMA phase of tile t and committed after it.
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-typedef const f32x4_t __attribute__((address_space(1)))* gf4_p;
 
 template <int KDH, int NCB>     // KDH = kd * kh (output rows per input voxel row), KT = 2 * KDH
 __global__ __launch_bounds__(256 * NCB) void convT_wgrad_v2_kernel(const float* __restrict__ x, const float* __restrict__ scale,
@@ -371,6 +372,94 @@ __global__ __launch_bounds__(256 * NCB) void convT_wgrad_v2_kernel(const float* 
     }
 }
 
+// ---- data gradient v2 (kw == 2, even W): dy tile staged once in LDS ---------------------------------------------------
+// dx[c, v] = sum_o sum_t W[c, o, t] * dy[o, out(v, t)].  A tile = 64 consecutive input voxels (lane = voxel); the dy
+// values of 32 output channels x KT taps are loaded as aligned float4 and scattered to an LDS image [tap][o][voxel];
+// each wave then walks its input channels and, per channel, the live output channels (scalar bit ops), reading dy
+// from LDS conflict free.  dy is read from HBM once instead of once per live (c, o) pair.
+template <int KDH>
+__global__ __launch_bounds__(256) void convT_dgrad_v2_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                             const unsigned* __restrict__ live_t, float* __restrict__ dx,
+                                                             int accumulate, int B, int Cin, int Cout, int D, int H, int W,
+                                                             int kd, int kh) {
+  constexpr int KT = 2 * KDH;
+  constexpr int OC = 32;                               // output channels per staged chunk
+  constexpr int TS = 64;                               // lane = voxel: consecutive lanes, consecutive banks
+  constexpr int NUY = OC * KDH * 32 / 256;             // float4 loads per thread per chunk
+  __shared__ __attribute__((aligned(16))) float ds[KT * OC * TS];
+
+  const long long spatial = (long long)D * H * W;
+  const long long tiles_per_n = e2e::cdivll(spatial, 64);
+  const long long tile = blockIdx.x;
+  const int n = (int)(tile / tiles_per_n);
+  const long long vbase = (tile - (long long)n * tiles_per_n) * 64;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int Ho = H * kh, Wo = W * 2;
+  const long long ospatial = spatial * KT;
+  const int words = e2e::cdiv(Cout, 32);
+  const long long vi_lane = vbase + lane;
+
+  for (int o0 = 0; o0 < Cout; o0 += OC) {
+    // ---- stage dy[o0 .. o0+32) for this tile: unit = (o, output row rr, voxel pair vp) ----
+    f32x4_t v[NUY];
+#pragma unroll
+    for (int i = 0; i < NUY; ++i) {
+      const int u = tid + i * 256;
+      const int ol = u / (KDH * 32);
+      const int rem = u - ol * (KDH * 32);
+      const int rr = rem >> 5, vp = rem & 31;
+      const long long vi = vbase + 2 * vp;
+      const int o = o0 + ol;
+      const bool ok = o < Cout && vi + 1 < spatial;
+      long long off = 0;
+      if (ok) {
+        const int wv = (int)(vi % W);
+        const long long r = vi / W;
+        const int hv = (int)(r % H), dv = (int)(r / H);
+        const int ii = rr / kh, jj = rr - ii * kh;
+        off = ((long long)n * Cout + o) * ospatial + ((long long)(dv * kd + ii) * Ho + (hv * kh + jj)) * Wo + 2 * wv;
+      }
+      v[i] = *reinterpret_cast<gf4_p>((gfloat_p)dy + off);
+    }
+    if (o0 > 0) __syncthreads();                       // previous chunk fully consumed
+#pragma unroll
+    for (int i = 0; i < NUY; ++i) {
+      const int u = tid + i * 256;
+      const int ol = u / (KDH * 32);
+      const int rem = u - ol * (KDH * 32);
+      const int rr = rem >> 5, vp = rem & 31;
+      const bool ok = o0 + ol < Cout && vbase + 2 * vp + 1 < spatial;
+      float2* d0 = reinterpret_cast<float2*>(ds + ((rr * 2 + 0) * OC + ol) * TS + 2 * vp);
+      float2* d1 = reinterpret_cast<float2*>(ds + ((rr * 2 + 1) * OC + ol) * TS + 2 * vp);
+      *d0 = ok ? make_float2(v[i][0], v[i][2]) : make_float2(0.f, 0.f);
+      *d1 = ok ? make_float2(v[i][1], v[i][3]) : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    // ---- compute: wave w owns input channels w, w+4, ... ----
+    for (int c = wave; c < Cin; c += 4) {
+      unsigned bits = live_t ? live_t[(long long)c * words + (o0 >> 5)] : 0xffffffffu;
+      const int remain = Cout - o0;
+      if (remain < 32) bits &= (1u << remain) - 1u;
+      bits = __builtin_amdgcn_readfirstlane(bits);
+      float acc = 0.f;
+      while (bits) {
+        const int ol = __builtin_ctz(bits);
+        bits &= bits - 1;
+        const float* wp = w + ((long long)c * Cout + o0 + ol) * KT;
+        const float* dp = ds + ol * TS + lane;
+#pragma unroll
+        for (int t = 0; t < KT; ++t) acc = fmaf(wp[t], dp[t * OC * TS], acc);
+      }
+      if (vi_lane < spatial) {
+        float* dst = dx + ((long long)n * Cin + c) * spatial + vi_lane;
+        if (accumulate || o0 > 0) *dst += acc;
+        else *dst = acc;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
                                                           long long numel, int nchunks) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -437,6 +526,15 @@ extern "C" int e2e_convT_dgrad(const float* dy, const float* w, const unsigned* 
   E2E_REQUIRE(check_k(kd, kh, kw), "convT_dgrad: kernel must be in {1,2}^3");
   hipStream_t st = (hipStream_t)stream;
   const long long spatial = (long long)D * H * W;
+  // v2 needs enough 64-voxel tiles to fill the chip (one workgroup per tile); small planes keep the gather kernel
+  if (kw == 2 && (kd * kh == 2 || kd * kh == 4) && (W % 2) == 0 && spatial % 4 == 0 && e2e::cdivll(spatial, 64) * B >= 1024) {
+    const unsigned tiles = (unsigned)(e2e::cdivll(spatial, 64) * B);
+    if (kd * kh == 4)
+      hipLaunchKernelGGL((convT_dgrad_v2_kernel<4>), dim3(tiles), dim3(256), 0, st, dy, w, live_t, dx, accumulate, B, Cin, Cout, D, H, W, kd, kh);
+    else
+      hipLaunchKernelGGL((convT_dgrad_v2_kernel<2>), dim3(tiles), dim3(256), 0, st, dy, w, live_t, dx, accumulate, B, Cin, Cout, D, H, W, kd, kh);
+    return e2e::check_launch("convT_dgrad_v2_kernel");
+  }
   dim3 grid((unsigned)e2e::cdivll(spatial, 256), Cin, B);
   DISPATCH_KT(kd * kh * kw, hipLaunchKernelGGL((convT_dgrad_kernel<KT>), grid, dim3(256), 0, st, dy, w, live_t, dx, accumulate,
                                                Cin, Cout, D, H, W, kd, kh, kw));
