@@ -330,22 +330,49 @@ __global__ __launch_bounds__(256 * NCB) void conv133_wgrad_v2_kernel(WgParams p)
       __syncthreads();
       if (more) prefetch(nn, nd0, nh0, nw0);              // in flight during the MFMA phase below
 
+      // MFMA phase.  The A/B fragments of k-step s+1 are read from LDS before the 9 MFMAs of k-step s are issued
+      // (explicit double registers + sched_barrier), so the matrix pipe never waits on an LDS round trip.
       const int li = lane & 15, lk = lane >> 4;
       const float* ap = ys + (oh * 16 + li) * C::OS + lk;
       const float* bp = xs + (cbl * 32 + ch * 16 + li) * C::CS + lk;
-      for (int nd = 0; nd < ND; ++nd) {
-        for (int r = 0; r < TH; ++r) {
-          const float* apr = ap + (nd * TH + r) * TW;
-          const float* bpr = bp + nd * (C::IH * C::PITCH) + r * C::PITCH;
-#pragma unroll 2
-          for (int cq = 0; cq < TW / 4; ++cq) {
-            const float a = apr[cq * 4];
+      float a_cur = ap[0];
+      float b_cur[9];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) b_cur[kh * 3 + kw] = bp[kh * C::PITCH + kw];
+      for (int row = 0; row < ND * TH; ++row) {
+        const int nd = row / TH, r = row - nd * TH;
+        const float* apr = ap + row * TW;
+        const float* bpr = bp + nd * (C::IH * C::PITCH) + r * C::PITCH;
+        // first k-step of the next row (a harmless read past the tile after the last row: still inside the LDS array)
+        const int row1 = row + 1;
+        const int nd1 = row1 / TH, r1 = row1 - nd1 * TH;
+        const float* apn = ap + row1 * TW;
+        const float* bpn = bp + nd1 * (C::IH * C::PITCH) + r1 * C::PITCH;
+#pragma unroll
+        for (int cq = 0; cq < TW / 4; ++cq) {
+          float a_nxt, b_nxt[9];
+          if (cq + 1 < TW / 4) {
+            a_nxt = apr[(cq + 1) * 4];
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-              for (int kw = 0; kw < 3; ++kw)
-                acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bpr[kh * C::PITCH + cq * 4 + kw], acc[kh * 3 + kw], 0, 0, 0);
+              for (int kw = 0; kw < 3; ++kw) b_nxt[kh * 3 + kw] = bpr[kh * C::PITCH + (cq + 1) * 4 + kw];
+          } else {
+            a_nxt = apn[0];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+              for (int kw = 0; kw < 3; ++kw) b_nxt[kh * 3 + kw] = bpn[kh * C::PITCH + kw];
           }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur, b_cur[t], acc[t], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          a_cur = a_nxt;
+#pragma unroll
+          for (int t = 0; t < 9; ++t) b_cur[t] = b_nxt[t];
         }
       }
       __syncthreads();
