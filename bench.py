@@ -90,6 +90,22 @@ class KernelTimer:
         return sum(e0.elapsed_time(e1) for e0, e1, _ in self.events)
 
 
+TRAFFIC_FILE = "r01b_pmc_traffic.json"
+
+
+def pmc_traffic(prefix):
+    """HBM bytes per launch of the kernels whose name starts with `prefix`, from the committed PMC summary
+    (measured by rocprofv3 outside this process: counters cannot be read from inside the benchmark)."""
+    path = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    n = sum(v["launches"] for k, v in d.items() if k.startswith(prefix))
+    if not n:
+        return None
+    return sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in d.items() if k.startswith(prefix)) / n
+
+
 def wgrad_flops(args):
     # e2e_conv133_wgrad(chans, dy, dw, ws, B, Cin, Cout, Di, Hi, Wi, sd, sh, sw, stream): dense 2*9*Cin*Cout*voxels_out
     b, cin, cout, di, hi, wi, sd, sh, sw = args[4:13]
@@ -237,9 +253,11 @@ def main():
             ms = wt.total_ms()
             flops = sum(wgrad_flops(a) for _, _, a in wt.events)
             achieved = flops / (ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "conv133_wgrad_kernel (+ slab reduce)", "achieved": achieved,
-                               "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TF,
-                               "traffic": None, "launches": len(wt.events), "avg_ms": ms / len(wt.events),
+            out["roofline"] = {"bound": "mfma", "kernel": "conv133_wgrad_v2_kernel (+ strided v1 + slab reduce)",
+                               "achieved": achieved, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                               "frac": achieved / MFMA_F32_PEAK_TF, "traffic": pmc_traffic("conv133_wgrad"),
+                               "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" % TRAFFIC_FILE,
+                               "launches": len(wt.events), "avg_ms": ms / len(wt.events),
                                "share_of_step": ms / (dt * 1e3)}
         if args.op_profile:
             prof = {k: round(t.total_ms() / args.steps, 3) for k, t in timers.items() if t.events}
