@@ -36,6 +36,7 @@ struct ConvParams {
   int groups;                          // ceil(Q / OCG)
   int total;                           // B * tiles_per_n * groups (logical work items)
   int padded_total;
+  int items_per_wg;
 };
 
 // wave-uniform description of one staged input plane, kept in LDS (double buffered per chunk)
@@ -101,7 +102,7 @@ __device__ __forceinline__ void load_row(const float* __restrict__ src, float* _
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef const f32x4_t __attribute__((address_space(1)))* gfloat4_p;
 
-template <int MODE, int SH, int SW, int DH, int DW, int TH, int TW, int LY, int LX, int OPW, int NW, int CK, int STG, int MINW, int PIPE>
+template <int MODE, int SH, int SW, int DH, int DW, int TH, int TW, int LY, int LX, int OPW, int NW, int CK, int STG, int MINW, int PIPE, int PERSIST>
 __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
   using C = Cfg<MODE, SH, SW, DH, DW, TH, TW, LY, LX, OPW, NW, CK, STG>;
   constexpr int WPAD = 12;                                     // 9 taps padded to 3 x 16 bytes
@@ -112,10 +113,26 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
   PlaneDesc* tab = reinterpret_cast<PlaneDesc*>(dyn_lds);      // [P]: built once per workgroup
 
-  const int logical = e2e::xcd_remap(blockIdx.x, p.padded_total);
-  if (logical >= p.total) return;
-  const int g = logical % p.groups;
-  int t = logical / p.groups;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int lx = lane % LX, ly = lane / LX;
+  const long long in_plane = (long long)p.Hi * p.Wi;
+  const long long src_plane = (long long)p.Hs * p.Ws;
+  const float* lane_tp = lds + (ly * C::PH * SH) * C::PITCH + lx * C::LSTEP;
+
+  // persistent workgroup: a run of consecutive logical work items (tile-major, output-plane group fastest), so that
+  // the plane descriptor table is rebuilt only when the (batch item, depth slice) changes
+  const int wg = e2e::xcd_remap(blockIdx.x, gridDim.x);
+  // (PERSIST = 0: one item per workgroup; the single-trip loop folds away and keeps the register count at 118)
+  const int item_lo = PERSIST ? wg * p.items_per_wg : wg;
+  const int item_hi = PERSIST ? (item_lo + p.items_per_wg < p.total ? item_lo + p.items_per_wg : p.total)
+                              : (item_lo < p.total ? item_lo + 1 : item_lo);
+  int tab_n = -1, tab_d = -1;
+
+  auto run_item = [&](const int item) {
+  const int g = item % p.groups;
+  int t = item / p.groups;
   const int n = t / p.tiles_per_n;
   t -= n * p.tiles_per_n;
   const int tile_in_n = t;
@@ -124,15 +141,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
   const int ty = t % p.tiles_y;
   const int d = t / p.tiles_y;
 
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lane = tid & 63;
-  const int lx = lane % LX, ly = lane / LX;
-
   const int h0 = ty * TH, w0 = tx * TW;                 // output tile origin
   const int hbase = h0 * SH - 1, wbase = w0 * SW - 1;   // input tile origin (incl. halo)
-  const long long in_plane = (long long)p.Hi * p.Wi;
-  const long long src_plane = (long long)p.Hs * p.Ws;
 
   float acc[OPW][C::PH][C::PW];
 #pragma unroll
@@ -144,7 +154,6 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
 
   const int qgroup = g * C::OCG;
   const int qbase = qgroup + wave * OPW;
-  const float* lane_tp = lds + (ly * C::PH * SH) * C::PITCH + lx * C::LSTEP;
 
   // data gradient of a depth-strided conv: only every sd-th slice of the (shifted) input received anything
   const bool dead_slice = (MODE == 1) && (d % p.sd != 0);
@@ -308,8 +317,11 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
   };
 
   if (nchunks > 0) {
-    for (int pl = tid; pl < p.P; pl += C::NT) tab[pl] = make_desc(pl);
-    __syncthreads();
+    if (n != tab_n || d != tab_d) {
+      for (int pl = tid; pl < p.P; pl += C::NT) tab[pl] = make_desc(pl);
+      tab_n = n; tab_d = d;
+      __syncthreads();
+    }
     prefetch(0);
   }
   for (int ci = 0; ci < nchunks; ++ci) {
@@ -465,6 +477,12 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
       }
     }
   }
+  };   // run_item
+  if (PERSIST) {
+    for (int item = item_lo; item < item_hi; ++item) run_item(item);
+  } else if (item_lo < item_hi) {
+    run_item(item_lo);
+  }
 }
 
 // ---- strided data gradient (encoder "convolutional pooling" convs, 5 layers, dense): gather form ------------
@@ -514,8 +532,18 @@ __global__ __launch_bounds__(256) void conv133_dgrad_strided_kernel(const float*
   else *dst = acc;
 }
 
+template <int MODE, int SH, int SW, int DH, int DW, int TH, int TW, int LY, int LX, int OPW, int NW, int CK, int STG, int MINW, int PIPE, int PERSIST>
+int launch_cfg_impl(ConvParams p, hipStream_t st);
+
 template <int MODE, int SH, int SW, int DH, int DW, int TH, int TW, int LY, int LX, int OPW, int NW, int CK, int STG, int MINW = 1, int PIPE = 0>
 int launch_cfg(ConvParams p, hipStream_t st) {
+  // thin layers (a single input chunk, e.g. the 4-modal network input): per-tile start-up dominates -> persistent
+  if (p.P <= CK) return launch_cfg_impl<MODE, SH, SW, DH, DW, TH, TW, LY, LX, OPW, NW, CK, STG, MINW, PIPE, 1>(p, st);
+  return launch_cfg_impl<MODE, SH, SW, DH, DW, TH, TW, LY, LX, OPW, NW, CK, STG, MINW, PIPE, 0>(p, st);
+}
+
+template <int MODE, int SH, int SW, int DH, int DW, int TH, int TW, int LY, int LX, int OPW, int NW, int CK, int STG, int MINW, int PIPE, int PERSIST>
+int launch_cfg_impl(ConvParams p, hipStream_t st) {
   using C = Cfg<MODE, SH, SW, DH, DW, TH, TW, LY, LX, OPW, NW, CK, STG>;
   p.tiles_x = e2e::cdiv(p.Wo, TW);
   p.tiles_y = e2e::cdiv(p.Ho, TH);
@@ -523,7 +551,12 @@ int launch_cfg(ConvParams p, hipStream_t st) {
   p.groups = e2e::cdiv(p.Q, C::OCG);
   p.total = p.B * p.tiles_per_n * p.groups;
   p.padded_total = (p.total + 7) & ~7;
-  hipLaunchKernelGGL((conv133_kernel<MODE, SH, SW, DH, DW, TH, TW, LY, LX, OPW, NW, CK, STG, MINW, PIPE>), dim3(p.padded_total),
+  // persistent grid: about 4 workgroup slots per CU (256 CUs), each walking a run of consecutive work items
+  int wgs = PERSIST ? 1024 : p.total;
+  if (wgs > p.total) wgs = p.total;
+  p.items_per_wg = e2e::cdiv(p.total, wgs);
+  wgs = (e2e::cdiv(p.total, p.items_per_wg) + 7) & ~7;
+  hipLaunchKernelGGL((conv133_kernel<MODE, SH, SW, DH, DW, TH, TW, LY, LX, OPW, NW, CK, STG, MINW, PIPE, PERSIST>), dim3(wgs),
                      dim3(C::NT), (size_t)p.P * sizeof(PlaneDesc), st, p);
   return e2e::check_launch("conv133_kernel");
 }
