@@ -292,3 +292,103 @@ def test_trainer_surface_runs_iterations():
         assert float((net.get_parameter(n).detach() * (1 - m)).abs().max()) == 0.0
     v = float(tr.run_iteration(tr.val_gen, False))
     assert np.isfinite(v)
+
+
+def test_btcv_like_anisotropic_config_vs_oracle():
+    """BASELINE config 3 shape family: 1 modality, 14 classes, anisotropic pooling [[1,2,2],[2,2,2]x3,[1,2,2]]
+    (depth stride 1 with in-plane stride 2, transposed convs with kernel (1,2,2)), batch 2, non-cubic patch."""
+    pools = [(1, 2, 2), (2, 2, 2), (2, 2, 2), (2, 2, 2), (1, 2, 2)]
+    patch, cin, base, k = (8, 64, 96), 1, 8, 14
+    net = build_net(patch, cin, base, k, pools, 40)
+    shapes, params = load_closed_form(net)
+    spec = oracle.make_spec(cin, base, k, pools, 2, 40)
+    assert list(onet.param_shapes(spec).keys()) == list(shapes.keys())
+    x = seeded_input((2, cin) + patch, seed=5)
+    eng = net.engine(x.cuda())
+    outs = eng.forward(x.cuda(), True)
+    targets = [seeded_labels((o.shape[0], 1) + tuple(o.shape[2:]), k, seed=90 + i) for i, o in enumerate(outs)]
+    w = oracle.ds_weights(5)
+    loss = eng.loss_backward([t.cuda() for t in targets], w, batch_dice=False)
+    leaves = {n: p.clone().requires_grad_(True) for n, p in params.items()}
+    ref = oracle.forward(spec, leaves, x)
+    ref_loss = oracle.deep_supervision_loss(ref, targets, w, False)
+    ref_loss.backward()
+    for o, r in zip(outs, ref):
+        assert o.shape == r.shape and (o.cpu() - r.detach()).abs().max() <= 1e-4
+    assert abs(loss.item() - ref_loss.item()) < 5e-5
+    for n in shapes:
+        rg = leaves[n].grad
+        err = (eng.grads[n].cpu() - rg).abs().max().item()
+        assert err <= 2e-4 * max(1.0, rg.abs().max().item()) + 1e-6, (n, err)
+
+
+def test_width48_density_quirk_masks_bit_exact():
+    """Reference quirk: tensors with shape[0] == 48 get density 0.2 whatever --density says (core_channel.py:147-151)."""
+    from e2enet_medical_amd.training.network_training.sparselearning.core_channel import Masking, CosineDecay
+    g = golden("masks.npz")
+    net = build_net((64, 64, 64), 4, 48, 4, [(2, 2, 2)] * 5)
+    opt = torch.optim.SGD(net.parameters(), 1e-2, momentum=0.99, nesterov=True)
+
+    class A:
+        adv = False
+        fix = False
+        update_frequency = 1200
+        final_density = 0.05
+    for dens in (0.1, 0.5):
+        random.seed(0)
+        mask = Masking(opt, death_rate=0.5, death_mode='magnitude', death_rate_decay=CosineDecay(0.5, 10),
+                       growth_mode='random', redistribution_mode='none', args=A())
+        mask.add_module(net, sparse_init='uniform', density=dens)
+        tag = "b48_d%s" % dens
+        assert list(mask.masks.keys()) == [str(s) for s in g[tag + "_names"]]
+        assert [sha_of(pack_kernel_mask(m.cpu())) for m in mask.masks.values()] == [str(s) for s in g[tag + "_sha"]]
+        assert [int(m.sum().item()) for m in mask.masks.values()] == list(g[tag + "_nnz"])
+
+
+def test_full_size_128_properties():
+    """BASELINE size (4 x 128^3, base 32, density 0.2): size-independent properties instead of an oracle run --
+    (a) skipping dead kernels via the liveness bits == dense execution of the same masked weights,
+    (b) liveness derived from the zero kernels of the weights == liveness from the masks (bit identical),
+    (c) run-to-run determinism, (d) every InstanceNorm'ed tensor really has zero mean / unit variance,
+    (e) flip equivariance does NOT hold for the depth-shifted net (sanity: the shift is applied)."""
+    from e2enet_medical_amd.training.network_training.sparselearning.core_channel import Masking, CosineDecay
+    torch.manual_seed(0)
+    net = build_net((128, 128, 128), 4, 32, 4, [(2, 2, 2)] * 5)
+    opt = torch.optim.SGD(net.parameters(), 1e-2, momentum=0.99, nesterov=True)
+
+    class A:
+        adv = False
+        fix = False
+        update_frequency = 1200
+        final_density = 0.05
+    random.seed(0)
+    mask = Masking(opt, death_rate=0.5, death_mode='magnitude', death_rate_decay=CosineDecay(0.5, 10), growth_mode='random',
+                   redistribution_mode='none', args=A())
+    mask.add_module(net, sparse_init='uniform', density=0.2)
+    total = sum(m.numel() for m in mask.masks.values())
+    nnz = sum(int(m.sum().item()) for m in mask.masks.values())
+    assert total == 12061696 and abs(nnz / total - 0.2) < 1e-4                # SURVEY §8a9: 12.06 M masked params at 32 ch
+    net.eval()
+    x = seeded_input((1, 4, 128, 128, 128), seed=3).cuda()
+    with torch.no_grad():
+        a = [o.clone() for o in net(x)]
+        b = [o.clone() for o in net(x)]
+        assert all(torch.equal(p, q) for p, q in zip(a, b))                     # (c)
+        net.enable_auto_sparsity(True)
+        c = net(x)
+        assert all(torch.equal(p, q) for p, q in zip(a, c))                     # (b)
+        net.set_kernel_masks(None)
+        dense = net(x)
+        assert max((p - q).abs().max().item() for p, q in zip(a, dense)) <= 2e-5   # (a): only the summation order differs
+        eng = net.engine(x)
+        for name in ("conv_blocks_context.0.blocks.1", "loc0.4.1.blocks.0", "loc2.0.0.blocks.0"):
+            op = [o for o in eng.conv_ops.values() if o.prefix == name][0]
+            y = op.out.data[0]
+            mu = y.double().mean(dim=(1, 2, 3))
+            var = y.double().var(dim=(1, 2, 3), unbiased=False)
+            assert (op.out.mean[:y.shape[0]].double() - mu).abs().max().item() < 1e-5 * max(1.0, mu.abs().max().item())
+            rstd = 1.0 / torch.sqrt(var + 1e-5)
+            assert ((op.out.rstd[:y.shape[0]].double() - rstd) / rstd).abs().max().item() < 1e-5   # (d)
+        flipped = net(torch.flip(x, (2,)))
+        assert (torch.flip(flipped[0], (2,)) - dense[0]).abs().max().item() > 1e-3                   # (e)
+    assert all(torch.isfinite(o).all() for o in a)
