@@ -14,6 +14,7 @@
 // with channel strides == 2 (mod 32) so that the A/B fragment reads (16 channels x 4 consecutive pixels) hit 32
 // distinct banks.  Per-chunk partial sums go to a slab, reduced in fixed order by a second kernel (deterministic).
 #include "e2e_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -28,6 +29,7 @@ struct WgParams {
   long long total_tiles;
   int tiles_per_chunk;
   int cblocks;
+  int dbg;     // diagnostic: bit0 = skip staging, bit1 = skip the MFMA phase (timing splits only; results are garbage)
 };
 
 constexpr int pad_mod32_2(int v) {
@@ -171,11 +173,16 @@ struct W2Cfg {
   static constexpr int TP = ND * TH * TW;
   static_assert(TP == 256, "one dy channel = 64 float4 groups = one wave-instruction");
   static constexpr int IH = TH + 2, IW = TW + 2;
-  static constexpr int PITCH = IW;
+  static constexpr int NQ = TW / 4 + 2;                       // float4 groups per input row (starts 4 left of the tile)
+  // LDS rows hold the float4 groups whole (tile column -1 sits at row index 3): every group is stored with two
+  // unconditional ds_write_b64, no per-element predicates; fragment reads are b32, so the +3 offset is free
+  // (NCB == 1 keeps the compact pitch: 80 KB of LDS -> two workgroups per CU, which is worth more there)
+  static constexpr bool PADDED = NCB == 2;
+  static constexpr int PITCH = PADDED ? 4 * NQ : IW;
+  static constexpr int COL0 = PADDED ? 3 : 0;                 // row index of tile column -1
   static constexpr int CS = pad_mod32_2(ND * IH * PITCH);
   static constexpr int OS = pad_mod32_2(TP);
   static constexpr int NT = 256 * NCB;
-  static constexpr int NQ = TW / 4 + 2;                       // float4 groups per input row (starts 4 left of the tile)
   static constexpr int GPC = ND * IH * NQ;                    // groups per input channel
   static constexpr int ITX = (GPC + 63) / 64;                 // wave iterations per input channel
   static constexpr int XCW = 8;                               // input channels staged per wave
@@ -294,11 +301,23 @@ __global__ __launch_bounds__(256 * NCB) void conv133_wgrad_v2_kernel(WgParams p)
       for (int k = 0; k < C::XCW; ++k) {
         const int din = dq * p.sd - xdsh[k];
         const bool ok = lane_ok && xval[k] && (unsigned)din < (unsigned)p.Di;
-        float* row = xs + (wave * C::XCW + k) * C::CS + g_lrow[it] * C::PITCH;
+        float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int lc = 4 * g_q[it] + j - 3;
-          if ((unsigned)lc < (unsigned)C::IW) row[lc] = ok ? e2e::in_act(vx[k][it][j], xa[k], xb[k], xsl[k]) : 0.f;
+          const float t = e2e::in_act(vx[k][it][j], xa[k], xb[k], xsl[k]);
+          v[j] = ok ? t : 0.f;
+        }
+        float* row = xs + (wave * C::XCW + k) * C::CS + g_lrow[it] * C::PITCH;
+        if (C::PADDED) {
+          float2* dst = reinterpret_cast<float2*>(row + 4 * g_q[it]);
+          dst[0] = make_float2(v[0], v[1]);
+          dst[1] = make_float2(v[2], v[3]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int lc = 4 * g_q[it] + j - 3;
+            if ((unsigned)lc < (unsigned)C::IW) row[lc] = v[j];
+          }
         }
       }
     }
@@ -318,9 +337,9 @@ __global__ __launch_bounds__(256 * NCB) void conv133_wgrad_v2_kernel(WgParams p)
     int n, d0, h0, w0;
     decode(tile_lo, n, d0, h0, w0);
     load_desc(n);
-    prefetch(n, d0, h0, w0);
+    if (!(p.dbg & 1)) prefetch(n, d0, h0, w0);
     for (long long tile = tile_lo; tile < tile_hi; ++tile) {
-      commit(d0, h0, w0);
+      if (!(p.dbg & 1)) commit(d0, h0, w0);
       int nn = n, nd0 = d0, nh0 = h0, nw0 = w0;
       const bool more = tile + 1 < tile_hi;
       if (more) {
@@ -328,20 +347,20 @@ __global__ __launch_bounds__(256 * NCB) void conv133_wgrad_v2_kernel(WgParams p)
         if (nn != n) load_desc(nn);                       // rare: the chunk crosses a batch item
       }
       __syncthreads();
-      if (more) prefetch(nn, nd0, nh0, nw0);              // in flight during the MFMA phase below
+      if (more && !(p.dbg & 1)) prefetch(nn, nd0, nh0, nw0);              // in flight during the MFMA phase below
 
       // MFMA phase.  The A/B fragments of k-step s+1 are read from LDS before the 9 MFMAs of k-step s are issued
       // (explicit double registers + sched_barrier), so the matrix pipe never waits on an LDS round trip.
       const int li = lane & 15, lk = lane >> 4;
       const float* ap = ys + (oh * 16 + li) * C::OS + lk;
-      const float* bp = xs + (cbl * 32 + ch * 16 + li) * C::CS + lk;
+      const float* bp = xs + (cbl * 32 + ch * 16 + li) * C::CS + lk + C::COL0;
       float a_cur = ap[0];
       float b_cur[9];
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) b_cur[kh * 3 + kw] = bp[kh * C::PITCH + kw];
-      for (int row = 0; row < ND * TH; ++row) {
+      for (int row = 0; row < ((p.dbg & 2) ? 0 : ND * TH); ++row) {
         const int nd = row / TH, r = row - nd * TH;
         const float* apr = ap + row * TW;
         const float* bpr = bp + nd * (C::IH * C::PITCH) + r * C::PITCH;
@@ -366,10 +385,14 @@ __global__ __launch_bounds__(256 * NCB) void conv133_wgrad_v2_kernel(WgParams p)
 #pragma unroll
               for (int kw = 0; kw < 3; ++kw) b_nxt[kh * 3 + kw] = bpn[kh * C::PITCH + kw];
           }
+#ifndef E2E_WG_NOSB
           __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
           for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur, b_cur[t], acc[t], 0, 0, 0);
+#ifndef E2E_WG_NOSB
           __builtin_amdgcn_sched_barrier(0);
+#endif
           a_cur = a_nxt;
 #pragma unroll
           for (int t = 0; t < 9; ++t) b_cur[t] = b_nxt[t];
@@ -447,7 +470,10 @@ int launch_v2(const WgParams& p, int nchunks, int pairs, hipStream_t st) {
 
 // v2 applies to stride-1 (in plane) convs whose rows are multiples of 4 floats
 inline bool use_v2(int Wi, int sh, int sw) { return sh == 1 && sw == 1 && (Wi % 4) == 0 && Wi > 4; }   // 4x4 planes: v1
-inline int v2_ncb(int Cin) { return Cin > 32 ? 2 : 1; }
+inline int v2_ncb(int Cin, int Ho, int Wo) {      // 8x8 planes: the (4,8,8) tile only fits one channel block in LDS
+  const int m = Ho < Wo ? Ho : Wo;
+  return (Cin > 32 && m > 8) ? 2 : 1;
+}
 
 template <int SH, int SW>
 int dispatch_strided(const WgParams& p, TileSel ts, int nchunks, int pairs, hipStream_t st) {
@@ -465,7 +491,7 @@ extern "C" long long e2e_conv133_wgrad_ws_bytes(int B, int Cin, int Cout, int Di
   p.Do = (Di - 1) / sd + 1; p.Ho = (Hi - 1) / sh + 1; p.Wo = (Wi - 1) / sw + 1;
   int nchunks;
   if (use_v2(Wi, sh, sw)) {
-    const int pairs = e2e::cdiv(Cin, 32 * v2_ncb(Cin)) * e2e::cdiv(Cout, 32);
+    const int pairs = e2e::cdiv(Cin, 32 * v2_ncb(Cin, p.Ho, p.Wo)) * e2e::cdiv(Cout, 32);
     plan(p, pick(p.Ho, p.Wo, false), pairs, &nchunks, 512);
   } else {
     const int pairs = e2e::cdiv(Cin, 32) * e2e::cdiv(Cout, 32);
@@ -480,6 +506,8 @@ extern "C" int e2e_conv133_wgrad(const e2e_in_chan_t* chans, const float* dy, fl
   E2E_REQUIRE((sd == 1 || sd == 2) && (sh == 1 || sh == 2) && (sw == 1 || sw == 2), "conv133_wgrad: stride must be 1 or 2");
   hipStream_t st = (hipStream_t)stream;
   WgParams p{};
+  static const int dbg = getenv("E2E_WG_DBG") ? atoi(getenv("E2E_WG_DBG")) : 0;
+  p.dbg = dbg;
   p.chans = chans; p.dy = dy; p.slab = reinterpret_cast<float*>(ws);
   p.B = B; p.Cin = Cin; p.Cout = Cout; p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.sd = sd;
   p.Do = (Di - 1) / sd + 1; p.Ho = (Hi - 1) / sh + 1; p.Wo = (Wi - 1) / sw + 1;
@@ -489,13 +517,13 @@ extern "C" int e2e_conv133_wgrad(const e2e_in_chan_t* chans, const float* dy, fl
   int rc;
   const long long numel = (long long)Cout * Cin * 9;
   if (use_v2(Wi, sh, sw)) {
-    const int ncb = v2_ncb(Cin);
+    const int ncb = v2_ncb(Cin, p.Ho, p.Wo);
     p.cblocks = e2e::cdiv(Cin, 32 * ncb);
     const int pairs = p.cblocks * e2e::cdiv(Cout, 32);
     plan(p, ts, pairs, &nchunks, 512);
     if (ts.nd == 1 && ts.tw == 32) rc = ncb == 2 ? launch_v2<1, 8, 32, 2>(p, nchunks, pairs, st) : launch_v2<1, 8, 32, 1>(p, nchunks, pairs, st);
     else if (ts.nd == 1) rc = ncb == 2 ? launch_v2<1, 16, 16, 2>(p, nchunks, pairs, st) : launch_v2<1, 16, 16, 1>(p, nchunks, pairs, st);
-    else rc = ncb == 2 ? launch_v2<4, 8, 8, 2>(p, nchunks, pairs, st) : launch_v2<4, 8, 8, 1>(p, nchunks, pairs, st);
+    else rc = launch_v2<4, 8, 8, 1>(p, nchunks, pairs, st);
     if (rc != E2E_OK) return rc;
     hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)e2e::cdivll(numel, 256)), dim3(256), 0, st, p.slab, dw, numel,
                        nchunks);
