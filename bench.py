@@ -115,10 +115,23 @@ def wgrad_flops(args):
 
 def cpu_baseline(seconds_budget=25.0):
     """The oracle (CPU restatement, kind "port") timed on the host cores on a bounded sample of the same workload:
-    fwd + loss + bwd of one 64^3 patch (same net, same density)."""
+    fwd + loss + bwd of one 64^3 patch (same net, same density).  Threads are capped (E2E_CPU_THREADS, default 16):
+    torch-CPU on 3D convs of this size stops scaling there, and the box may expose far more logical CPUs than its
+    cgroup lets us use (256 threads took minutes per step).  Hard wall-clock guard: after the first step the loop only
+    continues while the projected time stays inside the budget."""
     import oracle
     from oracle import network as onet
-    threads = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    try:                                       # cgroup v2 CPU quota (the GPU box: 256 logical CPUs visible, 16 granted)
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            avail = min(avail, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    threads = max(1, min(avail, int(os.environ.get("E2E_CPU_THREADS", "16"))))
     torch.set_num_threads(threads)
     spec = oracle.make_spec(CIN, BASE, K, POOLS)
     params = oracle.init_params(spec, seed=0)
@@ -139,15 +152,20 @@ def cpu_baseline(seconds_budget=25.0):
         outs = oracle.forward(spec, leaves, x)
         loss = oracle.deep_supervision_loss(outs, targets, w)
         loss.backward()
-        return float(loss)
-    step()                                     # warm-up
-    t0, n = time.time(), 0
-    while n < 3 or (time.time() - t0 < seconds_budget * 0.5 and n < 8):
-        step()
-        n += 1
-    dt = time.time() - t0
+        return float(loss.detach())
+    t0 = time.time()
+    step()                                     # first step doubles as warm-up and as the time probe
+    first = time.time() - t0
+    n, dt = 1, first
+    if first < seconds_budget / 3:
+        t1, n = time.time(), 0
+        while n < 2 or ((time.time() - t1) + first < seconds_budget and n < 8):
+            step()
+            n += 1
+        dt = time.time() - t1
     return {"value": n * 64 ** 3 / dt, "unit": "voxels/s", "cores": threads, "kind": "port",
-            "sample": "%d fwd+loss+bwd steps of one 64^3 patch (B=1, 32 ch, density 0.2), torch-CPU oracle, %.1f s" % (n, dt)}
+            "sample": "%d fwd+loss+bwd steps of one 64^3 patch (B=1, 32 ch, density 0.2), torch-CPU oracle, %d threads, "
+                      "%.1f s (+ %.1f s first step)" % (n, threads, dt, first)}
 
 
 def main():
