@@ -9,6 +9,9 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the oracle is torch-CPU: GPU boxes expose hundreds of logical CPUs but grant a small cgroup quota
+    import torch
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), 16)))
 
 
 def pytest_collection_modifyitems(config, items):
