@@ -187,8 +187,11 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     import torch.distributed as dist
-    if world > 1:
+    force_dist = os.environ.get("E2E_FORCE_DIST") == "1"      # self-test: run the RCCL path with a 1-rank group
+    use_dist = world > 1 or force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world)      # "nccl" is RCCL on ROCm
 
     from e2enet_medical_amd._lib import lib
@@ -205,8 +208,8 @@ def main():
         nonlocal flat
         eng.forward(x, True)
         loss = eng.loss_backward(targets, ds_w, batch_dice=False)
-        if world > 1:
-            flat = parallel.allreduce_mean_gradients(eng.grads, names, flat=flat)
+        if use_dist:
+            flat = parallel.allreduce_mean_gradients(eng.grads, names, flat=flat, force=force_dist)
         fused.step(eng.grads, mask.masks)
         mask.step(masks_already_applied=True)
         return loss
@@ -229,7 +232,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     for t in timers.values():
@@ -238,13 +241,13 @@ def main():
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     for t in timers.values():
         t.enabled = False
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -292,7 +295,7 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
