@@ -416,6 +416,199 @@ __global__ __launch_bounds__(256 * NCB) void conv133_wgrad_v2_kernel(WgParams p)
   }
 }
 
+// ---- stride (2,2) in the plane ("convolutional pooling" convs), rows that are multiples of 4 floats ------------------
+// Same pipeline as v2.  Output tile 4 x 16; the 9 x 33 input patch it needs is staged per channel as rows of
+// [20 even columns | 20 odd columns] so that the B fragments (4 consecutive output pixels = input columns 2 apart)
+// are unit-stride LDS reads: tap kw = 0 -> odd[wo + 1], kw = 1 -> even[wo + 2], kw = 2 -> odd[wo + 2].
+template <int DUMMY>
+struct WS2Cfg {
+  static constexpr int TH = 4, TW = 16, TP = 64;
+  static constexpr int IH = 2 * TH + 1;                       // 9 input rows
+  static constexpr int NQ = (2 * TW + 8) / 4;                 // 10 float4 groups per input row, from column 2*w0 - 4
+  static constexpr int HALF = 2 * NQ;                         // 20 even (odd) columns per row
+  static constexpr int PITCH = 2 * HALF;
+  static constexpr int CS = pad_mod32_2(IH * PITCH);
+  static constexpr int OS = pad_mod32_2(TP);
+  static constexpr int GPC = IH * NQ;
+  static constexpr int ITX = (GPC + 63) / 64;
+  static constexpr int XCW = 8, YCW = 8;
+  static constexpr int LDS_FLOATS = 32 * CS + 32 * OS;
+};
+
+__global__ __launch_bounds__(256) void conv133_wgrad_s2_kernel(WgParams p) {
+  using C = WS2Cfg<0>;
+  __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
+  float* xs = lds;
+  float* ys = lds + 32 * C::CS;
+
+  const int chunk = blockIdx.x;
+  const int cb = blockIdx.y % p.cblocks, ob = blockIdx.y / p.cblocks;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ch = wave & 1, oh = wave >> 1;
+  const long long in_plane = (long long)p.Hi * p.Wi;
+  const long long out_plane = (long long)p.Ho * p.Wo;
+  const int cbase = cb * 32;
+
+  f32x4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const long long tile_lo = (long long)chunk * p.tiles_per_chunk;
+  long long tile_hi = tile_lo + p.tiles_per_chunk;
+  if (tile_hi > p.total_tiles) tile_hi = p.total_tiles;
+
+  auto decode = [&](long long tile, int& n, int& d0, int& h0, int& w0) {
+    int t = (int)(tile % p.tiles_per_n);
+    n = (int)(tile / p.tiles_per_n);
+    const int tx = t % p.tiles_x;
+    t /= p.tiles_x;
+    const int ty = t % p.tiles_y;
+    d0 = t / p.tiles_y;
+    h0 = ty * C::TH;
+    w0 = tx * C::TW;
+  };
+
+  gfloat_p xbase[C::XCW];
+  float xa[C::XCW], xb[C::XCW], xsl[C::XCW];
+  int xdsh[C::XCW];
+  bool xval[C::XCW];
+  auto load_desc = [&](int n) {
+#pragma unroll
+    for (int k = 0; k < C::XCW; ++k) {
+      const int c = cbase + wave * C::XCW + k;
+      xval[k] = c < p.Cin;
+      const e2e_in_chan_t chd = p.chans[xval[k] ? c : 0];
+      xdsh[k] = chd.dshift;
+      xbase[k] = (gfloat_p)(chd.ptr + (long long)n * chd.nstride);
+      xa[k] = 1.f; xb[k] = 0.f; xsl[k] = 1.f;
+      if (xval[k] && chd.scale != nullptr) {
+        xa[k] = chd.scale[(long long)n * chd.ab_nstride];
+        xb[k] = chd.shift[(long long)n * chd.ab_nstride];
+        xsl[k] = chd.slope;
+      }
+    }
+  };
+
+  int g_r[C::ITX], g_q[C::ITX];
+#pragma unroll
+  for (int it = 0; it < C::ITX; ++it) {
+    int g = lane + 64 * it;
+    if (g >= C::GPC) g = C::GPC - 1;
+    g_r[it] = g / C::NQ;
+    g_q[it] = g - g_r[it] * C::NQ;
+  }
+  // dy: 8 channels x 16 float4 groups per wave = 2 iterations; lane -> (channel lane / 16 + 4 it, group lane % 16)
+  const int y_grp = lane & 15, y_kl = lane >> 4;
+  const int y_pi = y_grp * 4;
+  const int y_r = y_pi / C::TW, y_col = y_pi - y_r * C::TW;
+
+  f32x4_t vx[C::XCW][C::ITX], vy[2];
+  auto prefetch = [&](int n, int d0, int h0, int w0) {
+#pragma unroll
+    for (int it = 0; it < C::ITX; ++it) {
+      const int hi = 2 * h0 - 1 + g_r[it], gc = 2 * w0 - 4 + 4 * g_q[it];
+      const bool lane_ok = lane + 64 * it < C::GPC && (unsigned)hi < (unsigned)p.Hi && gc >= 0 && gc + 3 < p.Wi;
+      const long long lane_off = (long long)hi * p.Wi + gc;
+#pragma unroll
+      for (int k = 0; k < C::XCW; ++k) {
+        const int din = d0 * p.sd - xdsh[k];
+        const bool ok = lane_ok && xval[k] && (unsigned)din < (unsigned)p.Di;
+        vx[k][it] = *reinterpret_cast<gf4_p>(xbase[k] + (ok ? (long long)din * in_plane + lane_off : 0));
+      }
+    }
+    const int ho = h0 + y_r, wo = w0 + y_col;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int o = ob * 32 + wave * C::YCW + y_kl + 4 * it;
+      const bool ok = o < p.Cout && ho < p.Ho && wo + 3 < p.Wo;
+      const long long off = ok ? (((long long)n * p.Cout + o) * p.Do + d0) * out_plane + (long long)ho * p.Wo + wo : 0;
+      vy[it] = *reinterpret_cast<gf4_p>((gfloat_p)p.dy + off);
+    }
+  };
+  auto commit = [&](int d0, int h0, int w0) {
+#pragma unroll
+    for (int it = 0; it < C::ITX; ++it) {
+      if (lane + 64 * it >= C::GPC) continue;
+      const int hi = 2 * h0 - 1 + g_r[it], gc = 2 * w0 - 4 + 4 * g_q[it];
+      const bool lane_ok = (unsigned)hi < (unsigned)p.Hi && gc >= 0 && gc + 3 < p.Wi;
+#pragma unroll
+      for (int k = 0; k < C::XCW; ++k) {
+        const int din = d0 * p.sd - xdsh[k];
+        const bool ok = lane_ok && xval[k] && (unsigned)din < (unsigned)p.Di;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float t = e2e::in_act(vx[k][it][j], xa[k], xb[k], xsl[k]);
+          v[j] = ok ? t : 0.f;
+        }
+        float* row = xs + (wave * C::XCW + k) * C::CS + g_r[it] * C::PITCH;
+        *reinterpret_cast<float2*>(row + 2 * g_q[it]) = make_float2(v[0], v[2]);              // even columns
+        *reinterpret_cast<float2*>(row + C::HALF + 2 * g_q[it]) = make_float2(v[1], v[3]);    // odd columns
+      }
+    }
+    const int ho = h0 + y_r, wo = w0 + y_col;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int ol = wave * C::YCW + y_kl + 4 * it;
+      const bool ok = ob * 32 + ol < p.Cout && ho < p.Ho && wo + 3 < p.Wo;
+      float2* dst = reinterpret_cast<float2*>(ys + ol * C::OS + y_pi);
+      dst[0] = ok ? make_float2(vy[it][0], vy[it][1]) : make_float2(0.f, 0.f);
+      dst[1] = ok ? make_float2(vy[it][2], vy[it][3]) : make_float2(0.f, 0.f);
+    }
+  };
+
+  if (tile_lo < tile_hi) {
+    int n, d0, h0, w0;
+    decode(tile_lo, n, d0, h0, w0);
+    load_desc(n);
+    prefetch(n, d0, h0, w0);
+    for (long long tile = tile_lo; tile < tile_hi; ++tile) {
+      commit(d0, h0, w0);
+      int nn = n, nd0 = d0, nh0 = h0, nw0 = w0;
+      const bool more = tile + 1 < tile_hi;
+      if (more) {
+        decode(tile + 1, nn, nd0, nh0, nw0);
+        if (nn != n) load_desc(nn);
+      }
+      __syncthreads();
+      if (more) prefetch(nn, nd0, nh0, nw0);
+
+      const int li = lane & 15, lk = lane >> 4;
+      const float* ap = ys + (oh * 16 + li) * C::OS + lk;
+      const float* bp = xs + (ch * 16 + li) * C::CS + lk;
+#pragma unroll
+      for (int r = 0; r < C::TH; ++r) {
+#pragma unroll
+        for (int cq = 0; cq < C::TW / 4; ++cq) {
+          const float a = ap[r * C::TW + cq * 4];
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh) {
+            const float* brow = bp + (2 * r + kh) * C::PITCH + cq * 4;
+            acc[kh * 3 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, brow[C::HALF + 1], acc[kh * 3 + 0], 0, 0, 0);
+            acc[kh * 3 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, brow[2], acc[kh * 3 + 1], 0, 0, 0);
+            acc[kh * 3 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, brow[C::HALF + 2], acc[kh * 3 + 2], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();
+      n = nn; d0 = nd0; h0 = nh0; w0 = nw0;
+    }
+  }
+
+  float* sp = p.slab + (long long)chunk * p.Cout * p.Cin * 9;
+  const int c = cbase + ch * 16 + (lane & 15);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int o = ob * 32 + oh * 16 + (lane >> 4) * 4 + r;
+    if (o < p.Cout && c < p.Cin) {
+      float* dst = sp + ((long long)o * p.Cin + c) * 9;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) dst[t] = acc[t][r];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
                                                                 long long numel, int nchunks) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -475,6 +668,18 @@ inline int v2_ncb(int Cin, int Ho, int Wo) {      // 8x8 planes: the (4,8,8) til
   return (Cin > 32 && m > 8) ? 2 : 1;
 }
 
+// stride-(2,2) pipelined kernel: needs 16-byte aligned input rows and output planes at least one tile wide
+inline bool use_s2(int Wi, int Wo, int sh, int sw) { return sh == 2 && sw == 2 && (Wi % 4) == 0 && (Wo % 4) == 0 && Wo >= 16; }
+inline int s2_chunks(long long total_tiles, int pairs, int* tpc_out) {
+  long long want = 512 / (pairs > 0 ? pairs : 1);
+  if (want < 1) want = 1;
+  long long tpc = e2e::cdivll(total_tiles, want);
+  if (tpc < 8) tpc = 8;
+  if (tpc > total_tiles) tpc = total_tiles;
+  *tpc_out = (int)tpc;
+  return (int)e2e::cdivll(total_tiles, tpc);
+}
+
 template <int SH, int SW>
 int dispatch_strided(const WgParams& p, TileSel ts, int nchunks, int pairs, hipStream_t st) {
   if (ts.nd == 1) return launch<SH, SW, 1, 8, 16>(p, nchunks, pairs, st);
@@ -490,7 +695,13 @@ extern "C" long long e2e_conv133_wgrad_ws_bytes(int B, int Cin, int Cout, int Di
   p.B = B; p.Cin = Cin; p.Cout = Cout; p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.sd = sd;
   p.Do = (Di - 1) / sd + 1; p.Ho = (Hi - 1) / sh + 1; p.Wo = (Wi - 1) / sw + 1;
   int nchunks;
-  if (use_v2(Wi, sh, sw)) {
+  if (use_s2(Wi, p.Wo, sh, sw)) {
+    const int pairs = e2e::cdiv(Cin, 32) * e2e::cdiv(Cout, 32);
+    p.tiles_x = e2e::cdiv(p.Wo, 16); p.tiles_y = e2e::cdiv(p.Ho, 4); p.tiles_d = p.Do;
+    p.tiles_per_n = p.tiles_d * p.tiles_y * p.tiles_x;
+    p.total_tiles = (long long)p.tiles_per_n * B;
+    nchunks = s2_chunks(p.total_tiles, pairs, &p.tiles_per_chunk);
+  } else if (use_v2(Wi, sh, sw)) {
     const int pairs = e2e::cdiv(Cin, 32 * v2_ncb(Cin, p.Ho, p.Wo)) * e2e::cdiv(Cout, 32);
     plan(p, pick(p.Ho, p.Wo, false), pairs, &nchunks, 512);
   } else {
@@ -516,6 +727,20 @@ extern "C" int e2e_conv133_wgrad(const e2e_in_chan_t* chans, const float* dy, fl
   int nchunks;
   int rc;
   const long long numel = (long long)Cout * Cin * 9;
+  if (use_s2(Wi, p.Wo, sh, sw)) {
+    p.cblocks = e2e::cdiv(Cin, 32);
+    const int pairs = p.cblocks * e2e::cdiv(Cout, 32);
+    p.tiles_x = e2e::cdiv(p.Wo, 16); p.tiles_y = e2e::cdiv(p.Ho, 4); p.tiles_d = p.Do;
+    p.tiles_per_n = p.tiles_d * p.tiles_y * p.tiles_x;
+    p.total_tiles = (long long)p.tiles_per_n * B;
+    nchunks = s2_chunks(p.total_tiles, pairs, &p.tiles_per_chunk);
+    hipLaunchKernelGGL(conv133_wgrad_s2_kernel, dim3(nchunks, pairs), dim3(256), 0, st, p);
+    rc = e2e::check_launch("conv133_wgrad_s2_kernel");
+    if (rc != E2E_OK) return rc;
+    hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)e2e::cdivll(numel, 256)), dim3(256), 0, st, p.slab, dw, numel,
+                       nchunks);
+    return e2e::check_launch("wgrad_slab_reduce_kernel");
+  }
   if (use_v2(Wi, sh, sw)) {
     const int ncb = v2_ncb(Cin, p.Ho, p.Wo);
     p.cblocks = e2e::cdiv(Cin, 32 * ncb);

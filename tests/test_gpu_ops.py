@@ -66,6 +66,8 @@ CONV_CASES = [
     (1, [(70, True), (30, False)], 64, (2, 8, 8), (1, 1, 1), 0.5),           # small planes (8x8 tile kernel)
     (1, [(40, True)], 33, (4, 4, 4), (2, 2, 2), 1.0),
     (1, [(9, True)], 7, (1, 6, 5), (1, 1, 1), 1.0),                          # one-slice volume: all shifted groups vanish
+    (1, [(20, True), (15, False)], 40, (6, 32, 64), (2, 2, 2), 1.0),         # strided, wide planes (pipelined s2 wgrad)
+    (2, [(33, True)], 34, (3, 24, 40), (1, 2, 2), 1.0),                      # in-plane stride only, ragged tiles
 ]
 
 
