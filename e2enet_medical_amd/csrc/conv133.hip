@@ -50,16 +50,21 @@ template <int MODE, int SH, int SW, int DH, int DW, int TH, int TW, int LY, int 
 struct Cfg {
   static_assert(LY * LX == 64, "one wave covers the tile");
   static_assert(MODE == 1 || (DH == 1 && DW == 1), "dilation is a data-gradient feature");
+  // MODE 2 = sub-pixel data gradient of a stride-(2,2) conv: the LDS tile holds dy at its native resolution
+  // (TH/2+1 x TW/2+1 for a TH x TW tile of dx) and only the parity-matching taps are applied
+  static constexpr bool SUB = MODE == 2;
   static constexpr int PH = TH / LY, PW = TW / LX;
-  static constexpr int IH = (TH - 1) * SH + 3, IW = (TW - 1) * SW + 3;
-  // lane column offset in floats; decides the widest aligned LDS read of a neighbourhood row
-  static constexpr int LSTEP = PW * SW;
+  static_assert(!SUB || (PH % 2 == 0 && PW % 2 == 0 && SH == 1 && SW == 1), "sub-pixel mode needs even micro-tiles");
+  static constexpr int IH = SUB ? TH / 2 + 1 : (TH - 1) * SH + 3, IW = SUB ? TW / 2 + 1 : (TW - 1) * SW + 3;
+  // lane column / row offset in the LDS tile; the column step decides the widest aligned read of a neighbourhood row
+  static constexpr int LSTEP = SUB ? PW / 2 : PW * SW;
+  static constexpr int LROW = SUB ? PH / 2 : PH * SH;
   static constexpr int VEC = (LSTEP % 4 == 0) ? 4 : (LSTEP % 2 == 0 ? 2 : 1);
     static constexpr int pitch_for(int iw) {
     int p = (iw + 3) & ~3;
     // VEC 4: consecutive lane rows are PH*SH tile rows apart; (PH*SH*pitch) % 64 == 32 puts the four 16-lane groups
     // of a ds_read_b128 on disjoint bank quarters.  VEC 2: the same idea for the two lane rows of a ds_read_b64 group.
-    if (VEC == 4) { while ((PH * SH * p) % 64 != 32 && p < iw + 64) p += 4; }
+    if (VEC == 4) { while ((LROW * p) % 64 != 32 && p < iw + 64) p += 4; }
     else if (VEC == 2) { p = iw; while (p % 8 != 4) ++p; }
     else p = iw;
     return p;
@@ -68,11 +73,11 @@ struct Cfg {
   static constexpr int CHS = IH * PITCH;
   static constexpr int NT = NW * 64;
   static constexpr int OCG = OPW * NW;
-  static constexpr int NR = (PH - 1) * SH + 3, NC = (PW - 1) * SW + 3;
+  static constexpr int NR = SUB ? PH / 2 + 1 : (PH - 1) * SH + 3, NC = SUB ? PW / 2 + 1 : (PW - 1) * SW + 3;
   static constexpr int LDS_FLOATS = CK * CHS;
   // staging units: STG 1 = aligned float4 groups of a tile row (tile column origin is a multiple of 4, so the
   // group starting 4 columns left of it covers the halo), STG 0 = single elements
-  static constexpr int NQ = (IW + 3 + 3) / 4;
+  static constexpr int NQ = SUB ? (IW + 3) / 4 : (IW + 3 + 3) / 4;      // SUB: groups start at the (aligned) tile origin
   static constexpr int UNITS = STG ? CK * IH * NQ : CK * IH * IW;
   static constexpr int NU = (UNITS + NT - 1) / NT;
 };
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
   const int lx = lane % LX, ly = lane / LX;
   const long long in_plane = (long long)p.Hi * p.Wi;
   const long long src_plane = (long long)p.Hs * p.Ws;
-  const float* lane_tp = lds + (ly * C::PH * SH) * C::PITCH + lx * C::LSTEP;
+  const float* lane_tp = lds + (ly * C::LROW) * C::PITCH + lx * C::LSTEP;
 
   // persistent workgroup: a run of consecutive logical work items (tile-major, output-plane group fastest), so that
   // the plane descriptor table is rebuilt only when the (batch item, depth slice) changes
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
   const int qbase = qgroup + wave * OPW;
 
   // data gradient of a depth-strided conv: only every sd-th slice of the (shifted) input received anything
-  const bool dead_slice = (MODE == 1) && (d % p.sd != 0);
+  const bool dead_slice = (MODE != 0) && (d % p.sd != 0);
   const int nchunks = dead_slice ? 0 : (p.P + CK - 1) / CK;
 
   // ---- descriptor of plane `pl` for this workgroup's (n, d) -------------------------------------------------
@@ -192,25 +197,31 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
       int k = u / (C::IH * C::NQ);
       const int rem = u - k * (C::IH * C::NQ);
       const int r = rem / C::NQ, q = rem - r * C::NQ;
-      const int hi = hbase + r, gc = w0 * SW - 4 + 4 * q;
-      const bool ok = u < C::UNITS && (unsigned)hi < (unsigned)p.Hi && gc >= 0 && gc + 3 < p.Wi;
+      const int hi = C::SUB ? h0 / 2 + r : hbase + r;
+      const int gc = C::SUB ? w0 / 2 + 4 * q : w0 * SW - 4 + 4 * q;
+      const int lc0 = C::SUB ? 4 * q : 4 * q - 3;                 // tile column of the group's first element
+      const int srcH = MODE == 0 ? p.Hi : p.Hs, srcW = MODE == 0 ? p.Wi : p.Ws;
+      const bool ok = u < C::UNITS && (unsigned)hi < (unsigned)srcH && gc >= 0 && gc + 3 < srcW;
       int m = 0;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if ((unsigned)(4 * q + j - 3) < (unsigned)C::IW) m |= 1 << j;
+        if ((unsigned)(lc0 + j) < (unsigned)C::IW) m |= 1 << j;
       if (u >= C::UNITS) { m = 0; k = 0; }
       su_k[i] = k;
-      su_lds[i] = k * C::CHS + r * C::PITCH + 4 * q - 3;
-      su_goff[i] = ok ? hi * p.Wi + gc : -1;
+      su_lds[i] = k * C::CHS + r * C::PITCH + lc0;
+      su_goff[i] = ok ? hi * srcW + gc : -1;
       su_mask[i] = m;
     } else {
       int k = u / (C::IH * C::IW);
       const int rem = u - k * (C::IH * C::IW);
       const int r = rem / C::IW, cc = rem - r * C::IW;
-      const int hi = hbase + r, wi = wbase + cc;
+      const int hi = C::SUB ? h0 / 2 + r : hbase + r, wi = C::SUB ? w0 / 2 + cc : wbase + cc;
       bool ok = u < C::UNITS && hi >= 0 && wi >= 0;
       int off = 0;
-      if (DH == 1 && DW == 1) {
+      if (C::SUB) {
+        ok = ok && hi < p.Hs && wi < p.Ws;
+        off = hi * p.Ws + wi;
+      } else if (DH == 1 && DW == 1) {
         ok = ok && hi < p.Hi && wi < p.Wi;
         off = hi * p.Wi + wi;
       } else {   // dilated source: only positions that are multiples of the stride carry a value
@@ -312,8 +323,17 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-          for (int kw = 0; kw < 3; ++kw)
-            ac[i][j] = fmaf(wk[kh * 3 + kw], nb[i * SH + kh][j * SW + kw], ac[i][j]);
+          for (int kw = 0; kw < 3; ++kw) {
+            if (!C::SUB) {
+              ac[i][j] = fmaf(wk[kh * 3 + kw], nb[i * SH + kh][j * SW + kw], ac[i][j]);
+            } else {
+              // dx[2a + pi][2b + pj] += dy[(2a + pi + 1 - kh) / 2][(2b + pj + 1 - kw) / 2] * w[kh][kw] for matching parities:
+              // even output index -> centre tap only; odd -> the two outer taps (tap 0 reads the next dy sample)
+              const int pi = i & 1, pj = j & 1;
+              const bool hit = (pi == 0 ? kh == 1 : kh != 1) && (pj == 0 ? kw == 1 : kw != 1);
+              if (hit) ac[i][j] = fmaf(wk[kh * 3 + kw], nb[(i >> 1) + ((pi == 1 && kh == 0) ? 1 : 0)][(j >> 1) + ((pj == 1 && kw == 0) ? 1 : 0)], ac[i][j]);
+            }
+          }
   };
 
   if (nchunks > 0) {
@@ -561,6 +581,9 @@ int launch_cfg_impl(ConvParams p, hipStream_t st) {
   return e2e::check_launch("conv133_kernel");
 }
 
+// sub-pixel data gradient (stride (2,2) convs); dx planes of 8x8 and smaller keep the zero-dilated MODE 1 path
+int launch_sub(const ConvParams& p, int kind, hipStream_t st);
+
 inline int t32_variant_knob() {     // tuning knob for the large-plane tile (0/1: 32x32, 2: 16x32)
   static const int v = getenv("E2E_CONV_T32") ? atoi(getenv("E2E_CONV_T32")) : 2;
   return v;
@@ -605,6 +628,17 @@ inline void tile_dims(TileKind k, int& th, int& tw) {
     case T16x32S: th = 16; tw = 32; break;
     default: th = 8; tw = 8; break;
   }
+}
+
+
+
+int launch_sub(const ConvParams& p, int kind, hipStream_t st) {
+  const bool vec = (p.Ws % 4) == 0;
+  if (kind == 0)
+    return vec ? launch_cfg<2, 1, 1, 1, 1, 16, 32, 8, 8, 4, 8, 8, 1, 4, 0>(p, st)
+               : launch_cfg<2, 1, 1, 1, 1, 16, 32, 8, 8, 4, 8, 8, 0, 4, 0>(p, st);
+  return vec ? launch_cfg<2, 1, 1, 1, 1, 16, 16, 8, 8, 4, 8, 16, 1>(p, st)
+             : launch_cfg<2, 1, 1, 1, 1, 16, 16, 8, 8, 4, 8, 16, 0>(p, st);
 }
 
 }  // namespace
@@ -670,5 +704,9 @@ extern "C" int e2e_conv133_dgrad(const float* dy, const float* w, const unsigned
   const TileKind k = pick_tile(Hi, Wi, 1, 1);
   const int kind = k == T32 ? 0 : (k == T16 ? 1 : 2);
   if (sh == 1) return launch_s1<1, 1, 1>(p, kind, st);
+  if (kind <= 1 && (Hi % 2) == 0 && (Wi % 2) == 0) {     // sub-pixel form: weights are read un-reversed
+    p.wq_stride = 9; p.wp_stride = Cin * 9;
+    return launch_sub(p, kind, st);
+  }
   return launch_s1<1, 2, 2>(p, kind, st);
 }
