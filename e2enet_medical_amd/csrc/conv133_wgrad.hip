@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256 * NCB) void conv133_wgrad_v2_kernel(WgParams p)
 #pragma unroll
       for (int k = 0; k < C::XCW; ++k) {
         const int din = dq * p.sd - xdsh[k];
-        const bool ok = lane_ok && xval[k] && (unsigned)din < (unsigned)p.Di;
+        const bool ok = lane_ok && xval[k] && (unsigned)din < (unsigned)p.Di && !(p.dbg & 4);
         vx[k][it] = *reinterpret_cast<gf4_p>(xbase[k] + (ok ? (long long)din * in_plane + lane_off : 0));
       }
     }
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256 * NCB) void conv133_wgrad_v2_kernel(WgParams p)
 #pragma unroll
     for (int k = 0; k < C::YCW; ++k) {
       const int o = ob * 32 + wave * C::YCW + k;
-      const bool ok = lane_ok && o < p.Cout;
+      const bool ok = lane_ok && o < p.Cout && !(p.dbg & 4);
       const long long off = ok ? (((long long)n * p.Cout + o) * p.Do + dq) * out_plane + (long long)ho * p.Wo + wo : 0;
       vy[k] = *reinterpret_cast<gf4_p>((gfloat_p)p.dy + off);
     }
