@@ -611,11 +611,23 @@ __global__ __launch_bounds__(256) void conv133_wgrad_s2_kernel(WgParams p) {
 
 __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
                                                                 long long numel, int nchunks) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= numel) return;
-  float s = 0.f;
-  for (int k = 0; k < nchunks; ++k) s += slab[(long long)k * numel + i];
-  out[i] = s;
+  // out[e] = sum_k slab[k][e]: 4 waves x 4 independent running sums per element, combined in a fixed order
+  // (deterministic); the serial one-thread-per-element loop over up to 512 slabs was latency bound
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long long e = (long long)blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < numel) {
+    for (int k = w; k < nchunks; k += 16) {
+      s0 += slab[(long long)k * numel + e];
+      if (k + 4 < nchunks) s1 += slab[(long long)(k + 4) * numel + e];
+      if (k + 8 < nchunks) s2 += slab[(long long)(k + 8) * numel + e];
+      if (k + 12 < nchunks) s3 += slab[(long long)(k + 12) * numel + e];
+    }
+  }
+  part[w][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (w == 0 && e < numel) out[e] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
 struct TileSel {
@@ -737,7 +749,7 @@ extern "C" int e2e_conv133_wgrad(const e2e_in_chan_t* chans, const float* dy, fl
     hipLaunchKernelGGL(conv133_wgrad_s2_kernel, dim3(nchunks, pairs), dim3(256), 0, st, p);
     rc = e2e::check_launch("conv133_wgrad_s2_kernel");
     if (rc != E2E_OK) return rc;
-    hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)e2e::cdivll(numel, 256)), dim3(256), 0, st, p.slab, dw, numel,
+    hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)e2e::cdivll(numel, 64)), dim3(256), 0, st, p.slab, dw, numel,
                        nchunks);
     return e2e::check_launch("wgrad_slab_reduce_kernel");
   }
@@ -750,7 +762,7 @@ extern "C" int e2e_conv133_wgrad(const e2e_in_chan_t* chans, const float* dy, fl
     else if (ts.nd == 1) rc = ncb == 2 ? launch_v2<1, 16, 16, 2>(p, nchunks, pairs, st) : launch_v2<1, 16, 16, 1>(p, nchunks, pairs, st);
     else rc = launch_v2<4, 8, 8, 1>(p, nchunks, pairs, st);
     if (rc != E2E_OK) return rc;
-    hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)e2e::cdivll(numel, 256)), dim3(256), 0, st, p.slab, dw, numel,
+    hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)e2e::cdivll(numel, 64)), dim3(256), 0, st, p.slab, dw, numel,
                        nchunks);
     return e2e::check_launch("wgrad_slab_reduce_kernel");
   }
@@ -770,7 +782,7 @@ extern "C" int e2e_conv133_wgrad(const e2e_in_chan_t* chans, const float* dy, fl
     rc = dispatch_strided<2, 1>(p, ts, nchunks, pairs, st);
   }
   if (rc != E2E_OK) return rc;
-  hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)e2e::cdivll(numel, 256)), dim3(256), 0, st, p.slab, dw, numel,
+  hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)e2e::cdivll(numel, 64)), dim3(256), 0, st, p.slab, dw, numel,
                      nchunks);
   return e2e::check_launch("wgrad_slab_reduce_kernel");
 }

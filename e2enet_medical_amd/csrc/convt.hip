@@ -462,11 +462,23 @@ __global__ __launch_bounds__(256) void convT_dgrad_v2_kernel(const float* __rest
 
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
                                                           long long numel, int nchunks) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= numel) return;
-  float s = 0.f;
-  for (int k = 0; k < nchunks; ++k) s += slab[(long long)k * numel + i];
-  out[i] = s;
+  // out[e] = sum_k slab[k][e]: 4 waves x 4 independent running sums per element, combined in a fixed order
+  // (deterministic); the serial one-thread-per-element loop over up to 512 slabs was latency bound
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long long e = (long long)blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < numel) {
+    for (int k = w; k < nchunks; k += 16) {
+      s0 += slab[(long long)k * numel + e];
+      if (k + 4 < nchunks) s1 += slab[(long long)(k + 4) * numel + e];
+      if (k + 8 < nchunks) s2 += slab[(long long)(k + 8) * numel + e];
+      if (k + 12 < nchunks) s3 += slab[(long long)(k + 12) * numel + e];
+    }
+  }
+  part[w][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (w == 0 && e < numel) out[e] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
 inline int wgrad_chunks(long long total_tiles, int pairs, int* tiles_per_chunk) {
@@ -578,7 +590,7 @@ extern "C" int e2e_convT_wgrad(const float* x, const float* scale, const float* 
     if (kdh == 4) { if (ncb == 2) LAUNCH_V2(4, 2); else LAUNCH_V2(4, 1); }
     else { if (ncb == 2) LAUNCH_V2(2, 2); else LAUNCH_V2(2, 1); }
 #undef LAUNCH_V2
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)e2e::cdivll(numel_all, 256)), dim3(256), 0, st, slab, dw, numel_all, nch);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)e2e::cdivll(numel_all, 64)), dim3(256), 0, st, slab, dw, numel_all, nch);
     return e2e::check_launch("convT_wgrad_v2");
   }
   const int pairs = e2e::cdiv(Cin, 32) * e2e::cdiv(Cout, 32);
@@ -587,6 +599,6 @@ extern "C" int e2e_convT_wgrad(const float* x, const float* scale, const float* 
   DISPATCH_KT(kt, hipLaunchKernelGGL((convT_wgrad_kernel<KT>), grid, dim3(256), 0, st, x, scale, shift, slope, dy, slab, B,
                                      Cin, Cout, D, H, W, kd, kh, kw, tpc, nchunks));
   const long long numel = (long long)Cin * Cout * kt;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)e2e::cdivll(numel, 256)), dim3(256), 0, st, slab, dw, numel, nchunks);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)e2e::cdivll(numel, 64)), dim3(256), 0, st, slab, dw, numel, nchunks);
   return e2e::check_launch("convT_wgrad");
 }
