@@ -72,6 +72,19 @@ __global__ __launch_bounds__(256) void convT_fwd_kernel(const float* __restrict_
   }
   const int Ho = H * kh, Wo = W * kw;
   float* yp = y + ((long long)n * Cout + o) * spatial * KT;
+  if (VPL == 2 && kw == 2 && (W % 2) == 0 && v0 + 1 < spatial) {
+    const int wv = (int)(v0 % W);
+    const long long r = v0 / W;
+    const int hv = (int)(r % H), dv = (int)(r / H);
+#pragma unroll
+    for (int t = 0; t < KT; t += 2) {
+      int i, j, k;
+      tap_ijk(t, kh, kw, i, j, k);
+      *reinterpret_cast<float4*>(yp + ((long long)(dv * kd + i) * Ho + (hv * kh + j)) * Wo + wv * 2) =
+          make_float4(acc[0][t], acc[0][(t + 1) % KT], acc[1 % VPL][t], acc[1 % VPL][(t + 1) % KT]);
+    }
+    return;
+  }
 #pragma unroll
   for (int v = 0; v < VPL; ++v) {
     const long long vi = v0 + v;

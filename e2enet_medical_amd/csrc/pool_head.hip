@@ -67,6 +67,75 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
       }
 }
 
+// kw == 2 fast path: one thread = two adjacent pooled outputs -> each window row is one aligned float4 of the input
+__global__ __launch_bounds__(256) void maxpool_fwd_w2_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, float slope,
+                                                             float* __restrict__ y, int D, int H, int W, int kd, int kh, int Do,
+                                                             int Ho, int Wo) {
+  const int nc = blockIdx.y;
+  const long long pairs = (long long)Do * Ho * (Wo / 2);
+  const long long pi = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (pi >= pairs) return;
+  const int wp = (int)(pi % (Wo / 2));
+  const long long r = pi / (Wo / 2);
+  const int ho = (int)(r % Ho), dq = (int)(r / Ho);
+  float a = 1.f, b = 0.f, sl = 1.f;
+  if (scale) { a = scale[nc]; b = shift[nc]; sl = slope; }
+  const float* xp = x + (long long)nc * D * H * W;
+  float m0 = -INFINITY, m1 = -INFINITY;
+  for (int i = 0; i < kd; ++i)
+    for (int j = 0; j < kh; ++j) {
+      const float4 q = *reinterpret_cast<const float4*>(xp + ((long long)(dq * kd + i) * H + (ho * kh + j)) * W + wp * 4);
+      const float v0 = e2e::in_act(q.x, a, b, sl), v1 = e2e::in_act(q.y, a, b, sl);
+      const float v2 = e2e::in_act(q.z, a, b, sl), v3 = e2e::in_act(q.w, a, b, sl);
+      m0 = (v0 > m0 || v0 != v0) ? v0 : m0;
+      m0 = (v1 > m0 || v1 != v1) ? v1 : m0;
+      m1 = (v2 > m1 || v2 != v2) ? v2 : m1;
+      m1 = (v3 > m1 || v3 != v3) ? v3 : m1;
+    }
+  *reinterpret_cast<float2*>(y + (long long)nc * Do * Ho * Wo + ((long long)dq * Ho + ho) * Wo + wp * 2) = make_float2(m0, m1);
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_w2_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, float slope,
+                                                             const float* __restrict__ dy, float* __restrict__ dx,
+                                                             int accumulate, int D, int H, int W, int kd, int kh, int Do, int Ho,
+                                                             int Wo) {
+  const int nc = blockIdx.y;
+  const long long pairs = (long long)Do * Ho * (Wo / 2);
+  const long long pi = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (pi >= pairs) return;
+  const int wp = (int)(pi % (Wo / 2));
+  const long long r = pi / (Wo / 2);
+  const int ho = (int)(r % Ho), dq = (int)(r / Ho);
+  float a = 1.f, b = 0.f, sl = 1.f;
+  if (scale) { a = scale[nc]; b = shift[nc]; sl = slope; }
+  const float* xp = x + (long long)nc * D * H * W;
+  float* dxp = dx + (long long)nc * D * H * W;
+  float m0 = -INFINITY, m1 = -INFINITY;
+  int b0 = 0, b1 = 0;
+  for (int i = 0; i < kd; ++i)
+    for (int j = 0; j < kh; ++j) {
+      const float4 q = *reinterpret_cast<const float4*>(xp + ((long long)(dq * kd + i) * H + (ho * kh + j)) * W + wp * 4);
+      const float v0 = e2e::in_act(q.x, a, b, sl), v1 = e2e::in_act(q.y, a, b, sl);
+      const float v2 = e2e::in_act(q.z, a, b, sl), v3 = e2e::in_act(q.w, a, b, sl);
+      const int base = (i * kh + j) * 2;
+      if (v0 > m0 || v0 != v0) { m0 = v0; b0 = base; }
+      if (v1 > m0 || v1 != v1) { m0 = v1; b0 = base + 1; }
+      if (v2 > m1 || v2 != v2) { m1 = v2; b1 = base; }
+      if (v3 > m1 || v3 != v3) { m1 = v3; b1 = base + 1; }
+    }
+  const float2 g = *reinterpret_cast<const float2*>(dy + (long long)nc * Do * Ho * Wo + ((long long)dq * Ho + ho) * Wo + wp * 2);
+  for (int i = 0; i < kd; ++i)
+    for (int j = 0; j < kh; ++j) {
+      const int base = (i * kh + j) * 2;
+      float4* dst = reinterpret_cast<float4*>(dxp + ((long long)(dq * kd + i) * H + (ho * kh + j)) * W + wp * 4);
+      float4 v = make_float4(b0 == base ? g.x : 0.f, b0 == base + 1 ? g.x : 0.f, b1 == base ? g.y : 0.f, b1 == base + 1 ? g.y : 0.f);
+      if (accumulate) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+      *dst = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ 1x1x1 head
 // logits[n,k,v] = sum_c W[k,c] z[n,c,v]; KB classes per pass kept in registers, weights are wave-uniform scalars.
 template <int KB>
@@ -176,6 +245,12 @@ extern "C" int e2e_maxpool_fwd(const float* x, const float* scale, const float* 
   E2E_REQUIRE(x && y, "maxpool_fwd: null pointer");
   E2E_REQUIRE(kd >= 1 && kh >= 1 && kw >= 1 && D >= kd && H >= kh && W >= kw, "maxpool_fwd: bad dims");
   const int Do = D / kd, Ho = H / kh, Wo = W / kw;
+  if (kw == 2 && (W % 4) == 0) {      // (W % 4 == 0 => Wo even and every window row pair is a 16-byte aligned float4)
+    dim3 grid2((unsigned)e2e::cdivll((long long)Do * Ho * (Wo / 2), 256), B * C);
+    hipLaunchKernelGGL(maxpool_fwd_w2_kernel, grid2, dim3(256), 0, (hipStream_t)stream, x, scale, shift, slope, y, D, H, W, kd,
+                       kh, Do, Ho, Wo);
+    return e2e::check_launch("maxpool_fwd_w2_kernel");
+  }
   dim3 grid((unsigned)e2e::cdivll((long long)Do * Ho * Wo, 256), B * C);
   hipLaunchKernelGGL(maxpool_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, scale, shift, slope, y, D, H, W, kd, kh,
                      kw, Do, Ho, Wo);
@@ -194,6 +269,12 @@ extern "C" int e2e_maxpool_bwd(const float* x, const float* scale, const float* 
       e2e::set_error("maxpool_bwd: memset failed");
       return E2E_ERR_LAUNCH;
     }
+  }
+  if (kw == 2 && (W % 4) == 0) {
+    dim3 grid2((unsigned)e2e::cdivll((long long)Do * Ho * (Wo / 2), 256), B * C);
+    hipLaunchKernelGGL(maxpool_bwd_w2_kernel, grid2, dim3(256), 0, st, x, scale, shift, slope, dy, dx, accumulate, D, H, W, kd, kh,
+                       Do, Ho, Wo);
+    return e2e::check_launch("maxpool_bwd_w2_kernel");
   }
   dim3 grid((unsigned)e2e::cdivll((long long)Do * Ho * Wo, 256), B * C);
   hipLaunchKernelGGL(maxpool_bwd_kernel, grid, dim3(256), 0, st, x, scale, shift, slope, dy, dx, accumulate, D, H, W, kd, kh,
