@@ -63,6 +63,7 @@ SIGNATURES = {
     "e2e_dsff_kth_value": (I, [P, I, I, P, P, P]),
     "e2e_dsff_death": (I, [P, P, P, I, P]),
     "e2e_dsff_expand": (I, [P, P, P, P, I, I, I, P]),
+    "e2e_dsff_expand_quads": (I, [P, P, P, I, I, P]),
     "e2e_dsff_kmask_from_weights": (I, [P, P, I, I, I, P]),
     "e2e_flip3d": (I, [P, P, I, I, I, I, I, P]),
     "e2e_softmax_flip_acc": (I, [P, P, F, I, I, I, I, I, I, P]),

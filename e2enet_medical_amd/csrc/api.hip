@@ -13,4 +13,4 @@ void set_error(const char* fmt, ...) {
 }  // namespace e2e
 
 extern "C" const char* e2e_last_error(void) { return e2e::g_err; }
-extern "C" int e2e_abi_version(void) { return 1; }
+extern "C" int e2e_abi_version(void) { return 2; }

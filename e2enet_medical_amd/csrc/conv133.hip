@@ -16,6 +16,13 @@
 #include "e2e_common.h"
 #include <cstdlib>
 
+// phase-split diagnostics (tools/kbench.py): build with -DE2E_CONV_DEBUG, then E2E_CONV_DBG=1|2|4 at run time
+#ifdef E2E_CONV_DEBUG
+#define CDBG(bit) ((p.dbg & (bit)) != 0)
+#else
+#define CDBG(bit) false
+#endif
+
 namespace {
 
 struct ConvParams {
@@ -23,7 +30,7 @@ struct ConvParams {
   const float* xin;             // [B, P, Ds, Hs, Ws] when chans == null
   const float* w;
   const float* bias;            // fwd only (may be null)
-  const unsigned* live;         // [Q][live_words] or null
+  const unsigned* live;         // quad words [ceil(Q/4)][ceil(P/8)], bit (p % 8) * 4 + q % 4, or null (dense)
   float* y;                     // fwd
   float* part;                  // fwd, may be null
   const e2e_out_chan_t* outs;   // dgrad
@@ -37,6 +44,7 @@ struct ConvParams {
   int total;                           // B * tiles_per_n * groups (logical work items)
   int padded_total;
   int items_per_wg;
+  int dbg;                             // diagnostics (E2E_CONV_DBG): 1 = no staging, 2 = no FMA phase, 4 = no barriers
 };
 
 // wave-uniform description of one staged input plane, kept in LDS (double buffered per chunk)
@@ -69,7 +77,10 @@ struct Cfg {
     else p = iw;
     return p;
   }
-  static constexpr int PITCH = pitch_for(IW);
+  // (STG 1 writes whole float4 groups: the row pitch must also cover the last group's overhang, see commit())
+  static constexpr int NQ0 = SUB ? (IW + 3) / 4 : (IW + 3 + 3) / 4;
+  static constexpr int WMIN = STG ? 4 * NQ0 - (SUB ? 0 : 3) : IW;
+  static constexpr int PITCH = pitch_for(WMIN > IW ? WMIN : IW);
   static constexpr int CHS = IH * PITCH;
   static constexpr int NT = NW * 64;
   static constexpr int OCG = OPW * NW;
@@ -110,11 +121,14 @@ typedef const f32x4_t __attribute__((address_space(1)))* gfloat4_p;
 template <int MODE, int SH, int SW, int DH, int DW, int TH, int TW, int LY, int LX, int OPW, int NW, int CK, int STG, int MINW, int PIPE, int PERSIST>
 __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
   using C = Cfg<MODE, SH, SW, DH, DW, TH, TW, LY, LX, OPW, NW, CK, STG>;
+  static_assert(OPW == 4 && CK % 8 == 0 && CK <= 16, "liveness quad words: 4 output planes x 8 input planes per word");
   constexpr int WPAD = 12;                                     // 9 taps padded to 3 x 16 bytes
   constexpr int WUNITS = C::OCG * CK * 9;                      // weights of one chunk for this workgroup's planes
   constexpr int NUW = (WUNITS + C::NT - 1) / C::NT;
-  __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
+  __shared__ __attribute__((aligned(16))) float lds_raw[C::LDS_FLOATS + 4];   // 4 guard floats: see the group writes of commit()
   __shared__ __attribute__((aligned(16))) float wl[C::OCG * CK * WPAD];
+  float* const lds = lds_raw + 4;
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.Q * p.P * 36, 0x00020000);
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
   PlaneDesc* tab = reinterpret_cast<PlaneDesc*>(dyn_lds);      // [P]: built once per workgroup
 
@@ -188,30 +202,38 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
     return ds;
   };
 
-  // ---- per-thread staging geometry: constant over the chunks, decoded once ----------------------------------
-  int su_k[C::NU], su_lds[C::NU], su_goff[C::NU], su_mask[C::NU];      // mask: which of the unit's elements land in the tile
+  // ---- staging geometry, constant over the chunks, decoded once ----------------------------------------------
+  // STG 1 (aligned float4 groups): every wave stages PPW whole planes of the chunk, so the plane descriptor is
+  // wave-uniform (scalar registers, scalar-base global loads, no per-chunk address arithmetic in vector registers);
+  // a lane owns NUP groups (row r, group q) of each of its planes.  All four elements of a group are written: the ones
+  // outside the tile land in the pad columns of the row before / the same row (PITCH >= row + 3), never read back.
+  // STG 0 (single elements, strided / dilated sources): units are spread over the whole workgroup.
+  constexpr int PPW = CK / NW;
+  constexpr int UPP = C::IH * C::NQ;
+  constexpr int NUP = STG ? (UPP + 63) / 64 : 1;
+  static_assert(!STG || CK % NW == 0, "a wave stages whole planes");
+  static_assert(!STG || C::PITCH >= 4 * C::NQ - (C::SUB ? 0 : 3), "group writes stay inside the row pitch");
+  int su_k[STG ? 1 : C::NU], su_lds[STG ? NUP : C::NU], su_goff[STG ? NUP : C::NU], su_mask[STG ? 1 : C::NU];
+  bool su_ok[NUP];
+  if constexpr (STG) {
 #pragma unroll
-  for (int i = 0; i < C::NU; ++i) {
-    const int u = tid + i * C::NT;
-    if (STG) {
-      int k = u / (C::IH * C::NQ);
-      const int rem = u - k * (C::IH * C::NQ);
-      const int r = rem / C::NQ, q = rem - r * C::NQ;
+    for (int i = 0; i < NUP; ++i) {
+      int u = lane + 64 * i;
+      if (u >= UPP) u = UPP - 1;                                  // idle lanes of the last round: harmless duplicates (skipped at commit)
+      const int r = u / C::NQ, q = u - r * C::NQ;
       const int hi = C::SUB ? h0 / 2 + r : hbase + r;
       const int gc = C::SUB ? w0 / 2 + 4 * q : w0 * SW - 4 + 4 * q;
       const int lc0 = C::SUB ? 4 * q : 4 * q - 3;                 // tile column of the group's first element
       const int srcH = MODE == 0 ? p.Hi : p.Hs, srcW = MODE == 0 ? p.Wi : p.Ws;
-      const bool ok = u < C::UNITS && (unsigned)hi < (unsigned)srcH && gc >= 0 && gc + 3 < srcW;
-      int m = 0;
+      const bool ok = (unsigned)hi < (unsigned)srcH && gc >= 0 && gc + 3 < srcW;
+      su_lds[i] = r * C::PITCH + lc0;
+      su_goff[i] = ok ? (hi * srcW + gc) * 4 : 0;                 // byte offset inside the plane
+      su_ok[i] = ok;
+    }
+  } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if ((unsigned)(lc0 + j) < (unsigned)C::IW) m |= 1 << j;
-      if (u >= C::UNITS) { m = 0; k = 0; }
-      su_k[i] = k;
-      su_lds[i] = k * C::CHS + r * C::PITCH + lc0;
-      su_goff[i] = ok ? hi * srcW + gc : -1;
-      su_mask[i] = m;
-    } else {
+    for (int i = 0; i < C::NU; ++i) {
+      const int u = tid + i * C::NT;
       int k = u / (C::IH * C::IW);
       const int rem = u - k * (C::IH * C::IW);
       const int r = rem / C::IW, cc = rem - r * C::IW;
@@ -236,8 +258,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
       su_mask[i] = u < C::UNITS ? 1 : 0;
     }
   }
-  // weights of a chunk: element (ql, cl, tap) of this workgroup's OCG output planes
-  int wu_goff[NUW], wu_lds[NUW];
+  // weights of a chunk: element (ql, cl, tap) of this workgroup's OCG output planes, read through a raw buffer
+  // descriptor (out-of-range offsets return 0, so planes beyond Q and the tail of the last chunk need no select)
+  unsigned wu_off[NUW];
+  int wu_lds[NUW];
 #pragma unroll
   for (int i = 0; i < NUW; ++i) {
     const int u = tid + i * C::NT;
@@ -245,77 +269,110 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
     const int rem = u - ql * (CK * 9);
     const int cl = rem / 9, kk = rem - cl * 9;
     const bool ok = u < WUNITS && qgroup + ql < p.Q;
-    wu_goff[i] = ok ? (qgroup + ql) * p.wq_stride + cl * p.wp_stride + (MODE == 1 ? 8 - kk : kk) : -1;
-    wu_lds[i] = ok ? (ql * CK + cl) * WPAD + kk : -1;
-    if (u >= WUNITS) wu_lds[i] = -1;
-    else if (!ok) wu_lds[i] = (ql * CK + cl) * WPAD + kk;      // planes beyond Q: stage zeros
+    wu_off[i] = ok ? (unsigned)((qgroup + ql) * p.wq_stride + cl * p.wp_stride + (MODE == 1 ? 8 - kk : kk)) * 4u : 0x80000000u;
+    wu_lds[i] = u < WUNITS ? (ql * CK + cl) * WPAD + kk : -1;
   }
 
   // ---- staging: issue the global loads of one chunk into registers (prefetch), commit them to LDS later -----
-  f32x4_t v4[STG ? C::NU : 1];
-  float v1[STG ? 1 : C::NU];
   float vw[NUW];
+  f32x4_t v4[STG ? PPW : 1][NUP];
+  float v1[STG ? 1 : C::NU];
+  float pd_a[PPW], pd_b[PPW], pd_slope[PPW];     // wave-uniform descriptors of the planes in flight (STG 1)
+  bool pd_ok[PPW];
   auto prefetch = [&](int c0) {
+    if constexpr (STG) {
 #pragma unroll
-    for (int i = 0; i < C::NU; ++i) {
-      const int pl = c0 + su_k[i];
-      const PlaneDesc ds = tab[pl < p.P ? pl : p.P - 1];
-      const bool ok = su_goff[i] >= 0 && pl < p.P && ds.valid;
-      if (STG) v4[i] = *reinterpret_cast<gfloat4_p>(ds.base + (ok ? su_goff[i] : 0));
-      else v1[i] = ds.base[ok ? su_goff[i] : 0];
-    }
-    const int remain = p.P - c0;
+      for (int j = 0; j < PPW; ++j) {
+        const int pl = c0 + wave * PPW + j;
+        const PlaneDesc ds = tab[pl < p.P ? pl : p.P - 1];
+        const unsigned long long bb = (unsigned long long)ds.base;
+        const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)bb), bhi = __builtin_amdgcn_readfirstlane((unsigned)(bb >> 32));
+        const char __attribute__((address_space(1)))* base =
+            (const char __attribute__((address_space(1)))*)(((unsigned long long)bhi << 32) | blo);
+        pd_a[j] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ds.a)));
+        pd_b[j] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ds.b)));
+        pd_slope[j] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ds.slope)));
+        pd_ok[j] = pl < p.P && __builtin_amdgcn_readfirstlane(ds.valid) != 0;
+        if (pd_ok[j]) {
 #pragma unroll
-    for (int i = 0; i < NUW; ++i) {
-      const int cl = (wu_lds[i] / WPAD) % CK;
-      const bool ok = wu_goff[i] >= 0 && cl < remain;
-      vw[i] = ((gfloat_p)p.w)[ok ? wu_goff[i] + c0 * p.wp_stride : 0];
+          for (int i = 0; i < NUP; ++i) v4[j][i] = *reinterpret_cast<gfloat4_p>(base + (unsigned)su_goff[i]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < C::NU; ++i) {
+        const int pl = c0 + su_k[i];
+        const PlaneDesc ds = tab[pl < p.P ? pl : p.P - 1];
+        const bool ok = su_goff[i] >= 0 && pl < p.P && ds.valid;
+        v1[i] = ds.base[ok ? su_goff[i] : 0];
+      }
     }
+    const unsigned coff = (unsigned)(c0 * p.wp_stride) * 4u;
+#pragma unroll
+    for (int i = 0; i < NUW; ++i)
+      vw[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, (int)(wu_off[i] + coff), 0, 0));
   };
   auto commit = [&](int c0) {
+    if constexpr (STG) {
 #pragma unroll
-    for (int i = 0; i < C::NU; ++i) {
-      if (su_mask[i] == 0) continue;
-      const int pl = c0 + su_k[i];
-      const PlaneDesc ds = tab[pl < p.P ? pl : p.P - 1];
-      const bool ok = su_goff[i] >= 0 && pl < p.P && ds.valid;
-      if (STG) {
+      for (int j = 0; j < PPW; ++j) {
+        float* plane = lds + (wave * PPW + j) * C::CHS;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (su_mask[i] & (1 << j)) {
-            float val = v4[i][j];
-            if (MODE == 0) val = e2e::in_act(val, ds.a, ds.b, ds.slope);
-            lds[su_lds[i] + j] = ok ? val : 0.f;
+        for (int i = 0; i < NUP; ++i) {
+          if ((i + 1) * 64 > UPP && lane + 64 * i >= UPP) continue;
+          float* dst = plane + su_lds[i];
+          if (!pd_ok[j]) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[e] = 0.f;
+          } else if (MODE == 0) {
+            const float ae = su_ok[i] ? pd_a[j] : 0.f, be = su_ok[i] ? pd_b[j] : 0.f;   // out-of-image groups stage zeros
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[e] = e2e::in_act(v4[j][i][e], ae, be, pd_slope[j]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[e] = su_ok[i] ? v4[j][i][e] : 0.f;
           }
         }
-      } else {
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < C::NU; ++i) {
+        if (su_mask[i] == 0) continue;
+        const int pl = c0 + su_k[i];
+        const PlaneDesc ds = tab[pl < p.P ? pl : p.P - 1];
+        const bool ok = su_goff[i] >= 0 && pl < p.P && ds.valid;
         float val = v1[i];
         if (MODE == 0) val = e2e::in_act(val, ds.a, ds.b, ds.slope);
         lds[su_lds[i]] = ok ? val : 0.f;
       }
     }
-    const int remain = p.P - c0;
 #pragma unroll
     for (int i = 0; i < NUW; ++i) {
       if (wu_lds[i] < 0) continue;
-      const int cl = (wu_lds[i] / WPAD) % CK;
-      wl[wu_lds[i]] = (wu_goff[i] >= 0 && cl < remain) ? vw[i] : 0.f;
+      wl[wu_lds[i]] = vw[i];
     }
   };
 
-  // ---- one live (output plane a, input plane cl) kernel: LDS reads (issue) and the 9 x PH x PW FMAs (apply) ----
-  auto issue = [&](int a, int cl, float (&nb)[C::NR][C::NC], float (&wk)[WPAD]) {
+  // ---- one live (output plane a, input plane cl) kernel: neighbourhood rows from LDS (shared by the wave's output
+  // planes that consume the same input plane), 9 weights from scalar memory, 9 x PH x PW FMAs ----
+  constexpr int NCL = (C::VEC == 4) ? ((C::NC + 3) & ~3) : C::NC;     // VEC 4: whole float4s (conflict-free), over-read into the row pad
+  static_assert(C::VEC != 4 || (LX - 1) * C::LSTEP + NCL <= C::PITCH, "row over-read stays inside the pitch");
+  auto issue = [&](int cl, float (&nb)[C::NR][NCL]) {
+    const float* tp = lane_tp + cl * C::CHS;
+#pragma unroll
+    for (int r = 0; r < C::NR; ++r) load_row<NCL, C::VEC>(tp + r * C::PITCH, nb[r]);
+  };
+  auto load_w = [&](int a, int cl, float (&wk)[9]) {
     const float* wp = wl + ((wave * OPW + a) * CK + cl) * WPAD;
     const float4 w0v = *reinterpret_cast<const float4*>(wp);
     const float4 w1v = *reinterpret_cast<const float4*>(wp + 4);
     wk[0] = w0v.x; wk[1] = w0v.y; wk[2] = w0v.z; wk[3] = w0v.w;
     wk[4] = w1v.x; wk[5] = w1v.y; wk[6] = w1v.z; wk[7] = w1v.w;
     wk[8] = wp[8];
-    const float* tp = lane_tp + cl * C::CHS;
-#pragma unroll
-    for (int r = 0; r < C::NR; ++r) load_row<C::NC, C::VEC>(tp + r * C::PITCH, nb[r]);
   };
-  auto apply = [&](float (&ac)[C::PH][C::PW], const float (&nb)[C::NR][C::NC], const float (&wk)[WPAD]) {
+  // (v_pk_fma_f32 was tried here: on gfx950 a wave64 v_fma_f32 already issues in 2 cycles, so packing the FMAs buys
+  //  nothing -- measured equal -- and the loop is bounded by the LDS reads, not by the vector ALU)
+  auto apply = [&](float (&ac)[C::PH][C::PW], const float (&nb)[C::NR][NCL], const float (&wk)[9]) {
 #pragma unroll
     for (int i = 0; i < C::PH; ++i)
 #pragma unroll
@@ -336,67 +393,63 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
           }
   };
 
+  // liveness of this wave's 4 output planes x the chunk's CK input planes: quad words (bit = (plane % 8) * 4 + output % 4),
+  // input-plane-major, so consecutive set bits that share an input plane reuse the neighbourhood registers
+  const int nw8 = (p.P + 7) >> 3;
+  auto chunk_mask = [&](int c0) -> unsigned long long {
+    unsigned long long m = 0;
+    if (c0 >= p.P || qbase >= p.Q) return m;
+#pragma unroll
+    for (int wd = 0; wd < CK / 8; ++wd) {
+      const int wi = (c0 >> 3) + wd;
+      unsigned word = 0u;
+      if (wi < nw8) word = p.live != nullptr ? p.live[(long long)(qbase >> 2) * nw8 + wi] : 0xffffffffu;
+      m |= (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)word) << (32 * wd);
+    }
+    const int remain = p.P - c0;
+    if (remain < CK) m &= (1ull << (remain * 4)) - 1ull;
+    const int qleft = p.Q - qbase;                       // planes beyond Q (last group): clear their bit in every nibble
+    if (qleft < 4) m &= 0x1111111111111111ull * ((1ull << qleft) - 1ull);
+    return m;
+  };
+
+  unsigned long long m_cur = 0;
   if (nchunks > 0) {
     if (n != tab_n || d != tab_d) {
       for (int pl = tid; pl < p.P; pl += C::NT) tab[pl] = make_desc(pl);
       tab_n = n; tab_d = d;
       __syncthreads();
     }
-    prefetch(0);
+    if (!CDBG(1)) prefetch(0);
+    m_cur = chunk_mask(0);
   }
   for (int ci = 0; ci < nchunks; ++ci) {
     const int c0 = ci * CK;
-    commit(c0);
-    __syncthreads();
-    if (ci + 1 < nchunks) prefetch(c0 + CK);   // in flight while this chunk is computed
+    const unsigned long long m_next = ci + 1 < nchunks ? chunk_mask(c0 + CK) : 0ull;   // scalar loads, in flight during commit
+    if (!CDBG(1)) commit(c0);
+    if (!CDBG(4)) __syncthreads();
+    if (ci + 1 < nchunks && !CDBG(1)) prefetch(c0 + CK);   // in flight while this chunk is computed
 
-    // ---------------- compute: each wave walks the live input planes of its OPW output planes; the LDS reads of
-    // the next live kernel are issued before the FMAs of the current one (two register sets) ----------------
+    // walk the chunk's live input planes (nibbles of the quad mask); the neighbourhood rows of a plane are read once
+    // and shared by the 1..4 output planes of this wave that consume it
+    unsigned long long m = CDBG(2) ? 0ull : m_cur;
+    while (m) {
+      const int cl = __builtin_ctzll(m) >> 2;
+      const unsigned nib = (unsigned)(m >> (cl * 4)) & 15u;
+      m &= ~(15ull << (cl * 4));
+      float nb[C::NR][NCL];
+      issue(cl, nb);
 #pragma unroll
-    for (int a = 0; a < OPW; ++a) {
-      const int q = qbase + a;
-      if (q < p.Q) {
-        unsigned bits;
-        if (p.live != nullptr) {
-          const unsigned word = p.live[(long long)q * p.live_words + (c0 >> 5)];
-          bits = (CK == 32) ? word : ((word >> (c0 & 31)) & ((1u << (CK & 31)) - 1u));
-        } else {
-          bits = (CK == 32) ? 0xffffffffu : ((1u << (CK & 31)) - 1u);
-        }
-        const int remain = p.P - c0;
-        if (remain < CK) bits &= (1u << remain) - 1u;
-        bits = __builtin_amdgcn_readfirstlane(bits);
-        if (!PIPE) {
-          while (bits) {
-            const int cl = __builtin_ctz(bits);
-            bits &= bits - 1;
-            float nb[C::NR][C::NC];
-            float wk[WPAD];
-            issue(a, cl, nb, wk);
-            apply(acc[a], nb, wk);
-          }
-        } else if (bits) {
-          float nbA[C::NR][C::NC], nbB[C::NR][C::NC];
-          float wkA[WPAD], wkB[WPAD];
-          int cl = __builtin_ctz(bits);
-          bits &= bits - 1;
-          issue(a, cl, nbA, wkA);
-          while (true) {
-            if (!bits) { apply(acc[a], nbA, wkA); break; }
-            cl = __builtin_ctz(bits);
-            bits &= bits - 1;
-            issue(a, cl, nbB, wkB);
-            apply(acc[a], nbA, wkA);
-            if (!bits) { apply(acc[a], nbB, wkB); break; }
-            cl = __builtin_ctz(bits);
-            bits &= bits - 1;
-            issue(a, cl, nbA, wkA);
-            apply(acc[a], nbB, wkB);
-          }
+      for (int a = 0; a < OPW; ++a) {
+        if (nib & (1u << a)) {
+          float wk[9];
+          load_w(a, cl, wk);
+          apply(acc[a], nb, wk);
         }
       }
     }
-    __syncthreads();
+    m_cur = m_next;
+    if (!CDBG(4)) __syncthreads();
   }
 
   // ---------------- epilogue ------------------------------------------------------------------------------
@@ -571,6 +624,8 @@ int launch_cfg_impl(ConvParams p, hipStream_t st) {
   p.groups = e2e::cdiv(p.Q, C::OCG);
   p.total = p.B * p.tiles_per_n * p.groups;
   p.padded_total = (p.total + 7) & ~7;
+  static const int dbg_knob = getenv("E2E_CONV_DBG") ? atoi(getenv("E2E_CONV_DBG")) : 0;
+  p.dbg = dbg_knob;
   // persistent grid: about 4 workgroup slots per CU (256 CUs), each walking a run of consecutive work items
   int wgs = PERSIST ? 1024 : p.total;
   if (wgs > p.total) wgs = p.total;
@@ -605,8 +660,8 @@ int launch_s1(const ConvParams& p, int kind, hipStream_t st) {
       return vec ? launch_cfg<MODE, 1, 1, 1, 1, 16, 16, 8, 8, 4, 8, 16, 1>(p, st)
                  : launch_cfg<MODE, 1, 1, DH, DW, 16, 16, 8, 8, 4, 8, 16, 0>(p, st);
     default:
-      return vec ? launch_cfg<MODE, 1, 1, 1, 1, 8, 8, 8, 8, 4, 8, 32, 1>(p, st)
-                 : launch_cfg<MODE, 1, 1, DH, DW, 8, 8, 8, 8, 4, 8, 32, 0>(p, st);
+      return vec ? launch_cfg<MODE, 1, 1, 1, 1, 8, 8, 8, 8, 4, 8, 16, 1>(p, st)
+                 : launch_cfg<MODE, 1, 1, DH, DW, 8, 8, 8, 8, 4, 8, 16, 0>(p, st);
   }
 }
 

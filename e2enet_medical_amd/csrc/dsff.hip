@@ -104,6 +104,26 @@ __global__ __launch_bounds__(256) void cols_bits_kernel(const unsigned char* __r
   bits[i] = b;
 }
 
+// quad words for the 1x3x3 conv kernels: word [r / 4][c / 8], bit (c % 8) * 4 + r % 4 = kmask[r][c] (transpose = 0),
+// or word [c / 4][r / 8], bit (r % 8) * 4 + c % 4 (transpose = 1)
+__global__ __launch_bounds__(256) void quad_bits_kernel(const unsigned char* __restrict__ kmask, unsigned* __restrict__ bits,
+                                                        int R, int Cc, int transpose) {
+  const int Qn = transpose ? Cc : R, Pn = transpose ? R : Cc;      // quad rows run over q, words over p
+  const int words = e2e::cdiv(Pn, 8);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= e2e::cdiv(Qn, 4) * words) return;
+  const int qg = i / words, wd = i - qg * words;
+  unsigned b = 0u;
+  for (int j = 0; j < 32; ++j) {
+    const int q = qg * 4 + (j & 3), pp = wd * 8 + (j >> 2);
+    if (q < Qn && pp < Pn) {
+      const int r = transpose ? pp : q, c = transpose ? q : pp;
+      if (kmask[(long long)r * Cc + c]) b |= 1u << j;
+    }
+  }
+  bits[i] = b;
+}
+
 __global__ __launch_bounds__(256) void kmask_from_weights_kernel(const float* __restrict__ w, unsigned char* __restrict__ kmask,
                                                                  long long n, int ks) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -143,6 +163,17 @@ extern "C" int e2e_dsff_expand(const unsigned char* kmask, float* mask, unsigned
   if (bits_rows) hipLaunchKernelGGL(rows_bits_kernel, dim3(e2e::cdiv(R * e2e::cdiv(Cc, 32), 256)), dim3(256), 0, st, kmask, bits_rows, R, Cc);
   if (bits_cols) hipLaunchKernelGGL(cols_bits_kernel, dim3(e2e::cdiv(Cc * e2e::cdiv(R, 32), 256)), dim3(256), 0, st, kmask, bits_cols, R, Cc);
   return e2e::check_launch("dsff_expand");
+}
+
+extern "C" int e2e_dsff_expand_quads(const unsigned char* kmask, unsigned* quads_rows, unsigned* quads_cols, int R, int Cc,
+                                     void* stream) {
+  E2E_REQUIRE(kmask && R > 0 && Cc > 0, "dsff_expand_quads: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (quads_rows)
+    hipLaunchKernelGGL(quad_bits_kernel, dim3(e2e::cdiv(e2e::cdiv(R, 4) * e2e::cdiv(Cc, 8), 256)), dim3(256), 0, st, kmask, quads_rows, R, Cc, 0);
+  if (quads_cols)
+    hipLaunchKernelGGL(quad_bits_kernel, dim3(e2e::cdiv(e2e::cdiv(Cc, 4) * e2e::cdiv(R, 8), 256)), dim3(256), 0, st, kmask, quads_cols, R, Cc, 1);
+  return e2e::check_launch("dsff_expand_quads");
 }
 
 extern "C" int e2e_dsff_kmask_from_weights(const float* w, unsigned char* kmask, int R, int Cc, int ks, void* stream) {

@@ -98,8 +98,8 @@ class ConvOp:
         self.np = lib().conv133_num_partials(*self.out_dims, sh, sw)
         self.part = torch.empty(b * cout * self.np * 3, dtype=torch.float32, device=eng.device)
         self.w_name = prefix + ".conv.weight"
-        self.live = None        # [Cout, ceil(Cin/32)] int32
-        self.live_t = None      # [Cin, ceil(Cout/32)] int32
+        self.live = None        # quad words [ceil(Cout/4), ceil(Cin/8)] int32 (e2e_dsff_expand_quads)
+        self.live_t = None      # quad words [ceil(Cin/4), ceil(Cout/8)] int32
         # per input channel plane table
         shifts = shift_amounts(self.cin)
         structs = []
@@ -381,12 +381,15 @@ class Engine:
                 continue
             r, cc = km.shape
             km = km.to(device=self.device, dtype=torch.uint8).contiguous()
-            rows = torch.empty(r * ((cc + 31) // 32), dtype=torch.int32, device=self.device)
-            cols = torch.empty(cc * ((r + 31) // 32), dtype=torch.int32, device=self.device)
-            L.dsff_expand(km.data_ptr(), None, rows.data_ptr(), cols.data_ptr(), r, cc, 1, _stream())
-            if isinstance(op, ConvOp):         # weight [Cout, Cin, ...]: rows index out channels
+            if isinstance(op, ConvOp):         # weight [Cout, Cin, ...]: quad words (4 output x 8 input planes)
+                rows = torch.empty(((r + 3) // 4) * ((cc + 7) // 8), dtype=torch.int32, device=self.device)
+                cols = torch.empty(((cc + 3) // 4) * ((r + 7) // 8), dtype=torch.int32, device=self.device)
+                L.dsff_expand_quads(km.data_ptr(), rows.data_ptr(), cols.data_ptr(), r, cc, _stream())
                 op.live, op.live_t = rows, cols
-            else:                              # weight [Cin, Cout, ...]: rows index in channels
+            else:                              # weight [Cin, Cout, ...]: 32-plane words, rows index in channels
+                rows = torch.empty(r * ((cc + 31) // 32), dtype=torch.int32, device=self.device)
+                cols = torch.empty(cc * ((r + 31) // 32), dtype=torch.int32, device=self.device)
+                L.dsff_expand(km.data_ptr(), None, rows.data_ptr(), cols.data_ptr(), r, cc, 1, _stream())
                 op.live, op.live_t = cols, rows
 
     def kernel_masks_from_weights(self, names=None):

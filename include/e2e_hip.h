@@ -60,8 +60,8 @@ typedef struct {
  * statistics pass of nn.InstanceNorm3d (unetpp_d.py:99,111).
  *   chans   [Cin]            device table (see e2e_in_chan_t)
  *   w       [Cout,Cin,1,3,3] (DSFF-masked weights; dead kernels are exact zeros)
- *   live    [Cout, ceil(Cin/32)] bit c%32 of word c/32 set <=> kernel (o,c) is alive;
- *           NULL => dense
+ *   live    quad words [ceil(Cout/4), ceil(Cin/8)] (quads_rows of e2e_dsff_expand_quads): bit (c%8)*4 + o%4 of
+ *           word [o/4][c/8] set <=> kernel (o,c) is alive; NULL => dense
  *   y       [B,Cout,Do,Ho,Wo] pre-norm output, Do=(Di-1)/sd+1, Ho=(Hi-1)/sh+1, ...
  *   part    [B,Cout,np,3] per-tile (count, mean, M2) partials, np =
  *           e2e_conv133_num_partials(Do,Ho,Wo,sh,sw); NULL => no statistics
@@ -76,7 +76,7 @@ int e2e_conv133_fwd(const e2e_in_chan_t* chans, int Cin, const float* w, const f
  * (nnUNetTrainer_simple.py:572 l.backward()).
  *   dy    [B,Cout,Do,Ho,Wo] gradient w.r.t. the pre-norm conv output
  *   outs  [Cin] destinations, one per virtual-concat input channel (un-shift on store)
- *   live_t [Cin, ceil(Cout/32)] transposed liveness bits; NULL => dense
+ *   live_t quad words [ceil(Cin/4), ceil(Cout/8)] (quads_cols of e2e_dsff_expand_quads); NULL => dense
  */
 int e2e_conv133_dgrad(const float* dy, const float* w, const unsigned* live_t, const e2e_out_chan_t* outs,
                       int B, int Cin, int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw, void* stream);
@@ -189,6 +189,13 @@ int e2e_dsff_death(const float* l1, const float* thr, unsigned char* kmask, int 
  * bits_rows [R, ceil(Cc/32)] and bits_cols [Cc, ceil(R/32)] (either may be NULL) */
 int e2e_dsff_expand(const unsigned char* kmask, float* mask, unsigned* bits_rows, unsigned* bits_cols, int R,
                     int Cc, int ks, void* stream);
+/* liveness "quad words" consumed by e2e_conv133_fwd / e2e_conv133_dgrad (4 output planes x 8 input planes per word,
+ * input-plane-major so that the kernel walks the live kernels of one staged input plane back to back):
+ *   quads_rows [ceil(R/4), ceil(Cc/8)], bit (c % 8) * 4 + r % 4 = kmask[r][c]   (forward: R = Cout, Cc = Cin)
+ *   quads_cols [ceil(Cc/4), ceil(R/8)], bit (r % 8) * 4 + c % 4 = kmask[r][c]   (data gradient)
+ * either may be NULL */
+int e2e_dsff_expand_quads(const unsigned char* kmask, unsigned* quads_rows, unsigned* quads_cols, int R, int Cc,
+                          void* stream);
 /* kernel map from weights (inference: live <=> any nonzero tap) */
 int e2e_dsff_kmask_from_weights(const float* w, unsigned char* kmask, int R, int Cc, int ks, void* stream);
 

@@ -102,10 +102,10 @@ def test_conv133_fwd_bwd(case):
     e.batch = B
     op = ConvOp(e, "blk", srcs, cout, stride)
     if km is not None:
-        rows = torch.empty(cout * ((cin + 31) // 32), dtype=torch.int32, device=e.device)
-        cols = torch.empty(cin * ((cout + 31) // 32), dtype=torch.int32, device=e.device)
+        rows = torch.empty(((cout + 3) // 4) * ((cin + 7) // 8), dtype=torch.int32, device=e.device)
+        cols = torch.empty(((cin + 3) // 4) * ((cout + 7) // 8), dtype=torch.int32, device=e.device)
         kmd = km.to(e.device)
-        lib().dsff_expand(kmd.data_ptr(), None, rows.data_ptr(), cols.data_ptr(), cout, cin, 1, 0)
+        lib().dsff_expand_quads(kmd.data_ptr(), rows.data_ptr(), cols.data_ptr(), cout, cin, 0)
         op.live, op.live_t = rows, cols
     op.forward()
     torch.cuda.synchronize()
@@ -345,6 +345,20 @@ def test_dsff_death_and_expand():
         for j in range(c):
             assert ((rows_h[i, j // 32] >> (j % 32)) & 1) == km[i, j].item()
             assert ((cols_h[j, i // 32] >> (i % 32)) & 1) == km[i, j].item()
+    # quad words of the 1x3x3 conv kernels
+    qr = torch.empty(((r + 3) // 4) * ((c + 7) // 8), dtype=torch.int32, device="cuda")
+    qc = torch.empty(((c + 3) // 4) * ((r + 7) // 8), dtype=torch.int32, device="cuda")
+    lib().dsff_expand_quads(kmd.data_ptr(), qr.data_ptr(), qc.data_ptr(), r, c, 0)
+    qr_h = qr.cpu().numpy().view(np.uint32).reshape((r + 3) // 4, (c + 7) // 8)
+    qc_h = qc.cpu().numpy().view(np.uint32).reshape((c + 3) // 4, (r + 7) // 8)
+    want_r = np.zeros_like(qr_h)
+    want_c = np.zeros_like(qc_h)
+    for i in range(r):
+        for j in range(c):
+            if km[i, j].item():
+                want_r[i // 4, j // 8] |= np.uint32(1) << np.uint32((j % 8) * 4 + i % 4)
+                want_c[j // 4, i // 8] |= np.uint32(1) << np.uint32((i % 8) * 4 + j % 4)
+    assert np.array_equal(qr_h, want_r) and np.array_equal(qc_h, want_c)
     l1 = torch.rand(r * c, generator=torch.Generator().manual_seed(2))
     thr = torch.tensor([0.3])
     l1d, thrd = l1.cuda(), thr.cuda()                      # keep device buffers alive across the async launch

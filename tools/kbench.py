@@ -51,10 +51,14 @@ def conv_case(B, srcs, cout, dims, stride, density, tag):
     e.in_sums = torch.empty(B * cout * 3, dtype=torch.float64, device=dev)
     if density < 1.0:
         km = (torch.rand(cout, cin, device=dev) < density).to(torch.uint8)
+        if os.environ.get("KB_BALANCED"):      # diagnostic: exactly round(8*density) live kernels per (row, 8-plane chunk)
+            nl = max(1, round(8 * density))
+            r = torch.rand(cout, cin // 8, 8, device=dev).argsort(dim=-1)
+            km = (r < nl).reshape(cout, cin).to(torch.uint8)
         w.mul_(km.view(cout, cin, 1, 1, 1))
-        rows = torch.empty(cout * ((cin + 31) // 32), dtype=torch.int32, device=dev)
-        cols = torch.empty(cin * ((cout + 31) // 32), dtype=torch.int32, device=dev)
-        lib().dsff_expand(km.data_ptr(), None, rows.data_ptr(), cols.data_ptr(), cout, cin, 1, 0)
+        rows = torch.empty(((cout + 3) // 4) * ((cin + 7) // 8), dtype=torch.int32, device=dev)
+        cols = torch.empty(((cin + 3) // 4) * ((cout + 7) // 8), dtype=torch.int32, device=dev)
+        lib().dsff_expand_quads(km.data_ptr(), rows.data_ptr(), cols.data_ptr(), cout, cin, 0)
         op.live, op.live_t = rows, cols
     op.out.alloc_grad()
     op.plan_backward()
