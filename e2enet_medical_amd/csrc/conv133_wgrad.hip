@@ -29,6 +29,7 @@ struct WgParams {
   long long total_tiles;
   int tiles_per_chunk;
   int cblocks;
+  int cblocks_segs;   // v3: chunks per batch item
   int dbg;     // diagnostic: bit0 = skip staging, bit1 = skip the MFMA phase (timing splits only; results are garbage)
 };
 
@@ -416,6 +417,219 @@ __global__ __launch_bounds__(256 * NCB) void conv133_wgrad_v2_kernel(WgParams p)
   }
 }
 
+// ---- v3: large stride-1 planes (rows >= 32, multiples of 4 floats): double-buffered LDS ------------------------------
+// v2 alternates a staging phase (commit the prefetched registers to LDS) and an MFMA phase separated by two barriers,
+// and with one 8-wave workgroup per CU nothing else runs while it stages: the matrix pipe idles ~40 % of the time.
+// v3 keeps two LDS images (tile 4 x 32, 77 KB each for 64 input channels): while the MFMAs consume image t & 1, the
+// registers holding tile t+1 are committed to the other image piece by piece between the k-steps, the loads of tile
+// t+2 are issued when that is done, and one barrier per tile publishes the new image.  A chunk never crosses a batch
+// item, so the channel descriptors are loaded once per workgroup.
+template <int NCB>
+struct W3Cfg {
+  static constexpr int TH = 4, TW = 32, TP = TH * TW;
+  static constexpr int IH = TH + 2;
+  static constexpr int NQ = TW / 4 + 2;                       // float4 groups per input row (starts 4 left of the tile)
+  static constexpr int PITCH = 4 * NQ;                        // groups stored whole: tile column -1 sits at row index 3
+  static constexpr int COL0 = 3;
+  static constexpr int CS = IH * PITCH + 2;                   // 242 = 2 x odd: 16 channels x 2 k-lanes hit 32 distinct banks
+  static constexpr int OS = TP + 2;                           // 130 = 2 x odd
+  static_assert((CS / 2) % 2 == 1 && (OS / 2) % 2 == 1, "channel strides must be 2 x odd");
+  static constexpr int NT = 256 * NCB;
+  static constexpr int GPC = IH * NQ;                         // 60 groups per input channel: one wave-instruction
+  static_assert(GPC <= 64, "one float4 group per lane and channel");
+  static constexpr int XCW = 8;                               // input channels staged per wave
+  static constexpr int YIT = 32 * (TP / 4) / NT;              // dy float4 groups per thread
+  static constexpr int YCW = 32 / (4 * NCB);                  // dy channels staged per wave
+  static constexpr int XBUF = NCB * 32 * CS, YBUF = 32 * OS;
+  static constexpr int LDS_FLOATS = 2 * (XBUF + YBUF);
+  static constexpr int PIECES = XCW + YIT;
+  static_assert(PIECES <= TH * TW / 4, "one commit piece per k-step");
+};
+
+template <int NCB>
+__global__ __launch_bounds__(256 * NCB) void conv133_wgrad_v3_kernel(WgParams p) {
+  using C = W3Cfg<NCB>;
+  __shared__ __attribute__((aligned(16))) float lds3[C::LDS_FLOATS + 8];     // + slack for the read-ahead after the last k-step
+  float* const xs0 = lds3;
+  float* const ys0 = lds3 + 2 * C::XBUF;
+
+  // chunk = (batch item, run of tiles inside it)
+  const int segs = p.cblocks_segs;
+  const int n = blockIdx.x / segs, seg = blockIdx.x - n * segs;
+  const int cgroups = p.cblocks;
+  const int cg = blockIdx.y % cgroups, ob = blockIdx.y / cgroups;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cbl = wave >> 2, ch = wave & 1, oh = (wave >> 1) & 1;
+  const long long in_plane = (long long)p.Hi * p.Wi;
+  const long long out_plane = (long long)p.Ho * p.Wo;
+  const int cbase = cg * NCB * 32;
+
+  f32x4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int tile_lo = seg * p.tiles_per_chunk;
+  int tile_hi = tile_lo + p.tiles_per_chunk;
+  if (tile_hi > p.tiles_per_n) tile_hi = p.tiles_per_n;
+
+  auto decode = [&](int tile, int& d0, int& h0, int& w0) {
+    const int tx = tile % p.tiles_x;
+    const int t = tile / p.tiles_x;
+    const int ty = t % p.tiles_y;
+    d0 = t / p.tiles_y;
+    h0 = ty * C::TH;
+    w0 = tx * C::TW;
+  };
+
+  // ---- wave-uniform descriptors of this wave's 8 input channels (scalar registers, fixed for the workgroup) ----
+  gfloat_p xbase[C::XCW];
+  float xa[C::XCW], xb[C::XCW], xsl[C::XCW];
+  int xdsh[C::XCW];
+  bool xval[C::XCW];
+#pragma unroll
+  for (int k = 0; k < C::XCW; ++k) {
+    const int c = cbase + wave * C::XCW + k;
+    xval[k] = c < p.Cin;
+    const e2e_in_chan_t chd = p.chans[xval[k] ? c : 0];
+    xdsh[k] = chd.dshift;
+    xbase[k] = (gfloat_p)(chd.ptr + (long long)n * chd.nstride);
+    xa[k] = 1.f; xb[k] = 0.f; xsl[k] = 1.f;
+    if (xval[k] && chd.scale != nullptr) {
+      xa[k] = chd.scale[(long long)n * chd.ab_nstride];
+      xb[k] = chd.shift[(long long)n * chd.ab_nstride];
+      xsl[k] = chd.slope;
+    }
+  }
+
+  // ---- per-lane geometry ----
+  const int g_r = (lane < C::GPC ? lane : C::GPC - 1) / C::NQ;
+  const int g_q = (lane < C::GPC ? lane : C::GPC - 1) - g_r * C::NQ;
+  // dy: a wave stages YCW channels x 32 groups = YIT rounds of 64 lanes: lane -> (channel lane / 32 + 2 it, group lane % 32)
+  const int y_grp = lane & 31, y_kl = lane >> 5;
+  const int y_r = y_grp >> 3, y_col = (y_grp & 7) * 4;
+
+  f32x4_t vx[C::XCW], vy[C::YIT];
+  auto prefetch = [&](int d0, int h0, int w0) {
+    const int hi = h0 - 1 + g_r, gc = w0 - 4 + 4 * g_q;
+    const bool lane_ok = (unsigned)hi < (unsigned)p.Hi && gc >= 0 && gc + 3 < p.Wi;
+    const long long lane_off = (long long)hi * p.Wi + gc;
+#pragma unroll
+    for (int k = 0; k < C::XCW; ++k) {
+      const int din = d0 * p.sd - xdsh[k];
+      const bool ok = lane_ok && xval[k] && (unsigned)din < (unsigned)p.Di;
+      vx[k] = *reinterpret_cast<gf4_p>(xbase[k] + (ok ? (long long)din * in_plane + lane_off : 0));
+    }
+    const int ho = h0 + y_r, wo = w0 + y_col;
+    const bool yok = ho < p.Ho && wo + 3 < p.Wo;
+#pragma unroll
+    for (int it = 0; it < C::YIT; ++it) {
+      const int o = ob * 32 + wave * C::YCW + y_kl + 2 * it;
+      const bool ok = yok && o < p.Cout;
+      const long long off = ok ? (((long long)n * p.Cout + o) * p.Do + d0) * out_plane + (long long)ho * p.Wo + wo : 0;
+      vy[it] = *reinterpret_cast<gf4_p>((gfloat_p)p.dy + off);
+    }
+  };
+  // commit piece s of the registers (tile geometry d0, h0, w0) into image `buf`: s < XCW -> input channel s, else dy round
+  auto commit_piece = [&](int s, int buf, int d0, int h0, int w0) {
+    if (s < C::XCW) {
+      if (lane >= C::GPC) return;
+      const int k = s;
+      const int hi = h0 - 1 + g_r, gc = w0 - 4 + 4 * g_q;
+      const int din = d0 * p.sd - xdsh[k];
+      const bool ok = (unsigned)hi < (unsigned)p.Hi && gc >= 0 && gc + 3 < p.Wi && xval[k] && (unsigned)din < (unsigned)p.Di;
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float t = e2e::in_act(vx[k][j], xa[k], xb[k], xsl[k]);
+        v[j] = ok ? t : 0.f;
+      }
+      float2* dst = reinterpret_cast<float2*>(xs0 + buf * C::XBUF + (wave * C::XCW + k) * C::CS + g_r * C::PITCH + 4 * g_q);
+      dst[0] = make_float2(v[0], v[1]);
+      dst[1] = make_float2(v[2], v[3]);
+    } else {
+      const int it = s - C::XCW;
+      const int ho = h0 + y_r, wo = w0 + y_col;
+      const int ol = wave * C::YCW + y_kl + 2 * it;
+      const bool ok = ho < p.Ho && wo + 3 < p.Wo && ob * 32 + ol < p.Cout;
+      float2* dst = reinterpret_cast<float2*>(ys0 + buf * C::YBUF + ol * C::OS + y_grp * 4);
+      dst[0] = ok ? make_float2(vy[it][0], vy[it][1]) : make_float2(0.f, 0.f);
+      dst[1] = ok ? make_float2(vy[it][2], vy[it][3]) : make_float2(0.f, 0.f);
+    }
+  };
+
+  if (tile_lo < tile_hi) {
+    int d0, h0, w0;
+    decode(tile_lo, d0, h0, w0);
+    prefetch(d0, h0, w0);
+#pragma unroll
+    for (int s = 0; s < C::PIECES; ++s) commit_piece(s, 0, d0, h0, w0);
+    int nd0 = d0, nh0 = h0, nw0 = w0;
+    if (tile_lo + 1 < tile_hi) {
+      decode(tile_lo + 1, nd0, nh0, nw0);
+      prefetch(nd0, nh0, nw0);
+    }
+    __syncthreads();
+
+    const int li = lane & 15, lk = lane >> 4;
+    for (int tile = tile_lo; tile < tile_hi; ++tile) {
+      const int buf = (tile - tile_lo) & 1;
+      const bool more = tile + 1 < tile_hi;             // registers hold tile + 1 -> goes to image buf ^ 1 during this phase
+      const float* ap = ys0 + buf * C::YBUF + (oh * 16 + li) * C::OS + lk;
+      const float* bp = xs0 + buf * C::XBUF + (cbl * 32 + ch * 16 + li) * C::CS + lk + C::COL0;
+      float a_cur = ap[0];
+      float b_cur[9];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) b_cur[kh * 3 + kw] = bp[kh * C::PITCH + kw];
+#pragma unroll
+      for (int row = 0; row < C::TH; ++row) {
+        const float* apr = ap + row * C::TW;
+        const float* bpr = bp + row * C::PITCH;
+#pragma unroll
+        for (int cq = 0; cq < C::TW / 4; ++cq) {
+          float a_nxt, b_nxt[9];
+          // fragments of the next k-step (a harmless read past the tile after the last one: still inside the LDS image)
+          const int nrow = cq + 1 < C::TW / 4 ? row : row + 1, ncq = cq + 1 < C::TW / 4 ? cq + 1 : 0;
+          a_nxt = ap[nrow * C::TW + ncq * 4];
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) b_nxt[kh * 3 + kw] = bp[(nrow + kh) * C::PITCH + ncq * 4 + kw];
+          (void)apr; (void)bpr;
+          const int s = row * (C::TW / 4) + cq;
+          if (s < C::PIECES && more) commit_piece(s, buf ^ 1, nd0, nh0, nw0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur, b_cur[t], acc[t], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          a_cur = a_nxt;
+#pragma unroll
+          for (int t = 0; t < 9; ++t) b_cur[t] = b_nxt[t];
+        }
+      }
+      if (tile + 2 < tile_hi) {                          // the registers are free again: request tile + 2
+        decode(tile + 2, nd0, nh0, nw0);
+        prefetch(nd0, nh0, nw0);
+      }
+      __syncthreads();
+    }
+  }
+
+  float* sp = p.slab + (long long)blockIdx.x * p.Cout * p.Cin * 9;
+  const int c = cbase + cbl * 32 + ch * 16 + (lane & 15);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int o = ob * 32 + oh * 16 + (lane >> 4) * 4 + r;
+    if (o < p.Cout && c < p.Cin) {
+      float* dst = sp + ((long long)o * p.Cin + c) * 9;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) dst[t] = acc[t][r];
+    }
+  }
+}
+
 // ---- stride (2,2) in the plane ("convolutional pooling" convs), rows that are multiples of 4 floats ------------------
 // Same pipeline as v2.  Output tile 4 x 16; the 9 x 33 input patch it needs is staged per channel as rows of
 // [20 even columns | 20 odd columns] so that the B fragments (4 consecutive output pixels = input columns 2 apart)
@@ -680,6 +894,33 @@ inline int v2_ncb(int Cin, int Ho, int Wo) {      // 8x8 planes: the (4,8,8) til
   return (Cin > 32 && m > 8) ? 2 : 1;
 }
 
+// v3 (double-buffered 4 x 32 tiles): stride-1 planes at least 32 wide whose rows are multiples of 4 floats
+inline bool use_v3(int Cin, int Hi, int Wi, int sh, int sw) {
+  if (Cin <= 32) return false;
+  static const int off = getenv("E2E_WG_NOV3") ? atoi(getenv("E2E_WG_NOV3")) : 0;
+  return !off && sh == 1 && sw == 1 && (Wi % 4) == 0 && Wi >= 32 && Hi > 16;
+}
+// (one channel block needs 95 KB for the two images -> a single 4-wave workgroup per CU: v2 keeps those layers)
+inline int v3_ncb(int Cin) { return Cin > 32 ? 2 : 1; }
+// chunks never cross a batch item: `segs` runs of tiles_per_chunk tiles per item; returns the number of chunks
+inline int plan_v3(WgParams& p, int pairs) {
+  p.tiles_x = e2e::cdiv(p.Wo, 32);
+  p.tiles_y = e2e::cdiv(p.Ho, 4);
+  p.tiles_d = p.Do;
+  p.tiles_per_n = p.tiles_d * p.tiles_y * p.tiles_x;
+  p.total_tiles = (long long)p.tiles_per_n * p.B;
+  long long want = 512 / (pairs > 0 ? pairs : 1);           // workgroups per launch ~ 2 rounds over 256 CUs
+  if (want < p.B) want = p.B;
+  int segs = (int)(want / p.B);
+  int tpc = e2e::cdiv(p.tiles_per_n, segs);
+  if (tpc < 8) tpc = 8;
+  if (tpc > p.tiles_per_n) tpc = p.tiles_per_n;
+  segs = e2e::cdiv(p.tiles_per_n, tpc);
+  p.tiles_per_chunk = tpc;
+  p.cblocks_segs = segs;
+  return segs * p.B;
+}
+
 // stride-(2,2) pipelined kernel: needs 16-byte aligned input rows and output planes at least one tile wide
 inline bool use_s2(int Wi, int Wo, int sh, int sw) { return sh == 2 && sw == 2 && (Wi % 4) == 0 && (Wo % 4) == 0 && Wo >= 16; }
 inline int s2_chunks(long long total_tiles, int pairs, int* tpc_out) {
@@ -713,6 +954,8 @@ extern "C" long long e2e_conv133_wgrad_ws_bytes(int B, int Cin, int Cout, int Di
     p.tiles_per_n = p.tiles_d * p.tiles_y * p.tiles_x;
     p.total_tiles = (long long)p.tiles_per_n * B;
     nchunks = s2_chunks(p.total_tiles, pairs, &p.tiles_per_chunk);
+  } else if (use_v3(Cin, Hi, Wi, sh, sw)) {
+    nchunks = plan_v3(p, e2e::cdiv(Cin, 32 * v3_ncb(Cin)) * e2e::cdiv(Cout, 32));
   } else if (use_v2(Wi, sh, sw)) {
     const int pairs = e2e::cdiv(Cin, 32 * v2_ncb(Cin, p.Ho, p.Wo)) * e2e::cdiv(Cout, 32);
     plan(p, pick(p.Ho, p.Wo, false), pairs, &nchunks, 512);
@@ -748,6 +991,19 @@ extern "C" int e2e_conv133_wgrad(const e2e_in_chan_t* chans, const float* dy, fl
     nchunks = s2_chunks(p.total_tiles, pairs, &p.tiles_per_chunk);
     hipLaunchKernelGGL(conv133_wgrad_s2_kernel, dim3(nchunks, pairs), dim3(256), 0, st, p);
     rc = e2e::check_launch("conv133_wgrad_s2_kernel");
+    if (rc != E2E_OK) return rc;
+    hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)e2e::cdivll(numel, 64)), dim3(256), 0, st, p.slab, dw, numel,
+                       nchunks);
+    return e2e::check_launch("wgrad_slab_reduce_kernel");
+  }
+  if (use_v3(Cin, Hi, Wi, sh, sw)) {
+    const int ncb = v3_ncb(Cin);
+    p.cblocks = e2e::cdiv(Cin, 32 * ncb);
+    const int pairs = p.cblocks * e2e::cdiv(Cout, 32);
+    nchunks = plan_v3(p, pairs);
+    if (ncb == 2) hipLaunchKernelGGL((conv133_wgrad_v3_kernel<2>), dim3(nchunks, pairs), dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((conv133_wgrad_v3_kernel<1>), dim3(nchunks, pairs), dim3(256), 0, st, p);
+    rc = e2e::check_launch("conv133_wgrad_v3_kernel");
     if (rc != E2E_OK) return rc;
     hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)e2e::cdivll(numel, 64)), dim3(256), 0, st, p.slab, dw, numel,
                        nchunks);
