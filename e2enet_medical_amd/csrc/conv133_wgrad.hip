@@ -599,10 +599,12 @@ __global__ __launch_bounds__(256 * NCB) void conv133_wgrad_v3_kernel(WgParams p)
             for (int kw = 0; kw < 3; ++kw) b_nxt[kh * 3 + kw] = bp[(nrow + kh) * C::PITCH + ncq * 4 + kw];
           (void)apr; (void)bpr;
           const int s = row * (C::TW / 4) + cq;
-          if (s < C::PIECES && more) commit_piece(s, buf ^ 1, nd0, nh0, nw0);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur, b_cur[t], acc[t], 0, 0, 0);
+          for (int t = 0; t < 9; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur, b_cur[t], acc[t], 0, 0, 0);
+            if (t == 0 && s < C::PIECES && more) commit_piece(s, buf ^ 1, nd0, nh0, nw0);   // issues in the shadow of the MFMAs
+          }
           __builtin_amdgcn_sched_barrier(0);
           a_cur = a_nxt;
 #pragma unroll
@@ -896,7 +898,8 @@ inline int v2_ncb(int Cin, int Ho, int Wo) {      // 8x8 planes: the (4,8,8) til
 
 // v3 (double-buffered 4 x 32 tiles): stride-1 planes at least 32 wide whose rows are multiples of 4 floats
 inline bool use_v3(int Cin, int Hi, int Wi, int sh, int sw) {
-  if (Cin <= 32) return false;
+  static const int all = getenv("E2E_WG_V3ALL") ? atoi(getenv("E2E_WG_V3ALL")) : 0;
+  if (Cin <= 32 && !all) return false;
   static const int off = getenv("E2E_WG_NOV3") ? atoi(getenv("E2E_WG_NOV3")) : 0;
   return !off && sh == 1 && sw == 1 && (Wi % 4) == 0 && Wi >= 32 && Hi > 16;
 }

@@ -9,6 +9,7 @@
 // re-reads of z / dy are L2 hits) with the weights as wave-uniform scalars and the DSFF liveness bits walked
 // with scalar bit ops.  The dense weight gradient (huge reduction over voxels) runs on the fp32 MFMA.
 #include "e2e_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -473,6 +474,126 @@ __global__ __launch_bounds__(256) void convT_dgrad_v2_kernel(const float* __rest
   }
 }
 
+// ---- data gradient v3 (kw == 2): dense GEMM on the fp32 matrix cores ----------------------------------------------------
+// dx[c, v] = sum_{(t, o)} W[c, o, t] * dy[o, out(v, t)]:  M = 64 input channels per workgroup (16 per wave), N = 32
+// consecutive input voxels per tile, K = 32 output channels x KT taps per chunk.  At DSFF density 0.2 the dense GEMM does
+// 5x the useful FLOPs, but the sparse walk of v2 issues one scalar weight load and KT dependent LDS reads per live (c, o)
+// pair with two waves per SIMD -- latency bound at ~4x the HBM time of this op -- while the matrix pipe runs the dense
+// product in less time than that (dead kernels are exact zeros in W, so the result is the same sum).
+//   * a wave keeps its 16 x K slice of W in registers (K/4 A fragments) for the whole run of tiles;
+//   * the dy tile [K][32 voxels] is staged through LDS (row stride 48: the two k-rows of a 32-lane read group land on
+//     disjoint banks), software pipelined: the float4 loads of the next tile are issued before the MFMA phase.
+template <int KDH>
+__global__ __launch_bounds__(256) void convT_dgrad_v3_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                             float* __restrict__ dx, int accumulate, int B, int Cin, int Cout,
+                                                             int D, int H, int W, int kd, int kh, int tiles_per_wg) {
+  constexpr int KT = 2 * KDH;
+  constexpr int OC = 32, TV = 32, TS = 48;
+  constexpr int K = OC * KT, KS = K / 4;               // k-steps per chunk
+  constexpr int NUY = OC * KDH * (TV / 2) / 256;       // float4 loads per thread per tile
+  __shared__ __attribute__((aligned(16))) float ds[K * TS];
+
+  const long long spatial = (long long)D * H * W;
+  const long long tiles_per_n = e2e::cdivll(spatial, TV);
+  const long long total_tiles = tiles_per_n * B;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  const int Ho = H * kh, Wo = W * 2;
+  const long long ospatial = spatial * KT;
+  const int cbase = blockIdx.y * 64 + wave * 16;
+  const long long tile_lo = (long long)blockIdx.x * tiles_per_wg;
+  long long tile_hi = tile_lo + tiles_per_wg;
+  if (tile_hi > total_tiles) tile_hi = total_tiles;
+  if (tile_lo >= tile_hi) return;
+
+  f32x4_t v[NUY];
+  auto prefetch = [&](long long tile, int o0) {
+    const int n = (int)(tile / tiles_per_n);
+    const long long vbase = (tile - (long long)n * tiles_per_n) * TV;
+#pragma unroll
+    for (int i = 0; i < NUY; ++i) {
+      const int u = tid + i * 256;                       // unit = (o, output row rr, voxel pair vp)
+      const int ol = u / (KDH * (TV / 2));
+      const int rem = u - ol * (KDH * (TV / 2));
+      const int rr = rem / (TV / 2), vp = rem - rr * (TV / 2);
+      const long long vi = vbase + 2 * vp;
+      const int o = o0 + ol;
+      const bool ok = o < Cout && vi + 1 < spatial;
+      long long off = 0;
+      if (ok) {
+        const int wv = (int)(vi % W);
+        const long long r = vi / W;
+        const int hv = (int)(r % H), dv = (int)(r / H);
+        const int ii = rr / kh, jj = rr - ii * kh;
+        off = ((long long)n * Cout + o) * ospatial + ((long long)(dv * kd + ii) * Ho + (hv * kh + jj)) * Wo + 2 * wv;
+      }
+      v[i] = *reinterpret_cast<gf4_p>((gfloat_p)dy + off);
+    }
+  };
+  auto commit = [&](long long tile, int o0) {
+    const int n = (int)(tile / tiles_per_n);
+    const long long vbase = (tile - (long long)n * tiles_per_n) * TV;
+#pragma unroll
+    for (int i = 0; i < NUY; ++i) {
+      const int u = tid + i * 256;
+      const int ol = u / (KDH * (TV / 2));
+      const int rem = u - ol * (KDH * (TV / 2));
+      const int rr = rem / (TV / 2), vp = rem - rr * (TV / 2);
+      const bool ok = o0 + ol < Cout && vbase + 2 * vp + 1 < spatial;
+      float2* d0 = reinterpret_cast<float2*>(ds + ((rr * 2 + 0) * OC + ol) * TS + 2 * vp);
+      float2* d1 = reinterpret_cast<float2*>(ds + ((rr * 2 + 1) * OC + ol) * TS + 2 * vp);
+      *d0 = ok ? make_float2(v[i][0], v[i][2]) : make_float2(0.f, 0.f);
+      *d1 = ok ? make_float2(v[i][1], v[i][3]) : make_float2(0.f, 0.f);
+    }
+  };
+
+  for (int o0 = 0; o0 < Cout; o0 += OC) {
+    // A fragments of this wave: row c = cbase + li, k = 4 s + lk = t * 32 + ol
+    float afrag[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int k = 4 * s + lk;
+      const int t = k / OC, ol = k - t * OC;
+      const int c = cbase + li, o = o0 + ol;
+      afrag[s] = (c < Cin && o < Cout) ? w[((long long)c * Cout + o) * KT + t] : 0.f;
+    }
+    prefetch(tile_lo, o0);
+    for (long long tile = tile_lo; tile < tile_hi; ++tile) {
+      commit(tile, o0);
+      __syncthreads();
+      if (tile + 1 < tile_hi) prefetch(tile + 1, o0);    // in flight during the MFMA phase
+      f32x4 acc[TV / 16];
+#pragma unroll
+      for (int b = 0; b < TV / 16; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* bp = ds + lk * TS + li;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+#pragma unroll
+        for (int b = 0; b < TV / 16; ++b)
+          acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[s], bp[4 * s * TS + b * 16], acc[b], 0, 0, 0);
+      }
+      // D[i = c][j = v]: col = lane & 15 -> v, row = (lane >> 4) * 4 + reg -> c
+      const int n = (int)(tile / tiles_per_n);
+      const long long vbase = (tile - (long long)n * tiles_per_n) * TV;
+#pragma unroll
+      for (int b = 0; b < TV / 16; ++b) {
+        const long long vi = vbase + b * 16 + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = cbase + lk * 4 + r;
+          if (c < Cin && vi < spatial) {
+            float* dst = dx + ((long long)n * Cin + c) * spatial + vi;
+            if (accumulate || o0 > 0) *dst += acc[b][r];
+            else *dst = acc[b][r];
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
                                                           long long numel, int nchunks) {
   // out[e] = sum_k slab[k][e]: 4 waves x 4 independent running sums per element, combined in a fixed order
@@ -551,6 +672,22 @@ extern "C" int e2e_convT_dgrad(const float* dy, const float* w, const unsigned* 
   E2E_REQUIRE(check_k(kd, kh, kw), "convT_dgrad: kernel must be in {1,2}^3");
   hipStream_t st = (hipStream_t)stream;
   const long long spatial = (long long)D * H * W;
+  // v3 (dense GEMM on the matrix cores) for the large planes
+  static const int no_v3 = getenv("E2E_CT_NOV3") ? atoi(getenv("E2E_CT_NOV3")) : 0;
+  if (!no_v3 && kw == 2 && (kd * kh == 2 || kd * kh == 4) && (W % 2) == 0 && spatial % 4 == 0 && e2e::cdivll(spatial, 32) * B >= 2048) {
+    const long long total_tiles = e2e::cdivll(spatial, 32) * B;
+    const int cgroups = e2e::cdiv(Cin, 64);
+    long long wgs = 768 / cgroups;                       // ~3 workgroups per CU
+    if (wgs < 1) wgs = 1;
+    int tpw = (int)e2e::cdivll(total_tiles, wgs);
+    if (tpw < 4) tpw = 4;
+    dim3 grid((unsigned)e2e::cdivll(total_tiles, tpw), cgroups);
+    if (kd * kh == 4)
+      hipLaunchKernelGGL((convT_dgrad_v3_kernel<4>), grid, dim3(256), 0, st, dy, w, dx, accumulate, B, Cin, Cout, D, H, W, kd, kh, tpw);
+    else
+      hipLaunchKernelGGL((convT_dgrad_v3_kernel<2>), grid, dim3(256), 0, st, dy, w, dx, accumulate, B, Cin, Cout, D, H, W, kd, kh, tpw);
+    return e2e::check_launch("convT_dgrad_v3_kernel");
+  }
   // v2 needs enough 64-voxel tiles to fill the chip (one workgroup per tile); small planes keep the gather kernel
   if (kw == 2 && (kd * kh == 2 || kd * kh == 4) && (W % 2) == 0 && spatial % 4 == 0 && e2e::cdivll(spatial, 64) * B >= 1024) {
     const unsigned tiles = (unsigned)(e2e::cdivll(spatial, 64) * B);
