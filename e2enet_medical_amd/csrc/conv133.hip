@@ -15,11 +15,19 @@
 //     epilogue (dgrad): un-shift on store into the per-channel destination (scatter back through the concat).
 #include "e2e_common.h"
 #include <cstdlib>
+#include <cstdio>
 
 // phase-split diagnostics (tools/kbench.py): build with -DE2E_CONV_DEBUG, then E2E_CONV_DBG=1|2|4 at run time
 #ifdef E2E_CONV_DEBUG
 #define CDBG(bit) ((p.dbg & (bit)) != 0)
+// in-kernel phase stamps (s_memtime), summed over waves: [0] prologue [1] commit [2] barrier 1 [3] prefetch issue
+// [4] live-kernel walk [5] barrier 2 [6] epilogue [7] waves; E2E_CONV_DBG=8 prints the per-wave averages after each launch
+__device__ unsigned long long g_conv_stamps[1024 * 8];
+#define STAMP(var) const unsigned long long var = __builtin_readcyclecounter()
+#define STAMP_ADD(i, a, b) st_acc[i] += (b) - (a)
 #else
+#define STAMP(var)
+#define STAMP_ADD(i, a, b)
 #define CDBG(bit) false
 #endif
 
@@ -150,6 +158,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
   int tab_n = -1, tab_d = -1;
 
   auto run_item = [&](const int item) {
+#ifdef E2E_CONV_DEBUG
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  STAMP(t_begin);
   const int g = item % p.groups;
   int t = item / p.groups;
   const int n = t / p.tiles_per_n;
@@ -414,6 +426,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
   };
 
   unsigned long long m_cur = 0;
+  STAMP(t_pro);
+  STAMP_ADD(0, t_begin, t_pro);
   if (nchunks > 0) {
     if (n != tab_n || d != tab_d) {
       for (int pl = tid; pl < p.P; pl += C::NT) tab[pl] = make_desc(pl);
@@ -426,9 +440,13 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
   for (int ci = 0; ci < nchunks; ++ci) {
     const int c0 = ci * CK;
     const unsigned long long m_next = ci + 1 < nchunks ? chunk_mask(c0 + CK) : 0ull;   // scalar loads, in flight during commit
+    STAMP(t0);
     if (!CDBG(1)) commit(c0);
+    STAMP(t1);
     if (!CDBG(4)) __syncthreads();
+    STAMP(t2);
     if (ci + 1 < nchunks && !CDBG(1)) prefetch(c0 + CK);   // in flight while this chunk is computed
+    STAMP(t3);
 
     // walk the chunk's live input planes (nibbles of the quad mask); the neighbourhood rows of a plane are read once
     // and shared by the 1..4 output planes of this wave that consume it
@@ -449,12 +467,19 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
       }
     }
     m_cur = m_next;
+    STAMP(t4);
     if (!CDBG(4)) __syncthreads();
+    STAMP(t5);
+    STAMP_ADD(1, t0, t1); STAMP_ADD(2, t1, t2); STAMP_ADD(3, t2, t3); STAMP_ADD(4, t3, t4); STAMP_ADD(5, t4, t5);
   }
+  STAMP(t_epi);
 
   // ---------------- epilogue ------------------------------------------------------------------------------
   const int oh0 = h0 + ly * C::PH, ow0 = w0 + lx * C::PW;
   const long long out_plane = (long long)p.Ho * p.Wo;
+  float psum[OPW];                                      // fwd: per-lane sums of the stored values
+#pragma unroll
+  for (int a = 0; a < OPW; ++a) psum[a] = 0.f;
 #pragma unroll
   for (int a = 0; a < OPW; ++a) {
     const int q = qbase + a;
@@ -463,7 +488,6 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
       const float bq = p.bias ? p.bias[q] : 0.f;
       float* yp = p.y + (((long long)n * p.Q + q) * p.Do + d) * out_plane;
       float s = 0.f;
-      int cnt = 0;
       const bool vec_store = (C::PW == 4) && (p.Wo % 4 == 0);      // lane rows are 16-byte aligned
 #pragma unroll
       for (int i = 0; i < C::PH; ++i) {
@@ -476,36 +500,13 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
           if (oh < p.Ho && ow < p.Wo) {
             if (!vec_store) yp[(long long)oh * p.Wo + ow] = val;
             s += val;
-            ++cnt;
           }
         }
         if (vec_store && oh < p.Ho && ow0 < p.Wo)
           *reinterpret_cast<float4*>(yp + (long long)oh * p.Wo + ow0) =
               make_float4(acc[a][i][0], acc[a][i][1 % C::PW], acc[a][i][2 % C::PW], acc[a][i][3 % C::PW]);
       }
-      if (p.part != nullptr) {
-        const float tot = e2e::wave_sum(s);
-        const float tcnt = e2e::wave_sum((float)cnt);
-        const float mean = tot / tcnt;
-        float m2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < C::PH; ++i)
-#pragma unroll
-          for (int j = 0; j < C::PW; ++j) {
-            const int oh = oh0 + i, ow = ow0 + j;
-            if (oh < p.Ho && ow < p.Wo) {
-              const float dlt = acc[a][i][j] - mean;
-              m2 = fmaf(dlt, dlt, m2);
-            }
-          }
-        m2 = e2e::wave_sum(m2);
-        if (lane == 0) {
-          float* pp = p.part + (((long long)n * p.Q + q) * p.tiles_per_n + tile_in_n) * 3;
-          pp[0] = tcnt;
-          pp[1] = mean;
-          pp[2] = m2;
-        }
-      }
+      psum[a] = s;
     } else {
       // dgrad: gradient of virtual-concat channel q at (shifted) depth d goes to depth d - s(q) of its source
       const e2e_out_chan_t oc = p.outs[q];
@@ -550,6 +551,49 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
       }
     }
   }
+  if (MODE == 0 && p.part != nullptr) {
+    // per-tile (count, mean, M2) partials of the 4 output planes: the count is known from the tile geometry, the four
+    // sums (and then the four M2) are reduced side by side so their cross-lane steps overlap
+    const int vr = p.Ho - h0 < TH ? p.Ho - h0 : TH, vc = p.Wo - w0 < TW ? p.Wo - w0 : TW;
+    const float tcnt = (float)(vr * vc);
+    float mean[OPW], m2[OPW];
+#pragma unroll
+    for (int a = 0; a < OPW; ++a) mean[a] = e2e::wave_sum_dpp(psum[a]) / tcnt;
+#pragma unroll
+    for (int a = 0; a < OPW; ++a) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < C::PH; ++i)
+#pragma unroll
+        for (int j = 0; j < C::PW; ++j) {
+          const int oh = oh0 + i, ow = ow0 + j;
+          if (oh < p.Ho && ow < p.Wo) {
+            const float dlt = acc[a][i][j] - mean[a];
+            t = fmaf(dlt, dlt, t);
+          }
+        }
+      m2[a] = t;
+    }
+#pragma unroll
+    for (int a = 0; a < OPW; ++a) m2[a] = e2e::wave_sum_dpp(m2[a]);
+    if (lane < OPW && qbase + lane < p.Q) {
+      float mm = mean[0], vv = m2[0];
+#pragma unroll
+      for (int a = 1; a < OPW; ++a)
+        if (lane == a) { mm = mean[a]; vv = m2[a]; }
+      float* pp = p.part + (((long long)n * p.Q + qbase + lane) * p.tiles_per_n + tile_in_n) * 3;
+      pp[0] = tcnt;
+      pp[1] = mm;
+      pp[2] = vv;
+    }
+  }
+  STAMP(t_end);
+  STAMP_ADD(6, t_epi, t_end);
+  STAMP_ADD(7, t_end - 1, t_end);
+#ifdef E2E_CONV_DEBUG
+  if (lane == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_conv_stamps[(blockIdx.x & 1023) * 8 + i], st_acc[i]);
+#endif
   };   // run_item
   if (PERSIST) {
     for (int item = item_lo; item < item_hi; ++item) run_item(item);
@@ -633,6 +677,20 @@ int launch_cfg_impl(ConvParams p, hipStream_t st) {
   wgs = (e2e::cdiv(p.total, p.items_per_wg) + 7) & ~7;
   hipLaunchKernelGGL((conv133_kernel<MODE, SH, SW, DH, DW, TH, TW, LY, LX, OPW, NW, CK, STG, MINW, PIPE, PERSIST>), dim3(wgs),
                      dim3(C::NT), (size_t)p.P * sizeof(PlaneDesc), st, p);
+#ifdef E2E_CONV_DEBUG
+  if (p.dbg & 8) {
+    hipStreamSynchronize(st);
+    static unsigned long long hh[1024 * 8];
+    hipMemcpyFromSymbol(hh, HIP_SYMBOL(g_conv_stamps), sizeof(hh));
+    unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 1024 * 8; ++i) h[i & 7] += hh[i];
+    const double w = h[7] ? (double)h[7] : 1.0;
+    fprintf(stderr, "[conv133 MODE %d P %d Q %d] per-wave cycles(100MHz ticks): pro %.0f commit %.0f bar1 %.0f prefetch %.0f walk %.0f bar2 %.0f epi %.0f (waves %.0f)\n",
+            MODE, p.P, p.Q, h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[6] / w, w);
+    static unsigned long long zz[1024 * 8];
+    hipMemcpyToSymbol(HIP_SYMBOL(g_conv_stamps), zz, sizeof(zz));
+  }
+#endif
   return e2e::check_launch("conv133_kernel");
 }
 

@@ -37,6 +37,19 @@ __device__ __forceinline__ float in_act(float v, float a, float b, float slope) 
   return u > 0.f ? u : u * slope;
 }
 
+// full-wave (64 lane) sum, result valid in every lane; the first four steps are DPP moves inside the vector ALU
+// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror), only the last two cross the 16-lane rows
+// through ds_bpermute.  Six dependent ds_bpermute round trips cost several hundred cycles each under LDS load.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
 // full-wave (64 lane) sum, result valid in every lane
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
