@@ -779,6 +779,7 @@ extern "C" int e2e_conv133_fwd(const e2e_in_chan_t* chans, int Cin, const float*
   if (sh == 1 && sw == 1) return launch_s1<0, 1, 1>(p, k == T32 ? 0 : (k == T16 ? 1 : 2), st);
   // strided variants ("convolutional pooling", 5 layers): element staging with register prefetch
   if (sh == 2 && sw == 2) {
+    if (k == T16x32S && (Wi % 4) == 0) return launch_cfg<0, 2, 2, 1, 1, 16, 32, 4, 16, 4, 8, 8, 1>(p, st);   // float4 staging
     if (k == T16x32S) return launch_cfg<0, 2, 2, 1, 1, 16, 32, 4, 16, 4, 8, 8, 0>(p, st);
     return launch_cfg<0, 2, 2, 1, 1, 8, 8, 8, 8, 4, 8, 16, 0>(p, st);
   }
