@@ -233,6 +233,137 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
   }
 }
 
+// ---- float4 variants (spatial % 4 == 0): one thread = 4 consecutive voxels --------------------------------------------
+template <int KB>
+__global__ __launch_bounds__(256) void head_fwd_v4_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, float slope,
+                                                          const float* __restrict__ w, float* __restrict__ logits, int C,
+                                                          int K, long long spatial) {
+  const int n = blockIdx.y;
+  const long long v = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (v >= spatial) return;
+  for (int k0 = 0; k0 < K; k0 += KB) {
+    float acc[KB][4];
+#pragma unroll
+    for (int k = 0; k < KB; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[k][j] = 0.f;
+    for (int c = 0; c < C; ++c) {
+      float a = 1.f, b = 0.f, sl = 1.f;
+      if (scale) { a = scale[(long long)n * C + c]; b = shift[(long long)n * C + c]; sl = slope; }
+      const float4 q = *reinterpret_cast<const float4*>(x + ((long long)n * C + c) * spatial + v);
+      const float z[4] = {e2e::in_act(q.x, a, b, sl), e2e::in_act(q.y, a, b, sl), e2e::in_act(q.z, a, b, sl),
+                          e2e::in_act(q.w, a, b, sl)};
+#pragma unroll
+      for (int k = 0; k < KB; ++k)
+        if (k0 + k < K) {
+          const float wk = w[(long long)(k0 + k) * C + c];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[k][j] = fmaf(wk, z[j], acc[k][j]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KB; ++k)
+      if (k0 + k < K)
+        *reinterpret_cast<float4*>(logits + ((long long)n * K + k0 + k) * spatial + v) =
+            make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
+  }
+}
+
+template <int KB>
+__global__ __launch_bounds__(256) void head_dgrad_v4_kernel(const float* __restrict__ dl, const float* __restrict__ w,
+                                                            float* __restrict__ dx, int accumulate, int C, int K,
+                                                            long long spatial) {
+  const int n = blockIdx.y;
+  const long long v = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (v >= spatial) return;
+  for (int k0 = 0; k0 < K; k0 += KB) {
+    float g[KB][4];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k0 + k < K) q = *reinterpret_cast<const float4*>(dl + ((long long)n * K + k0 + k) * spatial + v);
+      g[k][0] = q.x; g[k][1] = q.y; g[k][2] = q.z; g[k][3] = q.w;
+    }
+    for (int c = 0; c < C; ++c) {
+      float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < KB; ++k)
+        if (k0 + k < K) {
+          const float wk = w[(long long)(k0 + k) * C + c];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) s[j] = fmaf(wk, g[k][j], s[j]);
+        }
+      float4* dst = reinterpret_cast<float4*>(dx + ((long long)n * C + c) * spatial + v);
+      float4 o = make_float4(s[0], s[1], s[2], s[3]);
+      if (accumulate || k0 > 0) { const float4 t = *dst; o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+      *dst = o;
+    }
+  }
+}
+
+// dW[k,c]: block = (voxel chunk, group of CG channels): dlogits are re-read C / CG times instead of C times
+template <int KB, int CG>
+__global__ __launch_bounds__(256) void head_wgrad_v4_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, float slope,
+                                                            const float* __restrict__ dl, double* __restrict__ acc_out,
+                                                            int C, int K, long long spatial, int B) {
+  const int c0 = blockIdx.y * CG;
+  __shared__ double sh[4][CG * KB];
+  for (int k0 = 0; k0 < K; k0 += KB) {
+    float acc[CG][KB];
+#pragma unroll
+    for (int i = 0; i < CG; ++i)
+#pragma unroll
+      for (int k = 0; k < KB; ++k) acc[i][k] = 0.f;
+    for (int n = 0; n < B; ++n) {
+      float a[CG], b[CG], sl[CG];
+#pragma unroll
+      for (int i = 0; i < CG; ++i) {
+        a[i] = 1.f; b[i] = 0.f; sl[i] = 1.f;
+        if (scale && c0 + i < C) { a[i] = scale[(long long)n * C + c0 + i]; b[i] = shift[(long long)n * C + c0 + i]; sl[i] = slope; }
+      }
+      for (long long v = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; v < spatial; v += (long long)gridDim.x * 1024) {
+        float g[KB][4];
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+          float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (k0 + k < K) q = *reinterpret_cast<const float4*>(dl + ((long long)n * K + k0 + k) * spatial + v);
+          g[k][0] = q.x; g[k][1] = q.y; g[k][2] = q.z; g[k][3] = q.w;
+        }
+#pragma unroll
+        for (int i = 0; i < CG; ++i) {
+          if (c0 + i >= C) continue;
+          const float4 q = *reinterpret_cast<const float4*>(x + ((long long)n * C + c0 + i) * spatial + v);
+          const float z[4] = {e2e::in_act(q.x, a[i], b[i], sl[i]), e2e::in_act(q.y, a[i], b[i], sl[i]),
+                              e2e::in_act(q.z, a[i], b[i], sl[i]), e2e::in_act(q.w, a[i], b[i], sl[i])};
+#pragma unroll
+          for (int k = 0; k < KB; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][k] = fmaf(g[k][j], z[j], acc[i][k]);
+        }
+      }
+    }
+    // (a thread accumulates a few hundred products in fp32; everything across threads is summed in fp64)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < CG; ++i)
+#pragma unroll
+      for (int k = 0; k < KB; ++k) {
+        const double t = e2e::wave_sum_d((double)acc[i][k]);
+        if (lane == 0) sh[wave][i * KB + k] = t;
+      }
+    __syncthreads();
+    if (threadIdx.x < CG * KB) {
+      const int i = threadIdx.x / KB, k = threadIdx.x - i * KB;
+      if (c0 + i < C && k0 + k < K)
+        atomicAdd(&acc_out[(long long)(k0 + k) * C + c0 + i],
+                  sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    }
+    __syncthreads();
+  }
+}
+
 __global__ void d2f_kernel(const double* __restrict__ src, float* __restrict__ dst, long long n) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = (float)src[i];
@@ -291,6 +422,12 @@ extern "C" int e2e_head1x1_fwd(const float* x, const float* scale, const float* 
                                float* logits, int B, int C, int K, long long spatial, void* stream) {
   E2E_REQUIRE(x && w && logits, "head1x1_fwd: null pointer");
   E2E_REQUIRE(B > 0 && C > 0 && K > 0 && spatial > 0, "head1x1_fwd: bad dims");
+  if (spatial % 4 == 0) {
+    dim3 grid4((unsigned)e2e::cdivll(spatial, 1024), B);
+    DISPATCH_KB(K, hipLaunchKernelGGL((head_fwd_v4_kernel<KB>), grid4, dim3(256), 0, (hipStream_t)stream, x, scale, shift, slope, w,
+                                      logits, C, K, spatial));
+    return e2e::check_launch("head_fwd_v4_kernel");
+  }
   dim3 grid((unsigned)e2e::cdivll(spatial, 256), B);
   DISPATCH_KB(K, hipLaunchKernelGGL((head_fwd_kernel<KB>), grid, dim3(256), 0, (hipStream_t)stream, x, scale, shift, slope, w,
                                     logits, C, K, spatial));
@@ -300,6 +437,12 @@ extern "C" int e2e_head1x1_fwd(const float* x, const float* scale, const float* 
 extern "C" int e2e_head1x1_dgrad(const float* dlogits, const float* w, float* dx, int accumulate, int B, int C, int K,
                                  long long spatial, void* stream) {
   E2E_REQUIRE(dlogits && w && dx, "head1x1_dgrad: null pointer");
+  if (spatial % 4 == 0) {
+    dim3 grid4((unsigned)e2e::cdivll(spatial, 1024), B);
+    DISPATCH_KB(K, hipLaunchKernelGGL((head_dgrad_v4_kernel<KB>), grid4, dim3(256), 0, (hipStream_t)stream, dlogits, w, dx,
+                                      accumulate, C, K, spatial));
+    return e2e::check_launch("head_dgrad_v4_kernel");
+  }
   dim3 grid((unsigned)e2e::cdivll(spatial, 256), B);
   DISPATCH_KB(K, hipLaunchKernelGGL((head_dgrad_kernel<KB>), grid, dim3(256), 0, (hipStream_t)stream, dlogits, w, dx,
                                     accumulate, C, K, spatial));
@@ -324,9 +467,18 @@ extern "C" int e2e_head1x1_wgrad(const float* x, const float* scale, const float
   long long blocks = e2e::cdivll(spatial, 256 * 16);
   if (blocks > 128) blocks = 128;
   if (blocks < 1) blocks = 1;
+  if (spatial % 4 == 0 && K <= 16) {
+    long long b4 = e2e::cdivll(spatial, 1024 * 8);
+    if (b4 > 256) b4 = 256;
+    if (b4 < 1) b4 = 1;
+    dim3 grid4((unsigned)b4, e2e::cdiv(C, 8));
+    if (K <= 4) hipLaunchKernelGGL((head_wgrad_v4_kernel<4, 8>), grid4, dim3(256), 0, st, x, scale, shift, slope, dlogits, acc, C, K, spatial, B);
+    else hipLaunchKernelGGL((head_wgrad_v4_kernel<8, 8>), grid4, dim3(256), 0, st, x, scale, shift, slope, dlogits, acc, C, K, spatial, B);
+  } else {
   dim3 grid((unsigned)blocks, C);
   DISPATCH_KB(K, hipLaunchKernelGGL((head_wgrad_kernel<KB>), grid, dim3(256), 0, st, x, scale, shift, slope, dlogits, acc, C, K,
                                     spatial, B));
+  }
   hipLaunchKernelGGL(d2f_kernel, dim3((unsigned)e2e::cdivll((long long)C * K, 256)), dim3(256), 0, st, acc, dw, (long long)C * K);
   return e2e::check_launch("head1x1_wgrad");
 }
