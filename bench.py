@@ -90,7 +90,7 @@ class KernelTimer:
         return sum(e0.elapsed_time(e1) for e0, e1, _ in self.events)
 
 
-TRAFFIC_FILE = "r01d_pmc_traffic.json"
+TRAFFIC_FILE = "r01e_pmc_traffic.json"
 
 
 def pmc_traffic(prefix):
@@ -274,7 +274,7 @@ def main():
             ms = wt.total_ms()
             flops = sum(wgrad_flops(a) for _, _, a in wt.events)
             achieved = flops / (ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "conv133_wgrad_v2_kernel (+ strided v1 + slab reduce)",
+            out["roofline"] = {"bound": "mfma", "kernel": "conv133_wgrad_v3/v2/s2_kernel (+ slab reduce): every launch of e2e_conv133_wgrad",
                                "achieved": achieved, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                "frac": achieved / MFMA_F32_PEAK_TF, "traffic": pmc_traffic("conv133_wgrad"),
                                "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" % TRAFFIC_FILE,
