@@ -424,8 +424,9 @@ __global__ __launch_bounds__(256 * NCB) void conv133_wgrad_v2_kernel(WgParams p)
 // registers holding tile t+1 are committed to the other image piece by piece between the k-steps, the loads of tile
 // t+2 are issued when that is done, and one barrier per tile publishes the new image.  A chunk never crosses a batch
 // item, so the channel descriptors are loaded once per workgroup.
-template <int NCB>
+template <int NCB, int NOB>
 struct W3Cfg {
+  static_assert(NCB * NOB == 2, "8 waves: 2 x 2 sub-blocks of 16 x 16 for each of the two 32 x 32 blocks");
   static constexpr int TH = 4, TW = 32, TP = TH * TW;
   static constexpr int IH = TH + 2;
   static constexpr int NQ = TW / 4 + 2;                       // float4 groups per input row (starts 4 left of the tile)
@@ -434,21 +435,21 @@ struct W3Cfg {
   static constexpr int CS = IH * PITCH + 2;                   // 242 = 2 x odd: 16 channels x 2 k-lanes hit 32 distinct banks
   static constexpr int OS = TP + 2;                           // 130 = 2 x odd
   static_assert((CS / 2) % 2 == 1 && (OS / 2) % 2 == 1, "channel strides must be 2 x odd");
-  static constexpr int NT = 256 * NCB;
+  static constexpr int NT = 512;
   static constexpr int GPC = IH * NQ;                         // 60 groups per input channel: one wave-instruction
   static_assert(GPC <= 64, "one float4 group per lane and channel");
-  static constexpr int XCW = 8;                               // input channels staged per wave
-  static constexpr int YIT = 32 * (TP / 4) / NT;              // dy float4 groups per thread
-  static constexpr int YCW = 32 / (4 * NCB);                  // dy channels staged per wave
-  static constexpr int XBUF = NCB * 32 * CS, YBUF = 32 * OS;
+  static constexpr int XCW = NCB * 32 / 8;                    // input channels staged per wave
+  static constexpr int YIT = NOB * 32 * (TP / 4) / NT;        // dy float4 groups per thread
+  static constexpr int YCW = NOB * 32 / 8;                    // dy channels staged per wave
+  static constexpr int XBUF = NCB * 32 * CS, YBUF = NOB * 32 * OS;
   static constexpr int LDS_FLOATS = 2 * (XBUF + YBUF);
   static constexpr int PIECES = XCW + YIT;
   static_assert(PIECES <= TH * TW / 4, "one commit piece per k-step");
 };
 
-template <int NCB>
-__global__ __launch_bounds__(256 * NCB) void conv133_wgrad_v3_kernel(WgParams p) {
-  using C = W3Cfg<NCB>;
+template <int NCB, int NOB>
+__global__ __launch_bounds__(512) void conv133_wgrad_v3_kernel(WgParams p) {
+  using C = W3Cfg<NCB, NOB>;
   __shared__ __attribute__((aligned(16))) float lds3[C::LDS_FLOATS + 8];     // + slack for the read-ahead after the last k-step
   float* const xs0 = lds3;
   float* const ys0 = lds3 + 2 * C::XBUF;
@@ -460,7 +461,8 @@ __global__ __launch_bounds__(256 * NCB) void conv133_wgrad_v3_kernel(WgParams p)
   const int cg = blockIdx.y % cgroups, ob = blockIdx.y / cgroups;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cbl = wave >> 2, ch = wave & 1, oh = (wave >> 1) & 1;
+  const int cbl = NCB == 2 ? wave >> 2 : 0, obl = NOB == 2 ? wave >> 2 : 0, ch = wave & 1, oh = (wave >> 1) & 1;
+  const int obase = ob * NOB * 32;
   const long long in_plane = (long long)p.Hi * p.Wi;
   const long long out_plane = (long long)p.Ho * p.Wo;
   const int cbase = cg * NCB * 32;
@@ -524,7 +526,7 @@ __global__ __launch_bounds__(256 * NCB) void conv133_wgrad_v3_kernel(WgParams p)
     const bool yok = ho < p.Ho && wo + 3 < p.Wo;
 #pragma unroll
     for (int it = 0; it < C::YIT; ++it) {
-      const int o = ob * 32 + wave * C::YCW + y_kl + 2 * it;
+      const int o = obase + wave * C::YCW + y_kl + 2 * it;
       const bool ok = yok && o < p.Cout;
       const long long off = ok ? (((long long)n * p.Cout + o) * p.Do + d0) * out_plane + (long long)ho * p.Wo + wo : 0;
       vy[it] = *reinterpret_cast<gf4_p>((gfloat_p)p.dy + off);
@@ -551,7 +553,7 @@ __global__ __launch_bounds__(256 * NCB) void conv133_wgrad_v3_kernel(WgParams p)
       const int it = s - C::XCW;
       const int ho = h0 + y_r, wo = w0 + y_col;
       const int ol = wave * C::YCW + y_kl + 2 * it;
-      const bool ok = ho < p.Ho && wo + 3 < p.Wo && ob * 32 + ol < p.Cout;
+      const bool ok = ho < p.Ho && wo + 3 < p.Wo && obase + ol < p.Cout;
       float2* dst = reinterpret_cast<float2*>(ys0 + buf * C::YBUF + ol * C::OS + y_grp * 4);
       dst[0] = ok ? make_float2(vy[it][0], vy[it][1]) : make_float2(0.f, 0.f);
       dst[1] = ok ? make_float2(vy[it][2], vy[it][3]) : make_float2(0.f, 0.f);
@@ -575,7 +577,7 @@ __global__ __launch_bounds__(256 * NCB) void conv133_wgrad_v3_kernel(WgParams p)
     for (int tile = tile_lo; tile < tile_hi; ++tile) {
       const int buf = (tile - tile_lo) & 1;
       const bool more = tile + 1 < tile_hi;             // registers hold tile + 1 -> goes to image buf ^ 1 during this phase
-      const float* ap = ys0 + buf * C::YBUF + (oh * 16 + li) * C::OS + lk;
+      const float* ap = ys0 + buf * C::YBUF + (obl * 32 + oh * 16 + li) * C::OS + lk;
       const float* bp = xs0 + buf * C::XBUF + (cbl * 32 + ch * 16 + li) * C::CS + lk + C::COL0;
       float a_cur = ap[0];
       float b_cur[9];
@@ -623,7 +625,7 @@ __global__ __launch_bounds__(256 * NCB) void conv133_wgrad_v3_kernel(WgParams p)
   const int c = cbase + cbl * 32 + ch * 16 + (lane & 15);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int o = ob * 32 + oh * 16 + (lane >> 4) * 4 + r;
+    const int o = obase + obl * 32 + oh * 16 + (lane >> 4) * 4 + r;
     if (o < p.Cout && c < p.Cin) {
       float* dst = sp + ((long long)o * p.Cin + c) * 9;
 #pragma unroll
@@ -898,13 +900,21 @@ inline int v2_ncb(int Cin, int Ho, int Wo) {      // 8x8 planes: the (4,8,8) til
 
 // v3 (double-buffered 4 x 32 tiles): stride-1 planes at least 32 wide whose rows are multiples of 4 floats
 inline bool use_v3(int Cin, int Hi, int Wi, int sh, int sw) {
-  static const int all = getenv("E2E_WG_V3ALL") ? atoi(getenv("E2E_WG_V3ALL")) : 0;
-  if (Cin <= 32 && !all) return false;
+  if (Cin <= 32) return false;
   static const int off = getenv("E2E_WG_NOV3") ? atoi(getenv("E2E_WG_NOV3")) : 0;
   return !off && sh == 1 && sw == 1 && (Wi % 4) == 0 && Wi >= 32 && Hi > 16;
 }
 // (one channel block needs 95 KB for the two images -> a single 4-wave workgroup per CU: v2 keeps those layers)
-inline int v3_ncb(int Cin) { return Cin > 32 ? 2 : 1; }
+// block shape of a v3 workgroup: 32 out x 64 in channels, or 64 out x 32 in.  The wide-out shape stages less (the
+// halo'd input tile is the expensive half) and pads fewer input channels (Cin = 160: three 64-blocks waste a sixth of
+// the MFMAs, five 32-blocks none): 160 -> 64 @64^3 runs at 122 instead of 97 TFLOP/s.
+inline bool v3_wide_out(int Cin, int Cout) {
+  (void)Cin;
+  return Cout >= 64 && (Cout % 64) <= 0;
+}
+inline int v3_pairs(int Cin, int Cout) {
+  return v3_wide_out(Cin, Cout) ? e2e::cdiv(Cin, 32) * e2e::cdiv(Cout, 64) : e2e::cdiv(Cin, 64) * e2e::cdiv(Cout, 32);
+}
 // chunks never cross a batch item: `segs` runs of tiles_per_chunk tiles per item; returns the number of chunks
 inline int plan_v3(WgParams& p, int pairs) {
   p.tiles_x = e2e::cdiv(p.Wo, 32);
@@ -958,7 +968,7 @@ extern "C" long long e2e_conv133_wgrad_ws_bytes(int B, int Cin, int Cout, int Di
     p.total_tiles = (long long)p.tiles_per_n * B;
     nchunks = s2_chunks(p.total_tiles, pairs, &p.tiles_per_chunk);
   } else if (use_v3(Cin, Hi, Wi, sh, sw)) {
-    nchunks = plan_v3(p, e2e::cdiv(Cin, 32 * v3_ncb(Cin)) * e2e::cdiv(Cout, 32));
+    nchunks = plan_v3(p, v3_pairs(Cin, Cout));
   } else if (use_v2(Wi, sh, sw)) {
     const int pairs = e2e::cdiv(Cin, 32 * v2_ncb(Cin, p.Ho, p.Wo)) * e2e::cdiv(Cout, 32);
     plan(p, pick(p.Ho, p.Wo, false), pairs, &nchunks, 512);
@@ -1000,12 +1010,12 @@ extern "C" int e2e_conv133_wgrad(const e2e_in_chan_t* chans, const float* dy, fl
     return e2e::check_launch("wgrad_slab_reduce_kernel");
   }
   if (use_v3(Cin, Hi, Wi, sh, sw)) {
-    const int ncb = v3_ncb(Cin);
-    p.cblocks = e2e::cdiv(Cin, 32 * ncb);
-    const int pairs = p.cblocks * e2e::cdiv(Cout, 32);
+    const bool wide = v3_wide_out(Cin, Cout);
+    p.cblocks = wide ? e2e::cdiv(Cin, 32) : e2e::cdiv(Cin, 64);
+    const int pairs = v3_pairs(Cin, Cout);
     nchunks = plan_v3(p, pairs);
-    if (ncb == 2) hipLaunchKernelGGL((conv133_wgrad_v3_kernel<2>), dim3(nchunks, pairs), dim3(512), 0, st, p);
-    else hipLaunchKernelGGL((conv133_wgrad_v3_kernel<1>), dim3(nchunks, pairs), dim3(256), 0, st, p);
+    if (wide) hipLaunchKernelGGL((conv133_wgrad_v3_kernel<1, 2>), dim3(nchunks, pairs), dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((conv133_wgrad_v3_kernel<2, 1>), dim3(nchunks, pairs), dim3(512), 0, st, p);
     rc = e2e::check_launch("conv133_wgrad_v3_kernel");
     if (rc != E2E_OK) return rc;
     hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)e2e::cdivll(numel, 64)), dim3(256), 0, st, p.slab, dw, numel,

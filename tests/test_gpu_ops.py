@@ -68,6 +68,7 @@ CONV_CASES = [
     (1, [(9, True)], 7, (1, 6, 5), (1, 1, 1), 1.0),                          # one-slice volume: all shifted groups vanish
     (1, [(20, True), (15, False)], 40, (6, 32, 64), (2, 2, 2), 1.0),         # strided, wide planes (pipelined s2 wgrad)
     (2, [(33, True)], 34, (3, 24, 40), (1, 2, 2), 1.0),                      # in-plane stride only, ragged tiles
+    (2, [(50, True), (40, False)], 70, (2, 20, 36), (1, 1, 1), 0.2),         # double-buffered wgrad, 64-out x 32-in blocks
 ]
 
 
