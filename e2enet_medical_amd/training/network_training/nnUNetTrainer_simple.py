@@ -229,8 +229,10 @@ class nnUNetTrainer_simple(object):
         print(*args)
 
     # ------------------------------------------------------------------------------------------ checkpoints
-    def save_checkpoint(self, fname, save_optimizer=True):
-        """reference :1140-1176 (same dict keys and the side-car .pkl)."""
+    def save_checkpoint(self, fname, save_optimizer=True, mask=None):
+        """reference :1140-1176 (same dict keys and the side-car .pkl).  With ``mask`` (a Masking) the checkpoint also
+        carries 'dsff_state' (packed kernel maps, death-rate schedule position, growth RNG state); reference loaders
+        ignore the extra key."""
         state_dict = OrderedDict((k, v.cpu()) for k, v in self.network.state_dict().items())
         save_this = {'epoch': self.epoch + 1, 'state_dict': state_dict,
                      'optimizer_state_dict': self.optimizer.state_dict() if save_optimizer else None,
@@ -239,14 +241,17 @@ class nnUNetTrainer_simple(object):
                                     self.all_val_eval_metrics),
                      'best_stuff': (self.best_epoch_based_on_MA_tr_loss, self.best_MA_tr_loss_for_patience,
                                     self.best_val_eval_criterion_MA)}
+        if mask is not None:
+            save_this['dsff_state'] = mask.state_dict()
         torch.save(save_this, fname)
         info = OrderedDict(init=self.init_args, name=self.__class__.__name__, plans=self.plans)
         info['class'] = str(self.__class__)
         with open(fname + ".pkl", 'wb') as f:
             pickle.dump(info, f)
 
-    def load_checkpoint_ram(self, checkpoint, train=True):
-        """reference :1211-1255"""
+    def load_checkpoint_ram(self, checkpoint, train=True, mask=None):
+        """reference :1211-1255; ``mask``: a Masking already attached to this trainer's network/optimizer
+        (add_module done) that is restored from checkpoint['dsff_state']."""
         if not self.was_initialized:
             self.initialize(train)
         keys = list(self.network.state_dict().keys())
@@ -264,12 +269,16 @@ class nnUNetTrainer_simple(object):
         if 'best_stuff' in checkpoint:
             self.best_epoch_based_on_MA_tr_loss, self.best_MA_tr_loss_for_patience, self.best_val_eval_criterion_MA = \
                 checkpoint['best_stuff']
+        if mask is not None:
+            if 'dsff_state' not in checkpoint:
+                raise KeyError("checkpoint carries no 'dsff_state' (written by save_checkpoint(..., mask=mask))")
+            mask.load_state_dict(checkpoint['dsff_state'])
         # DSFF checkpoints carry their masks implicitly (pruned kernels are exact zeros): skip them at inference
         if not train:
             self.network.enable_auto_sparsity(True)
 
-    def load_checkpoint(self, fname, train=True):
-        self.load_checkpoint_ram(torch.load(fname, map_location=torch.device('cpu'), weights_only=False), train)
+    def load_checkpoint(self, fname, train=True, mask=None):
+        self.load_checkpoint_ram(torch.load(fname, map_location=torch.device('cpu'), weights_only=False), train, mask)
 
     # ------------------------------------------------------------------------------------------ inference
     def predict_preprocessed_data_return_seg_and_softmax(self, data: np.ndarray, do_mirroring: bool = True,

@@ -165,6 +165,52 @@ class Masking(object):
         lib().dsff_expand(km.data_ptr(), mask.data_ptr(), None, None, r, cc, ks, _stream())
         self._table = None
 
+    # ------------------------------------------------------------------------------------------ checkpoint
+    def state_dict(self):
+        """DSFF state for a resumable checkpoint: the reference saves none of it (its resume re-draws the masks, §5 of
+        SURVEY.md).  Kernel maps are bit-packed ([dim0, dim1] -> ceil(dim0*dim1/8) bytes, 0.17 MB at 32 ch); the Python
+        `random` state is what the growth draws continue from."""
+        import random
+        sd = {'version': 1, 'steps': self.steps, 'explore_step': self.explore_step, 'death_rate': self.death_rate,
+              'decay_flag': self.decay_flag, 'density': getattr(self, 'density', None),
+              'kmasks': {n: (tuple(self._kmask_host[n].shape), np.packbits(self._kmask_host[n].reshape(-1)))
+                         for n in self.names},
+              'random_state': random.getstate()}
+        if isinstance(self.death_rate_decay, CosineDecay):
+            sd['decay'] = {'kind': 'cosine', 'scheduler': self.death_rate_decay.cosine_stepper.state_dict(),
+                           'lr': self.death_rate_decay.sgd.param_groups[0]['lr']}
+        elif isinstance(self.death_rate_decay, LinearDecay):
+            sd['decay'] = {'kind': 'linear', 'steps': self.death_rate_decay.steps}
+        return sd
+
+    def load_state_dict(self, sd):
+        """Restore after add_module() on the re-created network/optimizer: masks, schedule position, RNG."""
+        import random
+        if sd.get('version') != 1:
+            raise ValueError("unknown DSFF checkpoint version %r" % (sd.get('version'),))
+        missing = [n for n in self.names if n not in sd['kmasks']]
+        if missing or len(sd['kmasks']) != len(self.names):
+            raise KeyError("DSFF checkpoint does not match the masked tensors of this network: missing %s" % missing[:3])
+        for n in self.names:
+            shape, packed = sd['kmasks'][n]
+            w = self._params[n]
+            if tuple(shape) != (w.shape[0], w.shape[1]):
+                raise ValueError("kernel map of %s has shape %s, weight has %s" % (n, shape, tuple(w.shape[:2])))
+            km = np.unpackbits(np.asarray(packed, dtype=np.uint8))[:shape[0] * shape[1]].reshape(shape).astype(np.uint8)
+            self._set_kmask(n, km)
+        self.steps, self.explore_step = sd['steps'], sd['explore_step']
+        self.death_rate, self.decay_flag = sd['death_rate'], sd['decay_flag']
+        dec = sd.get('decay')
+        if dec is not None and dec['kind'] == 'cosine' and isinstance(self.death_rate_decay, CosineDecay):
+            self.death_rate_decay.cosine_stepper.load_state_dict(dec['scheduler'])
+            self.death_rate_decay.sgd.param_groups[0]['lr'] = dec['lr']
+        elif dec is not None and dec['kind'] == 'linear' and isinstance(self.death_rate_decay, LinearDecay):
+            self.death_rate_decay.steps = dec['steps']
+        random.setstate(sd['random_state'])
+        self.apply_mask()
+        self._push_liveness()
+        self.cal_nonzero_counts()
+
     def _push_liveness(self):
         for m in self.modules:
             if hasattr(m, "set_kernel_masks"):

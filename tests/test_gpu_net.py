@@ -294,6 +294,58 @@ def test_trainer_surface_runs_iterations():
     assert np.isfinite(v)
 
 
+def test_checkpoint_with_dsff_state_resumes_bit_exact(tmp_path):
+    """a checkpoint written with the Masking state (packed kernel maps, schedule position, growth RNG)
+    resumes to the same weights and masks as the uninterrupted run (the reference re-draws the masks on resume)."""
+    from e2enet_medical_amd.training.network_training.nnUNetTrainer_simple import nnUNetTrainer_simple
+    from e2enet_medical_amd.training.network_training.sparselearning.core_channel import Masking, CosineDecay
+    plans = {'plans_per_stage': {0: {'batch_size': 2, 'patch_size': [16, 32, 32], 'num_pool_per_axis': [3, 5, 5],
+                                     'pool_op_kernel_sizes': [[2, 2, 2]] * 3 + [[1, 2, 2]] * 2,
+                                     'conv_kernel_sizes': [[3, 3, 3]] * 6, 'do_dummy_2D_data_aug': False}},
+             'base_num_features': 32, 'num_modalities': 1, 'num_classes': 2, 'all_classes': [1, 2],
+             'transpose_forward': [0, 1, 2], 'transpose_backward': [0, 1, 2], 'conv_per_stage': 2}
+
+    class A:
+        adv = False
+        fix = False
+        update_frequency = 2
+        final_density = 0.05
+
+    def make():
+        tr = nnUNetTrainer_simple(plans, 0, output_folder=None, batch_dice=False, Tconv='shiftConvPP', max_num_epochs=2,
+                                  num_batches_per_epoch=2)
+        tr.base_num_features_override = 8
+        torch.manual_seed(0)
+        net, opt = tr.initialize(True)
+        random.seed(0)
+        mask = Masking(opt, death_rate=0.5, death_mode='magnitude', death_rate_decay=CosineDecay(0.5, 8),
+                       growth_mode='random', redistribution_mode='none', args=A())
+        mask.add_module(net, sparse_init='uniform', density=0.2)
+        return tr, net, mask
+
+    tr, net, mask = make()
+    batches = [next(tr.tr_gen) for _ in range(5)]
+    for b in batches[:3]:                       # 3 iterations: one prune/grow at step 2
+        tr.run_iteration(iter([b]), True, mask=mask)
+    fname = str(tmp_path / "ckpt.model")
+    tr.save_checkpoint(fname, mask=mask)
+    for b in batches[3:]:                       # uninterrupted: 2 more (another prune/grow at step 4)
+        tr.run_iteration(iter([b]), True, mask=mask)
+    want_w = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    want_m = {n: m.cpu().clone() for n, m in mask.kmasks.items()}
+
+    tr2, net2, mask2 = make()
+    random.seed(12345)                          # a different RNG position: must be overwritten by the checkpoint
+    tr2.load_checkpoint(fname, train=True, mask=mask2)
+    assert mask2.steps == 3
+    for b in batches[3:]:
+        tr2.run_iteration(iter([b]), True, mask=mask2)
+    for n in want_m:
+        assert torch.equal(mask2.kmasks[n].cpu(), want_m[n]), n
+    for k, v in net2.state_dict().items():
+        assert torch.equal(v.detach().cpu(), want_w[k]), k
+
+
 def test_btcv_like_anisotropic_config_vs_oracle():
     """BASELINE config 3 shape family: 1 modality, 14 classes, anisotropic pooling [[1,2,2],[2,2,2]x3,[1,2,2]]
     (depth stride 1 with in-plane stride 2, transposed convs with kernel (1,2,2)), batch 2, non-cubic patch."""
