@@ -101,7 +101,7 @@ class ConvOp:
         self.live = None        # quad words [ceil(Cout/4), ceil(Cin/8)] int32 (e2e_dsff_expand_quads)
         self.live_t = None      # quad words [ceil(Cin/4), ceil(Cout/8)] int32
         # per input channel plane table
-        shifts = shift_amounts(self.cin)
+        shifts = shift_amounts(self.cin, getattr(getattr(eng, 'cfg', None), 'shift_size', 5))
         structs = []
         c = 0
         for s in sources:
@@ -277,13 +277,17 @@ class NetConfig:
     """Static description of a shiftConvPP network (what reference Generic_UNetPlusPlus.__init__ derives,
     unetpp_d.py:227-445)."""
 
-    def __init__(self, in_channels, base_features, num_classes, pool_kernels, convs_per_stage=2, max_features=320):
+    def __init__(self, in_channels, base_features, num_classes, pool_kernels, convs_per_stage=2, max_features=320,
+                 shift_size=5):
         if len(pool_kernels) != 5:
             # reference forward() indexes six levels literally (unetpp_d.py:451-483)
             raise ValueError("shiftConvPP needs exactly 5 pooling stages, got %d" % len(pool_kernels))
         self.in_channels, self.base_features, self.num_classes = in_channels, base_features, num_classes
         self.pool_kernels = [tuple(int(v) for v in k) for k in pool_kernels]
         self.convs_per_stage, self.max_features = convs_per_stage, max_features
+        if shift_size < 1 or shift_size % 2 == 0:
+            raise ValueError("shift_size must be odd and >= 1 (reference unetpp_d.py:89 uses 5; 1 disables the shift)")
+        self.shift_size = shift_size      # groups of the restricted depth shift (SURVEY §8f N4: 3/7/11, 1 = 'noshift')
         feats, f = [], base_features
         for _ in range(6):
             feats.append(min(f, max_features))

@@ -130,7 +130,7 @@ class Generic_UNetPlusPlus(SegmentationNetwork):
                  deep_supervision=True, dropout_in_localization=False, final_nonlin=softmax_helper,
                  weightInitializer=InitWeights_He(1e-2), pool_op_kernel_sizes=None, conv_kernel_sizes=None,
                  upscale_logits=False, convolutional_pooling=False, convolutional_upsampling=False,
-                 max_num_features=None, basic_block=ConvDropoutNormNonlin, seg_output_use_bias=False):
+                 max_num_features=None, basic_block=ConvDropoutNormNonlin, seg_output_use_bias=False, shift_size=5):
         super().__init__()
         # ---- what the engine supports: exactly the configuration nnUNetTrainer_simple builds (:292-301) ----
         if conv_op != nn.Conv3d:
@@ -224,8 +224,10 @@ class Generic_UNetPlusPlus(SegmentationNetwork):
         if self.weightInitializer is not None:
             self.apply(self.weightInitializer)
 
+        # shift_size: keyword extension (default = the reference's hard-set 5, unetpp_d.py:89); 3/7/11 are the sizes its
+        # comment lists, 1 reproduces the 'noshift' ablation variant
         self._cfg = NetConfig(input_channels, base_num_features, num_classes, pool_op_kernel_sizes, num_conv_per_stage,
-                              self.max_num_features)
+                              self.max_num_features, shift_size=shift_size)
         self._engines = {}
         self._kernel_masks = None            # name -> uint8 [dim0, dim1]; None = dense
         self._auto_sparsity = False          # derive liveness from zero kernels (inference on DSFF checkpoints)

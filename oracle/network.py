@@ -28,6 +28,7 @@ class NetSpec:
     convs_per_stage: int = 2
     max_features: int = 320
     feats: List[int] = field(default_factory=list)
+    shift_size: int = 5          # reference hard-sets 5 (unetpp_d.py:89; the comment there lists 3/7/11); 1 = 'noshift' ablation
 
     @property
     def num_pool(self):
@@ -35,7 +36,7 @@ class NetSpec:
 
 
 def make_spec(in_channels, base_features, num_classes, pool_kernels=None, convs_per_stage=2,
-              max_features=320) -> NetSpec:
+              max_features=320, shift_size=5) -> NetSpec:
     if pool_kernels is None:
         pool_kernels = [(2, 2, 2)] * 5
     pool_kernels = [tuple(int(v) for v in k) for k in pool_kernels]
@@ -49,7 +50,7 @@ def make_spec(in_channels, base_features, num_classes, pool_kernels=None, convs_
         f = int(round(f * 2))
         f = min(f, max_features)
     return NetSpec(in_channels, base_features, num_classes, pool_kernels, convs_per_stage,
-                   max_features, feats)
+                   max_features, feats, shift_size)
 
 
 # --------------------------------------------------------------------------- naming
@@ -146,19 +147,19 @@ def init_params(spec: NetSpec, seed: int = 0, dtype=torch.float32) -> "Dict[str,
 
 
 # --------------------------------------------------------------------------- forward
-def conv_block(x, w, b, gamma, beta, stride=(1, 1, 1)):
+def conv_block(x, w, b, gamma, beta, stride=(1, 1, 1), shift_size=5):
     """unetpp_d.py:102-111 for kernel (1,3,3)."""
-    x = depth_shift(x)
+    x = depth_shift(x, shift_size)
     y = F.conv3d(x, w, b, stride=stride, padding=(0, 1, 1))
     y = F.instance_norm(y, weight=gamma, bias=beta, eps=1e-5)
     return F.leaky_relu(y, 0.01)
 
 
-def _run_blocks(params, prefixes, x, first_stride=(1, 1, 1)):
+def _run_blocks(params, prefixes, x, first_stride=(1, 1, 1), shift_size=5):
     for bi, p in enumerate(prefixes):
         x = conv_block(x, params[p + ".conv.weight"], params[p + ".conv.bias"],
                        params[p + ".instnorm.weight"], params[p + ".instnorm.bias"],
-                       stride=first_stride if bi == 0 else (1, 1, 1))
+                       stride=first_stride if bi == 0 else (1, 1, 1), shift_size=shift_size)
     return x
 
 
@@ -169,7 +170,7 @@ def forward(spec: NetSpec, params, x, do_ds=True, return_nodes=False):
     cur = x
     for st in range(P + 1):
         stride = (1, 1, 1) if st == 0 else spec.pool_kernels[st - 1]
-        cur = _run_blocks(params, encoder_block_prefixes(spec, st), cur, stride)
+        cur = _run_blocks(params, encoder_block_prefixes(spec, st), cur, stride, shift_size=spec.shift_size)
         nodes[(st, 0)] = cur
         if st == 0:
             continue
@@ -181,7 +182,7 @@ def forward(spec: NetSpec, params, x, do_ds=True, return_nodes=False):
                                         stride=spec.pool_kernels[lvl])]
             if lvl > 0:
                 parts.append(F.max_pool3d(nodes[(lvl - 1, j - 1)], spec.pool_kernels[lvl - 1]))
-            nodes[(lvl, j)] = _run_blocks(params, loc_block_prefixes(spec, z, m), torch.cat(parts, 1))
+            nodes[(lvl, j)] = _run_blocks(params, loc_block_prefixes(spec, z, m), torch.cat(parts, 1), shift_size=spec.shift_size)
     outs = [F.conv3d(nodes[(h, P - h)], params["seg_outputs.%d.weight" % h]) for h in range(4)]
     res = outs if do_ds else outs[0]
     if return_nodes:

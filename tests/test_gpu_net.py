@@ -16,13 +16,13 @@ pytestmark = pytest.mark.gpu
 TINY = dict(patch=(16, 32, 32), cin=2, base=8, k=3, pools=[(2, 2, 2)] * 3 + [(1, 2, 2)] * 2, max_feat=32)
 
 
-def build_net(patch, cin, base, k, pools, max_feat=None):
+def build_net(patch, cin, base, k, pools, max_feat=None, **extra):
     from e2enet_medical_amd.network_architecture.unetpp_d import Generic_UNetPlusPlus
     from e2enet_medical_amd.network_architecture.initialization import InitWeights_He
     net = Generic_UNetPlusPlus(patch, cin, base, k, 5, 2, 2, nn.Conv3d, nn.InstanceNorm3d, {'eps': 1e-5, 'affine': True},
                                nn.Dropout3d, {'p': 0, 'inplace': True}, nn.LeakyReLU,
                                {'negative_slope': 1e-2, 'inplace': True}, True, False, lambda x: x, InitWeights_He(1e-2),
-                               pools, None, False, True, True, max_num_features=max_feat)
+                               pools, None, False, True, True, max_num_features=max_feat, **extra)
     return net.cuda()
 
 
@@ -107,6 +107,32 @@ def test_tiny_engine_fastpath_matches_oracle_all_grads():
             rg = leaves[n].grad
             err = (eng.grads[n].cpu() - rg).abs().max().item()
             assert err <= 2e-4 * max(1.0, rg.abs().max().item()) + 1e-6, (n, err)
+
+
+@pytest.mark.parametrize("shift_size", [1, 3, 7])
+def test_shift_size_variants_match_oracle(shift_size):
+    """the other restricted-shift sizes (the reference's comment at unetpp_d.py:89 lists 3/7/11; 1 is the
+    'noshift' ablation) only change the per-channel depth offset table: logits and all gradients vs the oracle."""
+    net = build_net(TINY["patch"], TINY["cin"], TINY["base"], TINY["k"], TINY["pools"], TINY["max_feat"], shift_size=shift_size)
+    shapes, params = load_closed_form(net)
+    spec = oracle.make_spec(TINY["cin"], TINY["base"], TINY["k"], TINY["pools"], 2, TINY["max_feat"], shift_size=shift_size)
+    x = seeded_input((2, TINY["cin"]) + TINY["patch"], seed=78)
+    eng = net.engine(x.cuda())
+    outs = eng.forward(x.cuda(), True)
+    targets = [seeded_labels((o.shape[0], 1) + tuple(o.shape[2:]), TINY["k"], seed=90 + i) for i, o in enumerate(outs)]
+    w = oracle.ds_weights(5)
+    loss = eng.loss_backward([t.cuda() for t in targets], w, batch_dice=False)
+    leaves = {n: p.clone().requires_grad_(True) for n, p in params.items()}
+    ref = oracle.forward(spec, leaves, x)
+    ref_loss = oracle.deep_supervision_loss(ref, targets, w, False)
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < 2e-5
+    for o, r in zip(outs, ref):
+        assert (o.cpu() - r.detach()).abs().max() <= 1e-4
+    for n in shapes:
+        rg = leaves[n].grad
+        err = (eng.grads[n].cpu() - rg).abs().max().item()
+        assert err <= 5e-4 * max(1.0, rg.abs().max().item()) + 1e-6, (n, err)   # fp32 summation order over 16k voxels
 
 
 def test_net64_sparse_forward_vs_reference_golden():
