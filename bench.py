@@ -261,7 +261,9 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BraTS-shaped 4-modal %d^3 patches, shiftConvPP base 32, K=4, DSFF density 0.2, "
-                                   "batch %d per GPU, fwd+loss+bwd+clip+SGD+mask step, dense (parity) wgrad" % (patch[0], args.batch),
+                                   "batch %d per GPU, %s" % (patch[0], args.batch, "inference forward (deep supervision heads on)"
+                                                             if args.forward_only else
+                                                             "fwd+loss+bwd+clip+SGD+mask step, dense (parity) wgrad"),
                        "parallelism": "dp%d" % world},
             "per_gpu_voxels_per_s": value / world,
             "hbm_roofline_frac_whole_step": (value / world) * TRAIN_BYTES_PER_VOXEL / (HBM_PEAK_GBS * 1e9),
