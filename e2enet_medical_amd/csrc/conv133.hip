@@ -129,7 +129,8 @@ typedef const f32x4_t __attribute__((address_space(1)))* gfloat4_p;
 template <int MODE, int SH, int SW, int DH, int DW, int TH, int TW, int LY, int LX, int OPW, int NW, int CK, int STG, int MINW, int PIPE, int PERSIST>
 __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
   using C = Cfg<MODE, SH, SW, DH, DW, TH, TW, LY, LX, OPW, NW, CK, STG>;
-  static_assert(OPW == 4 && CK % 8 == 0 && CK <= 16, "liveness quad words: 4 output planes x 8 input planes per word");
+  static_assert((OPW == 4 || OPW == 8) && CK % 8 == 0 && CK <= 16, "liveness quad words: 4 output planes x 8 input planes per word");
+  constexpr int NQD = OPW / 4;                                 // quad rows (of 4 output planes) per wave
   constexpr int WPAD = 12;                                     // 9 taps padded to 3 x 16 bytes
   constexpr int WUNITS = C::OCG * CK * 9;                      // weights of one chunk for this workgroup's planes
   constexpr int NUW = (WUNITS + C::NT - 1) / C::NT;
@@ -408,24 +409,27 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
   // liveness of this wave's 4 output planes x the chunk's CK input planes: quad words (bit = (plane % 8) * 4 + output % 4),
   // input-plane-major, so consecutive set bits that share an input plane reuse the neighbourhood registers
   const int nw8 = (p.P + 7) >> 3;
-  auto chunk_mask = [&](int c0) -> unsigned long long {
+  auto chunk_mask = [&](int c0, int j) -> unsigned long long {      // j: quad row of this wave
     unsigned long long m = 0;
-    if (c0 >= p.P || qbase >= p.Q) return m;
+    const int qb = qbase + 4 * j;
+    if (c0 >= p.P || qb >= p.Q) return m;
 #pragma unroll
     for (int wd = 0; wd < CK / 8; ++wd) {
       const int wi = (c0 >> 3) + wd;
       unsigned word = 0u;
-      if (wi < nw8) word = p.live != nullptr ? p.live[(long long)(qbase >> 2) * nw8 + wi] : 0xffffffffu;
+      if (wi < nw8) word = p.live != nullptr ? p.live[(long long)(qb >> 2) * nw8 + wi] : 0xffffffffu;
       m |= (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)word) << (32 * wd);
     }
     const int remain = p.P - c0;
     if (remain < CK) m &= (1ull << (remain * 4)) - 1ull;
-    const int qleft = p.Q - qbase;                       // planes beyond Q (last group): clear their bit in every nibble
+    const int qleft = p.Q - qb;                          // planes beyond Q (last group): clear their bit in every nibble
     if (qleft < 4) m &= 0x1111111111111111ull * ((1ull << qleft) - 1ull);
     return m;
   };
 
-  unsigned long long m_cur = 0;
+  unsigned long long m_cur[NQD];
+#pragma unroll
+  for (int j = 0; j < NQD; ++j) m_cur[j] = 0;
   STAMP(t_pro);
   STAMP_ADD(0, t_begin, t_pro);
   if (nchunks > 0) {
@@ -435,11 +439,14 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
       __syncthreads();
     }
     if (!CDBG(1)) prefetch(0);
-    m_cur = chunk_mask(0);
+#pragma unroll
+    for (int j = 0; j < NQD; ++j) m_cur[j] = chunk_mask(0, j);
   }
   for (int ci = 0; ci < nchunks; ++ci) {
     const int c0 = ci * CK;
-    const unsigned long long m_next = ci + 1 < nchunks ? chunk_mask(c0 + CK) : 0ull;   // scalar loads, in flight during commit
+    unsigned long long m_next[NQD];                      // scalar loads, in flight during commit
+#pragma unroll
+    for (int j = 0; j < NQD; ++j) m_next[j] = ci + 1 < nchunks ? chunk_mask(c0 + CK, j) : 0ull;
     STAMP(t0);
     if (!CDBG(1)) commit(c0);
     STAMP(t1);
@@ -450,11 +457,16 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
 
     // walk the chunk's live input planes (nibbles of the quad mask); the neighbourhood rows of a plane are read once
     // and shared by the 1..4 output planes of this wave that consume it
-    unsigned long long m = CDBG(2) ? 0ull : m_cur;
+    unsigned long long m = 0;
+#pragma unroll
+    for (int j = 0; j < NQD; ++j) m |= m_cur[j];
+    if (CDBG(2)) m = 0;
     while (m) {
       const int cl = __builtin_ctzll(m) >> 2;
-      const unsigned nib = (unsigned)(m >> (cl * 4)) & 15u;
       m &= ~(15ull << (cl * 4));
+      unsigned nib = 0;
+#pragma unroll
+      for (int j = 0; j < NQD; ++j) nib |= ((unsigned)(m_cur[j] >> (cl * 4)) & 15u) << (4 * j);
       float nb[C::NR][NCL];
       issue(cl, nb);
 #pragma unroll
@@ -466,7 +478,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
         }
       }
     }
-    m_cur = m_next;
+#pragma unroll
+    for (int j = 0; j < NQD; ++j) m_cur[j] = m_next[j];
     STAMP(t4);
     if (!CDBG(4)) __syncthreads();
     STAMP(t5);
@@ -702,6 +715,11 @@ inline int t32_variant_knob() {     // tuning knob for the large-plane tile (0/1
   return v;
 }
 
+inline int opw8_knob() {
+  static const int v = getenv("E2E_CONV_OPW8") ? atoi(getenv("E2E_CONV_OPW8")) : 0;
+  return v;
+}
+
 // stride-1 tiles; STG = 1 (aligned float4 staging) needs rows that are multiples of 4 floats
 template <int MODE, int DH, int DW>
 int launch_s1(const ConvParams& p, int kind, hipStream_t st) {
@@ -712,6 +730,7 @@ int launch_s1(const ConvParams& p, int kind, hipStream_t st) {
       // 16x32 tile, 118 VGPRs -> two 512-thread workgroups per CU (measured best; the 32x32 tile and the double
       // register set variant of the live-kernel loop both lose to it because they halve the occupancy or spill)
       (void)t32_variant;
+      if (vec && opw8_knob() && p.P > 8) return launch_cfg<MODE, 1, 1, 1, 1, 16, 32, 8, 8, 8, 4, 8, 1, 3, 0>(p, st);   // 4 fat waves
       return vec ? launch_cfg<MODE, 1, 1, 1, 1, 16, 32, 8, 8, 4, 8, 8, 1, 4, 0>(p, st)
                  : launch_cfg<MODE, 1, 1, DH, DW, 16, 32, 8, 8, 4, 8, 8, 0, 4, 0>(p, st);
     case 1:
