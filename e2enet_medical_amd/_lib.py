@@ -110,6 +110,9 @@ class _Lib:
 _lib = None
 
 
+ABI_VERSION = 2          # e2e_abi_version() of the library this binding was written against
+
+
 def lib() -> _Lib:
     """The loaded library (loads on first use; raises ImportError when it has not been built)."""
     global _lib
@@ -117,5 +120,10 @@ def lib() -> _Lib:
         # torch first: libe2e_hip.so must bind to the HIP runtime PyTorch-ROCm has loaded (one runtime per process,
         # so that torch's streams and device pointers are valid in our launches)
         import torch  # noqa: F401
-        _lib = _Lib(LIB_PATH)
+        handle = _Lib(LIB_PATH)
+        got = handle.abi_version()
+        if got != ABI_VERSION:           # a stale in-tree .so from another revision: fail loudly, never guess
+            raise ImportError("%s reports ABI version %d, this package needs %d: rebuild with `make -C %s`"
+                              % (LIB_PATH, got, ABI_VERSION, os.path.dirname(LIB_PATH)))
+        _lib = handle
     return _lib
