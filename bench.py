@@ -209,7 +209,7 @@ def main():
         eng.forward(x, True)
         loss = eng.loss_backward(targets, ds_w, batch_dice=False)
         if use_dist:
-            flat = parallel.allreduce_mean_gradients(eng.grads, names, flat=flat, force=force_dist)
+            flat = parallel.allreduce_mean_flat(eng.grad_flat, force=force_dist)
         fused.step(eng.grads, mask.masks)
         mask.step(masks_already_applied=True)
         return loss

@@ -432,8 +432,15 @@ class Engine:
         for op in reversed(self.ops):          # backward order: first writer of a gradient buffer overwrites
             op.out.alloc_grad()
             op.plan_backward()
+        # all parameter gradients live in ONE flat buffer (each tensor at a 256-byte aligned offset): the data-parallel
+        # all-reduce runs on it in place, no gather / scatter copies around the collective
+        offs, total = {}, 0
         for name, p in self.params.items():
-            self.grads[name] = torch.zeros_like(p, device=self.device)
+            offs[name] = total
+            total += (p.numel() + 63) // 64 * 64
+        self.grad_flat = torch.zeros(total, dtype=torch.float32, device=self.device)
+        for name, p in self.params.items():
+            self.grads[name] = self.grad_flat[offs[name]:offs[name] + p.numel()].view(p.shape)
         ws = max([op.wgrad_ws_bytes() for op in self.ops if hasattr(op, "wgrad_ws_bytes")] +
                  [lib().head1x1_wgrad_ws_bytes(self.batch, h.src.shape[1], h.k, h.src.spatial) for h in self.heads])
         self.wgrad_ws = torch.empty((ws + 3) // 4, dtype=torch.float32, device=self.device)

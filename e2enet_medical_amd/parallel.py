@@ -64,6 +64,18 @@ def allreduce_mean_gradients(grads: Dict[str, torch.Tensor], names: List[str], g
     return flat
 
 
+def allreduce_mean_flat(flat: torch.Tensor, group=None, force: bool = False):
+    """Average the engine's flat gradient buffer (Engine.grad_flat: every parameter gradient is a view into it) over
+    the ranks in place: one RCCL all-reduce of 67 MB at 32 ch, no staging copies."""
+    world = dist.get_world_size(group)
+    if world == 1 and not force:
+        return flat
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if world > 1:
+        flat.mul_(1.0 / world)
+    return flat
+
+
 def broadcast_kernel_masks(kmasks: Dict[str, torch.Tensor], src: int = 0, group=None):
     """Broadcast the uint8 kernel maps (1.39 M kernels at 32 ch = 1.4 MB) from ``src`` as one tensor."""
     names = list(kmasks.keys())

@@ -168,6 +168,11 @@ grads = {"a": torch.full((5, 3), float(rank + 1)), "b": torch.arange(4, dtype=to
 parallel.allreduce_mean_gradients(grads, ["a", "b"])
 assert torch.allclose(grads["a"], torch.full((5, 3), (1 + world) / 2.0))
 assert torch.allclose(grads["b"], torch.arange(4, dtype=torch.float32) * (1 + world) / 2.0)
+flat = torch.arange(70, dtype=torch.float32) * (rank + 1)          # the engine's flat gradient buffer: in place
+views = [flat[0:6].view(2, 3), flat[64:70]]
+parallel.allreduce_mean_flat(flat)
+assert torch.allclose(flat, torch.arange(70, dtype=torch.float32) * (1 + world) / 2.0)
+assert torch.allclose(views[1], torch.arange(64, 70, dtype=torch.float32) * (1 + world) / 2.0)
 km = {"k": (torch.arange(12).reshape(3, 4) %% (rank + 2) == 0).to(torch.uint8)}
 want = (torch.arange(12).reshape(3, 4) %% 2 == 0).to(torch.uint8)
 parallel.broadcast_kernel_masks(km, src=0)
