@@ -363,6 +363,7 @@ class Engine:
             self.heads.append(head)
             self.ops.append(head)
         self.grads: Dict[str, torch.Tensor] = {}
+        self.grad_bucket_hook = None       # callable(lo, hi): flat gradient slice [lo, hi) is final (data-parallel overlap)
         self._backward_ready = False
         self.loss_ws = None
         self.loss_val = None
@@ -432,15 +433,38 @@ class Engine:
         for op in reversed(self.ops):          # backward order: first writer of a gradient buffer overwrites
             op.out.alloc_grad()
             op.plan_backward()
-        # all parameter gradients live in ONE flat buffer (each tensor at a 256-byte aligned offset): the data-parallel
-        # all-reduce runs on it in place, no gather / scatter copies around the collective
+        # all parameter gradients live in ONE flat buffer (each tensor at a 256-byte aligned offset), laid out in the
+        # order the backward pass completes them: the data-parallel all-reduce runs on it in place, and a prefix of the
+        # buffer can be reduced while the rest of the backward pass is still running (grad_bucket_hook)
+        order, seen = [], set()
+        for op in reversed(self.ops):
+            if isinstance(op, ConvOp):
+                produced = [op.w_name, op.prefix + ".conv.bias", op.prefix + ".instnorm.weight", op.prefix + ".instnorm.bias"]
+            elif isinstance(op, (UpOp, HeadOp)):
+                produced = [op.w_name]
+            else:
+                produced = []
+            for name in produced:
+                if name in self.params and name not in seen:
+                    order.append((name, op))
+                    seen.add(name)
+        order += [(name, None) for name in self.params if name not in seen]
         offs, total = {}, 0
-        for name, p in self.params.items():
+        for name, _ in order:
             offs[name] = total
-            total += (p.numel() + 63) // 64 * 64
+            total += (self.params[name].numel() + 63) // 64 * 64
         self.grad_flat = torch.zeros(total, dtype=torch.float32, device=self.device)
         for name, p in self.params.items():
             self.grads[name] = self.grad_flat[offs[name]:offs[name] + p.numel()].view(p.shape)
+        # bucket boundaries: after the op that completes roughly each quarter of the buffer
+        self._bucket_after_op, lo, nb = {}, 0, 4
+        for i, (name, op) in enumerate(order):
+            end = offs[name] + (self.params[name].numel() + 63) // 64 * 64
+            last_of_op = i + 1 == len(order) or order[i + 1][1] is not op
+            if op is not None and last_of_op and (end - lo >= total // nb):
+                self._bucket_after_op[id(op)] = (lo, end)
+                lo = end
+        self._bucket_tail = (lo, total)
         ws = max([op.wgrad_ws_bytes() for op in self.ops if hasattr(op, "wgrad_ws_bytes")] +
                  [lib().head1x1_wgrad_ws_bytes(self.batch, h.src.shape[1], h.k, h.src.spatial) for h in self.heads])
         self.wgrad_ws = torch.empty((ws + 3) // 4, dtype=torch.float32, device=self.device)
@@ -461,14 +485,19 @@ class Engine:
                     h.out.grad.zero_()
                 else:
                     h.out.grad.copy_(g)
+        hook = self.grad_bucket_hook
         for op in reversed(self.ops):
             if isinstance(op, HeadOp) and not op.active:
                 # inactive head (no deep supervision): its source still needs a defined gradient
                 if op.acc == 0:
                     op.src.grad.zero_()
                 self.grads[op.w_name].zero_()
-                continue
-            op.backward()
+            else:
+                op.backward()
+            if hook is not None and id(op) in self._bucket_after_op:
+                hook(*self._bucket_after_op[id(op)])           # gradients in flat[lo:hi] are final
+        if hook is not None and self._bucket_tail[1] > self._bucket_tail[0]:
+            hook(*self._bucket_tail)
         return self.grads
 
     def loss_backward(self, targets: Sequence[torch.Tensor], weights: Sequence[float], batch_dice=False, smooth=1e-5):

@@ -76,6 +76,34 @@ def allreduce_mean_flat(flat: torch.Tensor, group=None, force: bool = False):
     return flat
 
 
+class OverlappedGradAllReduce:
+    """Data-parallel gradient averaging overlapped with the backward pass.  The engine lays its flat gradient buffer
+    out in backward-completion order and calls ``grad_bucket_hook(lo, hi)`` when a slice is final; each slice goes out
+    as an asynchronous RCCL all-reduce (the process group's stream waits for the work issued so far, later backward
+    kernels keep running on the compute stream), finish() joins them and applies the 1/world scale."""
+
+    def __init__(self, engine, group=None, force: bool = False):
+        self.engine, self.group, self.force = engine, group, force
+        self.world = dist.get_world_size(group)
+        self.handles = []
+        self.active = self.world > 1 or force
+        if self.active:
+            engine.grad_bucket_hook = self._bucket
+
+    def _bucket(self, lo, hi):
+        self.handles.append(dist.all_reduce(self.engine.grad_flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
+                                            async_op=True))
+
+    def finish(self):
+        if not self.active:
+            return
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+        if self.world > 1:
+            self.engine.grad_flat.mul_(1.0 / self.world)
+
+
 def broadcast_kernel_masks(kmasks: Dict[str, torch.Tensor], src: int = 0, group=None):
     """Broadcast the uint8 kernel maps (1.39 M kernels at 32 ch = 1.4 MB) from ``src`` as one tensor."""
     names = list(kmasks.keys())

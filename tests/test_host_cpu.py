@@ -171,6 +171,14 @@ assert torch.allclose(grads["b"], torch.arange(4, dtype=torch.float32) * (1 + wo
 flat = torch.arange(70, dtype=torch.float32) * (rank + 1)          # the engine's flat gradient buffer: in place
 views = [flat[0:6].view(2, 3), flat[64:70]]
 parallel.allreduce_mean_flat(flat)
+
+class _Eng:                                                         # bucketed, overlapped variant (engine hook protocol)
+    pass
+eng = _Eng(); eng.grad_flat = torch.arange(70, dtype=torch.float32) * (rank + 1); eng.grad_bucket_hook = None
+ov = parallel.OverlappedGradAllReduce(eng)
+eng.grad_bucket_hook(0, 64); eng.grad_bucket_hook(64, 70)
+ov.finish()
+assert torch.allclose(eng.grad_flat, torch.arange(70, dtype=torch.float32) * (1 + world) / 2.0)
 assert torch.allclose(flat, torch.arange(70, dtype=torch.float32) * (1 + world) / 2.0)
 assert torch.allclose(views[1], torch.arange(64, 70, dtype=torch.float32) * (1 + world) / 2.0)
 km = {"k": (torch.arange(12).reshape(3, 4) %% (rank + 2) == 0).to(torch.uint8)}
