@@ -81,7 +81,14 @@ struct Cfg {
     // VEC 4: consecutive lane rows are PH*SH tile rows apart; (PH*SH*pitch) % 64 == 32 puts the four 16-lane groups
     // of a ds_read_b128 on disjoint bank quarters.  VEC 2: the same idea for the two lane rows of a ds_read_b64 group.
     if (VEC == 4) { while ((LROW * p) % 64 != 32 && p < iw + 64) p += 4; }
-    else if (VEC == 2) { p = iw; while (p % 8 != 4) ++p; }
+    else if (VEC == 2) {
+      // a 32-lane ds_read_b64 group = 32 / LX lane rows of LX lanes x 2 banks: row r must start at bank 2 LX r (mod 64)
+      p = (iw + 1) & ~1;
+      int q = p;
+      while ((LROW * q) % 64 != (2 * LX) % 64 && q < iw + 64) q += 2;
+      if (q < iw + 64) p = q;
+      else { p = iw; while (p % 8 != 4) ++p; }
+    }
     else p = iw;
     return p;
   }
@@ -502,6 +509,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
       float* yp = p.y + (((long long)n * p.Q + q) * p.Do + d) * out_plane;
       float s = 0.f;
       const bool vec_store = (C::PW == 4) && (p.Wo % 4 == 0);      // lane rows are 16-byte aligned
+      const bool vec2_store = (C::PW == 2) && (p.Wo % 2 == 0);     // ... or 8-byte aligned pairs
 #pragma unroll
       for (int i = 0; i < C::PH; ++i) {
         const int oh = oh0 + i;
@@ -511,13 +519,15 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
           const float val = acc[a][i][j] + bq;
           acc[a][i][j] = val;
           if (oh < p.Ho && ow < p.Wo) {
-            if (!vec_store) yp[(long long)oh * p.Wo + ow] = val;
+            if (!vec_store && !vec2_store) yp[(long long)oh * p.Wo + ow] = val;
             s += val;
           }
         }
         if (vec_store && oh < p.Ho && ow0 < p.Wo)
           *reinterpret_cast<float4*>(yp + (long long)oh * p.Wo + ow0) =
               make_float4(acc[a][i][0], acc[a][i][1 % C::PW], acc[a][i][2 % C::PW], acc[a][i][3 % C::PW]);
+        if (vec2_store && oh < p.Ho && ow0 < p.Wo)
+          *reinterpret_cast<float2*>(yp + (long long)oh * p.Wo + ow0) = make_float2(acc[a][i][0], acc[a][i][1 % C::PW]);
       }
       psum[a] = s;
     } else {
@@ -538,9 +548,20 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
       if (zero_fill && oc.accumulate) continue;
       float* xp = oc.ptr + (long long)n * oc.nstride + (long long)dd * out_plane;
       const bool vec_store = (C::PW == 4) && (p.Wo % 4 == 0);
+      const bool vec2_store = (C::PW == 2) && (p.Wo % 2 == 0);
 #pragma unroll
       for (int i = 0; i < C::PH; ++i) {
         const int oh = oh0 + i;
+        if (vec2_store) {
+          if (oh < p.Ho && ow0 < p.Wo) {
+            float2* dst = reinterpret_cast<float2*>(xp + (long long)oh * p.Wo + ow0);
+            float2 val = make_float2(acc[a][i][0], acc[a][i][1 % C::PW]);
+            if (zero_fill) val = make_float2(0.f, 0.f);
+            else if (oc.accumulate) { const float2 o = *dst; val.x += o.x; val.y += o.y; }
+            *dst = val;
+          }
+          continue;
+        }
         if (vec_store) {
           if (oh < p.Ho && ow0 < p.Wo) {
             float4* dst = reinterpret_cast<float4*>(xp + (long long)oh * p.Wo + ow0);
