@@ -16,6 +16,18 @@ namespace {
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef const f32x4_t __attribute__((address_space(1)))* gf4_p;
 
+// flat voxel index inside one sample -> (d, h, w).  A sample has fewer than 2^31 voxels (checked by the entry points),
+// so this is 32-bit unsigned arithmetic: the 64-bit `%` and `/` the index types would imply cost ~100 vector
+// instructions each and used to dominate the staging code of these kernels.
+__device__ __forceinline__ void decode_dhw(long long v, int W, int H, int& dv, int& hv, int& wv) {
+  const unsigned u = (unsigned)v;
+  const unsigned r = u / (unsigned)W;
+  wv = (int)(u - r * (unsigned)W);
+  const unsigned d = r / (unsigned)H;
+  hv = (int)(r - d * (unsigned)H);
+  dv = (int)d;
+}
+
 __device__ __forceinline__ void tap_ijk(int t, int kh, int kw, int& i, int& j, int& k) {
   k = t % kw;
   const int r = t / kw;
@@ -74,9 +86,8 @@ __global__ __launch_bounds__(256) void convT_fwd_kernel(const float* __restrict_
   const int Ho = H * kh, Wo = W * kw;
   float* yp = y + ((long long)n * Cout + o) * spatial * KT;
   if (VPL == 2 && kw == 2 && (W % 2) == 0 && v0 + 1 < spatial) {
-    const int wv = (int)(v0 % W);
-    const long long r = v0 / W;
-    const int hv = (int)(r % H), dv = (int)(r / H);
+    int dv, hv, wv;
+    decode_dhw(v0, W, H, dv, hv, wv);
 #pragma unroll
     for (int t = 0; t < KT; t += 2) {
       int i, j, k;
@@ -90,9 +101,8 @@ __global__ __launch_bounds__(256) void convT_fwd_kernel(const float* __restrict_
   for (int v = 0; v < VPL; ++v) {
     const long long vi = v0 + v;
     if (vi >= spatial) continue;
-    const int wv = (int)(vi % W);
-    const long long r = vi / W;
-    const int hv = (int)(r % H), dv = (int)(r / H);
+    int dv, hv, wv;
+    decode_dhw(vi, W, H, dv, hv, wv);
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
       int i, j, k;
@@ -113,9 +123,8 @@ __global__ __launch_bounds__(256) void convT_dgrad_kernel(const float* __restric
   const long long vi = (long long)blockIdx.x * 256 + threadIdx.x;
   const bool in = vi < spatial;
   const long long vv = in ? vi : 0;
-  const int wv = (int)(vv % W);
-  const long long r = vv / W;
-  const int hv = (int)(r % H), dv = (int)(r / H);
+  int dv, hv, wv;
+  decode_dhw(vv, W, H, dv, hv, wv);
   const int Ho = H * kh, Wo = W * kw;
   long long offs[KT];
 #pragma unroll
@@ -207,9 +216,8 @@ __global__ __launch_bounds__(256) void convT_wgrad_kernel(const float* __restric
       const long long vi = vbase + pv;
       float val = 0.f;
       if (o < Cout && vi < spatial) {
-        const int wv = (int)(vi % W);
-        const long long r = vi / W;
-        const int hv = (int)(r % H), dv = (int)(r / H);
+        int dv, hv, wv;
+        decode_dhw(vi, W, H, dv, hv, wv);
         int i, j, k;
         tap_ijk(t, kh, kw, i, j, k);
         val = dy[((long long)n * Cout + o) * spatial * KT + ((long long)(dv * kd + i) * Ho + (hv * kh + j)) * Wo + (wv * kw + k)];
@@ -309,9 +317,8 @@ __global__ __launch_bounds__(256 * NCB) void convT_wgrad_v2_kernel(const float* 
         const bool ok = o < Cout && vi + 1 < spatial;
         long long off = 0;
         if (ok) {
-          const int wv = (int)(vi % W);
-          const long long r = vi / W;
-          const int hv = (int)(r % H), dv = (int)(r / H);
+          int dv, hv, wv;
+          decode_dhw(vi, W, H, dv, hv, wv);
           const int i = rr / kh, j = rr - i * kh;
           off = ((long long)n * Cout + o) * ospatial + ((long long)(dv * kd + i) * Ho + (hv * kh + j)) * Wo + 2 * wv;
         }
@@ -428,9 +435,8 @@ __global__ __launch_bounds__(256) void convT_dgrad_v2_kernel(const float* __rest
       const bool ok = o < Cout && vi + 1 < spatial;
       long long off = 0;
       if (ok) {
-        const int wv = (int)(vi % W);
-        const long long r = vi / W;
-        const int hv = (int)(r % H), dv = (int)(r / H);
+        int dv, hv, wv;
+        decode_dhw(vi, W, H, dv, hv, wv);
         const int ii = rr / kh, jj = rr - ii * kh;
         off = ((long long)n * Cout + o) * ospatial + ((long long)(dv * kd + ii) * Ho + (hv * kh + jj)) * Wo + 2 * wv;
       }
@@ -508,9 +514,37 @@ __global__ __launch_bounds__(256) void convT_dgrad_v3_kernel(const float* __rest
   if (tile_lo >= tile_hi) return;
 
   f32x4_t v[NUY];
+  // per-thread part of the dy offsets, constant over the tiles when a tile (32 consecutive voxels) never crosses a row
+  // (W % 32 == 0): unit = (o, output row rr, voxel pair vp) -> o * ospatial + (ii * Ho + jj) * Wo + 4 vp; the tile adds
+  // a wave-uniform base.  (The general path below re-derives (d, h, w) per unit with 64-bit divisions: ~1000 vector
+  // instructions per tile and thread, more than the MFMA phase.)
+  const bool row_tiles = (W % TV) == 0;
+  long long uoff[NUY];
+#pragma unroll
+  for (int i = 0; i < NUY; ++i) {
+    const int u = tid + i * 256;
+    const int ol = u / (KDH * (TV / 2));
+    const int rem = u - ol * (KDH * (TV / 2));
+    const int rr = rem / (TV / 2), vp = rem - rr * (TV / 2);
+    const int ii = rr / kh, jj = rr - ii * kh;
+    uoff[i] = (long long)ol * ospatial + ((long long)ii * Ho + jj) * Wo + 4 * vp;
+  }
   auto prefetch = [&](long long tile, int o0) {
     const int n = (int)(tile / tiles_per_n);
     const long long vbase = (tile - (long long)n * tiles_per_n) * TV;
+    if (row_tiles) {
+      int dv, hv, w0;
+      decode_dhw(vbase, W, H, dv, hv, w0);
+      const long long tbase = ((long long)n * Cout + o0) * ospatial + ((long long)dv * kd * Ho + (long long)hv * kh) * Wo + 2 * w0;
+#pragma unroll
+      for (int i = 0; i < NUY; ++i) {
+        const int u = tid + i * 256;
+        const int ol = u / (KDH * (TV / 2));
+        const bool ok = o0 + ol < Cout;                  // (spatial % 32 == 0 here: no ragged last tile)
+        v[i] = *reinterpret_cast<gf4_p>((gfloat_p)dy + (ok ? tbase + uoff[i] : 0));
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NUY; ++i) {
       const int u = tid + i * 256;                       // unit = (o, output row rr, voxel pair vp)
@@ -522,9 +556,8 @@ __global__ __launch_bounds__(256) void convT_dgrad_v3_kernel(const float* __rest
       const bool ok = o < Cout && vi + 1 < spatial;
       long long off = 0;
       if (ok) {
-        const int wv = (int)(vi % W);
-        const long long r = vi / W;
-        const int hv = (int)(r % H), dv = (int)(r / H);
+        int dv, hv, wv;
+        decode_dhw(vi, W, H, dv, hv, wv);
         const int ii = rr / kh, jj = rr - ii * kh;
         off = ((long long)n * Cout + o) * ospatial + ((long long)(dv * kd + ii) * Ho + (hv * kh + jj)) * Wo + 2 * wv;
       }
@@ -567,11 +600,29 @@ __global__ __launch_bounds__(256) void convT_dgrad_v3_kernel(const float* __rest
 #pragma unroll
       for (int b = 0; b < TV / 16; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
       const float* bp = ds + lk * TS + li;
+      // B fragments in groups of G k-steps, two register sets: the LDS reads of group g + 1 are in flight while the
+      // MFMAs of group g issue (left to the compiler this loop was read -> wait -> 2 MFMAs, one LDS round trip per k-step)
+      constexpr int G = 8, NB = TV / 16;
+      float bfr[2][G][NB];
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
+      for (int i = 0; i < G; ++i)
 #pragma unroll
-        for (int b = 0; b < TV / 16; ++b)
-          acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[s], bp[4 * s * TS + b * 16], acc[b], 0, 0, 0);
+        for (int b = 0; b < NB; ++b) bfr[0][i][b] = bp[4 * i * TS + b * 16];
+#pragma unroll
+      for (int g = 0; g < KS / G; ++g) {
+        if (g + 1 < KS / G) {
+#pragma unroll
+          for (int i = 0; i < G; ++i)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) bfr[(g + 1) & 1][i][b] = bp[4 * ((g + 1) * G + i) * TS + b * 16];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < G; ++i)
+#pragma unroll
+          for (int b = 0; b < NB; ++b)
+            acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[g * G + i], bfr[g & 1][i][b], acc[b], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
       // D[i = c][j = v]: col = lane & 15 -> v, row = (lane >> 4) * 4 + reg -> c
       const int n = (int)(tile / tiles_per_n);
@@ -646,6 +697,7 @@ extern "C" int e2e_convT_fwd(const float* x, const float* scale, const float* sh
                              int kh, int kw, void* stream) {
   E2E_REQUIRE(x && w && y, "convT_fwd: null pointer");
   E2E_REQUIRE(check_k(kd, kh, kw), "convT_fwd: kernel must be in {1,2}^3");
+  E2E_REQUIRE((long long)D * H * W * kd * kh * kw < (1ll << 31), "convT_fwd: a sample must have fewer than 2^31 output voxels");
   E2E_REQUIRE((scale == nullptr) == (shift == nullptr), "convT_fwd: scale/shift must both be given");
   hipStream_t st = (hipStream_t)stream;
   const long long spatial = (long long)D * H * W;
@@ -670,6 +722,7 @@ extern "C" int e2e_convT_dgrad(const float* dy, const float* w, const unsigned* 
                                int B, int Cin, int Cout, int D, int H, int W, int kd, int kh, int kw, void* stream) {
   E2E_REQUIRE(dy && w && dx, "convT_dgrad: null pointer");
   E2E_REQUIRE(check_k(kd, kh, kw), "convT_dgrad: kernel must be in {1,2}^3");
+  E2E_REQUIRE((long long)D * H * W * kd * kh * kw < (1ll << 31), "convT_dgrad: a sample must have fewer than 2^31 output voxels");
   hipStream_t st = (hipStream_t)stream;
   const long long spatial = (long long)D * H * W;
   // v3 (dense GEMM on the matrix cores) for the large planes
@@ -722,6 +775,7 @@ extern "C" int e2e_convT_wgrad(const float* x, const float* scale, const float* 
                                int kw, void* stream) {
   E2E_REQUIRE(x && dy && dw && ws, "convT_wgrad: null pointer");
   E2E_REQUIRE(check_k(kd, kh, kw), "convT_wgrad: kernel must be in {1,2}^3");
+  E2E_REQUIRE((long long)D * H * W * kd * kh * kw < (1ll << 31), "convT_wgrad: a sample must have fewer than 2^31 output voxels");
   hipStream_t st = (hipStream_t)stream;
   const long long total_tiles = e2e::cdivll((long long)D * H * W, WG_TPX) * B;
   int tpc;
