@@ -70,8 +70,8 @@ __global__ __launch_bounds__(256) void conv133_wgrad_kernel(WgParams p) {
   for (int ti = 0; ti < p.tiles_per_chunk; ++ti) {
     const long long tile = (long long)chunk * p.tiles_per_chunk + ti;
     if (tile >= p.total_tiles) break;
-    int t = (int)(tile % p.tiles_per_n);
-    const int n = (int)(tile / p.tiles_per_n);
+    const int n = (int)((unsigned)tile / (unsigned)p.tiles_per_n);
+    int t = (int)tile - n * p.tiles_per_n;
     const int tx = t % p.tiles_x;
     t /= p.tiles_x;
     const int ty = t % p.tiles_y;
@@ -217,8 +217,8 @@ __global__ __launch_bounds__(256 * NCB) void conv133_wgrad_v2_kernel(WgParams p)
   if (tile_hi > p.total_tiles) tile_hi = p.total_tiles;
 
   auto decode = [&](long long tile, int& n, int& d0, int& h0, int& w0) {
-    int t = (int)(tile % p.tiles_per_n);
-    n = (int)(tile / p.tiles_per_n);
+    n = (int)((unsigned)tile / (unsigned)p.tiles_per_n);      // (fewer than 2^31 tiles: 32-bit division)
+    int t = (int)tile - n * p.tiles_per_n;
     const int tx = t % p.tiles_x;
     t /= p.tiles_x;
     const int ty = t % p.tiles_y;
@@ -677,8 +677,8 @@ __global__ __launch_bounds__(256) void conv133_wgrad_s2_kernel(WgParams p) {
   if (tile_hi > p.total_tiles) tile_hi = p.total_tiles;
 
   auto decode = [&](long long tile, int& n, int& d0, int& h0, int& w0) {
-    int t = (int)(tile % p.tiles_per_n);
-    n = (int)(tile / p.tiles_per_n);
+    n = (int)((unsigned)tile / (unsigned)p.tiles_per_n);      // (fewer than 2^31 tiles: 32-bit division)
+    int t = (int)tile - n * p.tiles_per_n;
     const int tx = t % p.tiles_x;
     t /= p.tiles_x;
     const int ty = t % p.tiles_y;

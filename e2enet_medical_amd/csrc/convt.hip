@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void convT_wgrad_kernel(const float* __restric
   for (int ti = 0; ti < tiles_per_chunk; ++ti) {
     const long long tile = (long long)chunk * tiles_per_chunk + ti;
     if (tile >= total_tiles) break;
-    const int n = (int)(tile / tiles_per_n);
+    const int n = (int)((unsigned)tile / (unsigned)tiles_per_n);
     const long long vbase = (tile - (long long)n * tiles_per_n) * WG_TPX;
     // stage z[32 c][64 v]
     for (int idx = tid; idx < 32 * WG_TPX; idx += 256) {
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256 * NCB) void convT_wgrad_v2_kernel(const float* 
   f32x4_t vz[2], vy[YCW][YIT];
   float za[2], zb[2];
   auto prefetch = [&](long long tile) {
-    const int n = (int)(tile / tiles_per_n);
+    const int n = (int)((unsigned)tile / (unsigned)tiles_per_n);
     const long long vbase = (tile - (long long)n * tiles_per_n) * WG_TPX;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256 * NCB) void convT_wgrad_v2_kernel(const float* 
     }
   };
   auto commit = [&](long long tile) {
-    const int n = (int)(tile / tiles_per_n);
+    const int n = (int)((unsigned)tile / (unsigned)tiles_per_n);
     const long long vbase = (tile - (long long)n * tiles_per_n) * WG_TPX;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) void convT_dgrad_v2_kernel(const float* __rest
   const long long spatial = (long long)D * H * W;
   const long long tiles_per_n = e2e::cdivll(spatial, 64);
   const long long tile = blockIdx.x;
-  const int n = (int)(tile / tiles_per_n);
+  const int n = (int)((unsigned)tile / (unsigned)tiles_per_n);
   const long long vbase = (tile - (long long)n * tiles_per_n) * 64;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256) void convT_dgrad_v3_kernel(const float* __rest
     uoff[i] = (long long)ol * ospatial + ((long long)ii * Ho + jj) * Wo + 4 * vp;
   }
   auto prefetch = [&](long long tile, int o0) {
-    const int n = (int)(tile / tiles_per_n);
+    const int n = (int)((unsigned)tile / (unsigned)tiles_per_n);
     const long long vbase = (tile - (long long)n * tiles_per_n) * TV;
     if (row_tiles) {
       int dv, hv, w0;
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(256) void convT_dgrad_v3_kernel(const float* __rest
     }
   };
   auto commit = [&](long long tile, int o0) {
-    const int n = (int)(tile / tiles_per_n);
+    const int n = (int)((unsigned)tile / (unsigned)tiles_per_n);
     const long long vbase = (tile - (long long)n * tiles_per_n) * TV;
 #pragma unroll
     for (int i = 0; i < NUY; ++i) {
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(256) void convT_dgrad_v3_kernel(const float* __rest
         __builtin_amdgcn_sched_barrier(0);
       }
       // D[i = c][j = v]: col = lane & 15 -> v, row = (lane >> 4) * 4 + reg -> c
-      const int n = (int)(tile / tiles_per_n);
+      const int n = (int)((unsigned)tile / (unsigned)tiles_per_n);
       const long long vbase = (tile - (long long)n * tiles_per_n) * TV;
 #pragma unroll
       for (int b = 0; b < TV / 16; ++b) {
