@@ -292,6 +292,15 @@ __global__ __launch_bounds__(256 * NCB) void convT_wgrad_v2_kernel(const float* 
   // z: each wave stages 8 channels x 64 voxels = 128 float4 -> 2 iterations; lane -> (channel k = g / 16, group g % 16)
   f32x4_t vz[2], vy[YCW][YIT];
   float za[2], zb[2];
+  const bool row_tiles = (W % WG_TPX) == 0;            // => spatial % 64 == 0 as well: no ragged last tile
+  long long yoff[YIT];
+#pragma unroll
+  for (int it = 0; it < YIT; ++it) {
+    const int g = lane + 64 * it;
+    const int rr = g >> 5, vp = g & 31;
+    const int i = rr / kh, j = rr - i * kh;
+    yoff[it] = ((long long)i * Ho + j) * Wo + 4 * vp;
+  }
   auto prefetch = [&](long long tile) {
     const int n = (int)((unsigned)tile / (unsigned)tiles_per_n);
     const long long vbase = (tile - (long long)n * tiles_per_n) * WG_TPX;
@@ -305,6 +314,20 @@ __global__ __launch_bounds__(256 * NCB) void convT_wgrad_v2_kernel(const float* 
       vz[it] = *reinterpret_cast<gf4_p>((gfloat_p)x + off);
       za[it] = 1.f; zb[it] = 0.f;
       if (scale != nullptr && c < Cin) { za[it] = scale[(long long)n * Cin + c]; zb[it] = shift[(long long)n * Cin + c]; }
+    }
+    if (row_tiles) {      // the 64-voxel tile lies inside one input row: wave-uniform base + per-thread constant offsets
+      int dv, hv, w0;
+      decode_dhw(vbase, W, H, dv, hv, w0);
+      const long long tbase = ((long long)n * Cout + ob * 32 + wave * YCW) * ospatial +
+                              ((long long)dv * kd * Ho + (long long)hv * kh) * Wo + 2 * w0;
+#pragma unroll
+      for (int k = 0; k < YCW; ++k)
+#pragma unroll
+        for (int it = 0; it < YIT; ++it) {
+          const bool ok = ob * 32 + wave * YCW + k < Cout;
+          vy[k][it] = *reinterpret_cast<gf4_p>((gfloat_p)dy + (ok ? tbase + k * ospatial + yoff[it] : 0));
+        }
+      return;
     }
 #pragma unroll
     for (int k = 0; k < YCW; ++k) {
