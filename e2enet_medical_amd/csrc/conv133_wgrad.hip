@@ -634,6 +634,181 @@ __global__ __launch_bounds__(512) void conv133_wgrad_v3_kernel(WgParams p) {
   }
 }
 
+// ---- network input layer: Cin <= 4 (BraTS: 4 modalities, CT: 1), stride 1, large planes ------------------------------
+// A 32 x 32 channel block would spend 7/8 of its MFMAs on padding.  Here the 16 columns of a B fragment are
+// (4 channels) x (4 taps): the 9 taps take 3 MFMAs per k-step instead of 9, the four waves split the 32 output
+// channels (2) and the rows of the 8 x 32 tile (2), and only the real input channels are staged.  The two row halves
+// write separate slabs (chunk 2 b + half), summed by the slab reduction like any other chunk.
+struct WSCfg {
+  static constexpr int TH = 8, TW = 32, TP = TH * TW;
+  static constexpr int IH = TH + 2, NQ = TW / 4 + 2, PITCH = 4 * NQ, COL0 = 3;
+  static constexpr int CS = IH * PITCH + 8;                  // 408: channel c starts 8 c banks further
+  static constexpr int OS = TP + 2;                          // 258 = 2 x odd
+  static constexpr int GPC = IH * NQ;                        // 100 float4 groups per channel
+  static constexpr int LDS_FLOATS = 4 * CS + 32 * OS;
+};
+
+__global__ __launch_bounds__(256) void conv133_wgrad_smallc_kernel(WgParams p) {
+  using C = WSCfg;
+  __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS + 8];
+  float* xs = lds;
+  float* ys = lds + 4 * C::CS;
+
+  const int segs = p.cblocks_segs;
+  const int n = blockIdx.x / segs, seg = blockIdx.x - n * segs;
+  const int ob = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int oh = wave & 1, kq = wave >> 1;
+  const long long in_plane = (long long)p.Hi * p.Wi;
+  const long long out_plane = (long long)p.Ho * p.Wo;
+
+  f32x4 acc[3];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int tile_lo = seg * p.tiles_per_chunk;
+  int tile_hi = tile_lo + p.tiles_per_chunk;
+  if (tile_hi > p.tiles_per_n) tile_hi = p.tiles_per_n;
+  auto decode = [&](int tile, int& d0, int& h0, int& w0) {
+    const int tx = tile % p.tiles_x;
+    const int t = tile / p.tiles_x;
+    const int ty = t % p.tiles_y;
+    d0 = t / p.tiles_y;
+    h0 = ty * C::TH;
+    w0 = tx * C::TW;
+  };
+
+  // wave w stages input channel w (if it exists): descriptor in scalar registers
+  const bool xval = wave < p.Cin;
+  const e2e_in_chan_t chd = p.chans[xval ? wave : 0];
+  const gfloat_p xbase = (gfloat_p)(chd.ptr + (long long)n * chd.nstride);
+  float xa = 1.f, xb = 0.f, xsl = 1.f;
+  if (xval && chd.scale != nullptr) {
+    xa = chd.scale[(long long)n * chd.ab_nstride];
+    xb = chd.shift[(long long)n * chd.ab_nstride];
+    xsl = chd.slope;
+  }
+  const int xdsh = chd.dshift;
+
+  // dy: 32 channels x 64 float4 groups = 8 per thread: thread -> (channel tid / 64 + 4 it, group lane)
+  const int y_pi = lane * 4;
+  const int y_r = y_pi / C::TW, y_col = y_pi - y_r * C::TW;
+  f32x4_t vx[2], vy[8];
+  auto prefetch = [&](int d0, int h0, int w0) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      int g = lane + 64 * it;
+      if (g >= C::GPC) g = C::GPC - 1;
+      const int r = g / C::NQ, q = g - r * C::NQ;
+      const int hi = h0 - 1 + r, gc = w0 - 4 + 4 * q;
+      const int din = d0 * p.sd - xdsh;
+      const bool ok = xval && (unsigned)hi < (unsigned)p.Hi && gc >= 0 && gc + 3 < p.Wi && (unsigned)din < (unsigned)p.Di;
+      vx[it] = *reinterpret_cast<gf4_p>(xbase + (ok ? (long long)din * in_plane + (long long)hi * p.Wi + gc : 0));
+    }
+    const int ho = h0 + y_r, wo = w0 + y_col;
+    const bool yok = ho < p.Ho && wo + 3 < p.Wo;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int o = ob * 32 + wave + 4 * it;
+      const bool ok = yok && o < p.Cout;
+      const long long off = ok ? (((long long)n * p.Cout + o) * p.Do + d0) * out_plane + (long long)ho * p.Wo + wo : 0;
+      vy[it] = *reinterpret_cast<gf4_p>((gfloat_p)p.dy + off);
+    }
+  };
+  auto commit = [&](int d0, int h0, int w0) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int g = lane + 64 * it;
+      if (g >= C::GPC) continue;
+      const int r = g / C::NQ, q = g - r * C::NQ;
+      const int hi = h0 - 1 + r, gc = w0 - 4 + 4 * q;
+      const int din = d0 * p.sd - xdsh;
+      const bool ok = xval && (unsigned)hi < (unsigned)p.Hi && gc >= 0 && gc + 3 < p.Wi && (unsigned)din < (unsigned)p.Di;
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float t = e2e::in_act(vx[it][j], xa, xb, xsl);
+        v[j] = ok ? t : 0.f;
+      }
+      float2* dst = reinterpret_cast<float2*>(xs + wave * C::CS + r * C::PITCH + 4 * q);
+      dst[0] = make_float2(v[0], v[1]);
+      dst[1] = make_float2(v[2], v[3]);
+    }
+    const int ho = h0 + y_r, wo = w0 + y_col;
+    const bool yok = ho < p.Ho && wo + 3 < p.Wo;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int ol = wave + 4 * it;
+      const bool ok = yok && ob * 32 + ol < p.Cout;
+      float2* dst = reinterpret_cast<float2*>(ys + ol * C::OS + y_pi);
+      dst[0] = ok ? make_float2(vy[it][0], vy[it][1]) : make_float2(0.f, 0.f);
+      dst[1] = ok ? make_float2(vy[it][2], vy[it][3]) : make_float2(0.f, 0.f);
+    }
+  };
+
+  // B-fragment column li = (channel li & 3, tap 4 m + (li >> 2)); taps >= 9 compute garbage columns that are never stored
+  const int li = lane & 15, lk = lane >> 4;
+  int boff[3];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    int tap = 4 * m + (li >> 2);
+    if (tap > 8) tap = 8;
+    boff[m] = (li & 3) * C::CS + (tap / 3) * C::PITCH + (tap % 3) + lk + C::COL0;
+  }
+
+  if (tile_lo < tile_hi) {
+    int d0, h0, w0;
+    decode(tile_lo, d0, h0, w0);
+    prefetch(d0, h0, w0);
+    for (int tile = tile_lo; tile < tile_hi; ++tile) {
+      commit(d0, h0, w0);
+      __syncthreads();
+      if (tile + 1 < tile_hi) {
+        decode(tile + 1, d0, h0, w0);
+        prefetch(d0, h0, w0);
+      }
+      const float* ap = ys + (oh * 16 + li) * C::OS + lk + kq * (C::TH / 2) * C::TW;
+      const float* bp = xs + kq * (C::TH / 2) * C::PITCH;
+      float a_cur = ap[0], b_cur[3];
+#pragma unroll
+      for (int m = 0; m < 3; ++m) b_cur[m] = bp[boff[m]];
+#pragma unroll
+      for (int row = 0; row < C::TH / 2; ++row) {
+#pragma unroll
+        for (int cq = 0; cq < C::TW / 4; ++cq) {
+          const int nrow = cq + 1 < C::TW / 4 ? row : row + 1, ncq = cq + 1 < C::TW / 4 ? cq + 1 : 0;
+          const float a_nxt = ap[nrow * C::TW + ncq * 4];           // (read-ahead past the last k-step stays inside LDS)
+          float b_nxt[3];
+#pragma unroll
+          for (int m = 0; m < 3; ++m) b_nxt[m] = bp[nrow * C::PITCH + ncq * 4 + boff[m]];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int m = 0; m < 3; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur, b_cur[m], acc[m], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          a_cur = a_nxt;
+#pragma unroll
+          for (int m = 0; m < 3; ++m) b_cur[m] = b_nxt[m];
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // D[i = o][j = column]: column = lane & 15 -> (c, tap), row = (lane >> 4) * 4 + reg -> o
+  float* sp = p.slab + ((long long)blockIdx.x * 2 + kq) * p.Cout * p.Cin * 9;
+  const int c = li & 3;
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    const int tap = 4 * m + (li >> 2);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = ob * 32 + oh * 16 + (lane >> 4) * 4 + r;
+      if (o < p.Cout && c < p.Cin && tap < 9) sp[((long long)o * p.Cin + c) * 9 + tap] = acc[m][r];
+    }
+  }
+}
+
 // ---- stride (2,2) in the plane ("convolutional pooling" convs), rows that are multiples of 4 floats ------------------
 // Same pipeline as v2.  Output tile 4 x 16; the 9 x 33 input patch it needs is staged per channel as rows of
 // [20 even columns | 20 odd columns] so that the B fragments (4 consecutive output pixels = input columns 2 apart)
@@ -934,6 +1109,29 @@ inline int plan_v3(WgParams& p, int pairs) {
   return segs * p.B;
 }
 
+// network input layer (Cin <= 4): stride 1, rows multiples of 4 floats, planes at least one 8 x 32 tile
+inline bool use_smallc(int Cin, int Hi, int Wi, int sh, int sw) {
+  static const int off = getenv("E2E_WG_NOSMALLC") ? atoi(getenv("E2E_WG_NOSMALLC")) : 0;
+  return !off && Cin <= 4 && sh == 1 && sw == 1 && (Wi % 4) == 0 && Wi >= 32 && Hi >= 8;
+}
+inline int plan_smallc(WgParams& p, int pairs) {        // returns the number of workgroup chunks (slabs = 2 x that)
+  p.tiles_x = e2e::cdiv(p.Wo, 32);
+  p.tiles_y = e2e::cdiv(p.Ho, 8);
+  p.tiles_d = p.Do;
+  p.tiles_per_n = p.tiles_d * p.tiles_y * p.tiles_x;
+  p.total_tiles = (long long)p.tiles_per_n * p.B;
+  long long want = 1024 / (pairs > 0 ? pairs : 1);          // 4 workgroups per CU
+  if (want < p.B) want = p.B;
+  int segs = (int)(want / p.B);
+  int tpc = e2e::cdiv(p.tiles_per_n, segs);
+  if (tpc < 4) tpc = 4;
+  if (tpc > p.tiles_per_n) tpc = p.tiles_per_n;
+  segs = e2e::cdiv(p.tiles_per_n, tpc);
+  p.tiles_per_chunk = tpc;
+  p.cblocks_segs = segs;
+  return segs * p.B;
+}
+
 // stride-(2,2) pipelined kernel: needs 16-byte aligned input rows and output planes at least one tile wide
 inline bool use_s2(int Wi, int Wo, int sh, int sw) { return sh == 2 && sw == 2 && (Wi % 4) == 0 && (Wo % 4) == 0 && Wo >= 16; }
 inline int s2_chunks(long long total_tiles, int pairs, int* tpc_out) {
@@ -967,6 +1165,8 @@ extern "C" long long e2e_conv133_wgrad_ws_bytes(int B, int Cin, int Cout, int Di
     p.tiles_per_n = p.tiles_d * p.tiles_y * p.tiles_x;
     p.total_tiles = (long long)p.tiles_per_n * B;
     nchunks = s2_chunks(p.total_tiles, pairs, &p.tiles_per_chunk);
+  } else if (use_smallc(Cin, Hi, Wi, sh, sw)) {
+    nchunks = 2 * plan_smallc(p, e2e::cdiv(Cout, 32));
   } else if (use_v3(Cin, Hi, Wi, sh, sw)) {
     nchunks = plan_v3(p, v3_pairs(Cin, Cout));
   } else if (use_v2(Wi, sh, sw)) {
@@ -1004,6 +1204,17 @@ extern "C" int e2e_conv133_wgrad(const e2e_in_chan_t* chans, const float* dy, fl
     nchunks = s2_chunks(p.total_tiles, pairs, &p.tiles_per_chunk);
     hipLaunchKernelGGL(conv133_wgrad_s2_kernel, dim3(nchunks, pairs), dim3(256), 0, st, p);
     rc = e2e::check_launch("conv133_wgrad_s2_kernel");
+    if (rc != E2E_OK) return rc;
+    hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)e2e::cdivll(numel, 64)), dim3(256), 0, st, p.slab, dw, numel,
+                       nchunks);
+    return e2e::check_launch("wgrad_slab_reduce_kernel");
+  }
+  if (use_smallc(Cin, Hi, Wi, sh, sw)) {
+    const int pairs = e2e::cdiv(Cout, 32);
+    const int wgs = plan_smallc(p, pairs);
+    nchunks = 2 * wgs;
+    hipLaunchKernelGGL(conv133_wgrad_smallc_kernel, dim3(wgs, pairs), dim3(256), 0, st, p);
+    rc = e2e::check_launch("conv133_wgrad_smallc_kernel");
     if (rc != E2E_OK) return rc;
     hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)e2e::cdivll(numel, 64)), dim3(256), 0, st, p.slab, dw, numel,
                        nchunks);

@@ -69,6 +69,8 @@ CONV_CASES = [
     (1, [(20, True), (15, False)], 40, (6, 32, 64), (2, 2, 2), 1.0),         # strided, wide planes (pipelined s2 wgrad)
     (2, [(33, True)], 34, (3, 24, 40), (1, 2, 2), 1.0),                      # in-plane stride only, ragged tiles
     (2, [(50, True), (40, False)], 70, (2, 20, 36), (1, 1, 1), 0.2),         # double-buffered wgrad, 64-out x 32-in blocks
+    (2, [(3, False)], 40, (3, 20, 36), (1, 1, 1), 1.0),                      # input layer: small-Cin wgrad (channel x tap columns)
+    (1, [(4, True)], 32, (2, 16, 64), (1, 1, 1), 1.0),
 ]
 
 
