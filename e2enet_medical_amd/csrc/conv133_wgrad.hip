@@ -424,9 +424,9 @@ __global__ __launch_bounds__(256 * NCB) void conv133_wgrad_v2_kernel(WgParams p)
 // registers holding tile t+1 are committed to the other image piece by piece between the k-steps, the loads of tile
 // t+2 are issued when that is done, and one barrier per tile publishes the new image.  A chunk never crosses a batch
 // item, so the channel descriptors are loaded once per workgroup.
-template <int NCB, int NOB>
+template <int NCB, int NOB, int NKB = 1>
 struct W3Cfg {
-  static_assert(NCB * NOB == 2, "8 waves: 2 x 2 sub-blocks of 16 x 16 for each of the two 32 x 32 blocks");
+  static_assert(NCB * NOB * NKB == 2, "8 waves: 2 x 2 sub-blocks of 16 x 16 for two 32 x 32 blocks, or for the two row halves of one");
   static constexpr int TH = 4, TW = 32, TP = TH * TW;
   static constexpr int IH = TH + 2;
   static constexpr int NQ = TW / 4 + 2;                       // float4 groups per input row (starts 4 left of the tile)
@@ -444,12 +444,13 @@ struct W3Cfg {
   static constexpr int XBUF = NCB * 32 * CS, YBUF = NOB * 32 * OS;
   static constexpr int LDS_FLOATS = 2 * (XBUF + YBUF);
   static constexpr int PIECES = XCW + YIT;
-  static_assert(PIECES <= TH * TW / 4, "one commit piece per k-step");
+  static constexpr int ROWS = TH / NKB;                       // tile rows per wave group
+  static_assert(PIECES <= ROWS * TW / 4, "one commit piece per k-step");
 };
 
-template <int NCB, int NOB>
+template <int NCB, int NOB, int NKB>
 __global__ __launch_bounds__(512) void conv133_wgrad_v3_kernel(WgParams p) {
-  using C = W3Cfg<NCB, NOB>;
+  using C = W3Cfg<NCB, NOB, NKB>;
   __shared__ __attribute__((aligned(16))) float lds3[C::LDS_FLOATS + 8];     // + slack for the read-ahead after the last k-step
   float* const xs0 = lds3;
   float* const ys0 = lds3 + 2 * C::XBUF;
@@ -462,6 +463,7 @@ __global__ __launch_bounds__(512) void conv133_wgrad_v3_kernel(WgParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cbl = NCB == 2 ? wave >> 2 : 0, obl = NOB == 2 ? wave >> 2 : 0, ch = wave & 1, oh = (wave >> 1) & 1;
+  const int kq = NKB == 2 ? wave >> 2 : 0;              // Cin <= 32 and Cout <= 32: the two wave groups split the tile rows
   const int obase = ob * NOB * 32;
   const long long in_plane = (long long)p.Hi * p.Wi;
   const long long out_plane = (long long)p.Ho * p.Wo;
@@ -577,8 +579,8 @@ __global__ __launch_bounds__(512) void conv133_wgrad_v3_kernel(WgParams p) {
     for (int tile = tile_lo; tile < tile_hi; ++tile) {
       const int buf = (tile - tile_lo) & 1;
       const bool more = tile + 1 < tile_hi;             // registers hold tile + 1 -> goes to image buf ^ 1 during this phase
-      const float* ap = ys0 + buf * C::YBUF + (obl * 32 + oh * 16 + li) * C::OS + lk;
-      const float* bp = xs0 + buf * C::XBUF + (cbl * 32 + ch * 16 + li) * C::CS + lk + C::COL0;
+      const float* ap = ys0 + buf * C::YBUF + (obl * 32 + oh * 16 + li) * C::OS + lk + kq * C::ROWS * C::TW;
+      const float* bp = xs0 + buf * C::XBUF + (cbl * 32 + ch * 16 + li) * C::CS + lk + C::COL0 + kq * C::ROWS * C::PITCH;
       float a_cur = ap[0];
       float b_cur[9];
 #pragma unroll
@@ -586,7 +588,7 @@ __global__ __launch_bounds__(512) void conv133_wgrad_v3_kernel(WgParams p) {
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) b_cur[kh * 3 + kw] = bp[kh * C::PITCH + kw];
 #pragma unroll
-      for (int row = 0; row < C::TH; ++row) {
+      for (int row = 0; row < C::ROWS; ++row) {
         const float* apr = ap + row * C::TW;
         const float* bpr = bp + row * C::PITCH;
 #pragma unroll
@@ -621,7 +623,7 @@ __global__ __launch_bounds__(512) void conv133_wgrad_v3_kernel(WgParams p) {
     }
   }
 
-  float* sp = p.slab + (long long)blockIdx.x * p.Cout * p.Cin * 9;
+  float* sp = p.slab + ((long long)blockIdx.x * NKB + kq) * p.Cout * p.Cin * 9;
   const int c = cbase + cbl * 32 + ch * 16 + (lane & 15);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -1075,11 +1077,9 @@ inline int v2_ncb(int Cin, int Ho, int Wo) {      // 8x8 planes: the (4,8,8) til
 
 // v3 (double-buffered 4 x 32 tiles): stride-1 planes at least 32 wide whose rows are multiples of 4 floats
 inline bool use_v3(int Cin, int Hi, int Wi, int sh, int sw) {
-  if (Cin <= 32) return false;
   static const int off = getenv("E2E_WG_NOV3") ? atoi(getenv("E2E_WG_NOV3")) : 0;
   return !off && sh == 1 && sw == 1 && (Wi % 4) == 0 && Wi >= 32 && Hi > 16;
 }
-// (one channel block needs 95 KB for the two images -> a single 4-wave workgroup per CU: v2 keeps those layers)
 // block shape of a v3 workgroup: 32 out x 64 in channels, or 64 out x 32 in.  The wide-out shape stages less (the
 // halo'd input tile is the expensive half) and pads fewer input channels (Cin = 160: three 64-blocks waste a sixth of
 // the MFMAs, five 32-blocks none): 160 -> 64 @64^3 runs at 122 instead of 97 TFLOP/s.
@@ -1087,7 +1087,9 @@ inline bool v3_wide_out(int Cin, int Cout) {
   (void)Cin;
   return Cout >= 64 && (Cout % 64) <= 0;
 }
+inline bool v3_ksplit(int Cin, int Cout) { return Cin <= 32 && Cout <= 32; }   // one 32 x 32 block: split the tile rows
 inline int v3_pairs(int Cin, int Cout) {
+  if (v3_ksplit(Cin, Cout)) return 1;
   return v3_wide_out(Cin, Cout) ? e2e::cdiv(Cin, 32) * e2e::cdiv(Cout, 64) : e2e::cdiv(Cin, 64) * e2e::cdiv(Cout, 32);
 }
 // chunks never cross a batch item: `segs` runs of tiles_per_chunk tiles per item; returns the number of chunks
@@ -1168,7 +1170,7 @@ extern "C" long long e2e_conv133_wgrad_ws_bytes(int B, int Cin, int Cout, int Di
   } else if (use_smallc(Cin, Hi, Wi, sh, sw)) {
     nchunks = 2 * plan_smallc(p, e2e::cdiv(Cout, 32));
   } else if (use_v3(Cin, Hi, Wi, sh, sw)) {
-    nchunks = plan_v3(p, v3_pairs(Cin, Cout));
+    nchunks = plan_v3(p, v3_pairs(Cin, Cout)) * (v3_ksplit(Cin, Cout) ? 2 : 1);
   } else if (use_v2(Wi, sh, sw)) {
     const int pairs = e2e::cdiv(Cin, 32 * v2_ncb(Cin, p.Ho, p.Wo)) * e2e::cdiv(Cout, 32);
     plan(p, pick(p.Ho, p.Wo, false), pairs, &nchunks, 512);
@@ -1225,8 +1227,12 @@ extern "C" int e2e_conv133_wgrad(const e2e_in_chan_t* chans, const float* dy, fl
     p.cblocks = wide ? e2e::cdiv(Cin, 32) : e2e::cdiv(Cin, 64);
     const int pairs = v3_pairs(Cin, Cout);
     nchunks = plan_v3(p, pairs);
-    if (wide) hipLaunchKernelGGL((conv133_wgrad_v3_kernel<1, 2>), dim3(nchunks, pairs), dim3(512), 0, st, p);
-    else hipLaunchKernelGGL((conv133_wgrad_v3_kernel<2, 1>), dim3(nchunks, pairs), dim3(512), 0, st, p);
+    if (v3_ksplit(Cin, Cout)) {
+      p.cblocks = 1;
+      hipLaunchKernelGGL((conv133_wgrad_v3_kernel<1, 1, 2>), dim3(nchunks, pairs), dim3(512), 0, st, p);
+      nchunks *= 2;                                      // two row-half slabs per workgroup
+    } else if (wide) hipLaunchKernelGGL((conv133_wgrad_v3_kernel<1, 2, 1>), dim3(nchunks, pairs), dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((conv133_wgrad_v3_kernel<2, 1, 1>), dim3(nchunks, pairs), dim3(512), 0, st, p);
     rc = e2e::check_launch("conv133_wgrad_v3_kernel");
     if (rc != E2E_OK) return rc;
     hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)e2e::cdivll(numel, 64)), dim3(256), 0, st, p.slab, dw, numel,

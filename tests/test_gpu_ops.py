@@ -71,6 +71,7 @@ CONV_CASES = [
     (2, [(50, True), (40, False)], 70, (2, 20, 36), (1, 1, 1), 0.2),         # double-buffered wgrad, 64-out x 32-in blocks
     (2, [(3, False)], 40, (3, 20, 36), (1, 1, 1), 1.0),                      # input layer: small-Cin wgrad (channel x tap columns)
     (1, [(4, True)], 32, (2, 16, 64), (1, 1, 1), 1.0),
+    (2, [(20, True)], 24, (2, 20, 36), (1, 1, 1), 1.0),                      # one 32 x 32 block: row-split double-buffered wgrad
 ]
 
 
