@@ -248,6 +248,7 @@ __global__ __launch_bounds__(256) void head_fwd_v4_kernel(const float* __restric
     for (int k = 0; k < KB; ++k)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[k][j] = 0.f;
+#pragma unroll 8
     for (int c = 0; c < C; ++c) {
       float a = 1.f, b = 0.f, sl = 1.f;
       if (scale) { a = scale[(long long)n * C + c]; b = shift[(long long)n * C + c]; sl = slope; }
@@ -285,6 +286,7 @@ __global__ __launch_bounds__(256) void head_dgrad_v4_kernel(const float* __restr
       if (k0 + k < K) q = *reinterpret_cast<const float4*>(dl + ((long long)n * K + k0 + k) * spatial + v);
       g[k][0] = q.x; g[k][1] = q.y; g[k][2] = q.z; g[k][3] = q.w;
     }
+#pragma unroll 8
     for (int c = 0; c < C; ++c) {
       float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
