@@ -1099,7 +1099,8 @@ inline int plan_v3(WgParams& p, int pairs) {
   p.tiles_d = p.Do;
   p.tiles_per_n = p.tiles_d * p.tiles_y * p.tiles_x;
   p.total_tiles = (long long)p.tiles_per_n * p.B;
-  long long want = 512 / (pairs > 0 ? pairs : 1);           // workgroups per launch ~ 2 rounds over 256 CUs
+  static const int target = getenv("E2E_WG_V3_TARGET") ? atoi(getenv("E2E_WG_V3_TARGET")) : 256;
+  long long want = target / (pairs > 0 ? pairs : 1);        // one workgroup per CU, equal work each; fewer chunks = fewer slabs to reduce
   if (want < p.B) want = p.B;
   int segs = (int)(want / p.B);
   int tpc = e2e::cdiv(p.tiles_per_n, segs);

@@ -690,8 +690,10 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 }
 
 inline int wgrad_chunks(long long total_tiles, int pairs, int* tiles_per_chunk) {
-  // aim at ~1024 workgroups, but keep slabs few: at least 8 tiles per chunk
-  long long want = 1024 / (pairs > 0 ? pairs : 1);
+  // aim at ~256 workgroups (one 84 KB workgroup per CU, equal work each) and keep the slabs few: every chunk is a slab
+  // the reduction has to read (1024 chunks cost 14 % more on the 64 -> 32 @64^3 layer); at least 8 tiles per chunk
+  static const int target = getenv("E2E_CT_WG_TARGET") ? atoi(getenv("E2E_CT_WG_TARGET")) : 256;
+  long long want = target / (pairs > 0 ? pairs : 1);
   if (want < 1) want = 1;
   long long tpc = e2e::cdivll(total_tiles, want);
   if (tpc < 8) tpc = 8;
