@@ -755,7 +755,8 @@ extern "C" int e2e_convT_dgrad(const float* dy, const float* w, const unsigned* 
   if (!no_v3 && kw == 2 && (kd * kh == 2 || kd * kh == 4) && (W % 2) == 0 && spatial % 4 == 0 && e2e::cdivll(spatial, 32) * B >= 2048) {
     const long long total_tiles = e2e::cdivll(spatial, 32) * B;
     const int cgroups = e2e::cdiv(Cin, 64);
-    long long wgs = 768 / cgroups;                       // ~3 workgroups per CU
+    static const int target = getenv("E2E_CT_DG_TARGET") ? atoi(getenv("E2E_CT_DG_TARGET")) : 512;   // two 4-wave workgroups fit a CU (186 VGPRs): exactly one round
+    long long wgs = target / cgroups;
     if (wgs < 1) wgs = 1;
     int tpw = (int)e2e::cdivll(total_tiles, wgs);
     if (tpw < 4) tpw = 4;
