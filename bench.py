@@ -90,7 +90,7 @@ class KernelTimer:
         return sum(e0.elapsed_time(e1) for e0, e1, _ in self.events)
 
 
-TRAFFIC_FILE = "r01g_pmc_traffic.json"
+TRAFFIC_FILE = "r01h_pmc_traffic.json"
 
 
 def pmc_traffic(prefix):
