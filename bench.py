@@ -303,7 +303,7 @@ def main():
                     launches.append((round(ms, 3), k, ints[:12]))
             launches.sort(key=lambda v: -v[0])
             out["top_launches"] = launches[:40]
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU port is timed on rank 0 of the single-GPU run only
             out["cpu_baseline"] = cpu_baseline()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
