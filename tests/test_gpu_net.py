@@ -1,6 +1,7 @@
 """Whole-network parity of the MI355X engine: against the reference's golden vectors (tests/golden, produced by
 tools/make_golden.py from the reference itself) and against the CPU oracle on the same seeded inputs.
 Bars (BASELINE.json north_star): |dlogit| <= 1e-4, Dice >= 1 - 1e-3, DSFF mask indices bit exact."""
+import os
 import random
 import numpy as np
 import pytest
@@ -371,6 +372,44 @@ def test_checkpoint_with_dsff_state_resumes_bit_exact(tmp_path):
         assert torch.equal(mask2.kmasks[n].cpu(), want_m[n]), n
     for k, v in net2.state_dict().items():
         assert torch.equal(v.detach().cpu(), want_w[k]), k
+
+
+def test_overlapped_gradient_allreduce_single_rank_rccl():
+    """Data-parallel path on one rank: the engine's bucket hook + asynchronous RCCL all-reduces over the flat gradient
+    buffer must leave exactly the gradients of the plain backward pass (sum over one rank), and every parameter
+    gradient must be a view into Engine.grad_flat."""
+    import torch.distributed as dist
+    from e2enet_medical_amd import parallel
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1)      # "nccl" is RCCL on ROCm
+    try:
+        net, shapes, params = tiny_net()
+        x = seeded_input((2, TINY["cin"]) + TINY["patch"], seed=79).cuda()
+        eng = net.engine(x)
+        outs = eng.forward(x, True)
+        targets = [seeded_labels((o.shape[0], 1) + tuple(o.shape[2:]), TINY["k"], seed=95 + i).cuda() for i, o in enumerate(outs)]
+        w = oracle.ds_weights(5)
+        eng.loss_backward(targets, w, batch_dice=False)
+        want = eng.grad_flat.clone()
+        lo, hi = eng.grad_flat.data_ptr(), eng.grad_flat.data_ptr() + 4 * eng.grad_flat.numel()
+        assert all(lo <= g.data_ptr() < hi for g in eng.grads.values())
+        buckets = []
+        ov = parallel.OverlappedGradAllReduce(eng, force=True)
+        hook = eng.grad_bucket_hook
+        eng.grad_bucket_hook = lambda a, b: (buckets.append((a, b)), hook(a, b))
+        eng.forward(x, True)
+        eng.loss_backward(targets, w, batch_dice=False)
+        ov.finish()
+        eng.grad_bucket_hook = None
+        assert torch.equal(eng.grad_flat, want)
+        assert buckets and buckets[0][0] == 0 and buckets[-1][1] == eng.grad_flat.numel()
+        assert all(b[1] == c[0] for b, c in zip(buckets, buckets[1:]))          # contiguous, in completion order
+    finally:
+        if created:
+            dist.destroy_process_group()
 
 
 def test_btcv_like_anisotropic_config_vs_oracle():
