@@ -8,9 +8,14 @@
 //   * the input tile of CK input planes (+1 halo) is staged through LDS once and shared by all OCG output
 //     planes; the depth shift is an index offset in the load stage (plane p is read at depth d*sd - s(p)),
 //     the concat is a per-plane pointer table, the producer's InstanceNorm+LeakyReLU is applied while staging;
+//     with float4 staging (STG 1) every wave stages whole planes: descriptor in scalar registers, scalar-base
+//     global loads prefetched one chunk ahead in registers; the chunk's weights go to LDS through a raw buffer
+//     descriptor (out-of-range offsets read 0);
 //   * one wave owns OPW output planes; a lane owns a PH x PW micro-tile of each (register accumulators);
-//   * DSFF sparsity: per (output plane, 32 input planes) liveness word; the wave walks the set bits with
-//     scalar bit ops, so dead (out,in) kernels cost nothing;
+//   * DSFF sparsity: "quad words" (4 output planes x 8 input planes, input-plane-major; e2e_dsff_expand_quads):
+//     the wave walks the live input planes of its output planes with scalar bit ops, reads the neighbourhood
+//     rows of a plane once and applies them to the 1..4 output planes that consume it; dead (out,in) kernels
+//     cost nothing;
 //   * epilogue (fwd): bias, store, per-tile (count, mean, M2) partial for InstanceNorm;
 //     epilogue (dgrad): un-shift on store into the per-channel destination (scatter back through the concat).
 #include "e2e_common.h"
@@ -731,10 +736,6 @@ int launch_cfg_impl(ConvParams p, hipStream_t st) {
 // sub-pixel data gradient (stride (2,2) convs); dx planes of 8x8 and smaller keep the zero-dilated MODE 1 path
 int launch_sub(const ConvParams& p, int kind, hipStream_t st);
 
-inline int t32_variant_knob() {     // tuning knob for the large-plane tile (0/1: 32x32, 2: 16x32)
-  static const int v = getenv("E2E_CONV_T32") ? atoi(getenv("E2E_CONV_T32")) : 2;
-  return v;
-}
 
 inline int opw8_knob() {
   static const int v = getenv("E2E_CONV_OPW8") ? atoi(getenv("E2E_CONV_OPW8")) : 0;
@@ -745,12 +746,10 @@ inline int opw8_knob() {
 template <int MODE, int DH, int DW>
 int launch_s1(const ConvParams& p, int kind, hipStream_t st) {
   const bool vec = (DH == 1 && DW == 1) && (p.Wi % 4 == 0);
-  const int t32_variant = t32_variant_knob();
   switch (kind) {
     case 0:
-      // 16x32 tile, 118 VGPRs -> two 512-thread workgroups per CU (measured best; the 32x32 tile and the double
-      // register set variant of the live-kernel loop both lose to it because they halve the occupancy or spill)
-      (void)t32_variant;
+      // 16x32 tile, 97 VGPRs -> two 512-thread workgroups per CU (measured best; see DESIGN.md §5 for the variants
+      // that were measured against it)
       if (vec && opw8_knob() && p.P > 8) return launch_cfg<MODE, 1, 1, 1, 1, 16, 32, 8, 8, 8, 4, 8, 1, 3, 0>(p, st);   // 4 fat waves
       return vec ? launch_cfg<MODE, 1, 1, 1, 1, 16, 32, 8, 8, 4, 8, 8, 1, 4, 0>(p, st)
                  : launch_cfg<MODE, 1, 1, DH, DW, 16, 32, 8, 8, 4, 8, 8, 0, 4, 0>(p, st);
