@@ -172,22 +172,39 @@ class SegmentationNetwork(NeuralNetwork):
         w = 1 / num_results
         # (flip dims in the reference's order, :529-560) as axis bit sets: bit0 = x (dim 2), bit1 = y, bit2 = z
         combos = [0, 4, 2, 6, 1, 5, 3, 7] if do_mirroring else [0]
-        flipped = torch.empty_like(x)
+        combos = [b for b in combos if all(a in mirror_axes for a in range(3) if b & (1 << a))]
         first = True
         ds = getattr(self, "do_ds", False)
         if hasattr(self, "do_ds"):
             self.do_ds = False
         try:
-            for bits in combos:
-                need = [a for a in range(3) if bits & (1 << a)]
-                if any(a not in mirror_axes for a in need):
-                    continue
-                if bits:
-                    lib().flip3d(x.data_ptr(), flipped.data_ptr(), c, X, Y, Z, bits, _stream())
-                    self._net_probs_into(flipped, result, w, first, bits)
-                else:
-                    self._net_probs_into(x, result, w, first, 0)
-                first = False
+            if getattr(self, "tta_batched", True) and len(combos) > 1:
+                # all mirrored copies in ONE forward pass (batch = number of mirrors): every sample of a batch is computed
+                # independently (per-sample tiles, per-sample InstanceNorm), so the logits equal the one-at-a-time ones bit
+                # for bit, while the deep, small layers finally get enough workgroups; accumulation order is unchanged
+                xb = torch.empty((len(combos),) + tuple(x.shape[1:]), dtype=torch.float32, device=dev)
+                for m, bits in enumerate(combos):
+                    if bits:
+                        lib().flip3d(x.data_ptr(), xb[m].data_ptr(), c, X, Y, Z, bits, _stream())
+                    else:
+                        xb[m].copy_(x[0])
+                logits = self(xb)
+                if isinstance(logits, (list, tuple)):
+                    logits = logits[0]
+                k = logits.shape[1]
+                for m, bits in enumerate(combos):
+                    lib().softmax_flip_acc(logits[m].data_ptr(), result.data_ptr(), float(w), 1 if first else 0, k, X, Y, Z,
+                                           bits, _stream())
+                    first = False
+            else:
+                flipped = torch.empty_like(x)
+                for bits in combos:
+                    if bits:
+                        lib().flip3d(x.data_ptr(), flipped.data_ptr(), c, X, Y, Z, bits, _stream())
+                        self._net_probs_into(flipped, result, w, first, bits)
+                    else:
+                        self._net_probs_into(x, result, w, first, 0)
+                    first = False
         finally:
             if hasattr(self, "do_ds"):
                 self.do_ds = ds

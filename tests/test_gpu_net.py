@@ -286,6 +286,11 @@ def test_predict_3d_vs_reference_golden(tag, kw):
     assert (seg != ref_seg).mean() < 1e-3
     assert np.abs(probs[:, 6, ::2, ::2] - g["pred_%s_probs_slice" % tag]).max() <= 2e-5
     np.testing.assert_allclose(probs.astype(np.float64).sum(axis=(1, 2, 3)), g["pred_%s_probs_sum" % tag], rtol=1e-5)
+    # the mirrors run as one batched forward by default: bit-identical to one forward per mirror
+    net.tta_batched = False
+    seg1, probs1 = net.predict_3D(vol, use_sliding_window=True, step_size=0.5, patch_size=TINY["patch"], use_gaussian=True,
+                                  all_in_gpu=False, verbose=False, mixed_precision=False, **kw)
+    assert np.array_equal(seg, seg1) and np.array_equal(probs, probs1)
 
 
 def test_trainer_surface_runs_iterations():
