@@ -1069,7 +1069,8 @@ int launch_v2(const WgParams& p, int nchunks, int pairs, hipStream_t st) {
 }
 
 // v2 applies to stride-1 (in plane) convs whose rows are multiples of 4 floats
-inline bool use_v2(int Wi, int sh, int sw) { return sh == 1 && sw == 1 && (Wi % 4) == 0 && Wi > 4; }   // 4x4 planes: v1
+// (planes whose smaller side is <= 4 get the (16, 4, 4) tile, which only the v1 kernel implements)
+inline bool use_v2(int Hi, int Wi, int sh, int sw) { return sh == 1 && sw == 1 && (Wi % 4) == 0 && Wi > 4 && Hi > 4; }
 inline int v2_ncb(int Cin, int Ho, int Wo) {      // 8x8 planes: the (4,8,8) tile only fits one channel block in LDS
   const int m = Ho < Wo ? Ho : Wo;
   return (Cin > 32 && m > 8) ? 2 : 1;
@@ -1172,7 +1173,7 @@ extern "C" long long e2e_conv133_wgrad_ws_bytes(int B, int Cin, int Cout, int Di
     nchunks = 2 * plan_smallc(p, e2e::cdiv(Cout, 32));
   } else if (use_v3(Cin, Hi, Wi, sh, sw)) {
     nchunks = plan_v3(p, v3_pairs(Cin, Cout)) * (v3_ksplit(Cin, Cout) ? 2 : 1);
-  } else if (use_v2(Wi, sh, sw)) {
+  } else if (use_v2(Hi, Wi, sh, sw)) {
     const int pairs = e2e::cdiv(Cin, 32 * v2_ncb(Cin, p.Ho, p.Wo)) * e2e::cdiv(Cout, 32);
     plan(p, pick(p.Ho, p.Wo, false), pairs, &nchunks, 512);
   } else {
@@ -1240,7 +1241,7 @@ extern "C" int e2e_conv133_wgrad(const e2e_in_chan_t* chans, const float* dy, fl
                        nchunks);
     return e2e::check_launch("wgrad_slab_reduce_kernel");
   }
-  if (use_v2(Wi, sh, sw)) {
+  if (use_v2(Hi, Wi, sh, sw)) {
     const int ncb = v2_ncb(Cin, p.Ho, p.Wo);
     p.cblocks = e2e::cdiv(Cin, 32 * ncb);
     const int pairs = p.cblocks * e2e::cdiv(Cout, 32);

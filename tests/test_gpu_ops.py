@@ -72,6 +72,7 @@ CONV_CASES = [
     (2, [(3, False)], 40, (3, 20, 36), (1, 1, 1), 1.0),                      # input layer: small-Cin wgrad (channel x tap columns)
     (1, [(4, True)], 32, (2, 16, 64), (1, 1, 1), 1.0),
     (2, [(20, True)], 24, (2, 20, 36), (1, 1, 1), 1.0),                      # one 32 x 32 block: row-split double-buffered wgrad
+    (2, [(33, True)], 40, (5, 4, 12), (1, 1, 1), 0.5),                       # 4-row planes with wide rows (found by tools/scratch/fuzz_ops.py)
 ]
 
 
