@@ -743,6 +743,11 @@ extern "C" int e2e_convT_fwd(const float* x, const float* scale, const float* sh
   return e2e::check_launch("convT_fwd_kernel");
 }
 
+static int dg_min_tiles() {
+  static const int v = getenv("E2E_CT_DG_MINTILES") ? atoi(getenv("E2E_CT_DG_MINTILES")) : 256;     // 256 tiles (16^3 x 2) still win over the gather kernel, 64 do not
+  return v;
+}
+
 extern "C" int e2e_convT_dgrad(const float* dy, const float* w, const unsigned* live_t, float* dx, int accumulate,
                                int B, int Cin, int Cout, int D, int H, int W, int kd, int kh, int kw, void* stream) {
   E2E_REQUIRE(dy && w && dx, "convT_dgrad: null pointer");
@@ -752,7 +757,7 @@ extern "C" int e2e_convT_dgrad(const float* dy, const float* w, const unsigned* 
   const long long spatial = (long long)D * H * W;
   // v3 (dense GEMM on the matrix cores) for the large planes
   static const int no_v3 = getenv("E2E_CT_NOV3") ? atoi(getenv("E2E_CT_NOV3")) : 0;
-  if (!no_v3 && kw == 2 && (kd * kh == 2 || kd * kh == 4) && (W % 2) == 0 && spatial % 4 == 0 && e2e::cdivll(spatial, 32) * B >= 2048) {
+  if (!no_v3 && kw == 2 && (kd * kh == 2 || kd * kh == 4) && (W % 2) == 0 && spatial % 4 == 0 && e2e::cdivll(spatial, 32) * B >= dg_min_tiles()) {
     const long long total_tiles = e2e::cdivll(spatial, 32) * B;
     const int cgroups = e2e::cdiv(Cin, 64);
     static const int target = getenv("E2E_CT_DG_TARGET") ? atoi(getenv("E2E_CT_DG_TARGET")) : 512;   // two 4-wave workgroups fit a CU (186 VGPRs): exactly one round
