@@ -36,6 +36,7 @@ P, I, F, LL = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 SIGNATURES = {
     "e2e_last_error": (C.c_char_p, []),
     "e2e_abi_version": (I, []),
+    "e2e_last_kernel": (C.c_char_p, []),
     "e2e_conv133_num_partials": (I, [I, I, I, I, I]),
     "e2e_conv133_fwd": (I, [P, I, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "e2e_conv133_dgrad": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
@@ -71,7 +72,7 @@ SIGNATURES = {
     "e2e_sw_finalize_argmax": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
 }
 
-_NO_STATUS = {"e2e_last_error", "e2e_abi_version", "e2e_conv133_num_partials", "e2e_conv133_wgrad_ws_bytes",
+_NO_STATUS = {"e2e_last_error", "e2e_abi_version", "e2e_last_kernel", "e2e_conv133_num_partials", "e2e_conv133_wgrad_ws_bytes",
               "e2e_convT_wgrad_ws_bytes", "e2e_head1x1_wgrad_ws_bytes", "e2e_loss_ws_bytes"}
 
 
@@ -110,7 +111,7 @@ class _Lib:
 _lib = None
 
 
-ABI_VERSION = 2          # e2e_abi_version() of the library this binding was written against
+ABI_VERSION = 3          # e2e_abi_version() of the library this binding was written against
 
 
 def lib() -> _Lib:

@@ -1206,6 +1206,7 @@ extern "C" int e2e_conv133_wgrad(const e2e_in_chan_t* chans, const float* dy, fl
     p.tiles_per_n = p.tiles_d * p.tiles_y * p.tiles_x;
     p.total_tiles = (long long)p.tiles_per_n * B;
     nchunks = s2_chunks(p.total_tiles, pairs, &p.tiles_per_chunk);
+    e2e::note_kernel("conv133_wgrad_s2 chunks=%d pairs=%d", nchunks, pairs);
     hipLaunchKernelGGL(conv133_wgrad_s2_kernel, dim3(nchunks, pairs), dim3(256), 0, st, p);
     rc = e2e::check_launch("conv133_wgrad_s2_kernel");
     if (rc != E2E_OK) return rc;
@@ -1217,6 +1218,7 @@ extern "C" int e2e_conv133_wgrad(const e2e_in_chan_t* chans, const float* dy, fl
     const int pairs = e2e::cdiv(Cout, 32);
     const int wgs = plan_smallc(p, pairs);
     nchunks = 2 * wgs;
+    e2e::note_kernel("conv133_wgrad_smallc chunks=%d pairs=%d", wgs, pairs);
     hipLaunchKernelGGL(conv133_wgrad_smallc_kernel, dim3(wgs, pairs), dim3(256), 0, st, p);
     rc = e2e::check_launch("conv133_wgrad_smallc_kernel");
     if (rc != E2E_OK) return rc;
@@ -1229,6 +1231,7 @@ extern "C" int e2e_conv133_wgrad(const e2e_in_chan_t* chans, const float* dy, fl
     p.cblocks = wide ? e2e::cdiv(Cin, 32) : e2e::cdiv(Cin, 64);
     const int pairs = v3_pairs(Cin, Cout);
     nchunks = plan_v3(p, pairs);
+    e2e::note_kernel("conv133_wgrad_v3<%s> chunks=%d pairs=%d", v3_ksplit(Cin, Cout) ? "1,1,2" : (wide ? "1,2,1" : "2,1,1"), nchunks, pairs);
     if (v3_ksplit(Cin, Cout)) {
       p.cblocks = 1;
       hipLaunchKernelGGL((conv133_wgrad_v3_kernel<1, 1, 2>), dim3(nchunks, pairs), dim3(512), 0, st, p);
@@ -1246,6 +1249,7 @@ extern "C" int e2e_conv133_wgrad(const e2e_in_chan_t* chans, const float* dy, fl
     p.cblocks = e2e::cdiv(Cin, 32 * ncb);
     const int pairs = p.cblocks * e2e::cdiv(Cout, 32);
     plan(p, ts, pairs, &nchunks, 512);
+    e2e::note_kernel("conv133_wgrad_v2<%d,%d,%d,%d> chunks=%d pairs=%d", ts.nd == 1 ? 1 : 4, ts.nd == 1 ? (ts.tw == 32 ? 8 : 16) : 8, ts.nd == 1 ? ts.tw : 8, ts.nd == 1 ? ncb : 1, nchunks, pairs);
     if (ts.nd == 1 && ts.tw == 32) rc = ncb == 2 ? launch_v2<1, 8, 32, 2>(p, nchunks, pairs, st) : launch_v2<1, 8, 32, 1>(p, nchunks, pairs, st);
     else if (ts.nd == 1) rc = ncb == 2 ? launch_v2<1, 16, 16, 2>(p, nchunks, pairs, st) : launch_v2<1, 16, 16, 1>(p, nchunks, pairs, st);
     else rc = launch_v2<4, 8, 8, 1>(p, nchunks, pairs, st);
@@ -1257,6 +1261,7 @@ extern "C" int e2e_conv133_wgrad(const e2e_in_chan_t* chans, const float* dy, fl
   p.cblocks = e2e::cdiv(Cin, 32);
   const int pairs = p.cblocks * e2e::cdiv(Cout, 32);
   plan(p, ts, pairs, &nchunks);
+  e2e::note_kernel("conv133_wgrad_v1<%d,%d,%d,%d,%d> chunks=%d pairs=%d", sh, sw, ts.nd, ts.th, ts.tw, nchunks, pairs);
   if (!strided) {
     if (ts.nd == 1 && ts.tw == 32) rc = launch<1, 1, 1, 8, 32>(p, nchunks, pairs, st);
     else if (ts.nd == 1) rc = launch<1, 1, 1, 16, 16>(p, nchunks, pairs, st);

@@ -727,6 +727,7 @@ extern "C" int e2e_convT_fwd(const float* x, const float* scale, const float* sh
   hipStream_t st = (hipStream_t)stream;
   const long long spatial = (long long)D * H * W;
   const int kt = kd * kh * kw;
+  e2e::note_kernel("convT_fwd_gather<%d,%d>", kt, spatial >= 4096 ? (kt <= 4 ? 4 : 2) : 1);
   if (spatial >= 4096 && kt <= 4) {
     dim3 grid((unsigned)e2e::cdivll(spatial, 256 * 4), Cout, B);
     DISPATCH_KT(kt, hipLaunchKernelGGL((convT_fwd_kernel<KT, 4>), grid, dim3(256), 0, st, x, scale, shift, slope, w, live, y,
@@ -766,6 +767,7 @@ extern "C" int e2e_convT_dgrad(const float* dy, const float* w, const unsigned* 
     int tpw = (int)e2e::cdivll(total_tiles, wgs);
     if (tpw < 4) tpw = 4;
     dim3 grid((unsigned)e2e::cdivll(total_tiles, tpw), cgroups);
+    e2e::note_kernel("convT_dgrad_v3<%d> wgs=%u cgroups=%d tiles_per_wg=%d", kd * kh, grid.x, cgroups, tpw);
     if (kd * kh == 4)
       hipLaunchKernelGGL((convT_dgrad_v3_kernel<4>), grid, dim3(256), 0, st, dy, w, dx, accumulate, B, Cin, Cout, D, H, W, kd, kh, tpw);
     else
@@ -775,6 +777,7 @@ extern "C" int e2e_convT_dgrad(const float* dy, const float* w, const unsigned* 
   // v2 needs enough 64-voxel tiles to fill the chip (one workgroup per tile); small planes keep the gather kernel
   if (kw == 2 && (kd * kh == 2 || kd * kh == 4) && (W % 2) == 0 && spatial % 4 == 0 && e2e::cdivll(spatial, 64) * B >= 1024) {
     const unsigned tiles = (unsigned)(e2e::cdivll(spatial, 64) * B);
+    e2e::note_kernel("convT_dgrad_v2<%d> tiles=%u", kd * kh, tiles);
     if (kd * kh == 4)
       hipLaunchKernelGGL((convT_dgrad_v2_kernel<4>), dim3(tiles), dim3(256), 0, st, dy, w, live_t, dx, accumulate, B, Cin, Cout, D, H, W, kd, kh);
     else
@@ -782,6 +785,7 @@ extern "C" int e2e_convT_dgrad(const float* dy, const float* w, const unsigned* 
     return e2e::check_launch("convT_dgrad_v2_kernel");
   }
   dim3 grid((unsigned)e2e::cdivll(spatial, 256), Cin, B);
+  e2e::note_kernel("convT_dgrad_gather<%d>", kd * kh * kw);
   DISPATCH_KT(kd * kh * kw, hipLaunchKernelGGL((convT_dgrad_kernel<KT>), grid, dim3(256), 0, st, dy, w, live_t, dx, accumulate,
                                                Cin, Cout, D, H, W, kd, kh, kw));
   return e2e::check_launch("convT_dgrad_kernel");
@@ -820,6 +824,7 @@ extern "C" int e2e_convT_wgrad(const float* x, const float* scale, const float* 
     const int nch = wgrad_chunks(total_tiles, pairs2, &tpc);
     dim3 grid2(nch, pairs2);
     const int kdh = kd * kh;
+    e2e::note_kernel("convT_wgrad_v2<%d,%d> chunks=%d pairs=%d", kdh, ncb, nch, pairs2);
 #define LAUNCH_V2(KDH, NCB) hipLaunchKernelGGL((convT_wgrad_v2_kernel<KDH, NCB>), grid2, dim3(256 * NCB), 0, st, x, scale, shift, \
                                                slope, dy, slab, B, Cin, Cout, D, H, W, kd, kh, tpc, cgroups)
     if (kdh == 4) { if (ncb == 2) LAUNCH_V2(4, 2); else LAUNCH_V2(4, 1); }
@@ -831,6 +836,7 @@ extern "C" int e2e_convT_wgrad(const float* x, const float* scale, const float* 
   const int pairs = e2e::cdiv(Cin, 32) * e2e::cdiv(Cout, 32);
   const int nchunks = wgrad_chunks(total_tiles, pairs, &tpc);
   dim3 grid(nchunks, pairs);
+  e2e::note_kernel("convT_wgrad_v1<%d> chunks=%d pairs=%d", kt, nchunks, pairs);
   DISPATCH_KT(kt, hipLaunchKernelGGL((convT_wgrad_kernel<KT>), grid, dim3(256), 0, st, x, scale, shift, slope, dy, slab, B,
                                      Cin, Cout, D, H, W, kd, kh, kw, tpc, nchunks));
   const long long numel = (long long)Cin * Cout * kt;

@@ -10,6 +10,8 @@ typedef const float __attribute__((address_space(1)))* gfloat_p;
 namespace e2e {
 
 void set_error(const char* fmt, ...);
+// dispatch diagnostics: which kernel variant the last entry point on this thread selected (e2e_last_kernel)
+void note_kernel(const char* fmt, ...);
 
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();

@@ -27,6 +27,10 @@ extern "C" {
 
 const char* e2e_last_error(void);
 int e2e_abi_version(void);
+/* Diagnostics: name and launch shape of the kernel variant the last conv133 / convT entry point called on this
+ * thread selected (size-dependent dispatch; the parity tests assert that the benchmarked shapes reach the intended
+ * variants).  Thread-local, valid until the next call. */
+const char* e2e_last_kernel(void);
 
 /* One input plane (channel) of a convolution whose input is the *virtual* concatenation
  * [skip, up, down] (unetpp_d.py:453-478) followed by the restricted depth shift

@@ -15,6 +15,8 @@ from tests.helpers import (golden, closed_form_params, seeded_input, seeded_labe
 pytestmark = pytest.mark.gpu
 
 TINY = dict(patch=(16, 32, 32), cin=2, base=8, k=3, pools=[(2, 2, 2)] * 3 + [(1, 2, 2)] * 2, max_feat=32)
+SPARSE_PATCH = (16, 64, 64)       # sparse training fixture: 2x2x2 = 8-voxel bottleneck (tools/make_golden.py)
+HIPPO = dict(patch=(40, 56, 40), cin=1, k=3, pools=[(2, 2, 2)] * 3 + [(1, 1, 1)] * 2)
 
 
 def build_net(patch, cin, base, k, pools, max_feat=None, **extra):
@@ -36,8 +38,8 @@ def load_closed_form(net):
     return shapes, params
 
 
-def tiny_net():
-    net = build_net(TINY["patch"], TINY["cin"], TINY["base"], TINY["k"], TINY["pools"], TINY["max_feat"])
+def tiny_net(patch=None):
+    net = build_net(patch or TINY["patch"], TINY["cin"], TINY["base"], TINY["k"], TINY["pools"], TINY["max_feat"])
     shapes, params = load_closed_form(net)
     return net, shapes, params
 
@@ -45,7 +47,7 @@ def tiny_net():
 def test_native_library_is_loaded():
     from e2enet_medical_amd._lib import lib, LIB_PATH
     from e2enet_medical_amd._lib import ABI_VERSION
-    assert lib().abi_version() == ABI_VERSION == 2
+    assert lib().abi_version() == ABI_VERSION == 3
     with open("/proc/self/maps") as f:
         assert any(LIB_PATH in line for line in f), "libe2e_hip.so is not mapped into this process"
 
@@ -184,7 +186,7 @@ def test_sparse_training_two_steps_vs_reference_golden():
     from e2enet_medical_amd.training.network_training.sparselearning.core_channel import Masking, CosineDecay
     from e2enet_medical_amd.training.fused_optim import FusedClipSGD
     g = golden("net_sparse_tiny.npz")
-    net, shapes, _ = tiny_net()
+    net, shapes, _ = tiny_net(SPARSE_PATCH)
     opt = torch.optim.SGD(net.parameters(), 1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)
 
     class A:
@@ -200,7 +202,8 @@ def test_sparse_training_two_steps_vs_reference_golden():
     assert list(mask.masks.keys()) == names
     for n in names:
         assert np.array_equal(pack_kernel_mask(mask.masks[n].cpu()), g["mask0::" + n]), n
-    x = seeded_input((2, TINY["cin"]) + TINY["patch"], seed=21).cuda()
+    assert tuple(g["patch"]) == SPARSE_PATCH
+    x = seeded_input((2, TINY["cin"]) + SPARSE_PATCH, seed=21).cuda()
     w = oracle.ds_weights(5)
     fused = FusedClipSGD(opt, list(net.named_parameters()), 12.0)
     eng = net.engine(x)
@@ -209,20 +212,18 @@ def test_sparse_training_two_steps_vs_reference_golden():
         outs = eng.forward(x, True)
         targets = [seeded_labels((o.shape[0], 1) + tuple(o.shape[2:]), TINY["k"], seed=30 + i).cuda() for i, o in enumerate(outs)]
         if it == 0:
-            assert np.abs(outs[0].cpu().numpy() - g["logits0_it0"]).max() <= 1e-4
+            assert np.abs(outs[0].cpu().numpy()[:, :, :, ::2, ::2] - g["logits0_it0"]).max() <= 1e-4
         loss = eng.loss_backward(targets, w, batch_dice=False)
         if it == 0:
             l2 = np.array([eng.grads[n].double().norm().item() for n in shapes])
             np.testing.assert_allclose(l2, g["grad_l2_it0"], rtol=5e-3, atol=2e-6)
         fused.step(eng.grads, mask.masks)
         tn = fused.total_norm()
-        # iteration 1 runs on weights already updated once: the 2-voxel InstanceNorm at the 2x1x1 bottleneck of this
-        # tiny patch amplifies last-ulp differences, so the second clip norm is only checked to 2 %
-        assert abs(tn - float(g["total_norm_it%d" % it])) <= (2e-3 if it == 0 else 2e-2) * float(g["total_norm_it%d" % it])
+        assert abs(tn - float(g["total_norm_it%d" % it])) <= 1e-3 * float(g["total_norm_it%d" % it])
         mask.step(masks_already_applied=True)
         assert mask.death_rate == float(g["death_rate_it%d" % it])
         losses.append(loss.item())
-    assert abs(losses[0] - g["losses"][0]) <= 5e-5 and abs(losses[1] - g["losses"][1]) <= 2e-3
+    assert abs(losses[0] - g["losses"][0]) <= 5e-5 and abs(losses[1] - g["losses"][1]) <= 5e-5
     nnz = {n: int(mask.masks[n].sum().item()) for n in names}
     assert nnz == {n: int(np.unpackbits(g["mask2::" + n]).sum()) * int(np.prod(mask.masks[n].shape[-3:])) for n in names}
     sd = net.state_dict()
@@ -235,7 +236,7 @@ def test_prune_grow_replay_bit_exact_masks():
     (golden pre_prune::*): kernel-L1 -> k-th threshold -> death -> random growth gives bit-identical mask indices."""
     from e2enet_medical_amd.training.network_training.sparselearning.core_channel import Masking, CosineDecay
     g = golden("net_sparse_tiny.npz")
-    net, shapes, _ = tiny_net()
+    net, shapes, _ = tiny_net(SPARSE_PATCH)
     opt = torch.optim.SGD(net.parameters(), 1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)
 
     class A:

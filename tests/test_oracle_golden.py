@@ -11,6 +11,8 @@ from tests.helpers import (golden, closed_form_params, closed_form_tensor, seede
                            pack_kernel_mask, sha_of)
 
 TINY = dict(patch=(16, 32, 32), cin=2, base=8, k=3, pools=[(2, 2, 2)] * 3 + [(1, 2, 2)] * 2, max_feat=32)
+SPARSE_PATCH = (16, 64, 64)       # sparse training fixture: 2x2x2 = 8-voxel bottleneck (tools/make_golden.py)
+HIPPO = dict(patch=(40, 56, 40), cin=1, k=3, pools=[(2, 2, 2)] * 3 + [(1, 1, 1)] * 2)
 
 
 def tiny_spec():
@@ -128,6 +130,80 @@ def test_net64_sparse_forward():
         assert abs(o.double().abs().sum().item() - float(g["abs%d" % i])) <= 1e-5 * float(g["abs%d" % i])
 
 
+def test_hippocampus_config1_vs_reference():
+    """BASELINE config 1: 40x56x40, Cin 1, K 3, pools [[2,2,2]]*3 + [[1,1,1]]*2, density 1.0.
+    The [1,1,1] stages make 'strided' convs, transposed convs and poolings with unit kernels and 5x7 planes."""
+    g = golden("net_hippo.npz")
+    spec = oracle.make_spec(HIPPO["cin"], 32, HIPPO["k"], HIPPO["pools"])
+    shapes = onet.param_shapes(spec)
+    assert list(shapes.keys()) == [str(s) for s in g["names"]]
+    params = closed_form_params(shapes)
+    for v in params.values():
+        v.requires_grad_(True)
+    x = seeded_input((1, HIPPO["cin"]) + HIPPO["patch"], seed=81)
+    outs = oracle.forward(spec, params, x)
+    assert [list(o.shape) for o in outs] == g["out_shapes"].tolist()
+    targets = [seeded_labels((o.shape[0], 1) + tuple(o.shape[2:]), HIPPO["k"], seed=90 + i) for i, o in enumerate(outs)]
+    loss = oracle.deep_supervision_loss(outs, targets, oracle.ds_weights(5))
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 2e-5
+    for i, o in enumerate(outs):
+        od = o.detach().numpy()
+        ref = g["b32_logits%d" % i]
+        np.testing.assert_allclose(od[:, :, ::2, ::2, ::2] if i == 0 else od, ref, rtol=0, atol=5e-5)
+        assert abs(o.detach().double().abs().sum().item() - float(g["b32_abs%d" % i])) <= 1e-5 * float(g["b32_abs%d" % i])
+    l2 = np.array([params[n].grad.double().norm().item() for n in shapes])
+    np.testing.assert_allclose(l2, g["grad_l2"], rtol=2e-3, atol=1e-6)
+    for key in g.files:
+        if key.startswith("grad::"):
+            ref = g[key]
+            got = params[key[6:]].grad.numpy()[:8]
+            assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), key
+    # the reference trainer's hard-coded width (nnUNetTrainer_simple.py:296), forward only
+    spec48 = oracle.make_spec(HIPPO["cin"], 48, HIPPO["k"], HIPPO["pools"])
+    p48 = closed_form_params(onet.param_shapes(spec48))
+    with torch.no_grad():
+        o = oracle.forward(spec48, p48, x, do_ds=False)
+    np.testing.assert_allclose(o.numpy()[:, :, ::2, ::2, ::2], g["b48_logits"], rtol=0, atol=5e-5)
+    assert abs(o.double().abs().sum().item() - float(g["b48_abs"])) <= 1e-5 * float(g["b48_abs"])
+
+
+@pytest.mark.parametrize("dens", [0.1, 0.5])
+def test_amos_config5_densities_vs_reference(dens):
+    """BASELINE config 5: AMOS-shaped net (Cin 1, K 16, base 32, 64^3) at DSFF density 0.1 / 0.5: fwd + loss + bwd."""
+    g = golden("net_amos.npz")
+    tag = "d%s" % dens
+    spec = oracle.make_spec(1, 32, 16)
+    shapes = onet.param_shapes(spec)
+    assert list(shapes.keys()) == [str(s) for s in g["names"]]
+    params = closed_form_params(shapes)
+    names = oracle.masked_names(spec)
+    random.seed(0)
+    masks = oracle.uniform_kernel_masks(shapes, names, dens)
+    assert [sha_of(pack_kernel_mask(masks[n])) for n in names] == [str(s) for s in g[tag + "_mask_sha"]]
+    for n in names:
+        params[n] = params[n] * masks[n]
+    for n in params:
+        params[n] = params[n].detach().requires_grad_(True)
+    x = seeded_input((1, 1, 64, 64, 64), seed=141)
+    outs = oracle.forward(spec, params, x)
+    targets = [seeded_labels((o.shape[0], 1) + tuple(o.shape[2:]), 16, seed=150 + i) for i, o in enumerate(outs)]
+    loss = oracle.deep_supervision_loss(outs, targets, oracle.ds_weights(5))
+    loss.backward()
+    assert abs(loss.item() - float(g[tag + "_loss"])) < 2e-5
+    np.testing.assert_allclose(outs[0].detach().numpy()[0, :, 31, ::2, ::2], g[tag + "_slice_d31"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(outs[3].detach().numpy(), g[tag + "_logits3"], rtol=0, atol=5e-5)
+    for i, o in enumerate(outs):
+        assert abs(o.detach().double().abs().sum().item() - float(g[tag + "_abs%d" % i])) <= 1e-5 * float(g[tag + "_abs%d" % i])
+    l2 = np.array([params[n].grad.double().norm().item() for n in shapes])
+    np.testing.assert_allclose(l2, g[tag + "_grad_l2"], rtol=2e-3, atol=1e-6)
+    for key in g.files:
+        if key.startswith(tag + "_grad::"):
+            ref = g[key]
+            got = params[key[len(tag) + 7:]].grad.numpy()
+            assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), key
+
+
 # ------------------------------------------------------------------ a9-a13 DSFF
 @pytest.mark.parametrize("base", [32, 48])
 @pytest.mark.parametrize("dens", [0.1, 0.2, 0.5])
@@ -176,7 +252,7 @@ def _train_two_steps_tiny():
     st = oracle.DsffState(params, names, density=0.3, death_rate=0.5, t_max=10, update_frequency=2,
                           momentum_buffers=mom)
     masks0 = {n: st.masks[n].clone() for n in names}
-    x = seeded_input((2, TINY["cin"]) + TINY["patch"], seed=21)
+    x = seeded_input((2, TINY["cin"]) + SPARSE_PATCH, seed=21)
     w = oracle.ds_weights(5)
     rec = dict(losses=[], total_norm=[], death_rate=[])
     for it in range(2):
@@ -188,7 +264,8 @@ def _train_two_steps_tiny():
         loss.backward()
         grads = {n: leaves[n].grad for n in leaves}
         if it == 0:
-            rec["logits0_it0"] = outs[0].detach().numpy()
+            rec["logits0_it0"] = outs[0].detach().numpy()[:, :, :, ::2, ::2]
+            rec["logits0_it0_sum"] = outs[0].detach().double().sum().item()
             rec["grad_l2_it0"] = np.array([grads[n].double().norm().item() for n in shapes])
         tn = oracle.clip_and_sgd_step(params, grads, mom, lr=1e-2)
         st.step()
@@ -201,7 +278,9 @@ def _train_two_steps_tiny():
 def test_sparse_train_steps_and_prune_grow_bit_exact_masks():
     g = golden("net_sparse_tiny.npz")
     spec, shapes, names, params, masks0, st, rec = _train_two_steps_tiny()
+    assert tuple(g["patch"]) == SPARSE_PATCH
     assert names == [str(s) for s in g["names"]]
+    assert abs(rec["logits0_it0_sum"] - float(g["logits0_it0_sum"])) < 0.05
     for n in names:
         assert np.array_equal(pack_kernel_mask(masks0[n]), g["mask0::" + n]), n
     np.testing.assert_allclose(rec["logits0_it0"], g["logits0_it0"], rtol=0, atol=2e-5)

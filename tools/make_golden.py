@@ -197,15 +197,21 @@ def gen_net_tiny():
     np.savez_compressed(os.path.join(OUT, "net_tiny.npz"), **out)
 
 
+# the sparse training fixture runs on a patch whose bottleneck is 2x2x2 = 8 voxels: with TINY's 2x1x1 bottleneck the
+# 2-voxel InstanceNorm amplifies last-ulp differences of the SECOND iteration beyond any useful tolerance
+SPARSE_PATCH = (16, 64, 64)
+
+
 def gen_net_sparse_tiny():
-    """Tiny net with DSFF masks (density 0.3) applied: forward + one full train-step."""
-    net = build_ref_net(TINY["patch"], TINY["cin"], TINY["base"], TINY["k"], TINY["pools"], TINY["max_feat"])
+    """Tiny net with DSFF masks (density 0.3) applied: forward + two full train-steps with a prune/grow."""
+    net = build_ref_net(SPARSE_PATCH, TINY["cin"], TINY["base"], TINY["k"], TINY["pools"], TINY["max_feat"])
     shapes = load_closed_form(net)
     mask, opt = make_masking(net, density=0.3, death_rate=0.5, t_max=10, update_frequency=2, seed=5)
     out = {"names": np.array(list(mask.masks.keys()))}
     for n, m in mask.masks.items():
         out["mask0::" + n] = pack_kernel_mask(m)
-    x = seeded_input((2, TINY["cin"]) + TINY["patch"], seed=21)
+    x = seeded_input((2, TINY["cin"]) + SPARSE_PATCH, seed=21)
+    out["patch"] = np.array(SPARSE_PATCH)
     w = np.array([1 / (2 ** i) for i in range(5)])
     w[-1] = 0
     w = w / w.sum()
@@ -220,7 +226,8 @@ def gen_net_sparse_tiny():
         loss = loss_fn(outs, targets)
         loss.backward()
         if it == 0:
-            out["logits0_it0"] = outs[0].detach().numpy()
+            out["logits0_it0"] = outs[0].detach().numpy()[:, :, :, ::2, ::2]          # (1, 2, 2)-subsampled
+            out["logits0_it0_sum"] = np.float64(outs[0].detach().double().sum().item())
             out["grad_l2_it0"] = np.array([p.grad.double().norm().item() for _, p in net.named_parameters()])
         tn = torch.nn.utils.clip_grad_norm_(net.parameters(), 12)
         opt.step()
@@ -268,6 +275,85 @@ def gen_net64():
     out["mask_sha"] = np.array([sha_of(pack_kernel_mask(m)) for m in mask.masks.values()])
     out["mask_nnz"] = np.array([int(m.sum().item()) for m in mask.masks.values()])
     np.savez_compressed(os.path.join(OUT, "net64.npz"), **out)
+
+
+HIPPO = dict(patch=(40, 56, 40), cin=1, k=3, pools=[[2, 2, 2]] * 3 + [[1, 1, 1]] * 2)
+
+
+def _ds_loss(batch_dice=False):
+    w = np.array([1 / (2 ** i) for i in range(5)])
+    w[-1] = 0
+    w = w / w.sum()
+    return MultipleOutputLoss2(DC_and_CE_loss({'batch_dice': batch_dice, 'smooth': 1e-5, 'do_bg': False}, {}), w)
+
+
+def gen_net_hippo():
+    """BASELINE config 1: Hippocampus-shaped plumbing case (5-pool plan [[2,2,2]]*3 + [[1,1,1]]*2, patch
+    40x56x40, 1 modality, 3 classes, density 1.0 = no masks), B = 1.  Base 32: forward + loss + backward; base 48 (the
+    reference trainer's hard-coded width): forward only."""
+    out = {}
+    net = build_ref_net(HIPPO["patch"], HIPPO["cin"], 32, HIPPO["k"], HIPPO["pools"])
+    shapes = load_closed_form(net)
+    x = seeded_input((1, HIPPO["cin"]) + HIPPO["patch"], seed=81)
+    outs = net(x)
+    targets = [seeded_labels((o.shape[0], 1) + tuple(o.shape[2:]), HIPPO["k"], seed=90 + i) for i, o in enumerate(outs)]
+    loss = _ds_loss()(outs, targets)
+    loss.backward()
+    out["loss"] = np.float64(loss.item())
+    out["out_shapes"] = np.array([list(o.shape) for o in outs])
+    for i, o in enumerate(outs):
+        od = o.detach()
+        out["b32_sum%d" % i] = np.float64(od.double().sum().item())
+        out["b32_abs%d" % i] = np.float64(od.double().abs().sum().item())
+        out["b32_logits%d" % i] = od.numpy()[:, :, ::2, ::2, ::2] if i == 0 else od.numpy()
+    names = list(shapes.keys())
+    out["names"] = np.array(names)
+    out["grad_l2"] = np.array([net.get_parameter(n).grad.double().norm().item() for n in names])
+    # full gradients of small tensors; the first 8 rows of the large ones that sit on the [1,1,1] stages
+    for n in ("conv_blocks_context.0.blocks.0.conv.weight", "loc0.4.1.blocks.0.conv.weight", "up0.0.weight", "up1.0.weight",
+              "seg_outputs.3.weight", "conv_blocks_context.4.blocks.0.conv.weight", "loc1.0.0.blocks.0.instnorm.weight"):
+        out["grad::" + n] = net.get_parameter(n).grad.numpy()[:8]
+    net48 = build_ref_net(HIPPO["patch"], HIPPO["cin"], 48, HIPPO["k"], HIPPO["pools"])
+    load_closed_form(net48)
+    net48.eval()
+    net48.do_ds = False
+    with torch.no_grad():
+        o = net48(x)
+    out["b48_sum"] = np.float64(o.double().sum().item())
+    out["b48_abs"] = np.float64(o.double().abs().sum().item())
+    out["b48_logits"] = o.numpy()[:, :, ::2, ::2, ::2]
+    np.savez_compressed(os.path.join(OUT, "net_hippo.npz"), **out)
+
+
+def gen_net_amos():
+    """BASELINE config 5: AMOS-shaped net (1 modality, 16 classes, base 32, 64^3 patch) at DSFF density 0.1 and 0.5
+    (random.seed(0)), closed-form weights: forward + deep-supervision loss + backward."""
+    pools = [[2, 2, 2]] * 5
+    out = {}
+    x = seeded_input((1, 1, 64, 64, 64), seed=141)
+    for dens in (0.1, 0.5):
+        tag = "d%s" % dens
+        net = build_ref_net((64, 64, 64), 1, 32, 16, pools)
+        shapes = load_closed_form(net)
+        mask, _ = make_masking(net, density=dens, seed=0)
+        outs = net(x)
+        targets = [seeded_labels((o.shape[0], 1) + tuple(o.shape[2:]), 16, seed=150 + i) for i, o in enumerate(outs)]
+        loss = _ds_loss()(outs, targets)
+        loss.backward()
+        out[tag + "_loss"] = np.float64(loss.item())
+        for i, o in enumerate(outs):
+            od = o.detach().double()
+            out[tag + "_sum%d" % i] = np.float64(od.sum().item())
+            out[tag + "_abs%d" % i] = np.float64(od.abs().sum().item())
+        out[tag + "_slice_d31"] = outs[0].detach().numpy()[0, :, 31, ::2, ::2]
+        out[tag + "_logits3"] = outs[3].detach().numpy()
+        names = list(shapes.keys())
+        out["names"] = np.array(names)
+        out[tag + "_grad_l2"] = np.array([net.get_parameter(n).grad.double().norm().item() for n in names])
+        for n in ("loc4.0.0.blocks.0.conv.weight", "up0.4.weight", "seg_outputs.0.weight"):
+            out[tag + "_grad::" + n] = net.get_parameter(n).grad.numpy()
+        out[tag + "_mask_sha"] = np.array([sha_of(pack_kernel_mask(m)) for m in mask.masks.values()])
+    np.savez_compressed(os.path.join(OUT, "net_amos.npz"), **out)
 
 
 def gen_masks():
@@ -384,6 +470,7 @@ def gen_init():
 
 
 ALL = dict(shift=gen_shift, block=gen_block, net=gen_net_tiny, sparse=gen_net_sparse_tiny, net64=gen_net64,
+           hippo=gen_net_hippo, amos=gen_net_amos,
            masks=gen_masks, loss=gen_loss, sliding=gen_sliding, dice=gen_dice, init=gen_init)
 
 if __name__ == "__main__":
