@@ -47,7 +47,7 @@ def tiny_net(patch=None):
 def test_native_library_is_loaded():
     from e2enet_medical_amd._lib import lib, LIB_PATH
     from e2enet_medical_amd._lib import ABI_VERSION
-    assert lib().abi_version() == ABI_VERSION == 3
+    assert lib().abi_version() == ABI_VERSION
     with open("/proc/self/maps") as f:
         assert any(LIB_PATH in line for line in f), "libe2e_hip.so is not mapped into this process"
 

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     handle = lib()                                   # dlopen + getattr on every symbol
     assert os.path.samefile(handle.path, LIB_PATH)
     from e2enet_medical_amd._lib import ABI_VERSION
-    assert handle.abi_version() == ABI_VERSION == 2
+    assert handle.abi_version() == ABI_VERSION
     assert handle.conv133_num_partials(128, 128, 128, 1, 1) == 128 * 8 * 4          # 16x32 output tiles
     assert handle.loss_ws_bytes(2, 4) == (2 * 4 * 3 + 1) * 8
 
