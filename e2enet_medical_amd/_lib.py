@@ -57,6 +57,8 @@ SIGNATURES = {
     "e2e_loss_ws_bytes": (LL, [I, I]),
     "e2e_dc_ce_reduce": (I, [P, P, P, I, I, LL, P]),
     "e2e_dc_ce_grad": (I, [P, P, P, F, I, F, P, P, I, I, LL, P]),
+    "e2e_dc_ce_fold_batch": (I, [P, I, I, P]),
+    "e2e_online_eval_counts": (I, [P, P, P, I, I, LL, P]),
     "e2e_grad_sqnorm": (I, [P, I, P, P]),
     "e2e_sgd_clip_mask_step": (I, [P, I, P, F, F, F, F, I, I, P]),
     "e2e_apply_mask": (I, [P, I, P]),
@@ -111,7 +113,7 @@ class _Lib:
 _lib = None
 
 
-ABI_VERSION = 3          # e2e_abi_version() of the library this binding was written against
+ABI_VERSION = 4          # e2e_abi_version() of the library this binding was written against
 
 
 def lib() -> _Lib:

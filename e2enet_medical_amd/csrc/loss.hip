@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void dc_ce_reduce_kernel(const float* __restri
     }
     const float inv = 1.f / s;
     const int t = (int)tp_[v];
-    float pt = 0.f;
+    float pt = (unsigned)t < (unsigned)K ? 0.f : NAN;     // label outside [0, K): torch's CrossEntropyLoss raises; here the loss turns NaN
 #pragma unroll
     for (int k = 0; k < KB; ++k) {
       const float pk = l[k] * inv;
@@ -129,6 +129,7 @@ __global__ __launch_bounds__(256) void dc_ce_grad_kernel(const float* __restrict
     *loss_out += (float)(weight * (ce - dsum));
   }
   __syncthreads();
+  if (dlogits == nullptr) return;                      // value only (validation batches)
   const float inv_cnt = 1.f / ((float)B * (float)spatial);
   const float* lp = logits + (long long)n * K * spatial;
   float* dp = dlogits + (long long)n * K * spatial;
@@ -160,6 +161,61 @@ __global__ __launch_bounds__(256) void dc_ce_grad_kernel(const float* __restrict
 #pragma unroll
     for (int k = 0; k < KB; ++k)
       if (k < K) dp[(long long)k * spatial + v] = weight * ((l[k] - (k == t ? 1.f : 0.f)) * inv_cnt + l[k] * (g[k] - dot));
+  }
+}
+// batch dice across data-parallel ranks (reference nnUNetTrainerV2_DDP.py:263-268 gathers the per-sample numerators and
+// denominators and sums them): fold the [B][K][3] rows into row 0 (rows 1.. zeroed) so that ONE small all-reduce of
+// row 0 gives every rank the global tp/fp/fn; dc_ce_grad(batch_dice = 1) then sums the rows as before.
+__global__ void dc_ce_fold_batch_kernel(double* __restrict__ acc, int B, int K) {
+  const int i = threadIdx.x;
+  if (i >= 3 * K) return;
+  double s = 0.0;
+  for (int b = 0; b < B; ++b) {
+    s += acc[(long long)b * K * 3 + i];
+    if (b > 0) acc[(long long)b * K * 3 + i] = 0.0;
+  }
+  acc[i] = s;
+}
+
+// online evaluation of a validation batch (reference nnUNetTrainer_simple.py:373-405): hard tp / fp / fn voxel counts per
+// class of argmax(softmax(logits)) against the target, summed over the batch.  counts [K][3] (class 0 is filled too,
+// the reference reports classes 1..K-1).
+template <int KB>
+__global__ __launch_bounds__(256) void online_eval_kernel(const float* __restrict__ logits, const float* __restrict__ target,
+                                                          unsigned long long* __restrict__ counts, int K, long long spatial) {
+  __shared__ unsigned int h[3][KB];
+  for (int i = threadIdx.x; i < 3 * KB; i += 256) (&h[0][0])[i] = 0u;
+  __syncthreads();
+  const int n = blockIdx.y;
+  const float* lp = logits + (long long)n * K * spatial;
+  const float* tg = target + (long long)n * spatial;
+  for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < spatial; v += (long long)gridDim.x * 256) {
+    float l[KB];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      l[k] = (k < K) ? lp[(long long)k * spatial + v] : -INFINITY;
+      m = fmaxf(m, l[k]);
+    }
+    // argmax of the softmax = first maximum of exp(l - m) (the common 1/sum factor keeps order and ties)
+    int seg = 0;
+    float best = -1.f;
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      const float ek = (k < K) ? expf(l[k] - m) : -1.f;
+      if (ek > best) { best = ek; seg = k; }
+    }
+    const int t = (int)tg[v];
+    if (seg == t) atomicAdd(&h[0][seg], 1u);
+    else {
+      atomicAdd(&h[1][seg], 1u);
+      if ((unsigned)t < (unsigned)K) atomicAdd(&h[2][t], 1u);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * K; i += 256) {
+    const int k = i / 3, j = i - 3 * k;
+    if (h[j][k]) atomicAdd(&counts[i], (unsigned long long)h[j][k]);
   }
 }
 }  // namespace
@@ -196,10 +252,32 @@ extern "C" int e2e_dc_ce_reduce(const float* logits, const float* target, void* 
 extern "C" int e2e_dc_ce_grad(const float* logits, const float* target, const void* acc, float weight, int batch_dice,
                               float smooth, float* dlogits, float* loss_out, int B, int K, long long spatial,
                               void* stream) {
-  E2E_REQUIRE(logits && target && acc && dlogits && loss_out, "dc_ce_grad: null pointer");
+  E2E_REQUIRE(logits && target && acc && loss_out, "dc_ce_grad: null pointer");
   E2E_REQUIRE(B > 0 && K > 1 && K <= KMAX && spatial > 0, "dc_ce_grad: need 2 <= K <= 32");
-  dim3 grid(loss_blocks(spatial), B);
+  dim3 grid(dlogits ? loss_blocks(spatial) : 1u, dlogits ? B : 1);
   DISPATCH_LK(K, hipLaunchKernelGGL((dc_ce_grad_kernel<KB>), grid, dim3(256), 0, (hipStream_t)stream, logits, target,
                                     (const double*)acc, weight, batch_dice, smooth, dlogits, loss_out, B, K, spatial));
   return e2e::check_launch("dc_ce_grad_kernel");
+}
+
+extern "C" int e2e_dc_ce_fold_batch(void* acc, int B, int K, void* stream) {
+  E2E_REQUIRE(acc, "dc_ce_fold_batch: null pointer");
+  E2E_REQUIRE(B > 0 && K > 1 && K <= KMAX, "dc_ce_fold_batch: need 2 <= K <= 32");
+  hipLaunchKernelGGL(dc_ce_fold_batch_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, (double*)acc, B, K);
+  return e2e::check_launch("dc_ce_fold_batch_kernel");
+}
+
+extern "C" int e2e_online_eval_counts(const float* logits, const float* target, long long* counts, int B, int K,
+                                      long long spatial, void* stream) {
+  E2E_REQUIRE(logits && target && counts, "online_eval_counts: null pointer");
+  E2E_REQUIRE(B > 0 && K > 1 && K <= KMAX && spatial > 0, "online_eval_counts: need 2 <= K <= 32");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(counts, 0, (size_t)K * 3 * sizeof(long long), st) != hipSuccess) {
+    e2e::set_error("online_eval_counts: memset failed");
+    return E2E_ERR_LAUNCH;
+  }
+  dim3 grid(loss_blocks(spatial), B);
+  DISPATCH_LK(K, hipLaunchKernelGGL((online_eval_kernel<KB>), grid, dim3(256), 0, st, logits, target,
+                                    (unsigned long long*)counts, K, spatial));
+  return e2e::check_launch("online_eval_kernel");
 }

@@ -364,9 +364,12 @@ class Engine:
             self.ops.append(head)
         self.grads: Dict[str, torch.Tensor] = {}
         self.grad_bucket_hook = None       # callable(lo, hi): flat gradient slice [lo, hi) is final (data-parallel overlap)
+        self.batch_dice_hook = None        # callable(fp64 tensor [K*3]): all-reduce of the folded tp/fp/fn (data-parallel batch dice)
         self._backward_ready = False
         self.loss_ws = None
         self.loss_val = None
+        self.generation = 0                # bumped by every forward(): activations are reused in place
+        self._eval_counts = None
 
     def _add_conv(self, prefix, sources, cout, stride):
         op = ConvOp(self, prefix, sources, cout, stride)
@@ -417,6 +420,7 @@ class Engine:
         assert x.is_cuda and x.dtype == torch.float32, "engine input must be a float32 GPU tensor"
         assert tuple(x.shape) == self.input.shape, "engine built for %s, got %s" % (self.input.shape, tuple(x.shape))
         self.input.data.copy_(x)
+        self.generation += 1
         for op in self.ops:
             if isinstance(op, HeadOp):
                 op.active = deep_supervision or op is self.heads[0]
@@ -470,9 +474,7 @@ class Engine:
         self.wgrad_ws = torch.empty((ws + 3) // 4, dtype=torch.float32, device=self.device)
         cmax = max(op.cout for op in self.conv_ops.values())
         self.in_sums = torch.empty(self.batch * cmax * 3, dtype=torch.float64, device=self.device)
-        self.loss_ws = torch.empty(lib().loss_ws_bytes(self.batch, self.cfg.num_classes) // 8, dtype=torch.float64,
-                                   device=self.device)
-        self.loss_val = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._loss_buffers()
         self._backward_ready = True
 
     def backward(self, dlogits: Optional[Sequence[Optional[torch.Tensor]]] = None):
@@ -500,26 +502,59 @@ class Engine:
             hook(*self._bucket_tail)
         return self.grads
 
-    def loss_backward(self, targets: Sequence[torch.Tensor], weights: Sequence[float], batch_dice=False, smooth=1e-5):
-        """Deep-supervision Dice+CE loss (reference MultipleOutputLoss2(DC_and_CE_loss), deep_supervision.py:31-43)
-        and the full backward pass.  targets[i]: [B,1,...] float labels at scale i.  Returns the device loss scalar."""
-        self.prepare_backward()
+    def _loss_buffers(self):
+        if self.loss_ws is None:
+            self.loss_ws = torch.empty(lib().loss_ws_bytes(self.batch, self.cfg.num_classes) // 8, dtype=torch.float64,
+                                       device=self.device)
+            self.loss_val = torch.zeros(1, dtype=torch.float32, device=self.device)
+
+    def _loss(self, targets, weights, batch_dice, smooth, with_grad):
         L = lib()
+        self._loss_buffers()
         self.loss_val.zero_()
         k = self.cfg.num_classes
         for i, h in enumerate(self.heads):
             wgt = float(weights[i]) if i < len(weights) else 0.0
-            if wgt == 0.0:
-                h.out.grad.zero_()
+            if wgt == 0.0 or not h.active:
+                if with_grad:
+                    h.out.grad.zero_()
                 continue
             t = targets[i]
             assert t.is_cuda and t.dtype == torch.float32 and t.numel() == self.batch * h.src.spatial
             L.dc_ce_reduce(h.out.data.data_ptr(), t.data_ptr(), self.loss_ws.data_ptr(), self.batch, k, h.src.spatial,
                            _stream())
+            if batch_dice and self.batch_dice_hook is not None:
+                # data-parallel batch dice (reference nnUNetTrainerV2_DDP.py:263-268): global tp/fp/fn over all ranks
+                L.dc_ce_fold_batch(self.loss_ws.data_ptr(), self.batch, k, _stream())
+                self.batch_dice_hook(self.loss_ws[:3 * k])
             L.dc_ce_grad(h.out.data.data_ptr(), t.data_ptr(), self.loss_ws.data_ptr(), wgt, 1 if batch_dice else 0,
-                         smooth, h.out.grad.data_ptr(), self.loss_val.data_ptr(), self.batch, k, h.src.spatial, _stream())
+                         smooth, h.out.grad.data_ptr() if with_grad else None, self.loss_val.data_ptr(), self.batch, k,
+                         h.src.spatial, _stream())
+        return self.loss_val
+
+    def loss_backward(self, targets: Sequence[torch.Tensor], weights: Sequence[float], batch_dice=False, smooth=1e-5):
+        """Deep-supervision Dice+CE loss (reference MultipleOutputLoss2(DC_and_CE_loss), deep_supervision.py:31-43)
+        and the full backward pass.  targets[i]: [B,1,...] float labels at scale i.  Returns the device loss scalar."""
+        self.prepare_backward()
+        self._loss(targets, weights, batch_dice, smooth, True)
         self.backward(None)
         return self.loss_val
+
+    def loss_value(self, targets: Sequence[torch.Tensor], weights: Sequence[float], batch_dice=False, smooth=1e-5):
+        """The same loss without gradients (validation batches, reference nnUNetTrainer_simple.py:980-988)."""
+        return self._loss(targets, weights, batch_dice, smooth, False)
+
+    def online_eval_counts(self, target: torch.Tensor) -> torch.Tensor:
+        """Hard tp/fp/fn voxel counts [K, 3] (int64, device) of the full-resolution prediction against `target`
+        (reference run_online_evaluation, nnUNetTrainer_simple.py:373-405)."""
+        h = self.heads[0]
+        k = self.cfg.num_classes
+        if self._eval_counts is None:
+            self._eval_counts = torch.zeros((k, 3), dtype=torch.int64, device=self.device)
+        assert target.is_cuda and target.dtype == torch.float32 and target.numel() == self.batch * h.src.spatial
+        lib().online_eval_counts(h.out.data.data_ptr(), target.data_ptr(), self._eval_counts.data_ptr(), self.batch, k,
+                                 h.src.spatial, _stream())
+        return self._eval_counts
 
     # ------------------------------------------------------------------------------------------ accounting
     def activation_bytes(self):

@@ -81,12 +81,14 @@ class SegmentationNetwork(NeuralNetwork):
         # tile sharding over a process group (None = this process evaluates every tile)
         self.tile_group = None
         self.tile_rank, self.tile_world = 0, 1
+        self.tile_force = False
 
     # ------------------------------------------------------------------------------------------ configuration
-    def shard_tiles(self, rank: int, world: int, group=None):
+    def shard_tiles(self, rank: int, world: int, group=None, force: bool = False):
         """Evaluate tiles ``rank::world`` of the x->y->z tile list on this process and exchange the weighted
-        probability patches with one all-gather over ``group`` (RCCL on GPUs, gloo in CPU tests)."""
-        self.tile_rank, self.tile_world, self.tile_group = int(rank), int(world), group
+        probability patches with one all-gather over ``group`` (RCCL on GPUs, gloo in CPU tests).  ``force`` takes the
+        sharded branch (all-gather included) even for a single rank: self-test of the exchange on one GPU."""
+        self.tile_rank, self.tile_world, self.tile_group, self.tile_force = int(rank), int(world), group, bool(force)
 
     # ------------------------------------------------------------------------------------------ public API
     def predict_3D(self, x: np.ndarray, do_mirroring: bool, mirror_axes: Tuple[int, ...] = (0, 1, 2),
@@ -251,30 +253,23 @@ class SegmentationNetwork(NeuralNetwork):
         L = lib()
 
         world, rank = self.tile_world, self.tile_rank
-        my = list(range(rank, num_tiles, world))            # parallel.partition_tiles
-        if world == 1:
-            for ti in my:
-                sx, sy, sz = tiles[ti]
-                tile = vol[None, :, sx:sx + px, sy:sy + py, sz:sz + pz].contiguous()
-                pred = self._internal_maybe_mirror_and_pred_3D(tile, mirror_axes, do_mirroring, None)
-                L.sw_accumulate(pred.data_ptr(), gauss_dev.data_ptr() if gauss_dev is not None else None,
-                                agg.data_ptr(), cnt.data_ptr(), K, X, Y, Z, px, py, pz, sx, sy, sz, _stream())
+
+        def predict_tile(ti):
+            sx, sy, sz = tiles[ti]
+            tile = vol[None, :, sx:sx + px, sy:sy + py, sz:sz + pz].contiguous()
+            return self._internal_maybe_mirror_and_pred_3D(tile, mirror_axes, do_mirroring, None)[0]
+
+        def accumulate(ti, patch):
+            sx, sy, sz = tiles[ti]
+            L.sw_accumulate(patch.data_ptr(), gauss_dev.data_ptr() if gauss_dev is not None else None,
+                            agg.data_ptr(), cnt.data_ptr(), K, X, Y, Z, px, py, pz, sx, sy, sz, _stream())
+
+        if world == 1 and not self.tile_force:
+            for ti in range(num_tiles):
+                accumulate(ti, predict_tile(ti))
         else:
-            from ..parallel import gather_patches, slots_per_rank, tile_slot
-            per = slots_per_rank(num_tiles, world)
-            mine = torch.zeros((per, K, px, py, pz), dtype=torch.float32, device=dev)
-            for slot, ti in enumerate(my):
-                sx, sy, sz = tiles[ti]
-                tile = vol[None, :, sx:sx + px, sy:sy + py, sz:sz + pz].contiguous()
-                pred = self._internal_maybe_mirror_and_pred_3D(tile, mirror_axes, do_mirroring, None)
-                mine[slot].copy_(pred[0])
-            gathered = gather_patches(mine, world, self.tile_group)
-            for ti in range(num_tiles):                       # reference accumulation order: x -> y -> z
-                sx, sy, sz = tiles[ti]
-                owner, slot = tile_slot(ti, world)
-                patch = gathered[owner, slot]
-                L.sw_accumulate(patch.data_ptr(), gauss_dev.data_ptr() if gauss_dev is not None else None,
-                                agg.data_ptr(), cnt.data_ptr(), K, X, Y, Z, px, py, pz, sx, sy, sz, _stream())
+            from ..parallel import run_tiles_sharded
+            run_tiles_sharded(num_tiles, rank, world, self.tile_group, predict_tile, accumulate, (K, px, py, pz), dev)
 
         crop = [(s.start, s.stop) for s in slicer[1:]]
         (cx0, cx1), (cy0, cy1), (cz0, cz1) = crop

@@ -9,6 +9,7 @@ The nn modules below are parameter containers only.  ``forward`` runs the HIP en
 shift, concat, conv, InstanceNorm, LeakyReLU, transposed conv, pooling and heads are hand-written gfx950
 kernels behind the C ABI of libe2e_hip.so.  There is no CPU / eager fallback: a CPU tensor raises.
 """
+import os
 from copy import deepcopy
 
 import numpy as np
@@ -103,12 +104,18 @@ class _EngineFunction(torch.autograd.Function):
         eng = net._engine_for(x)
         ctx.net, ctx.eng, ctx.ds = net, eng, deep_supervision
         outs = eng.forward(x, deep_supervision)
+        ctx.generation = eng.generation
         outs = outs if isinstance(outs, list) else [outs]
         return tuple(o.clone() for o in outs)
 
     @staticmethod
     def backward(ctx, *grad_outputs):
         eng = ctx.eng
+        if eng.generation != ctx.generation:
+            # the engine keeps ONE set of activation buffers per (batch, patch) shape; a second forward has overwritten them
+            raise RuntimeError("Generic_UNetPlusPlus: backward() after another forward() through the same network: the "
+                               "engine reuses its activation buffers in place; call backward() before the next forward "
+                               "(gradient accumulation over several forwards is not supported)")
         dl = list(grad_outputs) + [None] * (4 - len(grad_outputs))
         dl = [g.contiguous() if g is not None else None for g in dl]
         grads = eng.backward(dl)
@@ -231,8 +238,9 @@ class Generic_UNetPlusPlus(SegmentationNetwork):
         self._engines = {}
         self._kernel_masks = None            # name -> uint8 [dim0, dim1]; None = dense
         self._auto_sparsity = False          # derive liveness from zero kernels (inference on DSFF checkpoints)
+        self._weights_outside_masks = False  # weights were (re)loaded after the masks were pushed: see _on_state_loaded
         self._param_names = [n for n, _ in self.named_parameters()]
-        self.register_load_state_dict_post_hook(lambda module, keys: module._invalidate_sparsity())
+        self.register_load_state_dict_post_hook(lambda module, keys: module._on_state_loaded())
 
     def _create_nest(self, z, num_pool, final_num_features, n_conv, stacked):
         """reference create_nest (:491-550) for convolutional_upsampling=True."""
@@ -263,20 +271,40 @@ class Generic_UNetPlusPlus(SegmentationNetwork):
         key = (tuple(x.shape), x.device.index)
         eng = self._engines.get(key)
         if eng is None:
-            for k in x.shape[2:]:
-                pass
             div = self.input_shape_must_be_divisible_by
             if any(int(s) % int(d) for s, d in zip(x.shape[2:], div)):
                 raise ValueError("input spatial shape %s must be divisible by %s" % (tuple(x.shape[2:]), tuple(div)))
             eng = Engine(self._cfg, self._live_params(), x.shape[0], tuple(x.shape[2:]), x.device)
-            self._engines = {key: eng}                      # one live plan at a time (activations are large)
             eng._sparsity_version = -1
+            self._engines[key] = eng
+            # plans are kept per (batch, patch) shape, least recently used first out, inside a byte budget (288 GB of HBM:
+            # a training plan at 2 x 128^3 holds 8.6 GB, the 8-mirror inference plan 17 GB; alternating between them must
+            # not re-allocate every time)
+            budget = float(os.environ.get("E2E_PLAN_CACHE_GB", "96")) * 2 ** 30
+            while len(self._engines) > 1 and sum(e.activation_bytes() for e in self._engines.values()) > budget:
+                self._engines.pop(next(iter(self._engines)))
+        else:
+            self._engines[key] = self._engines.pop(key)     # most recently used last
         eng.params = self._live_params()
         self._sync_sparsity(eng)
         return eng
 
     def _invalidate_sparsity(self):
         self._sparsity_version = getattr(self, "_sparsity_version", 0) + 1
+
+    def _on_state_loaded(self):
+        """load_state_dict ran.  The reference creates ``Masking`` (fresh random masks) BEFORE it loads a checkpoint
+        (simple_main.py:163-177): until the next ``apply_mask`` the loaded weights are used as they are, whatever the
+        masks say (the reference's conv is dense).  So from here to the next mask application a kernel is alive when
+        its mask says so OR when it holds a non-zero weight."""
+        self._weights_outside_masks = self._kernel_masks is not None
+        self._invalidate_sparsity()
+
+    def masks_applied(self):
+        """Called by ``Masking`` after weights *= mask (apply_mask or the fused optimizer step): masks are authoritative."""
+        if self._weights_outside_masks:
+            self._weights_outside_masks = False
+            self._invalidate_sparsity()
 
     def set_kernel_masks(self, kmasks):
         """DSFF: name -> uint8 [dim0, dim1] kernel liveness map (from ``Masking``).  None = dense."""
@@ -285,8 +313,12 @@ class Generic_UNetPlusPlus(SegmentationNetwork):
         self._invalidate_sparsity()
 
     def enable_auto_sparsity(self, flag=True):
-        """Inference on a DSFF checkpoint: pruned kernels are exact zeros, skip them."""
+        """Inference on a DSFF checkpoint: pruned kernels are exact zeros, skip them.  Takes precedence over masks pushed
+        by a ``Masking`` object (the reference's inference path never consults the masks)."""
         self._auto_sparsity = flag
+        if flag:
+            self._kernel_masks = None
+            self._weights_outside_masks = False
         self._invalidate_sparsity()
 
     def _sync_sparsity(self, eng):
@@ -294,7 +326,11 @@ class Generic_UNetPlusPlus(SegmentationNetwork):
         if eng._sparsity_version == ver:
             return
         if self._kernel_masks is not None:
-            eng.set_kernel_masks(self._kernel_masks)
+            km = self._kernel_masks
+            if self._weights_outside_masks:
+                nz = eng.kernel_masks_from_weights(names=set(km.keys()))
+                km = {n: (torch.bitwise_or(km[n].to(nz[n].device), nz[n]) if n in nz else km[n]) for n in km}
+            eng.set_kernel_masks(km)
         elif self._auto_sparsity:
             eng.set_kernel_masks(eng.kernel_masks_from_weights())
         else:

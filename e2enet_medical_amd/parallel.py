@@ -6,8 +6,11 @@
   result -- is identical to the single-GPU run.  xGMI is point-to-point: an all-gather lets every peer push its
   shard over its own link instead of funnelling partial volumes through a ring all-reduce.
 * Data-parallel training (config 5): replicas with identical weights; gradients are averaged with one flat
-  all-reduce before the fused clip+SGD step (the clip norm must see the reduced gradients); the DSFF kernel maps
-  are broadcast from rank 0 after every prune/grow so that the random growth stays consistent.
+  all-reduce before the fused clip+SGD step (the clip norm must see the reduced gradients); after every prune/grow
+  ``Masking.sync_kernel_maps`` broadcasts rank 0's kernel maps (host mirror, device maps, element masks and liveness
+  tables are all rebuilt from them), so the random growth stays consistent whatever the ranks' RNG states are; with
+  ``batch_dice`` the per-class tp/fp/fn sums are all-reduced between the two loss kernels (``batch_dice_allreduce``).
+  ``nnUNetTrainer_simple.run_iteration`` wires all three when ``torch.distributed`` is initialised.
 """
 from typing import Dict, List
 
@@ -37,6 +40,24 @@ def gather_patches(mine: torch.Tensor, world: int, group=None) -> torch.Tensor:
         parts = [out[r] for r in range(world)]
         dist.all_gather(parts, mine.contiguous(), group=group)
     return out
+
+
+def run_tiles_sharded(num_tiles: int, rank: int, world: int, group, predict_tile, accumulate, patch_shape, device,
+                      dtype=torch.float32):
+    """The sharded tile loop of sliding-window inference (BASELINE config 4), shared by ``predict_3D`` and the tests:
+    this rank evaluates tiles ``rank::world`` (``predict_tile(ti) -> [K, px, py, pz]`` mirror-averaged probabilities),
+    ONE all-gather moves every rank's patches to every rank, and all tiles are then handed to ``accumulate(ti, patch)``
+    in the reference's x -> y -> z order (neural_network.py:373-393), so the fp32 overlap-add -- and the result -- is
+    bit-identical to the single-process loop.  Returns the gathered buffer [world, slots, K, px, py, pz]."""
+    per = slots_per_rank(num_tiles, world)
+    mine = torch.zeros((per,) + tuple(patch_shape), dtype=dtype, device=device)
+    for slot, ti in enumerate(partition_tiles(num_tiles, rank, world)):
+        mine[slot].copy_(predict_tile(ti))
+    gathered = gather_patches(mine, world, group)
+    for ti in range(num_tiles):
+        owner, slot = tile_slot(ti, world)
+        accumulate(ti, gathered[owner, slot])
+    return gathered
 
 
 def allreduce_mean_gradients(grads: Dict[str, torch.Tensor], names: List[str], group=None, flat: torch.Tensor = None,
@@ -104,14 +125,9 @@ class OverlappedGradAllReduce:
             self.engine.grad_flat.mul_(1.0 / self.world)
 
 
-def broadcast_kernel_masks(kmasks: Dict[str, torch.Tensor], src: int = 0, group=None):
-    """Broadcast the uint8 kernel maps (1.39 M kernels at 32 ch = 1.4 MB) from ``src`` as one tensor."""
-    names = list(kmasks.keys())
-    flat = torch.cat([kmasks[n].reshape(-1) for n in names])
-    dist.broadcast(flat, src=src, group=group)
-    off = 0
-    for n in names:
-        k = kmasks[n].numel()
-        kmasks[n].copy_(flat[off:off + k].view_as(kmasks[n]))
-        off += k
-    return kmasks
+def batch_dice_allreduce(group=None):
+    """Engine.batch_dice_hook for data-parallel batch dice (reference nnUNetTrainerV2_DDP.py:263-268): sums the folded
+    per-class (tp, fp, fn) doubles over the ranks in place."""
+    def hook(t: torch.Tensor):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return hook

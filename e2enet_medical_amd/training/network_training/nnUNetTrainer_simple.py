@@ -1,20 +1,33 @@
 """``nnUNetTrainer_simple`` on the MI355X engine.
 
-Keeps the operator surface of reference e2enet/training/network_training/nnUNetTrainer_simple.py that
-``simple_main.py`` / ``simple_predict.py`` / ``model_restore`` touch: constructor (:59-61), ``initialize`` (:178-253),
-``initialize_network`` (:255-363, shiftConvPP branch :292-301), ``initialize_optimizer_and_scheduler`` (:367-371),
-``run_iteration`` (:529-583), ``run_training`` (:929-1027), ``process_plans`` (:1036-1103), checkpoints (:1140-1255),
-``predict_preprocessed_data_return_seg_and_softmax`` (:491-527).  The arithmetic of an iteration -- forward, deep
-supervision Dice+CE, backward, clip_grad_norm_(12), SGD-Nesterov, DSFF mask -- is one chain of HIP kernel launches
-(``engine.Engine`` + ``fused_optim.FusedClipSGD``), fp32 throughout.
+Keeps the operator surface of reference e2enet/training/network_training/nnUNetTrainer_simple.py that ``simple_main.py``,
+``simple_predict.py`` and ``model_restore.load_model_and_checkpoint_files`` touch:
 
-Out of scope here: the batchgenerators data pipeline, NIfTI export and ``validate``.  Data
-arrives through any iterator of ``{'data': [B,C,...], 'target': [list of [B,1,...] per scale]}`` dicts (the format
-of the reference's augmenter output, :538-540); ``SyntheticGenerator`` provides seeded synthetic batches.
+  constructor (:59-176)                 initialize (:178-253)            initialize_network (:255-363, shiftConvPP :292-301)
+  initialize_optimizer_and_scheduler (:365-369)                          run_iteration (:529-583)
+  run_online_evaluation / finish_online_evaluation (:371-423)            update_fold (:653-680)
+  maybe_update_lr / maybe_save_checkpoint (:758-785)                     update_eval_criterion_MA (:787-810)
+  manage_patience (:812-860)            on_epoch_end (:863-877)          update_train_loss_MA (:879-884)
+  run_training (:929-1027)              process_plans (:1036-1103)       save_checkpoint (:1140-1176)
+  load_best / latest / final_checkpoint (:1178-1202)                     load_checkpoint(_ram) (:1204-1255)
+  predict_preprocessed_data_return_seg_and_softmax (:491-527)
+
+The arithmetic of an iteration -- forward, deep-supervision Dice+CE, backward, clip_grad_norm_(12), SGD-Nesterov, DSFF
+mask, and for validation batches the loss value and the hard tp/fp/fn counts -- is one chain of HIP kernel launches
+(``engine.Engine`` + ``fused_optim.FusedClipSGD``), fp32 throughout.  When ``torch.distributed`` is initialised the
+iteration is data parallel (one process per GPU, RCCL): bucketed gradient all-reduce overlapped with the backward pass,
+global batch dice, broadcast DSFF masks (``parallel``; the reference's collective inventory is nnUNetTrainerV2_DDP.py:198,
+:263-268).
+
+Out of scope: the batchgenerators data pipeline, preprocessing, NIfTI export and
+``validate``: those entry points raise NotImplementedError naming the subsystem.  Data arrives through any iterator of
+``{'data': [B,C,...], 'target': [list of [B,1,...] per scale]}`` dicts (the format of the reference's augmenter output,
+:538-540); ``SyntheticGenerator`` provides seeded synthetic batches.
 """
 import os
 import pickle
 from collections import OrderedDict
+from datetime import datetime
 from time import time
 from typing import Tuple
 
@@ -30,6 +43,8 @@ from ..fused_optim import FusedClipSGD
 from ..learning_rate.poly_lr import poly_lr
 from ..loss_functions.deep_supervision import MultipleOutputLoss2
 from ..loss_functions.dice_loss import DC_and_CE_loss
+
+join, isfile = os.path.join, os.path.isfile
 
 
 class SyntheticGenerator:
@@ -53,6 +68,14 @@ class SyntheticGenerator:
             targets.append(full[:, :, ::step[0], ::step[1], ::step[2]].contiguous())
         return {'data': data, 'target': targets}
 
+    next = __next__                      # the reference calls tr_gen.next() once before training (:946-947)
+
+
+def _out_of_scope(what, where):
+    raise NotImplementedError("%s needs the reference's %s, which is outside the MI355X hot path (SURVEY.md section 2, "
+                              "OUT OF SCOPE rows); run it with the reference package on the outputs of this trainer"
+                              % (what, where))
+
 
 class nnUNetTrainer_simple(object):
     def __init__(self, plans_file, fold, output_folder=None, dataset_directory=None, batch_dice=True, stage=None,
@@ -60,33 +83,93 @@ class nnUNetTrainer_simple(object):
                  num_batches_per_epoch=100, args=None):
         self.init_args = (plans_file, fold, output_folder, dataset_directory, batch_dice, stage, unpack_data,
                           deterministic, fp16)
-        self.plans_file, self.fold, self.output_folder = plans_file, fold, output_folder
-        self.dataset_directory, self.batch_dice, self.stage = dataset_directory, batch_dice, stage
-        self.unpack_data, self.deterministic = unpack_data, deterministic
+        self.deep_supervision_scales = self.ds_loss_weights = None
+        self.pin_memory = True
+        self.args = args
         # the engine computes in fp32 (1e-4 logit parity bar); the reference's AMP switch is accepted and ignored
         self.fp16 = False
-        self.Tconv = Tconv if Tconv is not None else 'shiftConvPP'
-        self.args = args
+        self.amp_grad_scaler = None
+        self.unpack_data, self.stage = unpack_data, stage
+        self.experiment_name = self.__class__.__name__
+        self.plans_file, self.output_folder, self.dataset_directory = plans_file, output_folder, dataset_directory
+        self.output_folder_base = self.output_folder
+        self.output_folder_pretrained = self.output_folder
+        self.fold = fold
         self.plans = None
+        self.Tconv = Tconv if Tconv is not None else 'shiftConvPP'
+        self.gt_niftis_folder = join(dataset_directory, "gt_segmentations") \
+            if dataset_directory is not None and os.path.isdir(dataset_directory) else None
+        self.folder_with_preprocessed_data = None
+        self.dl_tr = self.dl_val = None
+        self.num_input_channels = self.num_classes = self.net_pool_per_axis = self.patch_size = self.batch_size = \
+            self.threeD = self.base_num_features = self.intensity_properties = self.normalization_schemes = \
+            self.net_num_pool_op_kernel_sizes = self.net_conv_kernel_sizes = None
+        self.basic_generator_patch_size = self.transpose_forward = self.transpose_backward = None
+        self.data_aug_params = {'mirror_axes': (0, 1, 2), 'do_mirror': True}
+        self.batch_dice = batch_dice
+        self.loss = DC_and_CE_loss({'batch_dice': self.batch_dice, 'smooth': 1e-5, 'do_bg': False}, {})
+        self.online_eval_foreground_dc, self.online_eval_tp, self.online_eval_fp, self.online_eval_fn = [], [], [], []
+        self.classes = self.do_dummy_2D_aug = self.use_mask_for_norm = self.only_keep_largest_connected_component = \
+            self.min_region_size_per_class = self.min_size_per_class = None
+        self.inference_pad_border_mode = "constant"
+        self.inference_pad_kwargs = {'constant_values': 0}
+        self.update_fold(fold)
+        self.pad_all_sides = None
+        self.lr_scheduler_eps, self.lr_scheduler_patience = 1e-3, 30
+        self.initial_lr, self.weight_decay = 1e-2, 3e-5
+        self.oversample_foreground_percent = 0.33
+        self.conv_per_stage = None
+        self.regions_class_order = None
         self.network = self.optimizer = self.lr_scheduler = None
         self.tr_gen = self.val_gen = None
         self.was_initialized = False
-        self.loss = DC_and_CE_loss({'batch_dice': self.batch_dice, 'smooth': 1e-5, 'do_bg': False}, {})
-        self.initial_lr, self.weight_decay = 1e-2, 3e-5
+        self.dataset = self.dataset_tr = self.dataset_val = None
+        self.patience = 50
+        self.val_eval_criterion_alpha = 0.9
+        self.train_loss_MA_alpha = 0.93
+        self.train_loss_MA_eps = 5e-4
         self.max_num_epochs, self.num_batches_per_epoch = max_num_epochs, num_batches_per_epoch
         self.num_val_batches_per_epoch = 50
-        self.save_every = 50
-        self.epoch = 0
-        self.deep_supervision_scales = self.ds_loss_weights = None
+        self.also_val_in_tr_mode = False
+        self.lr_threshold = 1e-6
+        self.val_eval_criterion_MA = self.train_loss_MA = None
+        self.best_val_eval_criterion_MA = self.best_MA_tr_loss_for_patience = self.best_epoch_based_on_MA_tr_loss = None
         self.all_tr_losses, self.all_val_losses, self.all_val_losses_tr_mode, self.all_val_eval_metrics = [], [], [], []
-        self.best_epoch_based_on_MA_tr_loss = self.best_MA_tr_loss_for_patience = self.best_val_eval_criterion_MA = None
-        self.regions_class_order = None
-        self.data_aug_params = {'mirror_axes': (0, 1, 2), 'do_mirror': True}
-        self.base_num_features_override = None      # reference hard-codes 48 for shiftConvPP (:296)
-        self._fused = None
+        self.epoch = 0
         self.log_file = None
+        self.deterministic = deterministic
+        self.use_progress_bar = bool(int(os.environ.get('nnunet_use_progress_bar', '0')))
+        self.save_every = 50
+        self.save_latest_only = True
+        self.save_intermediate_checkpoints = True
+        self.save_best_checkpoint = True
+        self.save_final_checkpoint = True
+        # ---- this engine ----
+        self.base_num_features_override = None      # reference hard-codes 48 for shiftConvPP (:296)
+        self.process_group = None                   # torch.distributed group of the data-parallel replicas (None = world)
+        self._fused = None
+        self._dp = {}                               # id(engine) -> OverlappedGradAllReduce
+        self._mask = None                           # the Masking passed to run_training (checkpoints carry its state)
 
-    # ------------------------------------------------------------------------------------------ plans
+    # ------------------------------------------------------------------------------------------ folds / plans
+    def update_fold(self, fold):
+        """reference :653-680: swap between folds for inference (ensembles of cross-validation models)."""
+        if fold is not None:
+            of = self.output_folder
+            if isinstance(fold, str):
+                assert fold == "all", "if self.fold is a string then it must be 'all'"
+                if of is not None:
+                    if of.endswith("%s" % str(self.fold)):
+                        of = self.output_folder_base
+                    of = join(of, "%s" % str(fold))
+            elif of is not None:
+                if of.endswith("fold_%s" % str(self.fold)):
+                    of = self.output_folder_base
+                of = join(of, "fold_%s" % str(fold))
+            self.output_folder = of
+            self.fold = fold
+            self.output_folder_pretrained = self.output_folder      # reference :679-680 (its Tconv branch is commented out)
+
     def load_plans_file(self):
         if isinstance(self.plans_file, dict):
             self.plans = self.plans_file
@@ -106,9 +189,15 @@ class nnUNetTrainer_simple(object):
         self.patch_size = np.array(sp['patch_size']).astype(int)
         self.net_num_pool_op_kernel_sizes = sp['pool_op_kernel_sizes']
         self.net_conv_kernel_sizes = sp.get('conv_kernel_sizes')
+        self.do_dummy_2D_aug = sp.get('do_dummy_2D_data_aug', False)
         self.base_num_features = plans['base_num_features']
         self.num_input_channels = plans['num_modalities']
         self.num_classes = plans['num_classes'] + 1
+        self.classes = plans.get('all_classes')
+        self.intensity_properties = plans.get('dataset_properties', {}).get('intensityproperties') \
+            if isinstance(plans.get('dataset_properties'), dict) else None
+        self.normalization_schemes = plans.get('normalization_schemes')
+        self.use_mask_for_norm = plans.get('use_mask_for_norm')
         self.transpose_forward = plans.get('transpose_forward', [0, 1, 2])
         self.transpose_backward = plans.get('transpose_backward', [0, 1, 2])
         self.conv_per_stage = plans.get('conv_per_stage', 2)
@@ -172,6 +261,26 @@ class nnUNetTrainer_simple(object):
         self.lr_scheduler = None
         self._fused = None
 
+    # ------------------------------------------------------------------------------------------ data parallel
+    def _data_parallel(self):
+        """(active, group): data-parallel replicas exist when torch.distributed is initialised with more than one rank
+        (E2E_FORCE_DIST=1 runs the same code path on a single rank: self-test of the collectives)."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return False, None
+        force = os.environ.get("E2E_FORCE_DIST") == "1"
+        return dist.get_world_size(self.process_group) > 1 or force, self.process_group
+
+    def _dp_for(self, eng, group):
+        from ... import parallel
+        dp = self._dp.get(id(eng))
+        if dp is None:
+            eng.prepare_backward()
+            dp = parallel.OverlappedGradAllReduce(eng, group=group, force=os.environ.get("E2E_FORCE_DIST") == "1")
+            eng.batch_dice_hook = parallel.batch_dice_allreduce(group)
+            self._dp = {id(eng): dp}
+        return dp
+
     # ------------------------------------------------------------------------------------------ one iteration
     def run_iteration(self, data_generator, do_backprop=True, run_online_evaluation=False, mask=None):
         """reference :529-583.  Returns the loss as a numpy scalar (one device->host sync, like the reference)."""
@@ -185,54 +294,199 @@ class nnUNetTrainer_simple(object):
             target = [target]
         target = [torch.as_tensor(t).float().to(dev, non_blocking=True).contiguous() for t in target]
         eng = self.network.engine(data)
+        dp_on, group = self._data_parallel()
+        dp = self._dp_for(eng, group) if (dp_on and do_backprop) else None
+        if dp_on and eng.batch_dice_hook is None:
+            from ... import parallel
+            eng.batch_dice_hook = parallel.batch_dice_allreduce(group)
         eng.forward(data, deep_supervision=True)
         if do_backprop:
             loss = eng.loss_backward(target, self.ds_loss_weights, batch_dice=self.batch_dice)
+            if dp is not None:
+                dp.finish()                                     # gradients averaged over the replicas (clip norm sees these)
             if self._fused is None:
                 self._fused = FusedClipSGD(self.optimizer, list(self.network.named_parameters()), max_norm=12.0)
             masks = mask.masks if mask is not None else None
             self._fused.step(eng.grads, masks)                  # clip + SGD + (weight, momentum) *= mask
             if mask is not None:
+                if dp_on and getattr(mask, "process_group", None) is None:
+                    mask.process_group = group
                 mask.step(masks_already_applied=True)
         else:
-            outs = [h.out.data for h in eng.heads]
-            loss = self.loss(outs, target)
+            loss = eng.loss_value(target, self.ds_loss_weights, batch_dice=self.batch_dice)
+        if run_online_evaluation:
+            self.run_online_evaluation([h.out.data for h in eng.heads], target, _engine=eng)
         return loss.detach().cpu().numpy().reshape(())
 
+    def run_online_evaluation(self, output, target, _engine=None):
+        """reference :371-405: hard tp/fp/fn per foreground class of the full-resolution prediction, summed over the
+        batch (HIP kernel e2e_online_eval_counts; under data parallelism summed over the ranks as
+        nnUNetTrainerV2_DDP.py:303-305 does)."""
+        eng = _engine if _engine is not None else self.network.engine(output[0])
+        if _engine is None:                                      # called with foreign logits: evaluate those
+            eng.heads[0].out.data.copy_(output[0])
+        counts = eng.online_eval_counts(target[0])
+        dp_on, group = self._data_parallel()
+        if dp_on:
+            import torch.distributed as dist
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+        c = counts.cpu().numpy().astype(np.float32)[1:]          # foreground classes
+        tp_hard, fp_hard, fn_hard = c[:, 0], c[:, 1], c[:, 2]
+        self.online_eval_foreground_dc.append(list((2 * tp_hard) / (2 * tp_hard + fp_hard + fn_hard + 1e-8)))
+        self.online_eval_tp.append(list(tp_hard))
+        self.online_eval_fp.append(list(fp_hard))
+        self.online_eval_fn.append(list(fn_hard))
+
+    def finish_online_evaluation(self):
+        """reference :407-423"""
+        if len(self.online_eval_tp) == 0:
+            return
+        self.online_eval_tp = np.sum(self.online_eval_tp, 0)
+        self.online_eval_fp = np.sum(self.online_eval_fp, 0)
+        self.online_eval_fn = np.sum(self.online_eval_fn, 0)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            global_dc_per_class = [i for i in [2 * i / (2 * i + j + k) for i, j, k in
+                                               zip(self.online_eval_tp, self.online_eval_fp, self.online_eval_fn)]
+                                   if not np.isnan(i)]
+        self.all_val_eval_metrics.append(np.mean(global_dc_per_class))
+        self.print_to_log_file("Average global foreground Dice:", [np.round(i, 4) for i in global_dc_per_class])
+        self.print_to_log_file("(interpret this as an estimate for the Dice of the different classes. This is not exact.)")
+        self.online_eval_foreground_dc, self.online_eval_tp, self.online_eval_fp, self.online_eval_fn = [], [], [], []
+
+    # ------------------------------------------------------------------------------------------ epoch bookkeeping
     def maybe_update_lr(self, epoch=None):
+        """reference :758-773 (called in on_epoch_end before the epoch counter is incremented, hence the +1)."""
         ep = self.epoch + 1 if epoch is None else epoch
         self.optimizer.param_groups[0]['lr'] = poly_lr(ep, self.max_num_epochs, self.initial_lr, 0.9)
+        self.print_to_log_file("lr:", np.round(self.optimizer.param_groups[0]['lr'], decimals=6))
+
+    def maybe_save_checkpoint(self):
+        """reference :775-785"""
+        if self.output_folder and self.save_intermediate_checkpoints and (self.epoch % self.save_every == (self.save_every - 1)):
+            self.print_to_log_file("saving scheduled checkpoint file...")
+            if not self.save_latest_only:
+                self.save_checkpoint(join(self.output_folder, "model_ep_%03.0d.model" % (self.epoch + 1)), mask=self._mask)
+            self.save_checkpoint(join(self.output_folder, "%s_model_latest.model" % self.Tconv), mask=self._mask)
+            self.print_to_log_file("done")
+
+    def update_eval_criterion_MA(self):
+        """reference :787-810"""
+        if self.val_eval_criterion_MA is None:
+            self.val_eval_criterion_MA = - self.all_val_losses[-1] if len(self.all_val_eval_metrics) == 0 \
+                else self.all_val_eval_metrics[-1]
+        elif len(self.all_val_eval_metrics) == 0:
+            self.val_eval_criterion_MA = self.val_eval_criterion_alpha * self.val_eval_criterion_MA - (
+                1 - self.val_eval_criterion_alpha) * self.all_val_losses[-1]
+        else:
+            self.val_eval_criterion_MA = self.val_eval_criterion_alpha * self.val_eval_criterion_MA + (
+                1 - self.val_eval_criterion_alpha) * self.all_val_eval_metrics[-1]
+
+    def update_train_loss_MA(self):
+        """reference :879-884"""
+        if self.train_loss_MA is None:
+            self.train_loss_MA = self.all_tr_losses[-1]
+        else:
+            self.train_loss_MA = self.train_loss_MA_alpha * self.train_loss_MA + (1 - self.train_loss_MA_alpha) * \
+                self.all_tr_losses[-1]
+
+    def manage_patience(self):
+        """reference :812-860"""
+        continue_training = True
+        if self.patience is not None:
+            if self.best_MA_tr_loss_for_patience is None:
+                self.best_MA_tr_loss_for_patience = self.train_loss_MA
+            if self.best_epoch_based_on_MA_tr_loss is None:
+                self.best_epoch_based_on_MA_tr_loss = self.epoch
+            if self.best_val_eval_criterion_MA is None:
+                self.best_val_eval_criterion_MA = self.val_eval_criterion_MA
+            self.print_to_log_file("current best_val_eval_criterion_MA is %.4f" % self.best_val_eval_criterion_MA)
+            self.print_to_log_file("current val_eval_criterion_MA is %.4f" % self.val_eval_criterion_MA)
+            if self.val_eval_criterion_MA > self.best_val_eval_criterion_MA:
+                self.best_val_eval_criterion_MA = self.val_eval_criterion_MA
+                self.print_to_log_file("saving best epoch checkpoint...")
+                if self.save_best_checkpoint and self.output_folder:
+                    self.save_checkpoint(join(self.output_folder, "%s_model_best.model" % self.Tconv), mask=self._mask)
+            if self.train_loss_MA + self.train_loss_MA_eps < self.best_MA_tr_loss_for_patience:
+                self.best_MA_tr_loss_for_patience = self.train_loss_MA
+                self.best_epoch_based_on_MA_tr_loss = self.epoch
+                self.print_to_log_file("New best epoch (train loss MA): %03.4f" % self.best_MA_tr_loss_for_patience)
+            if self.epoch - self.best_epoch_based_on_MA_tr_loss > self.patience:
+                if self.optimizer.param_groups[0]['lr'] > self.lr_threshold:
+                    self.best_epoch_based_on_MA_tr_loss = self.epoch - self.patience // 2
+                else:
+                    self.print_to_log_file("My patience ended")
+                    continue_training = False
+        return continue_training
+
+    def on_epoch_end(self):
+        """reference :863-877"""
+        self.finish_online_evaluation()
+        self.maybe_update_lr()
+        self.maybe_save_checkpoint()
+        self.update_eval_criterion_MA()
+        return self.manage_patience()
 
     def run_training(self, mask=None):
-        """reference :929-1027 (epoch loop, poly LR, periodic checkpoints)."""
+        """reference :929-1027: epoch loop, validation batches with online evaluation, poly LR, moving averages, best /
+        latest / final checkpoints.  Checkpoints written from here carry the DSFF state of ``mask``."""
+        self._mask = mask
         self.maybe_update_lr(self.epoch)
+        ds = self.network.do_ds
         self.network.do_ds = True
+        if not self.was_initialized:
+            self.initialize(True)
+        if self.output_folder:
+            os.makedirs(self.output_folder, exist_ok=True)
         while self.epoch < self.max_num_epochs:
-            t0 = time()
+            self.print_to_log_file("\nepoch: ", self.epoch)
+            epoch_start_time = time()
             self.network.train()
-            losses = [self.run_iteration(self.tr_gen, True, mask=mask) for _ in range(self.num_batches_per_epoch)]
-            self.all_tr_losses.append(float(np.mean(losses)))
+            train_losses_epoch = [self.run_iteration(self.tr_gen, True, mask=mask) for _ in range(self.num_batches_per_epoch)]
+            self.all_tr_losses.append(np.mean(train_losses_epoch))
+            self.print_to_log_file("train loss : %.4f" % self.all_tr_losses[-1])
             with torch.no_grad():
                 self.network.eval()
-                vl = [self.run_iteration(self.val_gen, False, True) for _ in range(min(self.num_val_batches_per_epoch, 2))]
-                self.all_val_losses.append(float(np.mean(vl)))
-            self.print_to_log_file("epoch %d: train loss %.4f val loss %.4f (%.1f s)" %
-                                   (self.epoch, self.all_tr_losses[-1], self.all_val_losses[-1], time() - t0))
-            self.maybe_update_lr()
-            if self.output_folder and (self.epoch % self.save_every == self.save_every - 1):
-                self.save_checkpoint(os.path.join(self.output_folder, self.Tconv + "_model_latest.model"))
+                val_losses = [self.run_iteration(self.val_gen, False, True) for _ in range(self.num_val_batches_per_epoch)]
+                self.all_val_losses.append(np.mean(val_losses))
+                self.print_to_log_file("validation loss: %.4f" % self.all_val_losses[-1])
+            self.update_train_loss_MA()
+            continue_training = self.on_epoch_end()
+            if not continue_training:
+                break
             self.epoch += 1
+            self.print_to_log_file("This epoch took %f s\n" % (time() - epoch_start_time))
+        self.epoch -= 1          # reference :1018: otherwise the final checkpoint stores an epoch beyond the loss history
         if self.output_folder:
-            self.save_checkpoint(os.path.join(self.output_folder, self.Tconv + "_model_final_checkpoint.model"))
+            if self.save_final_checkpoint:
+                self.save_checkpoint(join(self.output_folder, "%s_model_final_checkpoint.model" % self.Tconv), mask=mask)
+            for f in ("%s_model_latest.model" % self.Tconv, "%s_model_latest.model.pkl" % self.Tconv):
+                if isfile(join(self.output_folder, f)):          # identical with final (reference :1022-1025)
+                    os.remove(join(self.output_folder, f))
+        self.network.do_ds = ds
 
-    def print_to_log_file(self, *args):
-        print(*args)
+    def print_to_log_file(self, *args, also_print_to_console=True, add_timestamp=True):
+        """reference :1106-1138 (timestamped text log next to the checkpoints)."""
+        if self.output_folder and self.log_file is None:
+            ts = datetime.now()
+            self.log_file = join(self.output_folder, "training_log_%d_%d_%d_%02.0d_%02.0d_%02.0d.txt" %
+                                 (ts.year, ts.month, ts.day, ts.hour, ts.minute, ts.second))
+        if self.log_file is not None:
+            try:
+                with open(self.log_file, 'a+') as f:
+                    if add_timestamp:
+                        f.write("%s: " % datetime.now())
+                    f.write(" ".join(str(a) for a in args) + "\n")
+            except IOError:
+                pass
+        if also_print_to_console:
+            print(*args)
 
     # ------------------------------------------------------------------------------------------ checkpoints
     def save_checkpoint(self, fname, save_optimizer=True, mask=None):
         """reference :1140-1176 (same dict keys and the side-car .pkl).  With ``mask`` (a Masking) the checkpoint also
         carries 'dsff_state' (packed kernel maps, death-rate schedule position, growth RNG state); reference loaders
         ignore the extra key."""
+        mask = mask if mask is not None else self._mask
         state_dict = OrderedDict((k, v.cpu()) for k, v in self.network.state_dict().items())
         save_this = {'epoch': self.epoch + 1, 'state_dict': state_dict,
                      'optimizer_state_dict': self.optimizer.state_dict() if save_optimizer else None,
@@ -249,9 +503,47 @@ class nnUNetTrainer_simple(object):
         with open(fname + ".pkl", 'wb') as f:
             pickle.dump(info, f)
 
+    def load_best_checkpoint(self, train=True, mask=None):
+        """reference :1178-1186"""
+        if self.fold is None:
+            raise RuntimeError("Cannot load best checkpoint if self.fold is None")
+        f = join(self.output_folder_pretrained, "%s_model_best.model" % self.Tconv)
+        if isfile(f):
+            return self.load_checkpoint(f, train=train, mask=mask)
+        self.print_to_log_file("WARNING! model_best.model does not exist! Cannot load best checkpoint. Falling "
+                               "back to load_latest_checkpoint")
+        return self.load_latest_checkpoint(train, mask=mask)
+
+    def load_latest_checkpoint(self, train=True, mask=None):
+        """reference :1188-1195.  The reference looks for un-prefixed names only and therefore cannot find what its own
+        run_training writes (``{Tconv}_model_latest.model``); both spellings are tried here, the
+        prefixed one first."""
+        folder = self.output_folder_pretrained
+        for stem in ("model_final_checkpoint.model", "model_latest.model"):
+            for name in ("%s_%s" % (self.Tconv, stem), stem):
+                if isfile(join(folder, name)):
+                    return self.load_checkpoint(join(folder, name), train=train, mask=mask)
+        if isfile(join(folder, "%s_model_best.model" % self.Tconv)) or isfile(join(folder, "model_best.model")):
+            return self.load_best_checkpoint(train, mask=mask)
+        raise RuntimeError("No checkpoint found")
+
+    def load_final_checkpoint(self, train=False, mask=None):
+        """reference :1197-1202"""
+        filename = join(self.output_folder_pretrained, "%s_model_final_checkpoint.model" % self.Tconv)
+        if not isfile(filename):
+            raise RuntimeError("Final checkpoint not found. Expected: %s. Please finish the training first." % filename)
+        return self.load_checkpoint(filename, train=train, mask=mask)
+
+    def load_checkpoint(self, fname, train=True, mask=None):
+        self.print_to_log_file("loading checkpoint", fname, "train=", train)
+        if not self.was_initialized:
+            self.initialize(train)
+        self.load_checkpoint_ram(torch.load(fname, map_location=torch.device('cpu'), weights_only=False), train, mask)
+
     def load_checkpoint_ram(self, checkpoint, train=True, mask=None):
         """reference :1211-1255; ``mask``: a Masking already attached to this trainer's network/optimizer
-        (add_module done) that is restored from checkpoint['dsff_state']."""
+        (add_module done) that is restored from checkpoint['dsff_state'].  Unlike the reference, the optimizer state is
+        restored too when training resumes (the reference restarts the momentum from zero)."""
         if not self.was_initialized:
             self.initialize(train)
         keys = list(self.network.state_dict().keys())
@@ -269,6 +561,14 @@ class nnUNetTrainer_simple(object):
         if 'best_stuff' in checkpoint:
             self.best_epoch_based_on_MA_tr_loss, self.best_MA_tr_loss_for_patience, self.best_val_eval_criterion_MA = \
                 checkpoint['best_stuff']
+        if self.epoch != len(self.all_tr_losses):               # reference :1245-1253 (old off-by-one of the final save)
+            self.print_to_log_file("WARNING in loading checkpoint: self.epoch != len(self.all_tr_losses). "
+                                   "self.epoch is now set to len(self.all_tr_losses)")
+            self.epoch = len(self.all_tr_losses)
+            self.all_tr_losses = self.all_tr_losses[:self.epoch]
+            self.all_val_losses = self.all_val_losses[:self.epoch]
+            self.all_val_losses_tr_mode = self.all_val_losses_tr_mode[:self.epoch]
+            self.all_val_eval_metrics = self.all_val_eval_metrics[:self.epoch]
         if mask is not None:
             if 'dsff_state' not in checkpoint:
                 raise KeyError("checkpoint carries no 'dsff_state' (written by save_checkpoint(..., mask=mask))")
@@ -276,9 +576,6 @@ class nnUNetTrainer_simple(object):
         # DSFF checkpoints carry their masks implicitly (pruned kernels are exact zeros): skip them at inference
         if not train:
             self.network.enable_auto_sparsity(True)
-
-    def load_checkpoint(self, fname, train=True, mask=None):
-        self.load_checkpoint_ram(torch.load(fname, map_location=torch.device('cpu'), weights_only=False), train, mask)
 
     # ------------------------------------------------------------------------------------------ inference
     def predict_preprocessed_data_return_seg_and_softmax(self, data: np.ndarray, do_mirroring: bool = True,
@@ -309,3 +606,26 @@ class nnUNetTrainer_simple(object):
         self.network.train(current_mode)
         self.network.do_ds = ds
         return ret
+
+    # ------------------------------------------------------------------------------------------ out of scope
+    def validate(self, *args, **kwargs):
+        """reference :1309-1479"""
+        _out_of_scope("validate()", "dataset loader, NIfTI export and evaluation tooling (e2enet/training/dataloading, "
+                                    "e2enet/inference/segmentation_export.py, e2enet/evaluation)")
+
+    def preprocess_patient(self, input_files):
+        """reference :425-452"""
+        _out_of_scope("preprocess_patient()", "preprocessing package (e2enet/preprocessing: crop, resample, normalise)")
+
+    def preprocess_predict_nifti(self, *args, **kwargs):
+        """reference :454-489"""
+        _out_of_scope("preprocess_predict_nifti()", "preprocessing and NIfTI export (e2enet/preprocessing, "
+                                                    "e2enet/inference/segmentation_export.py)")
+
+    def load_dataset(self):
+        """reference :585-586"""
+        _out_of_scope("load_dataset()", "dataset loader (e2enet/training/dataloading/dataset_loading.py)")
+
+    def do_split(self):
+        """reference :588-651"""
+        _out_of_scope("do_split()", "dataset loader and its KFold split (e2enet/training/dataloading)")

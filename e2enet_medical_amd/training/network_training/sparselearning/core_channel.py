@@ -216,6 +216,44 @@ class Masking(object):
             if hasattr(m, "set_kernel_masks"):
                 m.set_kernel_masks(dict(self.kmasks))
 
+    def _notify_masks_applied(self):
+        for m in self.modules:
+            if hasattr(m, "masks_applied"):
+                m.masks_applied()
+
+    # ------------------------------------------------------------------------------------------ data parallel
+    def _dist_world(self):
+        """(world size, group) when the masks must be kept consistent over data-parallel ranks."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return 1, None
+        group = getattr(self, "process_group", None)
+        return dist.get_world_size(group), group
+
+    def sync_kernel_maps(self, host_maps, src=0):
+        """Data-parallel replicas draw the growth indices with Python's ``random`` on every rank; identical seeds give
+        identical masks, but nothing in the reference guarantees identical seeds.  After a prune/grow the kernel maps of
+        rank ``src`` are therefore broadcast (one uint8 tensor, 1.39 M kernels = 1.4 MB at 32 ch; RCCL on GPUs, gloo in
+        the CPU tests) and adopted by every rank.  ``host_maps``: name -> numpy uint8 [dim0, dim1]; returns the same
+        dict holding rank src's maps."""
+        import torch.distributed as dist
+        world, group = self._dist_world()
+        if world <= 1 and not getattr(self, "force_sync", False):
+            return host_maps
+        names = list(host_maps.keys())
+        flat = np.concatenate([host_maps[n].reshape(-1) for n in names]).astype(np.uint8)
+        backend = dist.get_backend(group)
+        dev = self._params[self.names[0]].device if backend == "nccl" else torch.device("cpu")
+        t = torch.from_numpy(flat).to(dev)
+        dist.broadcast(t, src=src, group=group)
+        flat = t.cpu().numpy()
+        off = 0
+        for n in names:
+            k = host_maps[n].size
+            host_maps[n] = flat[off:off + k].reshape(host_maps[n].shape).copy()
+            off += k
+        return host_maps
+
     # ------------------------------------------------------------------------------------------ per-step
     def _build_table(self):
         entries, keep = [], []
@@ -244,12 +282,15 @@ class Masking(object):
         if self._table is None or keys != self._table_keys:
             self._build_table()
         lib().apply_mask(self._table.data_ptr(), len(self.names), _stream())
+        self._notify_masks_applied()
 
     def step(self, masks_already_applied=False):
         """reference :290-317.  ``masks_already_applied``: the fused optimizer kernel already multiplied weights and
         momentum by the masks this iteration."""
         if not masks_already_applied:
             self.apply_mask()
+        else:
+            self._notify_masks_applied()
         if self.decay_flag:
             self.death_rate_decay.step()
             self.death_rate = self.death_rate_decay.get_dr()
@@ -276,6 +317,10 @@ class Masking(object):
 
     # ------------------------------------------------------------------------------------------ prune / grow
     def truncate_weights(self):
+        """reference :556-611.  Death pass on the device (kernel L1 in the reference's association order, exact k-th order
+        statistic, `<=` comparison); ONE packed device->host copy of all kernel maps; the growth draws on the host with
+        Python's ``random`` (bit-identical indices: ``random.sample(range(n), k)`` draws exactly what the reference's
+        ``random.sample(list(range(n)), k)`` draws); one broadcast under data parallelism; masks re-expanded on device."""
         L = lib()
         dev = self._params[self.names[0]].device
         nmax = max(self._kmask_host[n].size for n in self.names)
@@ -296,13 +341,19 @@ class Masking(object):
             L.dsff_kth_value(l1.data_ptr(), r * cc, num_zeros + prune_num - 1, thr.data_ptr(), None, _stream())
             L.dsff_death(l1.data_ptr(), thr.data_ptr(), self.kmasks[name].data_ptr(), r * cc, _stream())
             self.num_death[name] = prune_num
+        packed = torch.cat([self.kmasks[n].reshape(-1) for n in self.names]).cpu().numpy()     # one D2H copy + one sync
+        new_maps, off = {}, 0
         for name in self.names:                                    # growth pass (reference :583-609)
-            km = self.kmasks[name].cpu().numpy().copy()
-            self.num_remove[name] = int(self._kmask_host[name].sum()) - int(km.sum())
-            cand = np.flatnonzero(km.reshape(-1) < 1)              # row-major (dim0, dim1), reference :732
-            idx_rand = random.sample(list(range(0, cand.shape[0])), self.num_death[name])
-            flat = km.reshape(-1)
+            shp = self._kmask_host[name].shape
+            flat = packed[off:off + shp[0] * shp[1]].copy()
+            off += shp[0] * shp[1]
+            self.num_remove[name] = int(self._kmask_host[name].sum()) - int(flat.sum())
+            cand = np.flatnonzero(flat < 1)                        # row-major (dim0, dim1), reference :732
+            idx_rand = random.sample(range(cand.shape[0]), self.num_death[name])
             flat[cand[np.asarray(idx_rand, dtype=np.int64)]] = 1
-            self._set_kmask(name, flat.reshape(km.shape))
+            new_maps[name] = flat.reshape(shp)
+        new_maps = self.sync_kernel_maps(new_maps)
+        for name in self.names:
+            self._set_kmask(name, new_maps[name])
         self._push_liveness()
         self.apply_mask()

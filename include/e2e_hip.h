@@ -162,6 +162,16 @@ int e2e_dc_ce_reduce(const float* logits, const float* target, void* acc, int B,
                      void* stream);
 int e2e_dc_ce_grad(const float* logits, const float* target, const void* acc, float weight, int batch_dice,
                    float smooth, float* dlogits, float* loss_out, int B, int K, long long spatial, void* stream);
+/* dlogits may be NULL: loss value only (validation batches, nnUNetTrainer_simple.py:980-988).  A label outside [0, K)
+ * turns the loss NaN (torch's CrossEntropyLoss raises).
+ * Data-parallel batch dice (reference nnUNetTrainerV2_DDP.py:263-268 all-gathers the per-sample dice numerators and
+ * denominators): e2e_dc_ce_fold_batch folds acc's [B][K][3] rows into row 0 (rows 1.. zeroed); the host all-reduces the
+ * 3*K doubles of row 0 over the ranks (RCCL) between e2e_dc_ce_reduce and e2e_dc_ce_grad(batch_dice = 1).           */
+int e2e_dc_ce_fold_batch(void* acc, int B, int K, void* stream);
+/* Online evaluation of a validation batch (nnUNetTrainer_simple.py:373-405): hard tp / fp / fn voxel counts of
+ * argmax(softmax(logits)) against the target per class, summed over the batch.  counts [K][3] int64 (zeroed by callee). */
+int e2e_online_eval_counts(const float* logits, const float* target, long long* counts, int B, int K,
+                           long long spatial, void* stream);
 
 /* ---- K10: clip_grad_norm_ + SGD(nesterov) + DSFF mask, multi-tensor ---------------------
  * Replaces: torch.nn.utils.clip_grad_norm_(params, 12) + torch.optim.SGD.step (nnUNetTrainer_simple.py:573-574,

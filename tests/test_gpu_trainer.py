@@ -1,0 +1,290 @@
+"""Trainer surface, data-parallel wiring on a single-rank RCCL group, and the reference's literal
+iteration body on the autograd path."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle
+from tests.helpers import golden, seeded_input, seeded_labels, pack_kernel_mask
+from tests.test_gpu_net import tiny_net, TINY, SPARSE_PATCH
+
+pytestmark = pytest.mark.gpu
+
+PLANS = {'plans_per_stage': {0: {'batch_size': 2, 'patch_size': [16, 32, 32], 'num_pool_per_axis': [3, 5, 5],
+                                 'pool_op_kernel_sizes': [[2, 2, 2]] * 3 + [[1, 2, 2]] * 2,
+                                 'conv_kernel_sizes': [[3, 3, 3]] * 6, 'do_dummy_2D_data_aug': False}},
+         'base_num_features': 32, 'num_modalities': 1, 'num_classes': 2, 'all_classes': [1, 2],
+         'transpose_forward': [0, 1, 2], 'transpose_backward': [0, 1, 2], 'conv_per_stage': 2}
+
+
+class _Args:
+    adv = False
+    fix = False
+    update_frequency = 2
+    final_density = 0.05
+
+
+def _trainer(out=None, epochs=2, batch_dice=False, fold=0):
+    from e2enet_medical_amd.training.network_training.nnUNetTrainer_simple import nnUNetTrainer_simple
+    tr = nnUNetTrainer_simple(PLANS, fold, output_folder=out, batch_dice=batch_dice, Tconv='shiftConvPP',
+                              max_num_epochs=epochs, num_batches_per_epoch=2)
+    tr.base_num_features_override = 8
+    tr.num_val_batches_per_epoch = 2
+    torch.manual_seed(0)
+    net, opt = tr.initialize(True)
+    return tr, net, opt
+
+
+def _masking(net, opt, t_max=8, density=0.2, seed=0):
+    from e2enet_medical_amd.training.network_training.sparselearning.core_channel import Masking, CosineDecay
+    random.seed(seed)
+    mask = Masking(opt, death_rate=0.5, death_mode='magnitude', death_rate_decay=CosineDecay(0.5, t_max),
+                   growth_mode='random', redistribution_mode='none', args=_Args())
+    mask.add_module(net, sparse_init='uniform', density=density)
+    return mask
+
+
+@pytest.fixture
+def rccl_single_rank():
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29578")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1)      # "nccl" is RCCL on ROCm
+    os.environ["E2E_FORCE_DIST"] = "1"
+    yield
+    os.environ.pop("E2E_FORCE_DIST", None)
+    if created:
+        dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ run_training surface
+def test_run_training_writes_reference_named_checkpoints_and_resumes(tmp_path):
+    """run_training: epoch loop with validation + online evaluation, poly LR, moving averages, {Tconv}_model_best /
+    _final_checkpoint files (+ .pkl), latest removed after the final save (reference :1020-1025); the final checkpoint's
+    epoch equals the loss history's length; load_final / load_latest / load_best find the files; a resumed trainer gets a
+    finite learning rate; checkpoints written by the loop carry the DSFF state."""
+    base = str(tmp_path)
+    tr, net, opt = _trainer(base, epochs=3)
+    out = tr.output_folder
+    assert out == os.path.join(base, "fold_0")                  # update_fold in the constructor (reference :111)
+    tr.save_every = 1
+    mask = _masking(net, opt)
+    tr.run_training(mask)
+    assert len(tr.all_tr_losses) == 3 and len(tr.all_val_losses) == 3 and len(tr.all_val_eval_metrics) == 3
+    assert all(np.isfinite(tr.all_tr_losses)) and all(0.0 <= m <= 1.0 for m in tr.all_val_eval_metrics)
+    assert tr.train_loss_MA is not None and tr.val_eval_criterion_MA is not None and tr.best_val_eval_criterion_MA is not None
+    final = os.path.join(out, "shiftConvPP_model_final_checkpoint.model")
+    assert os.path.isfile(final) and os.path.isfile(final + ".pkl")
+    assert not os.path.exists(os.path.join(out, "shiftConvPP_model_latest.model"))
+    ck = torch.load(final, map_location="cpu", weights_only=False)
+    assert ck['epoch'] == len(ck['plot_stuff'][0]) == 3
+    assert 'dsff_state' in ck and ck['dsff_state']['steps'] == mask.steps
+    # resume: same folder layout the reference's model_restore uses (output_folder ends with fold_0)
+    tr2, net2, opt2 = _trainer(base, epochs=6)
+    mask2 = _masking(net2, opt2, seed=99)
+    tr2.load_final_checkpoint(train=True, mask=mask2)
+    assert tr2.epoch == 3
+    tr2.maybe_update_lr(tr2.epoch)
+    assert np.isfinite(opt2.param_groups[0]['lr']) and opt2.param_groups[0]['lr'] > 0
+    for n in mask.kmasks:
+        assert torch.equal(mask.kmasks[n], mask2.kmasks[n])
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, net2.state_dict()[k]), k
+    tr3, _, _ = _trainer(base)
+    tr3.load_latest_checkpoint(train=False)           # falls through to the final checkpoint (prefixed name)
+    assert tr3.epoch == 3
+    tr3.load_best_checkpoint(train=False)
+    # update_fold (model_restore.py:142): swap folds for ensembling
+    tr3.update_fold(1)
+    assert tr3.fold == 1 and tr3.output_folder.endswith("fold_1") and tr3.output_folder_pretrained == tr3.output_folder
+    with pytest.raises(RuntimeError):
+        tr3.load_final_checkpoint()
+    for fn in (tr3.validate, lambda: tr3.preprocess_patient(["a.nii.gz"])):
+        with pytest.raises(NotImplementedError):
+            fn()
+
+
+def test_online_evaluation_counts_match_torch():
+    """run_online_evaluation (reference :371-405) on the HIP kernel against the reference's torch expressions."""
+    tr, net, opt = _trainer()
+    batch = next(tr.val_gen)
+    tr.network.eval()
+    tr.run_iteration(iter([batch]), False, True)
+    eng = net.engine(batch['data'].cuda())
+    logits = eng.heads[0].out.data
+    target = batch['target'][0].cuda()[:, 0]
+    seg = F.softmax(logits, 1).argmax(1)
+    k = logits.shape[1]
+    tp = np.array([((seg == c).float() * (target == c).float()).sum().item() for c in range(1, k)])
+    fp = np.array([((seg == c).float() * (target != c).float()).sum().item() for c in range(1, k)])
+    fn = np.array([((seg != c).float() * (target == c).float()).sum().item() for c in range(1, k)])
+    assert np.array_equal(np.array(tr.online_eval_tp[-1]), tp)
+    assert np.array_equal(np.array(tr.online_eval_fp[-1]), fp)
+    assert np.array_equal(np.array(tr.online_eval_fn[-1]), fn)
+    tr.finish_online_evaluation()
+    want = np.mean([2 * a / (2 * a + b + c) for a, b, c in zip(tp, fp, fn)])
+    assert abs(tr.all_val_eval_metrics[-1] - want) < 1e-6          # the reference keeps the counts in float32
+
+
+def test_validation_loss_value_matches_training_loss():
+    tr, net, opt = _trainer(batch_dice=True)
+    batch = next(tr.tr_gen)
+    v = float(tr.run_iteration(iter([batch]), False))
+    eng = net.engine(batch['data'].cuda())
+    assert eng.grads == {} or not eng._backward_ready          # a validation batch allocates no gradient buffers
+    t = float(tr.run_iteration(iter([batch]), True))
+    assert abs(v - t) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ ADVICE round 1
+def test_masks_then_checkpoint_load_uses_the_loaded_weights():
+    """simple_main order: Masking (fresh random masks) first, then a checkpoint is loaded (:163-177).  The reference's
+    conv is dense, so the loaded weights act in full until the next apply_mask; the engine's liveness tables must not
+    hide kernels that now hold weights."""
+    tr, net, opt = _trainer()
+    dense = {k: v.detach().clone() for k, v in net.state_dict().items()}      # dense He-init weights
+    x = seeded_input((2, 1, 16, 32, 32), seed=3).cuda()
+    net.eval()
+    with torch.no_grad():
+        want = [o.clone() for o in net(x)]
+    mask = _masking(net, opt)                                                 # zeroes 80 % of the fusion kernels
+    with torch.no_grad():
+        sparse = [o.clone() for o in net(x)]
+    assert (sparse[0] - want[0]).abs().max() > 1e-3
+    ck = {'epoch': 0, 'state_dict': dense, 'optimizer_state_dict': None, 'plot_stuff': ([], [], [], []),
+          'best_stuff': (None, None, None)}
+    tr.load_checkpoint_ram(ck, train=True)
+    with torch.no_grad():
+        got = net(x)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    mask.apply_mask()                                                         # the next mask application re-prunes
+    with torch.no_grad():
+        again = net(x)
+    assert torch.equal(again[0], sparse[0])
+    # inference-mode load: auto sparsity takes precedence over stale masks
+    tr.load_checkpoint_ram(ck, train=False)
+    with torch.no_grad():
+        got = net(x)
+    assert torch.equal(got[0], want[0])
+
+
+def test_backward_after_second_forward_raises():
+    net, _, _ = tiny_net()
+    x = seeded_input((1, TINY["cin"]) + TINY["patch"], seed=1).cuda()
+    net.train()
+    out1 = net(x)
+    net(x * 2)
+    with pytest.raises(RuntimeError, match="another forward"):
+        out1[0].sum().backward()
+
+
+def test_out_of_range_label_poisons_the_loss():
+    net, _, _ = tiny_net()
+    x = seeded_input((1, TINY["cin"]) + TINY["patch"], seed=1).cuda()
+    eng = net.engine(x)
+    outs = eng.forward(x, True)
+    targets = [seeded_labels((1, 1) + tuple(o.shape[2:]), TINY["k"], seed=5 + i).cuda() for i, o in enumerate(outs)]
+    assert np.isfinite(eng.loss_value(targets, oracle.ds_weights(5)).item())
+    targets[0][0, 0, 0, 0, 0] = -1.0
+    assert np.isnan(eng.loss_value(targets, oracle.ds_weights(5)).item())
+
+
+# ------------------------------------------------------------------------------------------------ reference iteration body
+def test_reference_literal_iteration_body_on_the_autograd_path():
+    """The reference's run_iteration body, verbatim (nnUNetTrainer_simple.py:566-576): output = network(data);
+    l = loss(output, target); l.backward(); clip_grad_norm_(parameters, 12); optimizer.step(); mask.step() -- against the
+    reference's own two iterations (golden net_sparse_tiny: losses, clip norms, death rates, masks after the prune/grow)."""
+    from e2enet_medical_amd.training.loss_functions.dice_loss import DC_and_CE_loss
+    from e2enet_medical_amd.training.loss_functions.deep_supervision import MultipleOutputLoss2
+    g = golden("net_sparse_tiny.npz")
+    network, shapes, _ = tiny_net(SPARSE_PATCH)
+    optimizer = torch.optim.SGD(network.parameters(), 1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)
+    from e2enet_medical_amd.training.network_training.sparselearning.core_channel import Masking, CosineDecay
+    random.seed(5)
+    mask = Masking(optimizer, death_rate=0.5, death_mode='magnitude', death_rate_decay=CosineDecay(0.5, 10),
+                   growth_mode='random', redistribution_mode='none', args=_Args())
+    mask.add_module(network, sparse_init='uniform', density=0.3)
+    loss = MultipleOutputLoss2(DC_and_CE_loss({'batch_dice': False, 'smooth': 1e-5, 'do_bg': False}, {}), oracle.ds_weights(5))
+    data = seeded_input((2, TINY["cin"]) + SPARSE_PATCH, seed=21).cuda()
+    network.train()
+    for it in range(2):
+        optimizer.zero_grad()
+        output = network(data)
+        target = [seeded_labels((o.shape[0], 1) + tuple(o.shape[2:]), TINY["k"], seed=30 + i).cuda() for i, o in enumerate(output)]
+        l = loss(output, target)
+        l.backward()
+        tn = torch.nn.utils.clip_grad_norm_(network.parameters(), 12)
+        optimizer.step()
+        mask.step()
+        assert abs(l.item() - g["losses"][it]) <= 5e-5
+        assert abs(tn.item() - float(g["total_norm_it%d" % it])) <= 1e-3 * float(g["total_norm_it%d" % it])
+        assert mask.death_rate == float(g["death_rate_it%d" % it])
+    names = [str(s) for s in g["names"]]
+    nnz = {n: int(mask.masks[n].sum().item()) for n in names}
+    assert nnz == {n: int(np.unpackbits(g["mask2::" + n]).sum()) * int(np.prod(mask.masks[n].shape[-3:])) for n in names}
+    sd = network.state_dict()
+    got_abs = np.array([sd[n].double().abs().sum().item() for n in shapes])
+    np.testing.assert_allclose(got_abs, g["param_abs_after"], rtol=5e-3, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------ data parallel, one rank
+def test_trainer_data_parallel_path_single_rank_rccl(rccl_single_rank):
+    """The product's data-parallel iteration (bucketed RCCL gradient all-reduce under the backward pass, global batch
+    dice, mask broadcast after the prune/grow) on a one-rank group gives exactly the single-process result."""
+    import torch.distributed as dist
+    os.environ.pop("E2E_FORCE_DIST")
+    tr0, net0, opt0 = _trainer(batch_dice=True)
+    mask0 = _masking(net0, opt0)
+    batches = [next(tr0.tr_gen) for _ in range(3)]
+    l0 = [float(tr0.run_iteration(iter([b]), True, mask=mask0)) for b in batches]
+    os.environ["E2E_FORCE_DIST"] = "1"
+    tr1, net1, opt1 = _trainer(batch_dice=True)
+    mask1 = _masking(net1, opt1)
+    mask1.force_sync = True
+    calls = {"bcast": 0, "allreduce": 0}
+    orig_b, orig_a = dist.broadcast, dist.all_reduce
+    dist.broadcast = lambda *a, **k: (calls.__setitem__("bcast", calls["bcast"] + 1), orig_b(*a, **k))[1]
+    dist.all_reduce = lambda *a, **k: (calls.__setitem__("allreduce", calls["allreduce"] + 1), orig_a(*a, **k))[1]
+    try:
+        l1 = [float(tr1.run_iteration(iter([b]), True, mask=mask1)) for b in batches]
+    finally:
+        dist.broadcast, dist.all_reduce = orig_b, orig_a
+    assert l0 == l1
+    assert calls["bcast"] == 1                                   # one prune/grow (update_frequency 2, 3 iterations)
+    assert calls["allreduce"] >= 3 * (1 + 4)                     # per iteration: >= 1 gradient bucket + 4 batch-dice sums
+    for k, v in net0.state_dict().items():
+        assert torch.equal(v, net1.state_dict()[k]), k
+    for n in mask0.kmasks:
+        assert torch.equal(mask0.kmasks[n], mask1.kmasks[n])
+    # validation batch with online evaluation under DP: counts summed over the ranks
+    tr1.run_iteration(tr1.val_gen, False, True)
+    assert len(tr1.online_eval_tp) == 1
+
+
+@pytest.mark.parametrize("tag,kw", [("tta", dict(do_mirroring=True, mirror_axes=(0, 1, 2)))])
+def test_sharded_predict_3d_branch_single_rank_rccl(rccl_single_rank, tag, kw):
+    """The sharded branch of predict_3D (partition -> RCCL all-gather -> ordered overlap-add) executed for real on a
+    one-rank group: bit-identical to the unsharded loop, and within the bars of the reference golden."""
+    from e2enet_medical_amd.utilities.nd_softmax import softmax_helper
+    g = golden("sliding.npz")
+    net, _, _ = tiny_net()
+    net.inference_apply_nonlin = softmax_helper
+    net.eval()
+    net.do_ds = False
+    vol = seeded_input((TINY["cin"], 13, 50, 70), seed=71).numpy()
+    args = dict(use_sliding_window=True, step_size=0.5, patch_size=TINY["patch"], use_gaussian=True, all_in_gpu=False,
+                verbose=False, mixed_precision=False, **kw)
+    seg0, probs0 = net.predict_3D(vol, **args)
+    net.shard_tiles(0, 1, None, force=True)
+    seg1, probs1 = net.predict_3D(vol, **args)
+    assert np.array_equal(seg0, seg1) and np.array_equal(probs0, probs1)
+    ref_seg = g["pred_%s_seg" % tag].astype(np.int64)
+    assert (seg1 != ref_seg).mean() < 1e-3
+    assert np.abs(probs1[:, 6, ::2, ::2] - g["pred_%s_probs_slice" % tag]).max() <= 2e-5

@@ -146,18 +146,22 @@ data, slicer = pad_nd_image(vol, patch, "constant", {'constant_values': 0}, True
 steps = SegmentationNetwork._compute_steps_for_sliding_window(patch, data.shape[1:], 0.5)
 tiles = [(a, b, c) for a in steps[0] for b in steps[1] for c in steps[2]]
 g = SegmentationNetwork._get_gaussian(patch)
-per = parallel.slots_per_rank(len(tiles), world)
-mine = torch.zeros((per, 3) + patch)
-for slot, ti in enumerate(parallel.partition_tiles(len(tiles), rank, world)):
-    sx, sy, sz = tiles[ti]
-    t = torch.from_numpy(np.ascontiguousarray(data[None, :, sx:sx + 16, sy:sy + 32, sz:sz + 32]))
-    mine[slot] = net_fn(t)[0]
-gathered = parallel.gather_patches(mine, world)
 agg = np.zeros((3,) + data.shape[1:], np.float32); cnt = np.zeros_like(agg)
-for ti, (sx, sy, sz) in enumerate(tiles):
-    o, s = parallel.tile_slot(ti, world)
-    agg[:, sx:sx + 16, sy:sy + 32, sz:sz + 32] += gathered[o, s].numpy() * g
+evaluated = []
+
+def predict_tile(ti):                      # stands in for the GPU forward + mirror averaging of predict_3D
+    sx, sy, sz = tiles[ti]
+    evaluated.append(ti)
+    return net_fn(torch.from_numpy(np.ascontiguousarray(data[None, :, sx:sx + 16, sy:sy + 32, sz:sz + 32])))[0]
+
+def accumulate(ti, patch_t):               # stands in for e2e_sw_accumulate
+    sx, sy, sz = tiles[ti]
+    agg[:, sx:sx + 16, sy:sy + 32, sz:sz + 32] += patch_t.numpy() * g
     cnt[:, sx:sx + 16, sy:sy + 32, sz:sz + 32] += g
+
+# the product's sharded tile loop (the function predict_3D itself runs when tile_world > 1)
+parallel.run_tiles_sharded(len(tiles), rank, world, None, predict_tile, accumulate, (3,) + patch, torch.device("cpu"))
+assert evaluated == list(range(rank, len(tiles), world))
 sl = tuple([slice(0, 3)] + slicer[1:])
 probs = agg[sl] / cnt[sl]
 assert np.array_equal(probs, probs_ref), "sharded overlap-add must be bit identical to the single-process order"
@@ -181,10 +185,20 @@ ov.finish()
 assert torch.allclose(eng.grad_flat, torch.arange(70, dtype=torch.float32) * (1 + world) / 2.0)
 assert torch.allclose(flat, torch.arange(70, dtype=torch.float32) * (1 + world) / 2.0)
 assert torch.allclose(views[1], torch.arange(64, 70, dtype=torch.float32) * (1 + world) / 2.0)
-km = {"k": (torch.arange(12).reshape(3, 4) %% (rank + 2) == 0).to(torch.uint8)}
-want = (torch.arange(12).reshape(3, 4) %% 2 == 0).to(torch.uint8)
-parallel.broadcast_kernel_masks(km, src=0)
-assert torch.equal(km["k"], want)
+# DSFF masks: every rank adopts rank 0's kernel maps after a prune/grow (the product's Masking.sync_kernel_maps)
+from e2enet_medical_amd.training.network_training.sparselearning.core_channel import Masking
+m = Masking.__new__(Masking)
+m.names = ["a", "b"]
+m._params = {"a": torch.zeros(3, 4, 1, 3, 3), "b": torch.zeros(2, 5, 2, 2, 2)}
+maps = {"a": (np.arange(12).reshape(3, 4) %% (rank + 2) == 0).astype(np.uint8),
+        "b": (np.arange(10).reshape(2, 5) %% (rank + 3) == 0).astype(np.uint8)}
+got = m.sync_kernel_maps(maps)
+assert np.array_equal(got["a"], (np.arange(12).reshape(3, 4) %% 2 == 0).astype(np.uint8))
+assert np.array_equal(got["b"], (np.arange(10).reshape(2, 5) %% 3 == 0).astype(np.uint8))
+# data-parallel batch dice: the folded (tp, fp, fn) sums of all ranks
+t = torch.arange(9, dtype=torch.float64) * (rank + 1)
+parallel.batch_dice_allreduce(None)(t)
+assert torch.equal(t, torch.arange(9, dtype=torch.float64) * sum(range(1, world + 1)))
 dist.barrier()
 if rank == 0:
     print("WORKER_OK")
