@@ -7,10 +7,23 @@ clip_grad_norm_, SGD-Nesterov, DSFF mask step) of the shiftConvPP network on syn
         bench.py --gpus N --steps K --warmup W
 
 Workload (BASELINE.json configs[1]): 4-modal 128^3 patches, base width 32, 4 classes, pools [[2,2,2]]*5, DSFF density
-0.2, batch 2 per GPU (the nnU-Net BraTS 3d_fullres plan batch), fp32.  N > 1: data-parallel replicas (weak scaling), one
-flat RCCL all-reduce of the gradients per step.  Prints ONE JSON line (rank 0).
+0.2, batch 2 per GPU (the nnU-Net BraTS 3d_fullres plan batch), fp32.  N > 1: data-parallel replicas (weak scaling),
+bucketed RCCL all-reduce of the gradients overlapped with the backward pass.  Prints ONE JSON line (rank 0):
+
+  value / ms_per_step    K timed steps, uninstrumented
+  roofline               the step's dominant kernel, the 1x3x3 conv walk (e2e_conv133_fwd + e2e_conv133_dgrad):
+                         HIP-event time of every launch over extra instrumented steps, algorithmic bytes against the
+                         HBM peak and live FLOPs (from the DSFF kernel maps) against the fp32 FMA peak
+  roofline_secondary     the dense weight gradient (fp32 MFMA)
+  forward_only           inference forward of the same batch
+  sliding_window         BASELINE config 4 shape: predict_3D of a [1,220,400,400] volume, 16 classes, patch 128^3,
+                         step 0.5, 8 mirrors, everything device resident
+  dsff_update            BASELINE config 3: one Masking.truncate_weights() (prune + grow of all 35 masked tensors)
+  cpu_baseline           the CPU oracle on the same 128^3 patch (B = 1: fwd + loss + bwd), 1 warm-up + up to 3 timed
 """
 import argparse
+import contextlib
+import io
 import json
 import os
 import random
@@ -27,19 +40,20 @@ PATCH = (128, 128, 128)
 BASE, CIN, K, DENSITY, BATCH = 32, 4, 4, 0.2, 2
 POOLS = [(2, 2, 2)] * 5
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
-MFMA_F32_PEAK_TF = 157.3       # fp32-input MFMA = fp32 vector peak
-FWD_BYTES_PER_VOXEL = 5393.0   # BASELINE.md §3 / SURVEY §8(d): algorithmic fwd bytes per voxel at 32 ch
+FP32_PEAK_TF = 157.3           # fp32 vector FMA peak = fp32-input MFMA peak (MI355X_MICROARCH.md)
+FWD_BYTES_PER_VOXEL = 5393.0   # BASELINE.md section 3 / SURVEY section 8(d): algorithmic fwd bytes per voxel at 32 ch
 TRAIN_BYTES_PER_VOXEL = 3 * FWD_BYTES_PER_VOXEL
+TRAFFIC_FILE = "r02_pmc_traffic.json"
 
 
-def build(device, patch=PATCH, batch=BATCH, seed=0):
+def build(device, patch=PATCH, cin=CIN, k=K, seed=0, density=DENSITY):
     from torch import nn
     from e2enet_medical_amd.network_architecture.unetpp_d import Generic_UNetPlusPlus
     from e2enet_medical_amd.network_architecture.initialization import InitWeights_He
     from e2enet_medical_amd.training.network_training.sparselearning.core_channel import Masking, CosineDecay
     from e2enet_medical_amd.training.fused_optim import FusedClipSGD
     torch.manual_seed(seed)
-    net = Generic_UNetPlusPlus(patch, CIN, BASE, K, 5, 2, 2, nn.Conv3d, nn.InstanceNorm3d, {'eps': 1e-5, 'affine': True},
+    net = Generic_UNetPlusPlus(patch, cin, BASE, k, 5, 2, 2, nn.Conv3d, nn.InstanceNorm3d, {'eps': 1e-5, 'affine': True},
                                nn.Dropout3d, {'p': 0, 'inplace': True}, nn.LeakyReLU,
                                {'negative_slope': 1e-2, 'inplace': True}, True, False, lambda x: x, InitWeights_He(1e-2),
                                POOLS, None, False, True, True).to(device)
@@ -53,18 +67,16 @@ def build(device, patch=PATCH, batch=BATCH, seed=0):
     random.seed(seed)
     mask = Masking(opt, death_rate=0.5, death_mode='magnitude', death_rate_decay=CosineDecay(0.5, 250 * 1000),
                    growth_mode='random', redistribution_mode='none', args=A())
-    import io
-    import contextlib
     with contextlib.redirect_stdout(io.StringIO()):
-        mask.add_module(net, sparse_init='uniform', density=DENSITY)
+        mask.add_module(net, sparse_init='uniform', density=density)
     fused = FusedClipSGD(opt, list(net.named_parameters()), 12.0)
     return net, opt, mask, fused
 
 
-def synthetic_batch(device, patch, batch, seed):
+def synthetic_batch(device, patch, batch, seed, cin=CIN, k=K):
     g = torch.Generator().manual_seed(seed)
-    x = torch.randn((batch, CIN) + tuple(patch), generator=g)
-    full = torch.randint(0, K, (batch, 1) + tuple(patch), generator=g).float()
+    x = torch.randn((batch, cin) + tuple(patch), generator=g)
+    full = torch.randint(0, k, (batch, 1) + tuple(patch), generator=g).float()
     targets = [full[:, :, ::s, ::s, ::s].contiguous() for s in (1, 2, 4, 8)]
     return x.to(device), [t.to(device) for t in targets]
 
@@ -90,12 +102,9 @@ class KernelTimer:
         return sum(e0.elapsed_time(e1) for e0, e1, _ in self.events)
 
 
-TRAFFIC_FILE = "r01h_pmc_traffic.json"
-
-
 def pmc_traffic(prefix):
     """HBM bytes per launch of the kernels whose name starts with `prefix`, from the committed PMC summary
-    (measured by rocprofv3 outside this process: counters cannot be read from inside the benchmark)."""
+    (measured by rocprofv3 outside this process, separate --pmc passes: tools/prof_bench.sh)."""
     path = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
     if not os.path.exists(path):
         return None
@@ -106,21 +115,26 @@ def pmc_traffic(prefix):
     return sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in d.items() if k.startswith(prefix)) / n
 
 
-def wgrad_flops(args):
-    # e2e_conv133_wgrad(chans, dy, dw, ws, B, Cin, Cout, Di, Hi, Wi, sd, sh, sw, stream): dense 2*9*Cin*Cout*voxels_out
-    b, cin, cout, di, hi, wi, sd, sh, sw = args[4:13]
-    vox = ((di - 1) // sd + 1) * ((hi - 1) // sh + 1) * ((wi - 1) // sw + 1)
-    return 2.0 * 9 * cin * cout * vox * b
+def conv_work(eng, mask):
+    """Per conv op: algorithmic bytes of one fwd (= one dgrad) launch and its live / dense FLOPs, keyed by the device
+    pointers the launches carry (chans table for e2e_conv133_fwd / wgrad, outs table for e2e_conv133_dgrad)."""
+    by_ptr = {}
+    for op in eng.conv_ops.values():
+        b = op.out.shape[0]
+        di, hi, wi = op.in_dims
+        vin = b * op.cin * di * hi * wi
+        vout = op.out.data.numel()
+        km = mask.kmasks.get(op.w_name) if mask is not None else None
+        live = int(km.sum().item()) if km is not None else op.cin * op.cout
+        per_kernel = 2.0 * 9 * (vout / op.cout)
+        rec = {"bytes": 4.0 * (vin + vout), "flops_live": per_kernel * live, "flops_dense": per_kernel * op.cin * op.cout}
+        by_ptr[op.chans.data_ptr()] = rec
+        if op.outs is not None:
+            by_ptr[op.outs.data_ptr()] = rec
+    return by_ptr
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """The oracle (CPU restatement, kind "port") timed on the host cores on a bounded sample of the same workload:
-    fwd + loss + bwd of one 64^3 patch (same net, same density).  Threads are capped (E2E_CPU_THREADS, default 16):
-    torch-CPU on 3D convs of this size stops scaling there, and the box may expose far more logical CPUs than its
-    cgroup lets us use (256 threads took minutes per step).  Hard wall-clock guard: after the first step the loop only
-    continues while the projected time stays inside the budget."""
-    import oracle
-    from oracle import network as onet
+def host_threads():
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -131,7 +145,16 @@ def cpu_baseline(seconds_budget=25.0):
             avail = min(avail, max(1, int(quota) // int(period)))
     except (OSError, ValueError):
         pass
-    threads = max(1, min(avail, int(os.environ.get("E2E_CPU_THREADS", "16"))))
+    return max(1, min(avail, int(os.environ.get("E2E_CPU_THREADS", "16"))))
+
+
+def cpu_baseline(patch_edge=128, budget_s=150.0):
+    """The oracle (CPU restatement, kind "port") on the host cores: fwd + loss + bwd of ONE patch of the benchmarked
+    network (B = 1, 4 x 128^3, 32 ch, density 0.2; dense masked weights like the reference), 1 warm-up + up to 3 timed
+    steps; the loop stops early when the projected time leaves the budget."""
+    import oracle
+    from oracle import network as onet
+    threads = host_threads()
     torch.set_num_threads(threads)
     spec = oracle.make_spec(CIN, BASE, K, POOLS)
     params = oracle.init_params(spec, seed=0)
@@ -140,7 +163,7 @@ def cpu_baseline(seconds_budget=25.0):
     masks = oracle.uniform_kernel_masks(onet.param_shapes(spec), names, DENSITY)
     for n in names:
         params[n] = params[n] * masks[n]
-    patch = (64, 64, 64)
+    patch = (patch_edge,) * 3
     g = torch.Generator().manual_seed(0)
     x = torch.randn((1, CIN) + patch, generator=g)
     full = torch.randint(0, K, (1, 1) + patch, generator=g).float()
@@ -154,18 +177,43 @@ def cpu_baseline(seconds_budget=25.0):
         loss.backward()
         return float(loss.detach())
     t0 = time.time()
-    step()                                     # first step doubles as warm-up and as the time probe
+    step()                                     # warm-up
     first = time.time() - t0
-    n, dt = 1, first
-    if first < seconds_budget / 3:
-        t1, n = time.time(), 0
-        while n < 2 or ((time.time() - t1) + first < seconds_budget and n < 8):
-            step()
-            n += 1
-        dt = time.time() - t1
-    return {"value": n * 64 ** 3 / dt, "unit": "voxels/s", "cores": threads, "kind": "port",
-            "sample": "%d fwd+loss+bwd steps of one 64^3 patch (B=1, 32 ch, density 0.2), torch-CPU oracle, %d threads, "
-                      "%.1f s (+ %.1f s first step)" % (n, threads, dt, first)}
+    n, t1 = 0, time.time()
+    while n < 3 and (n == 0 or (time.time() - t1) / n * (n + 1) + first < budget_s):
+        step()
+        n += 1
+    dt = time.time() - t1
+    return {"value": n * patch_edge ** 3 / dt, "unit": "voxels/s", "cores": threads, "kind": "port",
+            "sample": "%d timed fwd+loss+bwd steps (+1 warm-up of %.1f s) of one 4 x %d^3 patch (B=1, 32 ch, density 0.2, dense "
+                      "masked weights), torch-CPU oracle, %d threads, %.1f s" % (n, first, patch_edge, threads, dt)}
+
+
+def sliding_window_record(device):
+    """BASELINE config 4 shape: AMOS-like volume [1,220,400,400], 16 classes, base 32, patch 128^3,
+    step 0.5, 8 mirrors.  Wall time of predict_3D with the volume already on the host as float32 (the call uploads it
+    once, 141 MB; aggregation, softmax, flips, Gaussian weighting and argmax stay on the device)."""
+    from e2enet_medical_amd.utilities.nd_softmax import softmax_helper
+    net, _, mask, _ = build(device, PATCH, cin=1, k=16, seed=1)
+    net.inference_apply_nonlin = softmax_helper
+    net.eval()
+    net.do_ds = False
+    vol = torch.randn((1, 220, 400, 400), generator=torch.Generator().manual_seed(7)).numpy()
+    kw = dict(do_mirroring=True, mirror_axes=(0, 1, 2), use_sliding_window=True, step_size=0.5, patch_size=PATCH,
+              use_gaussian=True, verbose=False)
+    steps = net._compute_steps_for_sliding_window(PATCH, vol.shape[1:], 0.5)
+    tiles = len(steps[0]) * len(steps[1]) * len(steps[2])
+    net.predict_3D(vol[:, :128, :160, :160], **kw)          # warm-up: plan allocation for the 8-mirror batch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    seg, probs = net.predict_3D(vol, **kw)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    vox = float(np.prod(vol.shape[1:]))
+    return {"workload": "predict_3D [1,220,400,400] N(0,1), K=16, base 32, density 0.2, patch 128^3, step 0.5, 8 mirrors "
+                        "(%d tiles x 8 forwards, mirrors of a tile as one batch-8 forward)" % tiles,
+            "seconds": dt, "volume_voxels_per_s": vox / dt, "patch_voxels_per_s": tiles * 8 * 128 ** 3 / dt,
+            "includes": "host->device upload of the volume, device->host copy of seg + probs (1.4 GB)"}
 
 
 def main():
@@ -177,12 +225,13 @@ def main():
     os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--patch", type=int, default=128)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--forward-only", action="store_true", help="inference forward (reported under 'extra', never as value)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the forward_only / sliding_window / dsff_update sub-records")
+    ap.add_argument("--forward-only", action="store_true", help="time the inference forward as the main loop (diagnostic)")
     ap.add_argument("--op-profile", action="store_true", help="print per-entry-point GPU time (diagnostic)")
     args = ap.parse_args()
 
@@ -203,8 +252,7 @@ def main():
     from e2enet_medical_amd._lib import lib
     from e2enet_medical_amd import parallel
     patch = (args.patch,) * 3
-    net, opt, mask, fused = build(device, patch, args.batch)
-    names = [n for n, _ in net.named_parameters()]
+    net, opt, mask, fused = build(device, patch)
     x, targets = synthetic_batch(device, patch, args.batch, seed=100 + rank)
     eng = net.engine(x)
     ds_w = np.array([8, 4, 2, 1, 0], dtype=np.float64) / 15.0
@@ -229,82 +277,128 @@ def main():
 
     step = fwd_step if args.forward_only else train_step
     L = lib()
-    timers = {}
-    if args.op_profile:
-        for name in ["conv133_fwd", "conv133_dgrad", "conv133_wgrad", "in_stats_finalize", "in_lrelu_bwd", "convT_fwd",
-                     "convT_dgrad", "convT_wgrad", "maxpool_fwd", "maxpool_bwd", "head1x1_fwd", "head1x1_dgrad",
-                     "head1x1_wgrad", "dc_ce_reduce", "dc_ce_grad", "grad_sqnorm", "sgd_clip_mask_step"]:
-            timers[name] = KernelTimer(L, name)
-    else:
-        timers["conv133_wgrad"] = KernelTimer(L, "conv133_wgrad")
+
+    def timed(fn, n):
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    for t in timers.values():
-        t.enabled = True
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    for t in timers.values():
-        t.enabled = False
+    dt = timed(step, args.steps)
     if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # ---- instrumented steps (outside the timed region): HIP events around the conv entry points --------------------
+    names = ["conv133_fwd", "conv133_dgrad", "conv133_wgrad"]
+    if args.op_profile:
+        names += ["in_stats_finalize", "in_lrelu_bwd", "convT_fwd", "convT_dgrad", "convT_wgrad", "maxpool_fwd", "maxpool_bwd",
+                  "head1x1_fwd", "head1x1_dgrad", "head1x1_wgrad", "dc_ce_reduce", "dc_ce_grad", "grad_sqnorm", "sgd_clip_mask_step"]
+    timers = {n: KernelTimer(L, n) for n in names}
+    isteps = max(1, min(args.steps, 5))
+    for t in timers.values():
+        t.enabled = True
+    for _ in range(isteps):
+        step()
+    torch.cuda.synchronize()
+    for t in timers.values():
+        t.enabled = False
+
     if rank == 0:
         vox_per_step = world * args.batch * patch[0] * patch[1] * patch[2]
         value = vox_per_step * args.steps / dt
+        ms_step = dt / args.steps * 1e3
         out = {
             "metric": "voxels/sec (train step fwd+bwd+update), 128^3 patch 32ch density=0.2",
             "value": value, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BraTS-shaped 4-modal %d^3 patches, shiftConvPP base 32, K=4, DSFF density 0.2, "
-                                   "batch %d per GPU, %s" % (patch[0], args.batch, "inference forward (deep supervision heads on)"
+                                   "batch %d per GPU, %s" % (patch[0], args.batch, "inference forward (deep supervision heads off)"
                                                              if args.forward_only else
                                                              "fwd+loss+bwd+clip+SGD+mask step, dense (parity) wgrad"),
                        "parallelism": "dp%d" % world},
             "per_gpu_voxels_per_s": value / world,
-            "hbm_roofline_frac_whole_step": (value / world) * TRAIN_BYTES_PER_VOXEL / (HBM_PEAK_GBS * 1e9),
+            "hbm_roofline_frac_whole_step": (value / world) * (FWD_BYTES_PER_VOXEL if args.forward_only else TRAIN_BYTES_PER_VOXEL)
+            / (HBM_PEAK_GBS * 1e9),
         }
         if args.forward_only:
             out["metric"] = "voxels/sec (inference forward only), 128^3 patch 32ch density=0.2"
-            out["hbm_roofline_frac_whole_step"] = (value / world) * FWD_BYTES_PER_VOXEL / (HBM_PEAK_GBS * 1e9)
-        wt = timers.get("conv133_wgrad")
-        if wt is not None and wt.events:
+        work = conv_work(eng, mask)
+        ev = [(e0.elapsed_time(e1), work[a[0]]) for e0, e1, a in timers["conv133_fwd"].events]
+        ev += [(e0.elapsed_time(e1), work[a[3]]) for e0, e1, a in timers["conv133_dgrad"].events]
+        if ev:
+            ms = sum(t for t, _ in ev)
+            byt = sum(w["bytes"] for _, w in ev)
+            fl = sum(w["flops_live"] for _, w in ev)
+            gbs = byt / (ms * 1e-3) / 1e9
+            out["roofline"] = {
+                "bound": "hbm", "kernel": "conv133_t32_kernel / conv133_kernel: every launch of e2e_conv133_fwd and e2e_conv133_dgrad "
+                                          "(depth shift + concat + 1x3x3 conv, forward and data gradient)",
+                "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                "traffic": pmc_traffic("conv133_kernel") or pmc_traffic("conv133_t32"),
+                "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" % TRAFFIC_FILE,
+                "algorithmic_bytes_per_launch": byt / len(ev), "launches_per_step": len(ev) // isteps,
+                "avg_ms": ms / len(ev), "ms_per_step": ms / isteps, "share_of_step": (ms / isteps) / ms_step,
+                "fma": {"achieved": fl / (ms * 1e-3) / 1e12, "peak": FP32_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": fl / (ms * 1e-3) / 1e12 / FP32_PEAK_TF, "flops": "live (DSFF-masked) FLOPs from the kernel maps"},
+            }
+        wt = timers["conv133_wgrad"]
+        if wt.events:
             ms = wt.total_ms()
-            flops = sum(wgrad_flops(a) for _, _, a in wt.events)
-            achieved = flops / (ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "conv133_wgrad_v3/v2/s2_kernel (+ slab reduce): every launch of e2e_conv133_wgrad",
-                               "achieved": achieved, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                               "frac": achieved / MFMA_F32_PEAK_TF, "traffic": pmc_traffic("conv133_wgrad"),
-                               "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" % TRAFFIC_FILE,
-                               "launches": len(wt.events), "avg_ms": ms / len(wt.events),
-                               "share_of_step": ms / (dt * 1e3)}
+            fl = sum(work[a[0]]["flops_dense"] for _, _, a in wt.events)
+            tf = fl / (ms * 1e-3) / 1e12
+            out["roofline_secondary"] = {
+                "bound": "mfma", "kernel": "conv133_wgrad_v3/v2/s2_kernel (+ slab reduce): every launch of e2e_conv133_wgrad (dense)",
+                "achieved": tf, "peak": FP32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TF,
+                "traffic": pmc_traffic("conv133_wgrad"), "launches_per_step": len(wt.events) // isteps,
+                "avg_ms": ms / len(wt.events), "ms_per_step": ms / isteps, "share_of_step": (ms / isteps) / ms_step}
         if args.op_profile:
-            prof = {k: round(t.total_ms() / args.steps, 3) for k, t in timers.items() if t.events}
+            prof = {k: round(t.total_ms() / isteps, 3) for k, t in timers.items() if t.events}
             out["op_ms_per_step"] = dict(sorted(prof.items(), key=lambda kv: -kv[1]))
             launches = []
             for k, t in timers.items():
-                per = len(t.events) // args.steps
+                per = len(t.events) // isteps
                 for i in range(per):                      # same launch index across steps = same layer
-                    ms = sum(t.events[s * per + i][0].elapsed_time(t.events[s * per + i][1]) for s in range(args.steps)) / args.steps
+                    ms = sum(t.events[s * per + i][0].elapsed_time(t.events[s * per + i][1]) for s in range(isteps)) / isteps
                     ints = [a for a in t.events[i][2] if isinstance(a, int) and 0 < a < 100000]
                     launches.append((round(ms, 3), k, ints[:12]))
             launches.sort(key=lambda v: -v[0])
             out["top_launches"] = launches[:40]
+        if world == 1 and not args.no_extras and not args.forward_only:
+            for _ in range(2):
+                fwd_step()
+            fdt = timed(fwd_step, 10)
+            fvox = args.batch * patch[0] * patch[1] * patch[2] * 10 / fdt
+            out["forward_only"] = {"ms_per_batch": fdt / 10 * 1e3, "voxels_per_s": fvox,
+                                   "hbm_roofline_frac": fvox * FWD_BYTES_PER_VOXEL / (HBM_PEAK_GBS * 1e9)}
+            mask.truncate_weights()                       # warm-up (allocations)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                mask.truncate_weights()
+            torch.cuda.synchronize()
+            out["dsff_update"] = {"ms": (time.perf_counter() - t0) / 3 * 1e3, "tensors": len(mask.names),
+                                  "what": "Masking.truncate_weights(): kernel L1 + exact k-th value + death on device, one packed D2H, "
+                                          "growth draws on the host (Python random), masks and liveness tables re-expanded",
+                                  "amortised_ms_per_step_at_update_frequency_1200": (time.perf_counter() - t0) / 3 * 1e3 / 1200}
+            del eng
+            net._engines.clear()
+            torch.cuda.empty_cache()
+            out["sliding_window"] = sliding_window_record(device)
         if not args.no_cpu_baseline and world == 1:      # the CPU port is timed on rank 0 of the single-GPU run only
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(args.patch)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()

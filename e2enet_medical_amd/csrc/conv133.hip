@@ -218,6 +218,18 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
   const int qgroup = g * C::OCG;
   const int qbase = qgroup + wave * OPW;
 
+  // epilogue operands, requested before the main loop so that their (dependent) global loads are long done when the
+  // epilogue starts: in-kernel stamps showed the data-gradient epilogue at 7-11 k cycles per wave, eight serialised round
+  // trips (destination descriptor -> old value, per output plane)
+  e2e_out_chan_t ocs[MODE != 0 ? OPW : 1];
+  float bqs[MODE == 0 ? OPW : 1];
+#pragma unroll
+  for (int a = 0; a < OPW; ++a) {
+    const int q = qbase + a < p.Q ? qbase + a : p.Q - 1;
+    if (MODE == 0) bqs[a] = p.bias ? p.bias[q] : 0.f;
+    else ocs[a] = p.outs[q];
+  }
+
   // data gradient of a depth-strided conv: only every sd-th slice of the (shifted) input received anything
   const bool dead_slice = (MODE != 0) && (d % p.sd != 0);
   const int nchunks = dead_slice ? 0 : (p.P + CK - 1) / CK;
@@ -540,12 +552,22 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
   float psum[OPW];                                      // fwd: per-lane sums of the stored values
 #pragma unroll
   for (int a = 0; a < OPW; ++a) psum[a] = 0.f;
+  float4* vdst[MODE != 0 ? OPW : 1][C::PH];             // dgrad, float4 rows: destination (null = nothing to store) and mode
+  int vmode[MODE != 0 ? OPW : 1];
+  if (MODE != 0) {
+#pragma unroll
+    for (int a = 0; a < OPW; ++a) {
+      vmode[a] = 0;
+#pragma unroll
+      for (int i = 0; i < C::PH; ++i) vdst[a][i] = nullptr;
+    }
+  }
 #pragma unroll
   for (int a = 0; a < OPW; ++a) {
     const int q = qbase + a;
     if (q >= p.Q) continue;
     if (MODE == 0) {
-      const float bq = p.bias ? p.bias[q] : 0.f;
+      const float bq = bqs[a];
       float* yp = p.y + (((long long)n * p.Q + q) * p.Do + d) * out_plane;
       float s = 0.f;
       const bool vec_store = (C::PW == 4) && (p.Wo % 4 == 0);      // lane rows are 16-byte aligned
@@ -572,7 +594,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
       psum[a] = s;
     } else {
       // dgrad: gradient of virtual-concat channel q at (shifted) depth d goes to depth d - s(q) of its source
-      const e2e_out_chan_t oc = p.outs[q];
+      const e2e_out_chan_t oc = ocs[a];
       if (oc.ptr == nullptr) continue;
       int dd = d - oc.dshift;
       bool zero_fill = false;
@@ -602,13 +624,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
           }
           continue;
         }
-        if (vec_store) {
+        if (vec_store) {      // handled below: all old values are requested first, then added and stored
           if (oh < p.Ho && ow0 < p.Wo) {
-            float4* dst = reinterpret_cast<float4*>(xp + (long long)oh * p.Wo + ow0);
-            float4 val = make_float4(acc[a][i][0], acc[a][i][1 % C::PW], acc[a][i][2 % C::PW], acc[a][i][3 % C::PW]);
-            if (zero_fill) val = make_float4(0.f, 0.f, 0.f, 0.f);
-            else if (oc.accumulate) { const float4 o = *dst; val.x += o.x; val.y += o.y; val.z += o.z; val.w += o.w; }
-            *dst = val;
+            vdst[a][i] = reinterpret_cast<float4*>(xp + (long long)oh * p.Wo + ow0);
+            vmode[a] = zero_fill ? 2 : (oc.accumulate ? 1 : 0);
           }
           continue;
         }
@@ -624,6 +643,26 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
         }
       }
     }
+  }
+  if (MODE != 0 && C::PW == 4) {
+    float4 oldv[OPW][C::PH];
+#pragma unroll
+    for (int a = 0; a < OPW; ++a)
+#pragma unroll
+      for (int i = 0; i < C::PH; ++i) {
+        oldv[a][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (vdst[a][i] != nullptr && vmode[a] == 1) oldv[a][i] = *vdst[a][i];
+      }
+#pragma unroll
+    for (int a = 0; a < OPW; ++a)
+#pragma unroll
+      for (int i = 0; i < C::PH; ++i) {
+        if (vdst[a][i] == nullptr) continue;
+        float4 val = make_float4(acc[a][i][0], acc[a][i][1 % C::PW], acc[a][i][2 % C::PW], acc[a][i][3 % C::PW]);
+        if (vmode[a] == 2) val = make_float4(0.f, 0.f, 0.f, 0.f);
+        val.x += oldv[a][i].x; val.y += oldv[a][i].y; val.z += oldv[a][i].z; val.w += oldv[a][i].w;
+        *vdst[a][i] = val;
+      }
   }
   if (MODE == 0 && p.part != nullptr) {
     // per-tile (count, mean, M2) partials of the 4 output planes: the count is known from the tile geometry, the four

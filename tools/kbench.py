@@ -31,6 +31,8 @@ def time_ms(fn, iters=10, warm=3):
 
 def conv_case(B, srcs, cout, dims, stride, density, tag):
     dev = torch.device("cuda")
+    if density < 1.0 and os.environ.get("KB_DENSITY"):
+        density = float(os.environ["KB_DENSITY"])
     acts = []
     for i, (c, normed) in enumerate(srcs):
         a = Act("s%d" % i, (B, c) + dims, normed, dev)
