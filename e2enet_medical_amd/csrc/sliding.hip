@@ -94,7 +94,64 @@ __global__ __launch_bounds__(256) void sw_finalize_kernel(const float* __restric
   }
   seg[i] = arg;
 }
+// ---- N1: fold ensembling and segmentation export (reference e2enet/inference/predict.py:282-301,
+// e2enet/inference/segmentation_export.py:118-136) ----------------------------------------------------------------
+// dst (+)= src (first != 0: dst = src);  n_folds > 0: dst = dst / n_folds afterwards (softmax /= len(params), float32)
+__global__ __launch_bounds__(256) void ensemble_acc_kernel(float* __restrict__ dst, const float* __restrict__ src, long long n,
+                                                           int first, int n_folds) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float v = first ? src[i] : __fadd_rn(dst[i], src[i]);
+  if (n_folds > 0) v = __fdiv_rn(v, (float)n_folds);
+  dst[i] = v;
+}
+
+// seg[bbox + t] = argmax_k probs[k, permuted t] (first maximum) or, with region classes, the last region i whose
+// probability exceeds 0.5 (0 when none).  probs is [K, X, Y, Z] in network axis order; the output voxel t = (a, b, c)
+// lives in the transposed frame: source index = a * sa + b * sb + c * sc (strides of softmax.transpose(...)).
+__global__ __launch_bounds__(256) void export_argmax_kernel(const float* __restrict__ probs, unsigned char* __restrict__ seg, int K,
+                                                            long long kstride, int A, int B, int C, long long sa, long long sb,
+                                                            long long sc, int OA, int OB, int OC, int a0, int b0, int c0,
+                                                            const int* __restrict__ regions, int n_regions) {
+  const long long n = (long long)A * B * C;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)(i % C);
+  const long long r = i / C;
+  const int b = (int)(r % B), a = (int)(r / B);
+  if (a0 + a >= OA || b0 + b >= OB || c0 + c >= OC) return;      // bbox clipped to the original size (reference :127)
+  const long long o = a * sa + b * sb + c * sc;
+  int lab = 0;
+  if (regions == nullptr) {
+    float best = -INFINITY;
+    for (int k = 0; k < K; ++k) {
+      const float p = probs[(long long)k * kstride + o];
+      if (p > best || (p != p && best == best)) { best = p; lab = k; }
+    }
+  } else {
+    for (int k = 0; k < n_regions; ++k)
+      if (probs[(long long)k * kstride + o] > 0.5f) lab = regions[k];
+  }
+  seg[((long long)(a0 + a) * OB + (b0 + b)) * OC + (c0 + c)] = (unsigned char)lab;
+}
 }  // namespace
+
+extern "C" int e2e_ensemble_accumulate(float* dst, const float* src, long long n, int first, int n_folds, void* stream) {
+  E2E_REQUIRE(dst && src && n > 0 && n_folds >= 0, "ensemble_accumulate: bad arguments");
+  hipLaunchKernelGGL(ensemble_acc_kernel, dim3((unsigned)e2e::cdivll(n, 256)), dim3(256), 0, (hipStream_t)stream, dst, src, n, first, n_folds);
+  return e2e::check_launch("ensemble_acc_kernel");
+}
+
+extern "C" int e2e_export_argmax_u8(const float* probs, unsigned char* seg, int K, long long kstride, int A, int B, int C,
+                                    long long sa, long long sb, long long sc, int OA, int OB, int OC, int a0, int b0, int c0,
+                                    const int* regions, int n_regions, void* stream) {
+  E2E_REQUIRE(probs && seg && K > 0 && A > 0 && B > 0 && C > 0, "export_argmax_u8: bad arguments");
+  E2E_REQUIRE(a0 >= 0 && b0 >= 0 && c0 >= 0 && OA > 0 && OB > 0 && OC > 0, "export_argmax_u8: bad placement");
+  E2E_REQUIRE(regions == nullptr || (n_regions > 0 && n_regions <= K), "export_argmax_u8: bad region list");
+  hipLaunchKernelGGL(export_argmax_kernel, dim3((unsigned)e2e::cdivll((long long)A * B * C, 256)), dim3(256), 0, (hipStream_t)stream, probs,
+                     seg, K, kstride, A, B, C, sa, sb, sc, OA, OB, OC, a0, b0, c0, regions, n_regions);
+  return e2e::check_launch("export_argmax_kernel");
+}
 
 extern "C" int e2e_flip3d(const float* src, float* dst, int NC, int X, int Y, int Z, int axes, void* stream) {
   E2E_REQUIRE(src && dst && src != dst && NC > 0 && X > 0 && Y > 0 && Z > 0, "flip3d: bad arguments");

@@ -82,6 +82,8 @@ class SegmentationNetwork(NeuralNetwork):
         self.tile_group = None
         self.tile_rank, self.tile_world = 0, 1
         self.tile_force = False
+        # inference/predict.py (fold ensembling + export on device): predict_3D then returns device tensors
+        self.keep_on_device = False
 
     # ------------------------------------------------------------------------------------------ configuration
     def shard_tiles(self, rank: int, world: int, group=None, force: bool = False):
@@ -278,6 +280,8 @@ class SegmentationNetwork(NeuralNetwork):
         seg = torch.empty((CX, CY, CZ), dtype=torch.int64, device=dev)
         L.sw_finalize_argmax(agg.data_ptr(), cnt.data_ptr(), probs.data_ptr(), seg.data_ptr(), K, X, Y, Z, cx0, cy0, cz0,
                              CX, CY, CZ, _stream())
+        if self.keep_on_device:
+            return seg, probs
         probs_np = probs.cpu().numpy()
         if regions_class_order is None:
             seg_np = seg.cpu().numpy()
@@ -306,6 +310,8 @@ class SegmentationNetwork(NeuralNetwork):
         seg = torch.empty(probs.shape[1:], dtype=torch.int64, device=pred.device)
         lib().sw_finalize_argmax(pred.data_ptr(), ones.data_ptr(), probs.data_ptr(), seg.data_ptr(), K, X, Y, Z, cx0, cy0,
                                  cz0, cx1 - cx0, cy1 - cy0, cz1 - cz0, _stream())
+        if self.keep_on_device:
+            return seg, probs
         probs_np = probs.cpu().numpy()
         if regions_class_order is None:
             return seg.cpu().numpy(), probs_np

@@ -228,6 +228,20 @@ int e2e_sw_accumulate(const float* patch, const float* gauss, float* agg, float*
 int e2e_sw_finalize_argmax(const float* agg, const float* cnt, float* probs, long long* seg, int K, int X, int Y,
                            int Z, int cx0, int cy0, int cz0, int CX, int CY, int CZ, void* stream);
 
+/* ---- N1: fold ensembling and segmentation export on device --------------------------------------------------
+ * Replaces: the per-fold softmax accumulation and average of predict_cases (e2enet/inference/predict.py:282-296; a
+ * multi-GB device->host copy per fold in the reference) and transpose_backward + argmax / region thresholds + crop-box
+ * placement into the uint8 volume of save_segmentation_nifti_from_softmax (e2enet/inference/segmentation_export.py:
+ * 118-136, predict.py:298-301).  Resampling to another grid (skimage, :84-104) and the NIfTI writer stay on the host.
+ *   dst (+)= src over n floats (first != 0 overwrites); n_folds > 0 additionally divides by n_folds (float32 division) */
+int e2e_ensemble_accumulate(float* dst, const float* src, long long n, int first, int n_folds, void* stream);
+/*   probs [K, ...] with class stride kstride; output voxel (a,b,c) of the TRANSPOSED [A,B,C] frame reads source offset
+ *   a*sa + b*sb + c*sc; seg is the zero-initialised uint8 volume [OA,OB,OC] of the original (uncropped) size, written at
+ *   offset (a0,b0,c0) and clipped to it; regions (device int[n_regions]) != NULL selects the region-threshold rule   */
+int e2e_export_argmax_u8(const float* probs, unsigned char* seg, int K, long long kstride, int A, int B, int C,
+                         long long sa, long long sb, long long sc, int OA, int OB, int OC, int a0, int b0, int c0,
+                         const int* regions, int n_regions, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,3 +28,4 @@ from .sliding_window import (compute_steps, gaussian_map, pad_to_patch,  # noqa:
                              mirror_predict, predict_tiled)
 from .loss import dc_ce_loss, deep_supervision_loss, ds_weights, hard_dice  # noqa: F401
 from .optim import clip_and_sgd_step, poly_lr                          # noqa: F401
+from .export import ensemble_softmax, export_segmentation                  # noqa: F401

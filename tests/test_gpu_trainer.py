@@ -288,3 +288,59 @@ def test_sharded_predict_3d_branch_single_rank_rccl(rccl_single_rank, tag, kw):
     ref_seg = g["pred_%s_seg" % tag].astype(np.int64)
     assert (seg1 != ref_seg).mean() < 1e-3
     assert np.abs(probs1[:, 6, ::2, ::2] - g["pred_%s_probs_slice" % tag]).max() <= 2e-5
+
+
+# ------------------------------------------------------------------------------------------------ N1: ensemble + export
+@pytest.mark.parametrize("tag", ["plain", "transposed", "regions"])
+def test_export_kernels_match_reference_golden(tag):
+    """e2e_ensemble_accumulate + e2e_export_argmax_u8 against the reference's own output (golden export.npz): fold sum in
+    order, float32 division, transpose_backward, first-maximum argmax / region thresholds, crop-box placement."""
+    from e2enet_medical_amd._lib import lib
+    from e2enet_medical_amd.inference.predict import export_segmentation
+    g = golden("export.npz")
+    folds = [torch.from_numpy(g["fold%d" % i]).cuda() for i in range(3)]
+    total = folds[0].clone()
+    for i, f in enumerate(folds[1:]):
+        lib().ensemble_accumulate(total.data_ptr(), f.data_ptr(), total.numel(), 0, 3 if i == 1 else 0, 0)
+    assert np.array_equal(total.cpu().numpy(), oracle.ensemble_softmax([g["fold%d" % i] for i in range(3)]))
+    tb = [int(v) for v in g[tag + "_tb"]]
+    size = [total.shape[1 + i] for i in tb]
+    props = {'size_after_cropping': np.array(size), 'original_size_of_raw_data': np.array([size[0] + 3, size[1] + 1, size[2] + 4]),
+             'crop_bbox': [[2, 2 + size[0]], [0, size[1]], [3, 3 + size[2]]]}
+    regions = tuple(int(v) for v in g[tag + "_regions"]) if tag + "_regions" in g.files else None
+    seg = export_segmentation(total, props, tb, regions)
+    assert seg.dtype == np.uint8 and np.array_equal(seg, g[tag + "_seg"])
+    with pytest.raises(NotImplementedError):
+        export_segmentation(total, dict(props, size_after_cropping=np.array([s + 1 for s in size])), tb, regions)
+
+
+def test_predict_cases_fold_ensemble_on_device():
+    """inference.predict.predict_cases: two 'folds' (checkpoints), sliding window with mirroring per fold, ensemble and
+    export on the device == the host route (predict_3D per fold -> numpy sum / n -> oracle export)."""
+    from e2enet_medical_amd.inference.predict import predict_cases
+    tr, net, opt = _trainer()
+    sd0 = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    torch.manual_seed(123)
+    sd1 = {k: (v + 0.05 * torch.randn_like(v)) for k, v in sd0.items()}
+    params = [{'epoch': 0, 'state_dict': sd, 'optimizer_state_dict': None, 'plot_stuff': ([], [], [], []),
+               'best_stuff': (None, None, None)} for sd in (sd0, sd1)]
+    tr.plans['transpose_forward'], tr.plans['transpose_backward'] = [1, 2, 0], [2, 0, 1]
+    vol = seeded_input((1, 20, 40, 45), seed=9).numpy()
+    props = {'size_after_cropping': np.array([40, 45, 20])[[0, 1, 2]], 'original_size_of_raw_data': np.array([22, 41, 50]),
+             'crop_bbox': None}
+    # host route
+    host = []
+    for p in params:
+        tr.load_checkpoint_ram(p, False)
+        host.append(tr.predict_preprocessed_data_return_seg_and_softmax(vol, do_mirroring=True, mirror_axes=(0, 1, 2),
+                                                                       use_sliding_window=True, step_size=0.5, use_gaussian=True,
+                                                                       verbose=False)[1])
+    total = oracle.ensemble_softmax(host)
+    tb = tr.plans['transpose_backward']
+    size = [total.shape[1 + i] for i in tb]
+    props = {'size_after_cropping': np.array(size), 'original_size_of_raw_data': np.array([size[0] + 2, size[1], size[2] + 5]),
+             'crop_bbox': [[1, 1 + size[0]], [0, size[1]], [4, 4 + size[2]]]}
+    want = oracle.export_segmentation(total, props, tb, None)
+    got = {}
+    done = predict_cases(tr, params, [("case0.nii.gz", (vol, props))], lambda seg, fn, dct: got.__setitem__(fn, seg))
+    assert done == ["case0.nii.gz"] and np.array_equal(got["case0.nii.gz"], want)

@@ -411,3 +411,20 @@ def test_hard_dice():
     got = [oracle.hard_dice(a, b, l) for l in range(1, 4)]
     np.testing.assert_allclose(got, g["dice"], rtol=0, atol=1e-12)
     assert abs(oracle.hard_dice(np.array([0, 1, 1, 0]), np.array([0, 1, 0, 0])) - float(g["dice_small"])) < 1e-12
+
+
+# ------------------------------------------------------------------ N1 fold ensemble + export
+@pytest.mark.parametrize("tag", ["plain", "transposed", "regions"])
+def test_export_matches_reference(tag):
+    """oracle.export_segmentation against the uint8 volume the reference hands to its NIfTI writer
+    (segmentation_export.py:118-148), ensemble average as predict.py:282-296."""
+    g = golden("export.npz")
+    folds = [g["fold%d" % i] for i in range(3)]
+    total = oracle.ensemble_softmax(folds)
+    tb = [int(v) for v in g[tag + "_tb"]]
+    size = [total.shape[1 + i] for i in tb]
+    props = {'size_after_cropping': np.array(size), 'original_size_of_raw_data': np.array([size[0] + 3, size[1] + 1, size[2] + 4]),
+             'crop_bbox': [[2, 2 + size[0]], [0, size[1]], [3, 3 + size[2]]]}
+    regions = tuple(int(v) for v in g[tag + "_regions"]) if tag + "_regions" in g.files else None
+    seg = oracle.export_segmentation(total, props, tb, regions)
+    assert seg.dtype == np.uint8 and np.array_equal(seg, g[tag + "_seg"])

@@ -469,7 +469,64 @@ def gen_init():
     np.savez_compressed(os.path.join(OUT, "init.npz"), **out)
 
 
-ALL = dict(shift=gen_shift, block=gen_block, net=gen_net_tiny, sparse=gen_net_sparse_tiny, net64=gen_net64,
+def gen_export():
+    """save_segmentation_nifti_from_softmax (segmentation_export.py:27-160) on volumes that need no resampling, with the
+    SimpleITK writer, skimage and the batchgenerators file helpers stubbed (absent here): the uint8 array handed to the
+    NIfTI writer is captured.  Ensemble inputs: three seeded 'fold' softmax volumes (summed and averaged with the numpy
+    expressions of predict.py:282-296 by the oracle and the GPU path; the reference has no callable for that step)."""
+    import os.path as osp
+    captured = {}
+
+    class _Img:
+        def SetSpacing(self, *a): pass
+        def SetOrigin(self, *a): pass
+        def SetDirection(self, *a): pass
+    sitk = types.ModuleType('SimpleITK')
+    sitk.GetImageFromArray = lambda arr: (captured.__setitem__('arr', np.array(arr)), _Img())[1]
+    sitk.WriteImage = lambda img, fname: None
+    sys.modules['SimpleITK'] = sitk
+    ff = types.ModuleType('batchgenerators.utilities.file_and_folder_operations')
+    ff.isfile, ff.join, ff.isdir = osp.isfile, osp.join, osp.isdir
+    ff.os = os
+    ff.save_pickle = lambda *a, **k: None
+    for n in ('subfiles', 'subdirs', 'maybe_mkdir_p', 'load_pickle', 'write_pickle', 'save_json', 'load_json'):
+        setattr(ff, n, lambda *a, **k: None)
+    sys.modules['batchgenerators.utilities'] = types.ModuleType('batchgenerators.utilities')
+    sys.modules['batchgenerators.utilities.file_and_folder_operations'] = ff
+    sys.modules['batchgenerators.augmentations.utils'].resize_segmentation = lambda *a, **k: None
+    sk = types.ModuleType('skimage'); skt = types.ModuleType('skimage.transform'); skt.resize = lambda *a, **k: None
+    sys.modules['skimage'] = sk; sys.modules['skimage.transform'] = skt
+    for n in ('skimage.measure', 'skimage.morphology'):
+        sys.modules[n] = types.ModuleType(n)
+    from e2enet.inference.segmentation_export import save_segmentation_nifti_from_softmax
+    rng = np.random.RandomState(11)
+    out = {}
+    k, shp = 5, (9, 14, 11)                                  # network axis order
+    folds = [rng.rand(k, *shp).astype(np.float32) for _ in range(3)]
+    folds = [f / f.sum(0, keepdims=True) for f in folds]
+    for i, f in enumerate(folds):
+        out["fold%d" % i] = f
+    total = folds[0].copy()
+    for f in folds[1:]:
+        total += f
+    total /= len(folds)                                      # predict.py:295-296
+    for tag, tb, regions in (("plain", [0, 1, 2], None), ("transposed", [2, 0, 1], None), ("regions", [1, 0, 2], (1, 3, 2))):
+        sm = total.transpose([0] + [i + 1 for i in tb])      # predict.py:298-301
+        size = sm.shape[1:]
+        props = {'size_after_cropping': np.array(size), 'original_size_of_raw_data': np.array([size[0] + 3, size[1] + 1, size[2] + 4]),
+                 'crop_bbox': [[2, 2 + size[0]], [0, size[1]], [3, 3 + size[2]]], 'original_spacing': np.array([1., 1., 1.]),
+                 'spacing_after_resampling': np.array([1., 1., 1.]), 'itk_spacing': (1., 1., 1.), 'itk_origin': (0., 0., 0.),
+                 'itk_direction': (1., 0., 0., 0., 1., 0., 0., 0., 1.)}
+        save_segmentation_nifti_from_softmax(sm.copy(), "/tmp/_x.nii.gz", props, 1, regions, None, None, None, None, None, 0,
+                                             verbose=False)
+        out[tag + "_seg"] = captured['arr'].astype(np.uint8)
+        out[tag + "_tb"] = np.array(tb)
+        if regions is not None:
+            out[tag + "_regions"] = np.array(regions)
+    np.savez_compressed(os.path.join(OUT, "export.npz"), **out)
+
+
+ALL = dict(export=gen_export, shift=gen_shift, block=gen_block, net=gen_net_tiny, sparse=gen_net_sparse_tiny, net64=gen_net64,
            hippo=gen_net_hippo, amos=gen_net_amos,
            masks=gen_masks, loss=gen_loss, sliding=gen_sliding, dice=gen_dice, init=gen_init)
 
