@@ -344,10 +344,10 @@ def main():
             fl = sum(w["flops_live"] for _, w in ev)
             gbs = byt / (ms * 1e-3) / 1e9
             out["roofline"] = {
-                "bound": "hbm", "kernel": "conv133_t32_kernel / conv133_kernel: every launch of e2e_conv133_fwd and e2e_conv133_dgrad "
+                "bound": "hbm", "kernel": "conv133_kernel: every launch of e2e_conv133_fwd and e2e_conv133_dgrad "
                                           "(depth shift + concat + 1x3x3 conv, forward and data gradient)",
                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                "traffic": pmc_traffic("conv133_kernel") or pmc_traffic("conv133_t32"),
+                "traffic": pmc_traffic("conv133_kernel"),
                 "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" % TRAFFIC_FILE,
                 "algorithmic_bytes_per_launch": byt / len(ev), "launches_per_step": len(ev) // isteps,
                 "avg_ms": ms / len(ev), "ms_per_step": ms / isteps, "share_of_step": (ms / isteps) / ms_step,
