@@ -135,6 +135,17 @@ __device__ __forceinline__ void load_row(const float* __restrict__ src, float* _
   for (; c < NC; ++c) dst[c] = src[c];
 }
 
+// wave-uniform read-only operands (liveness words, bias, destination descriptors) go through the scalar cache: a vector
+// load of them would sit in the same vmcnt queue as the staged planes and make the wave wait for those too
+template <class T>
+__device__ __forceinline__ T load_uniform(const T* ptr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return *reinterpret_cast<const T __attribute__((address_space(4)))*>((unsigned long long)ptr);
+#else
+  return *ptr;
+#endif
+}
+
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef const f32x4_t __attribute__((address_space(1)))* gfloat4_p;
 
@@ -144,14 +155,26 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
   static_assert((OPW == 4 || OPW == 8) && CK % 8 == 0 && CK <= 16, "liveness quad words: 4 output planes x 8 input planes per word");
   constexpr int NQD = OPW / 4;                                 // quad rows (of 4 output planes) per wave
   constexpr int WPAD = 12;                                     // 9 taps padded to 3 x 16 bytes
-  constexpr int WUNITS = C::OCG * CK * 9;                      // weights of one chunk for this workgroup's planes
-  constexpr int NUW = (WUNITS + C::NT - 1) / C::NT;
+  // weights of one chunk for this workgroup's OCG output planes.  Two thread mappings:
+  //  WRND: a thread keeps one (input plane, tap) unit and steps through the output planes QPR at a time -- one vector
+  //        register for the global offset, one for the LDS address, everything else is scalar / immediate;
+  //  else: unit u = tid + i * NT, decoded per round (used when the rounds of WRND would be more loads than that).
+  // Out-of-range rows (planes beyond Q, the tail of the last chunk) read 0 through the buffer descriptor or are never
+  // used (their liveness bits are cleared); idle threads write into the 3 pad floats of a kernel slot: no branches.
+  constexpr int KU = CK * 9;
+  constexpr int QPR = C::NT / KU;
+  constexpr int NRW = QPR > 0 ? (C::OCG + (QPR > 0 ? QPR : 1) - 1) / (QPR > 0 ? QPR : 1) : 1 << 20;
+  constexpr int WUNITS = C::OCG * KU;
+  constexpr int NUW0 = (WUNITS + C::NT - 1) / C::NT;
+  constexpr bool WRND = NRW <= NUW0;
+  constexpr int NUW = WRND ? NRW : NUW0;
+  constexpr int WROWS = WRND ? NRW * QPR : C::OCG;             // kernel-slot rows of `wl` (WRND: the last round overhangs)
   __shared__ __attribute__((aligned(16))) float lds_raw[C::LDS_FLOATS + 4];   // 4 guard floats: see the group writes of commit()
-  __shared__ __attribute__((aligned(16))) float wl[C::OCG * CK * WPAD];
+  __shared__ __attribute__((aligned(16))) float wl[WROWS * CK * WPAD];
   float* const lds = lds_raw + 4;
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.Q * p.P * 36, 0x00020000);
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-  PlaneDesc* tab = reinterpret_cast<PlaneDesc*>(dyn_lds);      // [P]: built once per workgroup
+  PlaneDesc* tab = reinterpret_cast<PlaneDesc*>(dyn_lds);      // [P]: rebuilt when the (batch item, depth slice) changes
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -160,82 +183,39 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
   const long long in_plane = (long long)p.Hi * p.Wi;
   const long long src_plane = (long long)p.Hs * p.Ws;
   const float* lane_tp = lds + (ly * C::LROW) * C::PITCH + lx * C::LSTEP;
+  const long long out_plane = (long long)p.Ho * p.Wo;
 
-  // persistent workgroup: a run of consecutive logical work items (tile-major, output-plane group fastest), so that
-  // the plane descriptor table is rebuilt only when the (batch item, depth slice) changes
+  // persistent workgroup: a run of consecutive logical work items (tile-major, output-plane group fastest).  The plane
+  // descriptor table is rebuilt only when the (batch item, depth slice) changes, and the first chunk of the next item
+  // is requested before the epilogue of the current one, so that a tile's start-up (dependent descriptor loads, first
+  // chunk latency: 0.14 of 0.86 ms on 64->32 @128^3 when every tile was its own workgroup) is paid once per run.
   const int wg = e2e::xcd_remap(blockIdx.x, gridDim.x);
-  // (PERSIST = 0: one item per workgroup; the single-trip loop folds away and keeps the register count at 118)
   const int item_lo = PERSIST ? wg * p.items_per_wg : wg;
   const int item_hi = PERSIST ? (item_lo + p.items_per_wg < p.total ? item_lo + p.items_per_wg : p.total)
                               : (item_lo < p.total ? item_lo + 1 : item_lo);
-  int tab_n = -1, tab_d = -1;
+  if (item_lo >= item_hi) return;
 
-  auto run_item = [&](const int item) {
-#ifdef E2E_CONV_DEBUG
-  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-  STAMP(t_begin);
-  const int g = item % p.groups;
-  int t = item / p.groups;
-  const int n = t / p.tiles_per_n;
-  t -= n * p.tiles_per_n;
-  const int tile_in_n = t;
-  const int tx = t % p.tiles_x;
-  t /= p.tiles_x;
-  const int ty = t % p.tiles_y;
-  const int d = t / p.tiles_y;
-
-  const int h0 = ty * TH, w0 = tx * TW;                 // output tile origin
-  const int hbase = h0 * SH - 1, wbase = w0 * SW - 1;   // input tile origin (incl. halo)
-
-  float acc[OPW][C::PH][C::PW];
-#pragma unroll
-  for (int a = 0; a < OPW; ++a)
-#pragma unroll
-    for (int i = 0; i < C::PH; ++i)
-#pragma unroll
-      for (int j = 0; j < C::PW; ++j) acc[a][i][j] = 0.f;
-
-  // small tiles serve the deep levels, where a sum runs over up to 896 x 9 products: one sequential fp32 chain of that
-  // length is 3-6x noisier than the blocked summation of a CPU conv (measured against fp64, tools/scratch/conv_err.py).
-  // Two-level summation: the chunk's partial sum (CK x 9 terms) is flushed into an outer accumulator after every chunk;
-  // the extra registers are free here (4 or 16 accumulators per plane), the large 16x32 tile (Cin <= 160) keeps one level.
-#ifdef E2E_TWOLVL_ALL
-  constexpr bool TWOLVL = true;          // diagnostic build (tools/scratch/node_err.py): every tile shape, spills allowed
-#else
-  constexpr bool TWOLVL = (C::PH * C::PW <= 4);
-#endif
-  float acc2[TWOLVL ? OPW : 1][TWOLVL ? C::PH : 1][TWOLVL ? C::PW : 1];
-  if constexpr (TWOLVL) {
-#pragma unroll
-    for (int a = 0; a < OPW; ++a)
-#pragma unroll
-      for (int i = 0; i < C::PH; ++i)
-#pragma unroll
-        for (int j = 0; j < C::PW; ++j) acc2[a][i][j] = 0.f;
-  }
-
-  const int qgroup = g * C::OCG;
-  const int qbase = qgroup + wave * OPW;
-
-  // epilogue operands, requested before the main loop so that their (dependent) global loads are long done when the
-  // epilogue starts: in-kernel stamps showed the data-gradient epilogue at 7-11 k cycles per wave, eight serialised round
-  // trips (destination descriptor -> old value, per output plane)
-  e2e_out_chan_t ocs[MODE != 0 ? OPW : 1];
-  float bqs[MODE == 0 ? OPW : 1];
-#pragma unroll
-  for (int a = 0; a < OPW; ++a) {
-    const int q = qbase + a < p.Q ? qbase + a : p.Q - 1;
-    if (MODE == 0) bqs[a] = p.bias ? p.bias[q] : 0.f;
-    else ocs[a] = p.outs[q];
-  }
-
+  struct Item { int g, n, d, tile_in_n, h0, w0; };
+  auto decode = [&](int item) {
+    Item it;
+    it.g = item % p.groups;
+    int t = item / p.groups;
+    it.n = t / p.tiles_per_n;
+    t -= it.n * p.tiles_per_n;
+    it.tile_in_n = t;
+    const int tx = t % p.tiles_x;
+    t /= p.tiles_x;
+    const int ty = t % p.tiles_y;
+    it.d = t / p.tiles_y;
+    it.h0 = ty * TH;
+    it.w0 = tx * TW;
+    return it;
+  };
   // data gradient of a depth-strided conv: only every sd-th slice of the (shifted) input received anything
-  const bool dead_slice = (MODE != 0) && (d % p.sd != 0);
-  const int nchunks = dead_slice ? 0 : (p.P + CK - 1) / CK;
+  auto chunks_of = [&](const Item& it) { return ((MODE != 0) && (it.d % p.sd != 0)) ? 0 : (p.P + CK - 1) / CK; };
 
-  // ---- descriptor of plane `pl` for this workgroup's (n, d) -------------------------------------------------
-  auto make_desc = [&](int pl) {
+  // ---- descriptor of plane `pl` for the (n, d) of an item ------------------------------------------------------
+  auto make_desc = [&](int pl, int n, int d) {
     PlaneDesc ds;
     ds.a = 1.f; ds.b = 0.f; ds.slope = 1.f; ds.valid = 0;
     if (MODE == 0) {
@@ -257,8 +237,17 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
     }
     return ds;
   };
+  int tab_n = -1, tab_d = -1;
+  // (all waves must be past their last read of the old table: callers sit behind the second barrier of a chunk loop)
+  auto ensure_table = [&](const Item& it) {
+    if (it.n != tab_n || it.d != tab_d) {
+      for (int pl = tid; pl < p.P; pl += C::NT) tab[pl] = make_desc(pl, it.n, it.d);
+      tab_n = it.n; tab_d = it.d;
+      __syncthreads();
+    }
+  };
 
-  // ---- staging geometry, constant over the chunks, decoded once ----------------------------------------------
+  // ---- staging geometry of an item ---------------------------------------------------------------------------
   // STG 1 (aligned float4 groups): every wave stages PPW whole planes of the chunk, so the plane descriptor is
   // wave-uniform (scalar registers, scalar-base global loads, no per-chunk address arithmetic in vector registers);
   // a lane owns NUP groups (row r, group q) of each of its planes.  All four elements of a group are written: the ones
@@ -271,62 +260,74 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
   static_assert(!STG || C::PITCH >= 4 * C::NQ - (C::SUB ? 0 : 3), "group writes stay inside the row pitch");
   int su_k[STG ? 1 : C::NU], su_lds[STG ? NUP : C::NU], su_goff[STG ? NUP : C::NU], su_mask[STG ? 1 : C::NU];
   bool su_ok[NUP];
-  if constexpr (STG) {
+  auto set_geometry = [&](const Item& it) {
+    const int h0 = it.h0, w0 = it.w0;
+    const int hbase = h0 * SH - 1, wbase = w0 * SW - 1;   // input tile origin (incl. halo)
+    if constexpr (STG) {
 #pragma unroll
-    for (int i = 0; i < NUP; ++i) {
-      int u = lane + 64 * i;
-      if (u >= UPP) u = UPP - 1;                                  // idle lanes of the last round: harmless duplicates (skipped at commit)
-      const int r = u / C::NQ, q = u - r * C::NQ;
-      const int hi = C::SUB ? h0 / 2 + r : hbase + r;
-      const int gc = C::SUB ? w0 / 2 + 4 * q : w0 * SW - 4 + 4 * q;
-      const int lc0 = C::SUB ? 4 * q : 4 * q - 3;                 // tile column of the group's first element
-      const int srcH = MODE == 0 ? p.Hi : p.Hs, srcW = MODE == 0 ? p.Wi : p.Ws;
-      const bool ok = (unsigned)hi < (unsigned)srcH && gc >= 0 && gc + 3 < srcW;
-      su_lds[i] = r * C::PITCH + lc0;
-      su_goff[i] = ok ? (hi * srcW + gc) * 4 : 0;                 // byte offset inside the plane
-      su_ok[i] = ok;
+      for (int i = 0; i < NUP; ++i) {
+        int u = lane + 64 * i;
+        if (u >= UPP) u = UPP - 1;                                  // idle lanes of the last round: harmless duplicates (skipped at commit)
+        const int r = u / C::NQ, q = u - r * C::NQ;
+        const int hi = C::SUB ? h0 / 2 + r : hbase + r;
+        const int gc = C::SUB ? w0 / 2 + 4 * q : w0 * SW - 4 + 4 * q;
+        const int lc0 = C::SUB ? 4 * q : 4 * q - 3;                 // tile column of the group's first element
+        const int srcH = MODE == 0 ? p.Hi : p.Hs, srcW = MODE == 0 ? p.Wi : p.Ws;
+        const bool ok = (unsigned)hi < (unsigned)srcH && gc >= 0 && gc + 3 < srcW;
+        su_lds[i] = r * C::PITCH + lc0;
+        su_goff[i] = ok ? (hi * srcW + gc) * 4 : 0;                 // byte offset inside the plane
+        su_ok[i] = ok;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < C::NU; ++i) {
+        const int u = tid + i * C::NT;
+        int k = u / (C::IH * C::IW);
+        const int rem = u - k * (C::IH * C::IW);
+        const int r = rem / C::IW, cc = rem - r * C::IW;
+        const int hi = C::SUB ? h0 / 2 + r : hbase + r, wi = C::SUB ? w0 / 2 + cc : wbase + cc;
+        bool ok = u < C::UNITS && hi >= 0 && wi >= 0;
+        int off = 0;
+        if (C::SUB) {
+          ok = ok && hi < p.Hs && wi < p.Ws;
+          off = hi * p.Ws + wi;
+        } else if (DH == 1 && DW == 1) {
+          ok = ok && hi < p.Hi && wi < p.Wi;
+          off = hi * p.Wi + wi;
+        } else {   // dilated source: only positions that are multiples of the stride carry a value
+          const int hs = hi / DH, wsrc = wi / DW;
+          ok = ok && (hi - hs * DH) == 0 && (wi - wsrc * DW) == 0 && hs < p.Hs && wsrc < p.Ws;
+          off = hs * p.Ws + wsrc;
+        }
+        if (u >= C::UNITS) k = 0;
+        su_k[i] = k;
+        su_lds[i] = k * C::CHS + r * C::PITCH + cc;
+        su_goff[i] = ok ? off : -1;
+        su_mask[i] = u < C::UNITS ? 1 : 0;
+      }
     }
+  };
+
+  // ---- weight units of this thread (item-invariant; the item's plane group and the chunk enter as a scalar offset) ----
+  unsigned wu_off[WRND ? 1 : NUW];
+  int wu_lds[WRND ? 1 : NUW];
+  if constexpr (WRND) {
+    const bool act = tid < QPR * KU;
+    const int ql = tid / KU, rem = tid - ql * KU;
+    const int cl = rem / 9, kk = rem - cl * 9;
+    wu_off[0] = act ? (unsigned)(ql * p.wq_stride + cl * p.wp_stride + (MODE == 1 ? 8 - kk : kk)) * 4u : 0x80000000u;
+    wu_lds[0] = act ? (ql * CK + cl) * WPAD + kk : (tid - QPR * KU) * WPAD + 9;
   } else {
 #pragma unroll
-    for (int i = 0; i < C::NU; ++i) {
+    for (int i = 0; i < NUW; ++i) {
       const int u = tid + i * C::NT;
-      int k = u / (C::IH * C::IW);
-      const int rem = u - k * (C::IH * C::IW);
-      const int r = rem / C::IW, cc = rem - r * C::IW;
-      const int hi = C::SUB ? h0 / 2 + r : hbase + r, wi = C::SUB ? w0 / 2 + cc : wbase + cc;
-      bool ok = u < C::UNITS && hi >= 0 && wi >= 0;
-      int off = 0;
-      if (C::SUB) {
-        ok = ok && hi < p.Hs && wi < p.Ws;
-        off = hi * p.Ws + wi;
-      } else if (DH == 1 && DW == 1) {
-        ok = ok && hi < p.Hi && wi < p.Wi;
-        off = hi * p.Wi + wi;
-      } else {   // dilated source: only positions that are multiples of the stride carry a value
-        const int hs = hi / DH, wsrc = wi / DW;
-        ok = ok && (hi - hs * DH) == 0 && (wi - wsrc * DW) == 0 && hs < p.Hs && wsrc < p.Ws;
-        off = hs * p.Ws + wsrc;
-      }
-      if (u >= C::UNITS) k = 0;
-      su_k[i] = k;
-      su_lds[i] = k * C::CHS + r * C::PITCH + cc;
-      su_goff[i] = ok ? off : -1;
-      su_mask[i] = u < C::UNITS ? 1 : 0;
+      const int ql = u / KU;
+      const int rem = u - ql * KU;
+      const int cl = rem / 9, kk = rem - cl * 9;
+      const bool ok = u < WUNITS;
+      wu_off[i] = ok ? (unsigned)(ql * p.wq_stride + cl * p.wp_stride + (MODE == 1 ? 8 - kk : kk)) * 4u : 0x80000000u;
+      wu_lds[i] = ok ? (ql * CK + cl) * WPAD + kk : ((u - WUNITS) % (C::OCG * CK)) * WPAD + 9;
     }
-  }
-  // weights of a chunk: element (ql, cl, tap) of this workgroup's OCG output planes, read through a raw buffer
-  // descriptor (out-of-range offsets return 0, so planes beyond Q and the tail of the last chunk need no select)
-  unsigned wu_off[NUW];
-  int wu_lds[NUW];
-#pragma unroll
-  for (int i = 0; i < NUW; ++i) {
-    const int u = tid + i * C::NT;
-    const int ql = u / (CK * 9);
-    const int rem = u - ql * (CK * 9);
-    const int cl = rem / 9, kk = rem - cl * 9;
-    const bool ok = u < WUNITS && qgroup + ql < p.Q;
-    wu_off[i] = ok ? (unsigned)((qgroup + ql) * p.wq_stride + cl * p.wp_stride + (MODE == 1 ? 8 - kk : kk)) * 4u : 0x80000000u;
-    wu_lds[i] = u < WUNITS ? (ql * CK + cl) * WPAD + kk : -1;
   }
 
   // ---- staging: issue the global loads of one chunk into registers (prefetch), commit them to LDS later -----
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
   float v1[STG ? 1 : C::NU];
   float pd_a[PPW], pd_b[PPW], pd_slope[PPW];     // wave-uniform descriptors of the planes in flight (STG 1)
   bool pd_ok[PPW];
-  auto prefetch = [&](int c0) {
+  auto prefetch = [&](int c0, int qgroup) {
     if constexpr (STG) {
 #pragma unroll
       for (int j = 0; j < PPW; ++j) {
@@ -363,10 +364,14 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
         v1[i] = ds.base[ok ? su_goff[i] : 0];
       }
     }
-    const unsigned coff = (unsigned)(c0 * p.wp_stride) * 4u;
+    const unsigned coff = (unsigned)(qgroup * p.wq_stride + c0 * p.wp_stride) * 4u;
+    if (!CDBG(16)) {
 #pragma unroll
-    for (int i = 0; i < NUW; ++i)
-      vw[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, (int)(wu_off[i] + coff), 0, 0));
+      for (int i = 0; i < NUW; ++i) {
+        const unsigned off = WRND ? wu_off[0] + coff + (unsigned)(i * QPR * p.wq_stride) * 4u : wu_off[i] + coff;
+        vw[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, (int)off, 0, 0));
+      }
+    }
   };
   auto commit = [&](int c0) {
     if constexpr (STG) {
@@ -402,15 +407,14 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
         lds[su_lds[i]] = ok ? val : 0.f;
       }
     }
+    if (!CDBG(16)) {
 #pragma unroll
-    for (int i = 0; i < NUW; ++i) {
-      if (wu_lds[i] < 0) continue;
-      wl[wu_lds[i]] = vw[i];
+      for (int i = 0; i < NUW; ++i) wl[(WRND ? wu_lds[0] + i * QPR * CK * WPAD : wu_lds[i])] = vw[i];
     }
   };
 
   // ---- one live (output plane a, input plane cl) kernel: neighbourhood rows from LDS (shared by the wave's output
-  // planes that consume the same input plane), 9 weights from scalar memory, 9 x PH x PW FMAs ----
+  // planes that consume the same input plane), 9 weights from LDS (broadcast reads), 9 x PH x PW FMAs ----
   constexpr int NCL = (C::VEC == 4) ? ((C::NC + 3) & ~3) : C::NC;     // VEC 4: whole float4s (conflict-free), over-read into the row pad
   static_assert(C::VEC != 4 || (LX - 1) * C::LSTEP + NCL <= C::PITCH, "row over-read stays inside the pitch");
   auto issue = [&](int cl, float (&nb)[C::NR][NCL]) {
@@ -427,7 +431,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
     wk[8] = wp[8];
   };
   // (v_pk_fma_f32 was tried here: on gfx950 a wave64 v_fma_f32 already issues in 2 cycles, so packing the FMAs buys
-  //  nothing -- measured equal -- and the loop is bounded by the LDS reads, not by the vector ALU)
+  //  nothing -- measured equal)
   auto apply = [&](float (&ac)[C::PH][C::PW], const float (&nb)[C::NR][NCL], const float (&wk)[9]) {
 #pragma unroll
     for (int i = 0; i < C::PH; ++i)
@@ -452,7 +456,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
   // liveness of this wave's 4 output planes x the chunk's CK input planes: quad words (bit = (plane % 8) * 4 + output % 4),
   // input-plane-major, so consecutive set bits that share an input plane reuse the neighbourhood registers
   const int nw8 = (p.P + 7) >> 3;
-  auto chunk_mask = [&](int c0, int j) -> unsigned long long {      // j: quad row of this wave
+  auto chunk_mask = [&](int c0, int j, int qbase) -> unsigned long long {      // j: quad row of this wave
     unsigned long long m = 0;
     const int qb = qbase + 4 * j;
     if (c0 >= p.P || qb >= p.Q) return m;
@@ -460,8 +464,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
     for (int wd = 0; wd < CK / 8; ++wd) {
       const int wi = (c0 >> 3) + wd;
       unsigned word = 0u;
-      if (wi < nw8) word = p.live != nullptr ? p.live[(long long)(qb >> 2) * nw8 + wi] : 0xffffffffu;
-      m |= (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)word) << (32 * wd);
+      if (wi < nw8) word = p.live != nullptr ? load_uniform(p.live + (long long)(qb >> 2) * nw8 + wi) : 0xffffffffu;
+      m |= (unsigned long long)word << (32 * wd);                  // (scalar load: already wave-uniform)
     }
     const int remain = p.P - c0;
     if (remain < CK) m &= (1ull << (remain * 4)) - 1ull;
@@ -470,248 +474,307 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
     return m;
   };
 
-  unsigned long long m_cur[NQD];
-#pragma unroll
-  for (int j = 0; j < NQD; ++j) m_cur[j] = 0;
-  STAMP(t_pro);
-  STAMP_ADD(0, t_begin, t_pro);
-  if (nchunks > 0) {
-    if (n != tab_n || d != tab_d) {
-      for (int pl = tid; pl < p.P; pl += C::NT) tab[pl] = make_desc(pl);
-      tab_n = n; tab_d = d;
-      __syncthreads();
-    }
-    if (!CDBG(1)) prefetch(0);
-#pragma unroll
-    for (int j = 0; j < NQD; ++j) m_cur[j] = chunk_mask(0, j);
-  }
-  for (int ci = 0; ci < nchunks; ++ci) {
-    const int c0 = ci * CK;
-    unsigned long long m_next[NQD];                      // scalar loads, in flight during commit
-#pragma unroll
-    for (int j = 0; j < NQD; ++j) m_next[j] = ci + 1 < nchunks ? chunk_mask(c0 + CK, j) : 0ull;
-    STAMP(t0);
-    if (!CDBG(1)) commit(c0);
-    STAMP(t1);
-    if (!CDBG(4)) __syncthreads();
-    STAMP(t2);
-    if (ci + 1 < nchunks && !CDBG(1)) prefetch(c0 + CK);   // in flight while this chunk is computed
-    STAMP(t3);
+  // small tiles serve the deep levels, where a sum runs over up to 896 x 9 products: one sequential fp32 chain of that
+  // length is 3-6x noisier than the blocked summation of a CPU conv (measured against fp64, tools/scratch/conv_err.py).
+  // Two-level summation: the chunk's partial sum (CK x 9 terms) is flushed into an outer accumulator after every chunk;
+  // the extra registers are free here (4 or 16 accumulators per plane), the large 16x32 tile (Cin <= 160) keeps one level.
+#ifdef E2E_TWOLVL_ALL
+  constexpr bool TWOLVL = true;          // diagnostic build (tools/scratch/node_err.py): every tile shape, spills allowed
+#else
+  constexpr bool TWOLVL = (C::PH * C::PW <= 4);
+#endif
 
-    // walk the chunk's live input planes (nibbles of the quad mask); the neighbourhood rows of a plane are read once
-    // and shared by the 1..4 output planes of this wave that consume it
-    unsigned long long m = 0;
-#pragma unroll
-    for (int j = 0; j < NQD; ++j) m |= m_cur[j];
-    if (CDBG(2)) m = 0;
-    while (m) {
-      const int cl = __builtin_ctzll(m) >> 2;
-      m &= ~(15ull << (cl * 4));
-      unsigned nib = 0;
-#pragma unroll
-      for (int j = 0; j < NQD; ++j) nib |= ((unsigned)(m_cur[j] >> (cl * 4)) & 15u) << (4 * j);
-      float nb[C::NR][NCL];
-      issue(cl, nb);
-#pragma unroll
-      for (int a = 0; a < OPW; ++a) {
-        if (nib & (1u << a)) {
-          float wk[9];
-          load_w(a, cl, wk);
-          apply(acc[a], nb, wk);
-        }
+  // ================= the run of items =============================================================================
+  Item cur = decode(item_lo);
+  bool requested = false;        // the first chunk of `cur` is already in flight (requested under the previous item)
+  for (int item = item_lo;; ++item) {
+#ifdef E2E_CONV_DEBUG
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    STAMP(t_begin);
+    const int n = cur.n, d = cur.d, h0 = cur.h0, w0 = cur.w0, tile_in_n = cur.tile_in_n;
+    const int qgroup = cur.g * C::OCG;
+    const int qbase = qgroup + wave * OPW;
+    const int nchunks = chunks_of(cur);
+    const bool has_next = PERSIST && item + 1 < item_hi;
+    Item nxt = cur;
+    if (has_next) nxt = decode(item + 1);
+    if (!requested) {             // first item of the run, another (batch item, depth slice), or the previous item had no chunks
+      set_geometry(cur);
+      if (nchunks > 0) {
+        ensure_table(cur);
+        if (!CDBG(1)) prefetch(0, qgroup);
       }
     }
+    requested = false;
+
+    float acc[OPW][C::PH][C::PW];
 #pragma unroll
-    for (int j = 0; j < NQD; ++j) m_cur[j] = m_next[j];
+    for (int a = 0; a < OPW; ++a)
+#pragma unroll
+      for (int i = 0; i < C::PH; ++i)
+#pragma unroll
+        for (int j = 0; j < C::PW; ++j) acc[a][i][j] = 0.f;
+    float acc2[TWOLVL ? OPW : 1][TWOLVL ? C::PH : 1][TWOLVL ? C::PW : 1];
     if constexpr (TWOLVL) {
 #pragma unroll
       for (int a = 0; a < OPW; ++a)
 #pragma unroll
         for (int i = 0; i < C::PH; ++i)
 #pragma unroll
-          for (int j = 0; j < C::PW; ++j) { acc2[a][i][j] += acc[a][i][j]; acc[a][i][j] = 0.f; }
+          for (int j = 0; j < C::PW; ++j) acc2[a][i][j] = 0.f;
     }
-    STAMP(t4);
-    if (!CDBG(4)) __syncthreads();
-    STAMP(t5);
-    STAMP_ADD(1, t0, t1); STAMP_ADD(2, t1, t2); STAMP_ADD(3, t2, t3); STAMP_ADD(4, t3, t4); STAMP_ADD(5, t4, t5);
-  }
-  STAMP(t_epi);
-  if constexpr (TWOLVL) {
-#pragma unroll
-    for (int a = 0; a < OPW; ++a)
-#pragma unroll
-      for (int i = 0; i < C::PH; ++i)
-#pragma unroll
-        for (int j = 0; j < C::PW; ++j) acc[a][i][j] = acc2[a][i][j];
-  }
 
-  // ---------------- epilogue ------------------------------------------------------------------------------
-  const int oh0 = h0 + ly * C::PH, ow0 = w0 + lx * C::PW;
-  const long long out_plane = (long long)p.Ho * p.Wo;
-  float psum[OPW];                                      // fwd: per-lane sums of the stored values
-#pragma unroll
-  for (int a = 0; a < OPW; ++a) psum[a] = 0.f;
-  float4* vdst[MODE != 0 ? OPW : 1][C::PH];             // dgrad, float4 rows: destination (null = nothing to store) and mode
-  int vmode[MODE != 0 ? OPW : 1];
-  if (MODE != 0) {
+    // epilogue operands, requested before the main loop so that their (dependent) global loads are long done when the
+    // epilogue starts: in-kernel stamps showed the data-gradient epilogue at 7-11 k cycles per wave, eight serialised round
+    // trips (destination descriptor -> old value, per output plane)
+    e2e_out_chan_t ocs[MODE != 0 ? OPW : 1];
+    float bqs[MODE == 0 ? OPW : 1];
 #pragma unroll
     for (int a = 0; a < OPW; ++a) {
-      vmode[a] = 0;
-#pragma unroll
-      for (int i = 0; i < C::PH; ++i) vdst[a][i] = nullptr;
+      const int q = qbase + a < p.Q ? qbase + a : p.Q - 1;
+      if (MODE == 0) bqs[a] = p.bias ? load_uniform(p.bias + q) : 0.f;
+      else ocs[a] = load_uniform(p.outs + q);
     }
-  }
+
+    unsigned long long m_cur[NQD];
 #pragma unroll
-  for (int a = 0; a < OPW; ++a) {
-    const int q = qbase + a;
-    if (q >= p.Q) continue;
-    if (MODE == 0) {
-      const float bq = bqs[a];
-      float* yp = p.y + (((long long)n * p.Q + q) * p.Do + d) * out_plane;
-      float s = 0.f;
-      const bool vec_store = (C::PW == 4) && (p.Wo % 4 == 0);      // lane rows are 16-byte aligned
-      const bool vec2_store = (C::PW == 2) && (p.Wo % 2 == 0);     // ... or 8-byte aligned pairs
+    for (int j = 0; j < NQD; ++j) m_cur[j] = nchunks > 0 ? chunk_mask(0, j, qbase) : 0ull;
+    STAMP(t_pro);
+    STAMP_ADD(0, t_begin, t_pro);
+
+    for (int ci = 0; ci < nchunks; ++ci) {
+      const int c0 = ci * CK;
+      unsigned long long m_next[NQD];                      // scalar loads, in flight during commit
 #pragma unroll
-      for (int i = 0; i < C::PH; ++i) {
-        const int oh = oh0 + i;
-#pragma unroll
-        for (int j = 0; j < C::PW; ++j) {
-          const int ow = ow0 + j;
-          const float val = acc[a][i][j] + bq;
-          acc[a][i][j] = val;
-          if (oh < p.Ho && ow < p.Wo) {
-            if (!vec_store && !vec2_store) yp[(long long)oh * p.Wo + ow] = val;
-            s += val;
-          }
-        }
-        if (vec_store && oh < p.Ho && ow0 < p.Wo)
-          *reinterpret_cast<float4*>(yp + (long long)oh * p.Wo + ow0) =
-              make_float4(acc[a][i][0], acc[a][i][1 % C::PW], acc[a][i][2 % C::PW], acc[a][i][3 % C::PW]);
-        if (vec2_store && oh < p.Ho && ow0 < p.Wo)
-          *reinterpret_cast<float2*>(yp + (long long)oh * p.Wo + ow0) = make_float2(acc[a][i][0], acc[a][i][1 % C::PW]);
+      for (int j = 0; j < NQD; ++j) m_next[j] = ci + 1 < nchunks ? chunk_mask(c0 + CK, j, qbase) : 0ull;
+      STAMP(t0);
+      if (!CDBG(1)) commit(c0);
+      STAMP(t1);
+      if (!CDBG(4)) __syncthreads();
+      STAMP(t2);
+      // one request site for "next chunk of this item" and "first chunk of the next item" (same descriptor table): the
+      // staging registers must have one home, or the compiler copies them and waits for the loads right here
+      int pf_c0 = c0 + CK, pf_qg = qgroup;
+      bool pf = ci + 1 < nchunks;
+      if (!pf && has_next && nxt.n == n && nxt.d == d && !CDBG(128)) {
+        set_geometry(nxt);          // travels under this item's last walk and epilogue
+        pf_c0 = 0; pf_qg = nxt.g * C::OCG;
+        pf = true; requested = true;
       }
-      psum[a] = s;
-    } else {
-      // dgrad: gradient of virtual-concat channel q at (shifted) depth d goes to depth d - s(q) of its source
-      const e2e_out_chan_t oc = ocs[a];
-      if (oc.ptr == nullptr) continue;
-      int dd = d - oc.dshift;
-      bool zero_fill = false;
-      if (dd < 0) {              // s > 0: slices [max(D-s,0), D) receive nothing -> this workgroup zero-fills one
-        const int lo = p.Do - oc.dshift > 0 ? p.Do - oc.dshift : 0;
-        dd = lo + d;
-        zero_fill = true;
-      } else if (dd >= p.Do) {   // s < 0: slices [0, min(-s, D)) receive nothing
-        const int lo = p.Do + oc.dshift > 0 ? p.Do + oc.dshift : 0;
-        dd = d - lo;
-        zero_fill = true;
+      if (pf && !CDBG(1)) prefetch(pf_c0, pf_qg);           // in flight while this chunk is computed
+      STAMP(t3);
+
+      // walk the chunk's live input planes (nibbles of the quad mask); the neighbourhood rows of a plane are read once
+      // and shared by the 1..4 output planes of this wave that consume it
+      unsigned long long m = 0;
+#pragma unroll
+      for (int j = 0; j < NQD; ++j) m |= m_cur[j];
+      if (CDBG(2)) m = 0;
+      while (m) {
+        const int cl = __builtin_ctzll(m) >> 2;
+        m &= ~(15ull << (cl * 4));
+        unsigned nib = 0;
+#pragma unroll
+        for (int j = 0; j < NQD; ++j) nib |= ((unsigned)(m_cur[j] >> (cl * 4)) & 15u) << (4 * j);
+        float nb[C::NR][NCL];
+        issue(cl, nb);
+#pragma unroll
+        for (int a = 0; a < OPW; ++a) {
+          if (nib & (1u << a)) {
+            float wk[9];
+            load_w(a, cl, wk);
+            apply(acc[a], nb, wk);
+          }
+        }
       }
-      if (zero_fill && oc.accumulate) continue;
-      float* xp = oc.ptr + (long long)n * oc.nstride + (long long)dd * out_plane;
-      const bool vec_store = (C::PW == 4) && (p.Wo % 4 == 0);
-      const bool vec2_store = (C::PW == 2) && (p.Wo % 2 == 0);
 #pragma unroll
-      for (int i = 0; i < C::PH; ++i) {
-        const int oh = oh0 + i;
-        if (vec2_store) {
-          if (oh < p.Ho && ow0 < p.Wo) {
-            float2* dst = reinterpret_cast<float2*>(xp + (long long)oh * p.Wo + ow0);
-            float2 val = make_float2(acc[a][i][0], acc[a][i][1 % C::PW]);
-            if (zero_fill) val = make_float2(0.f, 0.f);
-            else if (oc.accumulate) { const float2 o = *dst; val.x += o.x; val.y += o.y; }
-            *dst = val;
-          }
-          continue;
-        }
-        if (vec_store) {      // handled below: all old values are requested first, then added and stored
-          if (oh < p.Ho && ow0 < p.Wo) {
-            vdst[a][i] = reinterpret_cast<float4*>(xp + (long long)oh * p.Wo + ow0);
-            vmode[a] = zero_fill ? 2 : (oc.accumulate ? 1 : 0);
-          }
-          continue;
-        }
+      for (int j = 0; j < NQD; ++j) m_cur[j] = m_next[j];
+      if constexpr (TWOLVL) {
 #pragma unroll
-        for (int j = 0; j < C::PW; ++j) {
-          const int ow = ow0 + j;
-          if (oh < p.Ho && ow < p.Wo) {
-            float* dst = xp + (long long)oh * p.Wo + ow;
-            if (zero_fill) *dst = 0.f;
-            else if (oc.accumulate) *dst += acc[a][i][j];
-            else *dst = acc[a][i][j];
-          }
-        }
+        for (int a = 0; a < OPW; ++a)
+#pragma unroll
+          for (int i = 0; i < C::PH; ++i)
+#pragma unroll
+            for (int j = 0; j < C::PW; ++j) { acc2[a][i][j] += acc[a][i][j]; acc[a][i][j] = 0.f; }
+      }
+      STAMP(t4);
+      if (!CDBG(4)) __syncthreads();
+      STAMP(t5);
+      STAMP_ADD(1, t0, t1); STAMP_ADD(2, t1, t2); STAMP_ADD(3, t2, t3); STAMP_ADD(4, t3, t4); STAMP_ADD(5, t4, t5);
+    }
+    STAMP(t_epi);
+    if constexpr (TWOLVL) {
+#pragma unroll
+      for (int a = 0; a < OPW; ++a)
+#pragma unroll
+        for (int i = 0; i < C::PH; ++i)
+#pragma unroll
+          for (int j = 0; j < C::PW; ++j) acc[a][i][j] = acc2[a][i][j];
+    }
+
+    // ---------------- epilogue ------------------------------------------------------------------------------
+    const int oh0 = h0 + ly * C::PH, ow0 = w0 + lx * C::PW;
+    float psum[OPW];                                      // fwd: per-lane sums of the stored values
+#pragma unroll
+    for (int a = 0; a < OPW; ++a) psum[a] = 0.f;
+    float4* vdst[MODE != 0 ? OPW : 1][C::PH];             // dgrad, float4 rows: destination (null = nothing to store) and mode
+    int vmode[MODE != 0 ? OPW : 1];
+    if (MODE != 0) {
+#pragma unroll
+      for (int a = 0; a < OPW; ++a) {
+        vmode[a] = 0;
+#pragma unroll
+        for (int i = 0; i < C::PH; ++i) vdst[a][i] = nullptr;
       }
     }
-  }
-  if (MODE != 0 && C::PW == 4) {
-    float4 oldv[OPW][C::PH];
-#pragma unroll
-    for (int a = 0; a < OPW; ++a)
-#pragma unroll
-      for (int i = 0; i < C::PH; ++i) {
-        oldv[a][i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (vdst[a][i] != nullptr && vmode[a] == 1) oldv[a][i] = *vdst[a][i];
-      }
-#pragma unroll
-    for (int a = 0; a < OPW; ++a)
-#pragma unroll
-      for (int i = 0; i < C::PH; ++i) {
-        if (vdst[a][i] == nullptr) continue;
-        float4 val = make_float4(acc[a][i][0], acc[a][i][1 % C::PW], acc[a][i][2 % C::PW], acc[a][i][3 % C::PW]);
-        if (vmode[a] == 2) val = make_float4(0.f, 0.f, 0.f, 0.f);
-        val.x += oldv[a][i].x; val.y += oldv[a][i].y; val.z += oldv[a][i].z; val.w += oldv[a][i].w;
-        *vdst[a][i] = val;
-      }
-  }
-  if (MODE == 0 && p.part != nullptr) {
-    // per-tile (count, mean, M2) partials of the 4 output planes: the count is known from the tile geometry, the four
-    // sums (and then the four M2) are reduced side by side so their cross-lane steps overlap
-    const int vr = p.Ho - h0 < TH ? p.Ho - h0 : TH, vc = p.Wo - w0 < TW ? p.Wo - w0 : TW;
-    const float tcnt = (float)(vr * vc);
-    float mean[OPW], m2[OPW];
-#pragma unroll
-    for (int a = 0; a < OPW; ++a) mean[a] = e2e::wave_sum_dpp(psum[a]) / tcnt;
 #pragma unroll
     for (int a = 0; a < OPW; ++a) {
-      float t = 0.f;
+      const int q = qbase + a;
+      if (q >= p.Q || CDBG(64)) continue;
+      if (MODE == 0) {
+        const float bq = bqs[a];
+        float* yp = p.y + (((long long)n * p.Q + q) * p.Do + d) * out_plane;
+        float s = 0.f;
+        const bool vec_store = (C::PW == 4) && (p.Wo % 4 == 0);      // lane rows are 16-byte aligned
+        const bool vec2_store = (C::PW == 2) && (p.Wo % 2 == 0);     // ... or 8-byte aligned pairs
 #pragma unroll
-      for (int i = 0; i < C::PH; ++i)
+        for (int i = 0; i < C::PH; ++i) {
+          const int oh = oh0 + i;
 #pragma unroll
-        for (int j = 0; j < C::PW; ++j) {
-          const int oh = oh0 + i, ow = ow0 + j;
-          if (oh < p.Ho && ow < p.Wo) {
-            const float dlt = acc[a][i][j] - mean[a];
-            t = fmaf(dlt, dlt, t);
+          for (int j = 0; j < C::PW; ++j) {
+            const int ow = ow0 + j;
+            const float val = acc[a][i][j] + bq;
+            acc[a][i][j] = val;
+            if (oh < p.Ho && ow < p.Wo) {
+              if (!vec_store && !vec2_store) yp[(long long)oh * p.Wo + ow] = val;
+              s += val;
+            }
+          }
+          if (vec_store && oh < p.Ho && ow0 < p.Wo)
+            *reinterpret_cast<float4*>(yp + (long long)oh * p.Wo + ow0) =
+                make_float4(acc[a][i][0], acc[a][i][1 % C::PW], acc[a][i][2 % C::PW], acc[a][i][3 % C::PW]);
+          if (vec2_store && oh < p.Ho && ow0 < p.Wo)
+            *reinterpret_cast<float2*>(yp + (long long)oh * p.Wo + ow0) = make_float2(acc[a][i][0], acc[a][i][1 % C::PW]);
+        }
+        psum[a] = s;
+      } else {
+        // dgrad: gradient of virtual-concat channel q at (shifted) depth d goes to depth d - s(q) of its source
+        const e2e_out_chan_t oc = ocs[a];
+        if (oc.ptr == nullptr) continue;
+        int dd = d - oc.dshift;
+        bool zero_fill = false;
+        if (dd < 0) {              // s > 0: slices [max(D-s,0), D) receive nothing -> this workgroup zero-fills one
+          const int lo = p.Do - oc.dshift > 0 ? p.Do - oc.dshift : 0;
+          dd = lo + d;
+          zero_fill = true;
+        } else if (dd >= p.Do) {   // s < 0: slices [0, min(-s, D)) receive nothing
+          const int lo = p.Do + oc.dshift > 0 ? p.Do + oc.dshift : 0;
+          dd = d - lo;
+          zero_fill = true;
+        }
+        if (zero_fill && oc.accumulate) continue;
+        float* xp = oc.ptr + (long long)n * oc.nstride + (long long)dd * out_plane;
+        const bool vec_store = (C::PW == 4) && (p.Wo % 4 == 0);
+        const bool vec2_store = (C::PW == 2) && (p.Wo % 2 == 0);
+#pragma unroll
+        for (int i = 0; i < C::PH; ++i) {
+          const int oh = oh0 + i;
+          if (vec2_store) {
+            if (oh < p.Ho && ow0 < p.Wo) {
+              float2* dst = reinterpret_cast<float2*>(xp + (long long)oh * p.Wo + ow0);
+              float2 val = make_float2(acc[a][i][0], acc[a][i][1 % C::PW]);
+              if (zero_fill) val = make_float2(0.f, 0.f);
+              else if (oc.accumulate) { const float2 o = *dst; val.x += o.x; val.y += o.y; }
+              *dst = val;
+            }
+            continue;
+          }
+          if (vec_store) {      // handled below: all old values are requested first, then added and stored
+            if (oh < p.Ho && ow0 < p.Wo) {
+              vdst[a][i] = reinterpret_cast<float4*>(xp + (long long)oh * p.Wo + ow0);
+              vmode[a] = zero_fill ? 2 : (oc.accumulate ? 1 : 0);
+            }
+            continue;
+          }
+#pragma unroll
+          for (int j = 0; j < C::PW; ++j) {
+            const int ow = ow0 + j;
+            if (oh < p.Ho && ow < p.Wo) {
+              float* dst = xp + (long long)oh * p.Wo + ow;
+              if (zero_fill) *dst = 0.f;
+              else if (oc.accumulate) *dst += acc[a][i][j];
+              else *dst = acc[a][i][j];
+            }
           }
         }
-      m2[a] = t;
+      }
     }
+    if (MODE != 0 && C::PW == 4) {
+      float4 oldv[OPW][C::PH];
 #pragma unroll
-    for (int a = 0; a < OPW; ++a) m2[a] = e2e::wave_sum_dpp(m2[a]);
-    if (lane < OPW && qbase + lane < p.Q) {
-      float mm = mean[0], vv = m2[0];
+      for (int a = 0; a < OPW; ++a)
 #pragma unroll
-      for (int a = 1; a < OPW; ++a)
-        if (lane == a) { mm = mean[a]; vv = m2[a]; }
-      float* pp = p.part + (((long long)n * p.Q + qbase + lane) * p.tiles_per_n + tile_in_n) * 3;
-      pp[0] = tcnt;
-      pp[1] = mm;
-      pp[2] = vv;
+        for (int i = 0; i < C::PH; ++i) {
+          oldv[a][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (vdst[a][i] != nullptr && vmode[a] == 1) oldv[a][i] = *vdst[a][i];
+        }
+#pragma unroll
+      for (int a = 0; a < OPW; ++a)
+#pragma unroll
+        for (int i = 0; i < C::PH; ++i) {
+          if (vdst[a][i] == nullptr) continue;
+          float4 val = make_float4(acc[a][i][0], acc[a][i][1 % C::PW], acc[a][i][2 % C::PW], acc[a][i][3 % C::PW]);
+          if (vmode[a] == 2) val = make_float4(0.f, 0.f, 0.f, 0.f);
+          val.x += oldv[a][i].x; val.y += oldv[a][i].y; val.z += oldv[a][i].z; val.w += oldv[a][i].w;
+          *vdst[a][i] = val;
+        }
     }
-  }
-  STAMP(t_end);
-  STAMP_ADD(6, t_epi, t_end);
-  STAMP_ADD(7, t_end - 1, t_end);
+    if (MODE == 0 && p.part != nullptr && !CDBG(32)) {
+      // per-tile (count, mean, M2) partials of the 4 output planes: the count is known from the tile geometry, the four
+      // sums (and then the four M2) are reduced side by side so their cross-lane steps overlap
+      const int vr = p.Ho - h0 < TH ? p.Ho - h0 : TH, vc = p.Wo - w0 < TW ? p.Wo - w0 : TW;
+      const float tcnt = (float)(vr * vc);
+      float mean[OPW], m2[OPW];
+#pragma unroll
+      for (int a = 0; a < OPW; ++a) mean[a] = e2e::wave_sum_dpp(psum[a]) / tcnt;
+#pragma unroll
+      for (int a = 0; a < OPW; ++a) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < C::PH; ++i)
+#pragma unroll
+          for (int j = 0; j < C::PW; ++j) {
+            const int oh = oh0 + i, ow = ow0 + j;
+            if (oh < p.Ho && ow < p.Wo) {
+              const float dlt = acc[a][i][j] - mean[a];
+              t = fmaf(dlt, dlt, t);
+            }
+          }
+        m2[a] = t;
+      }
+#pragma unroll
+      for (int a = 0; a < OPW; ++a) m2[a] = e2e::wave_sum_dpp(m2[a]);
+      if (lane < OPW && qbase + lane < p.Q) {
+        float mm = mean[0], vv = m2[0];
+#pragma unroll
+        for (int a = 1; a < OPW; ++a)
+          if (lane == a) { mm = mean[a]; vv = m2[a]; }
+        float* pp = p.part + (((long long)n * p.Q + qbase + lane) * p.tiles_per_n + tile_in_n) * 3;
+        pp[0] = tcnt;
+        pp[1] = mm;
+        pp[2] = vv;
+      }
+    }
+    STAMP(t_end);
+    STAMP_ADD(6, t_epi, t_end);
+    STAMP_ADD(7, t_end - 1, t_end);
 #ifdef E2E_CONV_DEBUG
-  if (lane == 0)
-    for (int i = 0; i < 8; ++i) atomicAdd(&g_conv_stamps[(blockIdx.x & 1023) * 8 + i], st_acc[i]);
+    if (lane == 0)
+      for (int i = 0; i < 8; ++i) atomicAdd(&g_conv_stamps[(blockIdx.x & 1023) * 8 + i], st_acc[i]);
 #endif
-  };   // run_item
-  if (PERSIST) {
-    for (int item = item_lo; item < item_hi; ++item) run_item(item);
-  } else if (item_lo < item_hi) {
-    run_item(item_lo);
+    if (!has_next) break;
+    cur = nxt;
   }
 }
 
@@ -765,10 +828,29 @@ __global__ __launch_bounds__(256) void conv133_dgrad_strided_kernel(const float*
 template <int MODE, int SH, int SW, int DH, int DW, int TH, int TW, int LY, int LX, int OPW, int NW, int CK, int STG, int MINW, int PIPE, int PERSIST>
 int launch_cfg_impl(ConvParams p, hipStream_t st);
 
+// persistent grid: 4 workgroup slots' worth per CU (256 CUs x 2 resident workgroups x 2 rounds); E2E_CONV_WGS overrides (A/B)
+inline int persist_knob() {
+  static const int v = getenv("E2E_CONV_PERSIST") ? atoi(getenv("E2E_CONV_PERSIST")) : 0;
+  return v;
+}
+inline int persist_wgs() {
+  static const int v = getenv("E2E_CONV_WGS") ? atoi(getenv("E2E_CONV_WGS")) : 1024;
+  return v > 8 ? v : 8;
+}
+
 template <int MODE, int SH, int SW, int DH, int DW, int TH, int TW, int LY, int LX, int OPW, int NW, int CK, int STG, int MINW = 1, int PIPE = 0>
 int launch_cfg(ConvParams p, hipStream_t st) {
   // thin layers (a single input chunk, e.g. the 4-modal network input): per-tile start-up dominates -> persistent
-  if (p.P <= CK) return launch_cfg_impl<MODE, SH, SW, DH, DW, TH, TW, LY, LX, OPW, NW, CK, STG, MINW, PIPE, 1>(p, st);
+  // workgroups that walk runs of consecutive items and request the next item's planes under the current epilogue.
+  // For multi-chunk layers the run loop was measured SLOWER than one workgroup per item (0.91 vs 0.83 ms on 64->32
+  // @128^3: the hardware dispatcher hides the start-up of the next workgroup behind the running ones, and runs that
+  // start together stay in phase); E2E_CONV_PERSIST=1 forces it for A/B runs.  (Element staging keeps one item per
+  // workgroup: the run loop would spill there.)
+  if constexpr (STG == 1) {
+    const long long total = (long long)p.B * p.Do * e2e::cdiv(p.Ho, TH) * e2e::cdiv(p.Wo, TW) * e2e::cdiv(p.Q, Cfg<MODE, SH, SW, DH, DW, TH, TW, LY, LX, OPW, NW, CK, STG>::OCG);
+    if ((p.P <= CK || persist_knob()) && total > persist_wgs())
+      return launch_cfg_impl<MODE, SH, SW, DH, DW, TH, TW, LY, LX, OPW, NW, CK, STG, MINW, PIPE, 1>(p, st);
+  }
   return launch_cfg_impl<MODE, SH, SW, DH, DW, TH, TW, LY, LX, OPW, NW, CK, STG, MINW, PIPE, 0>(p, st);
 }
 
@@ -783,8 +865,7 @@ int launch_cfg_impl(ConvParams p, hipStream_t st) {
   p.padded_total = (p.total + 7) & ~7;
   static const int dbg_knob = getenv("E2E_CONV_DBG") ? atoi(getenv("E2E_CONV_DBG")) : 0;
   p.dbg = dbg_knob;
-  // persistent grid: about 4 workgroup slots per CU (256 CUs), each walking a run of consecutive work items
-  int wgs = PERSIST ? 1024 : p.total;
+  int wgs = PERSIST ? persist_wgs() : p.total;
   if (wgs > p.total) wgs = p.total;
   p.items_per_wg = e2e::cdiv(p.total, wgs);
   wgs = (e2e::cdiv(p.total, p.items_per_wg) + 7) & ~7;
