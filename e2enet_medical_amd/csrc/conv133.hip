@@ -907,7 +907,8 @@ int launch_s1(const ConvParams& p, int kind, hipStream_t st) {
     case 0:
       // 16x32 tile, 97 VGPRs -> two 512-thread workgroups per CU (measured best; see DESIGN.md §5 for the variants
       // that were measured against it)
-      if (vec && opw8_knob() && p.P > 8) return launch_cfg<MODE, 1, 1, 1, 1, 16, 32, 8, 8, 8, 4, 8, 1, 3, 0>(p, st);   // 4 fat waves
+      if (vec && opw8_knob() == 1 && p.P > 8) return launch_cfg<MODE, 1, 1, 1, 1, 16, 32, 8, 8, 8, 4, 8, 1, 3, 0>(p, st);   // 4 fat waves
+      if (vec && opw8_knob() == 2 && p.P > 8) return launch_cfg<MODE, 1, 1, 1, 1, 16, 32, 8, 8, 4, 4, 8, 1, 4, 0>(p, st);   // 4 waves, 16 output planes: 4 workgroups per CU
       return vec ? launch_cfg<MODE, 1, 1, 1, 1, 16, 32, 8, 8, 4, 8, 8, 1, 4, 0>(p, st)
                  : launch_cfg<MODE, 1, 1, DH, DW, 16, 32, 8, 8, 4, 8, 8, 0, 4, 0>(p, st);
     case 1:

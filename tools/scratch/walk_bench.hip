@@ -7,8 +7,10 @@
 
 constexpr int PITCH = 48, CHS = 18 * PITCH + 16;
 
+__device__ unsigned long long g_clk[2];
 template <int MODE, int K>   // MODE bit0: neighbourhood reads, bit1: weight reads, bit2: FMAs, bit3: halo columns as a second b128
 __global__ __launch_bounds__(512, 2) void walk(float* out, const float* in, int visits) {
+  const unsigned long long c0 = __builtin_readcyclecounter(), r0 = wall_clock64();
   __shared__ __attribute__((aligned(16))) float lds[8 * CHS];
   __shared__ __attribute__((aligned(16))) float wl[32 * 8 * 12];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lx = lane & 7, ly = lane >> 3;
@@ -91,6 +93,7 @@ __global__ __launch_bounds__(512, 2) void walk(float* out, const float* in, int 
 #pragma unroll
       for (int j = 0; j < 4; ++j) s += acc[a][i][j];
   out[blockIdx.x * 512 + tid] = s;
+  if (tid == 0) { atomicAdd(&g_clk[0], __builtin_readcyclecounter() - c0); atomicAdd(&g_clk[1], wall_clock64() - r0); }
 }
 
 template <class F> float run(F f) {
@@ -105,8 +108,9 @@ template <int MODE, int K> void one(float* out, float* in, const char* name, int
   float ms = run([&] { hipLaunchKernelGGL((walk<MODE, K>), dim3(blocks), dim3(512), 0, 0, out, in, visits); });
   const double kern = (double)blocks * 8 * visits * K;
   // cycles of CU time per kernel-wave: blocks/256 rounds... report ns per (CU, kernel-wave) and TFLOP/s
-  printf("%-44s K=%d blocks=%4d  %.3f ms  %6.1f TFLOP/s  %.1f CU-clk(2.0GHz)/kernel\n", name, K, blocks, ms,
-         (MODE & 4) ? kern * 64 * 144 / ms / 1e9 : 0.0, ms * 1e-3 * 2.0e9 * 256 / kern);
+  unsigned long long h[2]; hipMemcpyFromSymbol(h, HIP_SYMBOL(g_clk), 16); unsigned long long z[2] = {0, 0}; hipMemcpyToSymbol(HIP_SYMBOL(g_clk), z, 16);
+  printf("%-44s K=%d blocks=%4d  %.3f ms  %6.1f TFLOP/s  %.1f CU-clk(2.0GHz)/kernel  sclk %.0f MHz\n", name, K, blocks, ms,
+         (MODE & 4) ? kern * 64 * 144 / ms / 1e9 : 0.0, ms * 1e-3 * 2.0e9 * 256 / kern, 100.0 * (double)h[0] / (double)h[1]);
 }
 
 
