@@ -421,9 +421,12 @@ __global__ __launch_bounds__(256 * NCB) void conv133_wgrad_v2_kernel(WgParams p)
 // v2 alternates a staging phase (commit the prefetched registers to LDS) and an MFMA phase separated by two barriers,
 // and with one 8-wave workgroup per CU nothing else runs while it stages: the matrix pipe idles ~40 % of the time.
 // v3 keeps two LDS images (tile 4 x 32, 77 KB each for 64 input channels): while the MFMAs consume image t & 1, the
-// registers holding tile t+1 are committed to the other image piece by piece between the k-steps, the loads of tile
-// t+2 are issued when that is done, and one barrier per tile publishes the new image.  A chunk never crosses a batch
-// item, so the channel descriptors are loaded once per workgroup.
+// registers holding tile t+1 are committed to the other image piece by piece between the k-steps, piece s of tile t+2
+// is requested one k-step after piece s of tile t+1 left its registers (straight-line code, no branch: see the loop),
+// and one barrier per tile publishes the new image.  A chunk never crosses a batch item, so the channel descriptors
+// are loaded once per workgroup.  Phase split on 64->32 @128^3 (E2E_WG_DBG builds of round 2): MFMAs alone 1.07 ms
+// (144 TFLOP/s), + commits 1.19, + the ten loads per lane in one block before the barrier 1.37; with the loads spread
+// over the k-steps 1.29.
 template <int NCB, int NOB, int NKB = 1>
 struct W3Cfg {
   static_assert(NCB * NOB * NKB == 2, "8 waves: 2 x 2 sub-blocks of 16 x 16 for two 32 x 32 blocks, or for the two row halves of one");
@@ -514,30 +517,39 @@ __global__ __launch_bounds__(512) void conv133_wgrad_v3_kernel(WgParams p) {
   const int y_r = y_grp >> 3, y_col = (y_grp & 7) * 4;
 
   f32x4_t vx[C::XCW], vy[C::YIT];
-  auto prefetch = [&](int d0, int h0, int w0) {
-    const int hi = h0 - 1 + g_r, gc = w0 - 4 + 4 * g_q;
-    const bool lane_ok = (unsigned)hi < (unsigned)p.Hi && gc >= 0 && gc + 3 < p.Wi;
-    const long long lane_off = (long long)hi * p.Wi + gc;
-#pragma unroll
-    for (int k = 0; k < C::XCW; ++k) {
+  // request piece s of a tile (s < XCW: input channel s of this wave, else dy round s - XCW) into its registers.  Inside the
+  // MFMA loop the pieces of tile t+2 are requested one per k-step, each right after the registers' previous content (tile
+  // t+1) went to LDS: ten back-to-back 16-byte loads per lane from all eight waves (80 KB) keep the texture addresser busy
+  // for > 1 k cycles with every wave stuck in issue order behind them -- measured 13 % of the kernel when they sat in
+  // one block in front of the barrier.
+  auto prefetch_piece = [&](int s, int d0, int h0, int w0) {
+    if (s < C::XCW) {
+      const int k = s;
+      const int hi = h0 - 1 + g_r, gc = w0 - 4 + 4 * g_q;
+      const bool lane_ok = (unsigned)hi < (unsigned)p.Hi && gc >= 0 && gc + 3 < p.Wi;
+      const long long lane_off = (long long)hi * p.Wi + gc;
       const int din = d0 * p.sd - xdsh[k];
       const bool ok = lane_ok && xval[k] && (unsigned)din < (unsigned)p.Di;
       vx[k] = *reinterpret_cast<gf4_p>(xbase[k] + (ok ? (long long)din * in_plane + lane_off : 0));
-    }
-    const int ho = h0 + y_r, wo = w0 + y_col;
-    const bool yok = ho < p.Ho && wo + 3 < p.Wo;
-#pragma unroll
-    for (int it = 0; it < C::YIT; ++it) {
+    } else {
+      const int it = s - C::XCW;
+      const int ho = h0 + y_r, wo = w0 + y_col;
+      const bool yok = ho < p.Ho && wo + 3 < p.Wo;
       const int o = obase + wave * C::YCW + y_kl + 2 * it;
       const bool ok = yok && o < p.Cout;
       const long long off = ok ? (((long long)n * p.Cout + o) * p.Do + d0) * out_plane + (long long)ho * p.Wo + wo : 0;
       vy[it] = *reinterpret_cast<gf4_p>((gfloat_p)p.dy + off);
     }
   };
+  auto prefetch = [&](int d0, int h0, int w0) {
+#pragma unroll
+    for (int s = 0; s < C::PIECES; ++s) prefetch_piece(s, d0, h0, w0);
+  };
   // commit piece s of the registers (tile geometry d0, h0, w0) into image `buf`: s < XCW -> input channel s, else dy round
   auto commit_piece = [&](int s, int buf, int d0, int h0, int w0) {
     if (s < C::XCW) {
-      if (lane >= C::GPC) return;
+      // (lanes beyond the last group hold a clamped copy of it: same address, same value -- no divergent branch here, so
+      //  that the in-loop staging below stays straight-line code and its loads get exact vmcnt distances)
       const int k = s;
       const int hi = h0 - 1 + g_r, gc = w0 - 4 + 4 * g_q;
       const int din = d0 * p.sd - xdsh[k];
@@ -573,12 +585,13 @@ __global__ __launch_bounds__(512) void conv133_wgrad_v3_kernel(WgParams p) {
       decode(tile_lo + 1, nd0, nh0, nw0);
       prefetch(nd0, nh0, nw0);
     }
+    int fd0 = nd0, fh0 = nh0, fw0 = nw0;               // tile + 2: requested piece by piece inside the loop
     __syncthreads();
 
     const int li = lane & 15, lk = lane >> 4;
     for (int tile = tile_lo; tile < tile_hi; ++tile) {
       const int buf = (tile - tile_lo) & 1;
-      const bool more = tile + 1 < tile_hi;             // registers hold tile + 1 -> goes to image buf ^ 1 during this phase
+      decode(tile + 2 < tile_hi ? tile + 2 : tile_hi - 1, fd0, fh0, fw0);   // registers hold tile + 1 -> image buf ^ 1 during this phase
       const float* ap = ys0 + buf * C::YBUF + (obl * 32 + oh * 16 + li) * C::OS + lk + kq * C::ROWS * C::TW;
       const float* bp = xs0 + buf * C::XBUF + (cbl * 32 + ch * 16 + li) * C::CS + lk + C::COL0 + kq * C::ROWS * C::PITCH;
       float a_cur = ap[0];
@@ -607,7 +620,11 @@ __global__ __launch_bounds__(512) void conv133_wgrad_v3_kernel(WgParams p) {
 #pragma unroll
           for (int t = 0; t < 9; ++t) {
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur, b_cur[t], acc[t], 0, 0, 0);
-            if (t == 0 && s < C::PIECES && more) commit_piece(s, buf ^ 1, nd0, nh0, nw0);   // issues in the shadow of the MFMAs
+            // staging in the shadow of the MFMAs, one piece per k-step, unconditionally (past the end of the chunk the
+            // last tile is simply staged again into the image nobody reads): any branch here makes the compiler wait
+            // for vmcnt(0) at every piece, i.e. for the load it issued one k-step earlier
+            if (t == 0 && s < C::PIECES) commit_piece(s < C::PIECES ? s : 0, buf ^ 1, nd0, nh0, nw0);
+            if (t == 4 && s >= 1 && s - 1 < C::PIECES) prefetch_piece(s >= 1 && s - 1 < C::PIECES ? s - 1 : 0, fd0, fh0, fw0);   // registers committed one k-step ago
           }
           __builtin_amdgcn_sched_barrier(0);
           a_cur = a_nxt;
@@ -615,11 +632,8 @@ __global__ __launch_bounds__(512) void conv133_wgrad_v3_kernel(WgParams p) {
           for (int t = 0; t < 9; ++t) b_cur[t] = b_nxt[t];
         }
       }
-      if (tile + 2 < tile_hi) {                          // the registers are free again: request tile + 2
-        decode(tile + 2, nd0, nh0, nw0);
-        prefetch(nd0, nh0, nw0);
-      }
-      __syncthreads();
+      nd0 = fd0; nh0 = fh0; nw0 = fw0;
+      if (!(p.dbg & 32)) __syncthreads();
     }
   }
 
