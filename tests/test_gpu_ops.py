@@ -1,6 +1,7 @@
 """Op-level parity of the HIP kernels (through the C ABI) against the CPU oracle on seeded inputs.
 Tolerances: fp32 paths compare at 1e-4-ish absolute on O(1) data; index / mask / integer results are bit exact."""
 import math
+import os
 import random
 import numpy as np
 import pytest
@@ -448,3 +449,20 @@ def test_sliding_window_kernels():
     L.sw_finalize_argmax(agg.data_ptr(), cnt.data_ptr(), probs.data_ptr(), seg.data_ptr(), K, VX, VY, VZ, 2, 1, 3, 5, 6, 7, 0)
     rp = (ra / rc)[:, 2:7, 1:7, 3:10]
     assert torch.equal(probs.cpu(), rp) and torch.equal(seg.cpu(), rp.argmax(0))
+
+
+def test_conv133_persistent_run_loop_forced():
+    """The persistent run loop of conv133_kernel (a workgroup walks a run of consecutive tiles, rebuilds the plane table
+    when the (batch item, slice) changes and requests the next tile's first chunk under the current epilogue) is only
+    selected for single-chunk layers with more tiles than workgroup slots.  Force it for every float4-staged shape with
+    a budget of 16 workgroups (runs that cross plane groups, slices, batch items and the dead slices of depth-strided
+    data gradients) in a child process -- the knobs are read once per process -- and run the operator cases again."""
+    import subprocess
+    import sys
+    env = dict(os.environ, E2E_CONV_PERSIST="1", E2E_CONV_WGS="16")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "test_conv133_fwd_bwd", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=900,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "passed" in r.stdout
