@@ -373,6 +373,44 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
       }
     }
   };
+  // ---- straight-line variant of the request (occupancy-tuned 16x32 configurations): the walk below is unrolled over the
+  // CK plane slots of a chunk and slot cl issues request step cl -- unconditionally, so that the code has no branch
+  // around a load (a branch there makes the wait-count pass drain vmcnt to 0 at every use; measured in the weight
+  // gradient and in an earlier version of this loop).  Without a next chunk the steps read one dummy line / an
+  // out-of-range buffer offset.  Why not one block after the barrier: all eight waves queue up in the texture addresser
+  // and none of them can start its walk before its last load is accepted (in-order issue).
+  constexpr bool UNROLL = STG && MINW >= 3 && PPW == 1 && OPW == 4;
+  constexpr int NSTEP = STG ? PPW * NUP + NUW : 0;
+  unsigned pf_blo = 0, pf_bhi = 0, pf_coff = 0;
+  auto request_begin = [&](int c0, int qgroup) {
+    if constexpr (UNROLL) {
+      const int pl = c0 + wave;
+      const PlaneDesc ds = tab[pl < p.P ? pl : p.P - 1];
+      const unsigned long long bb = (unsigned long long)ds.base;
+      pf_blo = __builtin_amdgcn_readfirstlane((unsigned)bb);
+      pf_bhi = __builtin_amdgcn_readfirstlane((unsigned)(bb >> 32));
+      pd_a[0] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ds.a)));
+      pd_b[0] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ds.b)));
+      pd_slope[0] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ds.slope)));
+      pd_ok[0] = pl < p.P && __builtin_amdgcn_readfirstlane(ds.valid) != 0;
+      pf_coff = (unsigned)(qgroup * p.wq_stride + c0 * p.wp_stride) * 4u;
+    }
+  };
+  auto request_step = [&](int k, bool live) {              // k: compile-time; live: wave-uniform
+    if constexpr (UNROLL) {
+      if (k < NUP) {
+        const char __attribute__((address_space(1)))* base =
+            (const char __attribute__((address_space(1)))*)(((unsigned long long)pf_bhi << 32) | pf_blo);
+        const unsigned off = live && pd_ok[0] ? (unsigned)su_goff[k] : 0u;      // (plane bases are always dereferenceable)
+        v4[0][k] = *reinterpret_cast<gfloat4_p>(base + off);
+      } else if (k < NSTEP) {
+        const int i = k - NUP;
+        const unsigned off = WRND ? wu_off[0] + pf_coff + (unsigned)(i * QPR * p.wq_stride) * 4u : wu_off[WRND ? 0 : i] + pf_coff;
+        vw[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, (int)(live && !CDBG(16) ? off : 0x80000000u), 0, 0));
+      }
+    }
+  };
+
   auto commit = [&](int c0) {
     if constexpr (STG) {
 #pragma unroll
@@ -562,11 +600,37 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
         pf_c0 = 0; pf_qg = nxt.g * C::OCG;
         pf = true; requested = true;
       }
-      if (pf && !CDBG(1)) prefetch(pf_c0, pf_qg);           // in flight while this chunk is computed
+      if constexpr (UNROLL) {
+        pf = pf && !CDBG(1);
+        request_begin(pf ? pf_c0 : c0, pf ? pf_qg : qgroup);
+      } else {
+        if (pf && !CDBG(1)) prefetch(pf_c0, pf_qg);         // in flight while this chunk is computed
+      }
       STAMP(t3);
 
       // walk the chunk's live input planes (nibbles of the quad mask); the neighbourhood rows of a plane are read once
       // and shared by the 1..4 output planes of this wave that consume it
+      if constexpr (UNROLL) {
+        const unsigned long long mw = CDBG(2) ? 0ull : m_cur[0];
+#pragma unroll
+        for (int cl = 0; cl < CK; ++cl) {
+#pragma unroll
+          for (int k = cl; k < NSTEP; k += CK) request_step(k, pf);
+          const unsigned nib = (unsigned)(mw >> (cl * 4)) & 15u;
+          if (nib) {
+            float nb[C::NR][NCL];
+            issue(cl, nb);
+#pragma unroll
+            for (int a = 0; a < OPW; ++a) {
+              if (nib & (1u << a)) {
+                float wk[9];
+                load_w(a, cl, wk);
+                apply(acc[a], nb, wk);
+              }
+            }
+          }
+        }
+      } else {
       unsigned long long m = 0;
 #pragma unroll
       for (int j = 0; j < NQD; ++j) m |= m_cur[j];
@@ -587,6 +651,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
             apply(acc[a], nb, wk);
           }
         }
+      }
       }
 #pragma unroll
       for (int j = 0; j < NQD; ++j) m_cur[j] = m_next[j];
