@@ -96,6 +96,10 @@ class StackedConvLayers(nn.Module):
         return self.blocks(x)
 
 
+_VARIANT_PERM = {"133": (0, 1, 2), "313": (1, 0, 2), "331": (2, 0, 1)}
+_VARIANT_KERNEL = {"133": (1, 3, 3), "313": (3, 1, 3), "331": (3, 3, 1)}
+
+
 class _EngineFunction(torch.autograd.Function):
     """One autograd node for the whole network: forward/backward are the engine's op lists."""
 
@@ -137,8 +141,22 @@ class Generic_UNetPlusPlus(SegmentationNetwork):
                  deep_supervision=True, dropout_in_localization=False, final_nonlin=softmax_helper,
                  weightInitializer=InitWeights_He(1e-2), pool_op_kernel_sizes=None, conv_kernel_sizes=None,
                  upscale_logits=False, convolutional_pooling=False, convolutional_upsampling=False,
-                 max_num_features=None, basic_block=ConvDropoutNormNonlin, seg_output_use_bias=False, shift_size=5):
+                 max_num_features=None, basic_block=ConvDropoutNormNonlin, seg_output_use_bias=False, shift_size=5,
+                 conv_variant="133"):
         super().__init__()
+        # conv_variant: "133" = the shiftConvPP network; "313" / "331" = the reference's ablation networks
+        # unetpp_d_313.py / unetpp_d_331.py (conv kernel (3,1,3) / (3,3,1), shift switched off in their source, :102).
+        # They run on the SAME kernels: a (3,1,3) conv on [D,H,W] volumes is the (1,3,3) conv on the volumes stored as
+        # [H,D,W], and a contiguous [o,i,3,1,3] weight tensor has the memory layout of [o,i,1,3,3] (kd in the row slot).
+        # So the engine works on axis-permuted tensors (engine axis a = reference axis _perm[a]); only the transposed-conv
+        # weights and the pooling plan have to be permuted, and forward() permutes at the boundary.
+        if conv_variant not in _VARIANT_PERM:
+            raise ValueError("conv_variant must be one of %s" % sorted(_VARIANT_PERM))
+        self.conv_variant = conv_variant
+        self._perm = _VARIANT_PERM[conv_variant]
+        self._inv_perm = tuple(self._perm.index(a) for a in range(3))
+        if conv_variant != "133":
+            shift_size = 1
         # ---- what the engine supports: exactly the configuration nnUNetTrainer_simple builds (:292-301) ----
         if conv_op != nn.Conv3d:
             raise ValueError("the MI355X engine implements the 3D shiftConvPP network only (conv_op=nn.Conv3d)")
@@ -178,7 +196,9 @@ class Generic_UNetPlusPlus(SegmentationNetwork):
 
         if pool_op_kernel_sizes is None:
             pool_op_kernel_sizes = [(2, 2, 2)] * num_pool
-        conv_kernel_sizes = [(1, 3, 3)] * (num_pool + 1)          # forced, reference :286-287
+        conv_kernel_sizes = [_VARIANT_KERNEL[conv_variant]] * (num_pool + 1)          # forced, reference :286-287
+        # pooling plan in engine axis order (what the transposed convs, max-pools and strided convs of the modules below use)
+        self._pool_e = [tuple(int(k[a]) for a in self._perm) for k in pool_op_kernel_sizes]
         self.input_shape_must_be_divisible_by = np.prod(pool_op_kernel_sizes, 0, dtype=np.int64)
         self.pool_op_kernel_sizes = pool_op_kernel_sizes
         self.conv_kernel_sizes = conv_kernel_sizes
@@ -190,8 +210,8 @@ class Generic_UNetPlusPlus(SegmentationNetwork):
 
         def stacked(cin, cout, n, first_stride=None):
             kw = dict(self.conv_kwargs)
-            kw['kernel_size'] = (1, 3, 3)
-            kw['padding'] = [0, 1, 1]
+            kw['kernel_size'] = _VARIANT_KERNEL[conv_variant]
+            kw['padding'] = [1 if v == 3 else 0 for v in kw['kernel_size']]
             return StackedConvLayers(cin, cout, n, blk[0], kw, *blk[2:], first_stride, basic_block=basic_block)
 
         # ---- construction order == reference (RNG parity): encoder, bottleneck, nests 0..4, heads ----
@@ -233,7 +253,16 @@ class Generic_UNetPlusPlus(SegmentationNetwork):
 
         # shift_size: keyword extension (default = the reference's hard-set 5, unetpp_d.py:89); 3/7/11 are the sizes its
         # comment lists, 1 reproduces the 'noshift' ablation variant
-        self._cfg = NetConfig(input_channels, base_num_features, num_classes, pool_op_kernel_sizes, num_conv_per_stage,
+        if conv_variant != "133":
+            # He-init parity: the reference draws a transposed-conv weight as [in, out, kD, kH, kW]; the same draws, taken
+            # in that shape and moved to the engine's axis order, are the same network
+            with torch.no_grad():
+                for n, p_ in self.named_parameters():
+                    if self._is_up_weight(n):
+                        p_.copy_(self._up_to_engine(p_.detach().clone().view(self._up_ref_shape(p_))))
+            self._register_state_dict_hook(Generic_UNetPlusPlus._state_dict_to_reference)
+            self._register_load_state_dict_pre_hook(self._state_dict_from_reference)
+        self._cfg = NetConfig(input_channels, base_num_features, num_classes, self._pool_e, num_conv_per_stage,
                               self.max_num_features, shift_size=shift_size)
         self._engines = {}
         self._kernel_masks = None            # name -> uint8 [dim0, dim1]; None = dense
@@ -241,6 +270,48 @@ class Generic_UNetPlusPlus(SegmentationNetwork):
         self._weights_outside_masks = False  # weights were (re)loaded after the masks were pushed: see _on_state_loaded
         self._param_names = [n for n, _ in self.named_parameters()]
         self.register_load_state_dict_post_hook(lambda module, keys: module._on_state_loaded())
+
+    # ---- axis-permuted variants: layout helpers --------------------------------------------------------------------
+    @staticmethod
+    def _is_up_weight(name):
+        return name.startswith("up") and name.endswith(".weight")
+
+    def _up_ref_shape(self, w):
+        """shape of an engine-order transposed-conv weight in the reference's axis order"""
+        k = tuple(w.shape[2:])
+        return tuple(w.shape[:2]) + tuple(k[self._inv_perm[a]] for a in range(3))
+
+    def _up_to_engine(self, w_ref):
+        return w_ref.permute(0, 1, *[2 + a for a in self._perm]).contiguous()
+
+    def _up_to_reference(self, w_eng):
+        return w_eng.permute(0, 1, *[2 + a for a in self._inv_perm]).contiguous()
+
+    @staticmethod
+    def _state_dict_to_reference(module, state_dict, prefix, local_metadata):
+        """state_dict(): tensors in the reference's shapes (checkpoint wire format)"""
+        for key in list(state_dict.keys()):
+            name = key[len(prefix):]
+            if module._is_up_weight(name):
+                state_dict[key] = module._up_to_reference(state_dict[key])
+        return state_dict
+
+    def _state_dict_from_reference(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        for key in list(state_dict.keys()):
+            if key.startswith(prefix) and self._is_up_weight(key[len(prefix):]):
+                state_dict[key] = self._up_to_engine(state_dict[key])
+
+    def to_engine_layout(self, t: torch.Tensor) -> torch.Tensor:
+        """[N, C, D, H, W] tensor in the reference's axis order -> the axis order the engine of this network runs in
+        (identity for the (1,3,3) network).  The trainer's fast path feeds ``engine()`` with data and targets in this layout."""
+        if self.conv_variant == "133":
+            return t
+        return t.permute(0, 1, *[2 + a for a in self._perm]).contiguous()
+
+    def from_engine_layout(self, t: torch.Tensor) -> torch.Tensor:
+        if self.conv_variant == "133":
+            return t
+        return t.permute(0, 1, *[2 + a for a in self._inv_perm]).contiguous()
 
     def _create_nest(self, z, num_pool, final_num_features, n_conv, stacked):
         """reference create_nest (:491-550) for convolutional_upsampling=True."""
@@ -253,10 +324,10 @@ class Generic_UNetPlusPlus(SegmentationNetwork):
             if unet_final is None:
                 unet_final = from_skip
             final_num_features = from_skip
-            tu.append(nn.ConvTranspose3d(from_down, from_skip, self.pool_op_kernel_sizes[-(u + 1)],
-                                         self.pool_op_kernel_sizes[-(u + 1)], bias=False))
-            if u + 2 <= len(self.pool_op_kernel_sizes):
-                tdown.append(nn.MaxPool3d(self.pool_op_kernel_sizes[-(u + 2)]))
+            # (engine axis order: the weight tensor [in, out, k0, k1, k2] is what the kernels read)
+            tu.append(nn.ConvTranspose3d(from_down, from_skip, self._pool_e[-(u + 1)], self._pool_e[-(u + 1)], bias=False))
+            if u + 2 <= len(self._pool_e):
+                tdown.append(nn.MaxPool3d(self._pool_e[-(u + 2)]))
             if z != 0:
                 loc.append(nn.Sequential(stacked(concat, final_num_features, n_conv - 1)))
             else:
@@ -271,7 +342,7 @@ class Generic_UNetPlusPlus(SegmentationNetwork):
         key = (tuple(x.shape), x.device.index)
         eng = self._engines.get(key)
         if eng is None:
-            div = self.input_shape_must_be_divisible_by
+            div = [int(self.input_shape_must_be_divisible_by[a]) for a in self._perm]      # x is in engine axis order
             if any(int(s) % int(d) for s, d in zip(x.shape[2:], div)):
                 raise ValueError("input spatial shape %s must be divisible by %s" % (tuple(x.shape[2:]), tuple(div)))
             eng = Engine(self._cfg, self._live_params(), x.shape[0], tuple(x.shape[2:]), x.device)
@@ -341,7 +412,7 @@ class Generic_UNetPlusPlus(SegmentationNetwork):
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("Generic_UNetPlusPlus (MI355X engine) needs a GPU tensor: there is no CPU fallback")
-        x = x.contiguous().float()
+        x = self.to_engine_layout(x.float()).contiguous()
         ds = bool(self._deep_supervision and self.do_ds)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             params = [p for _, p in self.named_parameters()]
@@ -350,9 +421,10 @@ class Generic_UNetPlusPlus(SegmentationNetwork):
             eng = self._engine_for(x)
             o = eng.forward(x, ds)
             outs = [t.clone() for t in (o if isinstance(o, list) else [o])]
-        outs = [self.final_nonlin(o) for o in outs]
+        outs = [self.final_nonlin(self.from_engine_layout(o)) for o in outs]
         return outs if ds else outs[0]
 
     def engine(self, x):
-        """The execution plan for inputs shaped like ``x`` (fast path used by the trainer and the benchmark)."""
+        """The execution plan for inputs shaped like ``x`` (fast path used by the trainer and the benchmark).  ``x`` is in
+        engine axis order (``to_engine_layout``; the reference's own order for the (1,3,3) network)."""
         return self._engine_for(x)

@@ -239,17 +239,29 @@ class nnUNetTrainer_simple(object):
         return self.network, self.optimizer
 
     def initialize_network(self):
-        """reference :292-301 (Tconv == 'shiftConvPP'); other Tconv values are ablations outside this engine."""
-        if self.Tconv != 'shiftConvPP':
-            raise NotImplementedError("the MI355X engine implements Tconv='shiftConvPP' (got %r)" % (self.Tconv,))
+        """reference :292-301 (Tconv == 'shiftConvPP') and its kernel-shape ablations 'shiftConvPP_313' / 'shiftConvPP_331'
+        (:303-323, same constructor arguments) and 'shiftConvPP_noshift' (:337-346: the (1,3,3) network without the shift);
+        the other Tconv values ('shiftConvPP_nodff', the non-nested baselines) are different graphs outside this engine."""
+        extra = {}
+        if self.Tconv == 'shiftConvPP':
+            net_cls = Generic_UNetPlusPlus
+        elif self.Tconv == 'shiftConvPP_313':
+            from ...network_architecture.unetpp_d_313 import Generic_UNetPlusPlus as net_cls
+        elif self.Tconv == 'shiftConvPP_331':
+            from ...network_architecture.unetpp_d_331 import Generic_UNetPlusPlus as net_cls
+        elif self.Tconv == 'shiftConvPP_noshift':
+            net_cls, extra = Generic_UNetPlusPlus, {"shift_size": 1}
+        else:
+            raise NotImplementedError("the MI355X engine implements Tconv='shiftConvPP' and its ablations "
+                                      "'shiftConvPP_313', 'shiftConvPP_331', 'shiftConvPP_noshift' (got %r)" % (self.Tconv,))
         base = 48 if self.base_num_features_override is None else self.base_num_features_override
-        self.network = Generic_UNetPlusPlus(self.patch_size, self.num_input_channels, base, self.num_classes,
+        self.network = net_cls(self.patch_size, self.num_input_channels, base, self.num_classes,
                                             len(self.net_num_pool_op_kernel_sizes), self.conv_per_stage, 2, nn.Conv3d,
                                             nn.InstanceNorm3d, {'eps': 1e-5, 'affine': True}, nn.Dropout3d,
                                             {'p': 0, 'inplace': True}, nn.LeakyReLU,
                                             {'negative_slope': 1e-2, 'inplace': True}, True, False, lambda x: x,
                                             InitWeights_He(1e-2), self.net_num_pool_op_kernel_sizes,
-                                            self.net_conv_kernel_sizes, False, True, True)
+                                            self.net_conv_kernel_sizes, False, True, True, **extra)
         if torch.cuda.is_available():
             self.network.cuda()
         self.network.inference_apply_nonlin = softmax_helper
@@ -293,6 +305,9 @@ class nnUNetTrainer_simple(object):
         if not isinstance(target, (list, tuple)):
             target = [target]
         target = [torch.as_tensor(t).float().to(dev, non_blocking=True).contiguous() for t in target]
+        if getattr(self.network, "conv_variant", "133") != "133":     # kernel-shape ablations run on axis-permuted tensors
+            data = self.network.to_engine_layout(data)
+            target = [self.network.to_engine_layout(t) for t in target]
         eng = self.network.engine(data)
         dp_on, group = self._data_parallel()
         dp = self._dp_for(eng, group) if (dp_on and do_backprop) else None

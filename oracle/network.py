@@ -29,14 +29,21 @@ class NetSpec:
     max_features: int = 320
     feats: List[int] = field(default_factory=list)
     shift_size: int = 5          # reference hard-sets 5 (unetpp_d.py:89; the comment there lists 3/7/11); 1 = 'noshift' ablation
+    conv_variant: str = "133"    # "313" / "331": the ablation networks unetpp_d_313.py / unetpp_d_331.py (kernel (3,1,3) /
+                                 # (3,3,1), padding on the axes of size 3, and NO shift: their forward has `and False`, :102)
 
     @property
     def num_pool(self):
         return len(self.pool_kernels)
 
 
+CONV_KERNELS = {"133": (1, 3, 3), "313": (3, 1, 3), "331": (3, 3, 1)}
+
+
 def make_spec(in_channels, base_features, num_classes, pool_kernels=None, convs_per_stage=2,
-              max_features=320, shift_size=5) -> NetSpec:
+              max_features=320, shift_size=5, conv_variant="133") -> NetSpec:
+    if conv_variant not in CONV_KERNELS:
+        raise ValueError("conv_variant must be one of %s" % sorted(CONV_KERNELS))
     if pool_kernels is None:
         pool_kernels = [(2, 2, 2)] * 5
     pool_kernels = [tuple(int(v) for v in k) for k in pool_kernels]
@@ -50,7 +57,7 @@ def make_spec(in_channels, base_features, num_classes, pool_kernels=None, convs_
         f = int(round(f * 2))
         f = min(f, max_features)
     return NetSpec(in_channels, base_features, num_classes, pool_kernels, convs_per_stage,
-                   max_features, feats, shift_size)
+                   max_features, feats, shift_size, conv_variant)
 
 
 # --------------------------------------------------------------------------- naming
@@ -94,7 +101,7 @@ def param_shapes(spec: NetSpec) -> "Dict[str, Tuple[int, ...]]":
     shapes: Dict[str, Tuple[int, ...]] = {}
 
     def add_block(prefix, cin, cout):
-        shapes[prefix + ".conv.weight"] = (cout, cin, 1, 3, 3)
+        shapes[prefix + ".conv.weight"] = (cout, cin) + CONV_KERNELS[spec.conv_variant]
         shapes[prefix + ".conv.bias"] = (cout,)
         shapes[prefix + ".instnorm.weight"] = (cout,)
         shapes[prefix + ".instnorm.bias"] = (cout,)
@@ -148,9 +155,12 @@ def init_params(spec: NetSpec, seed: int = 0, dtype=torch.float32) -> "Dict[str,
 
 # --------------------------------------------------------------------------- forward
 def conv_block(x, w, b, gamma, beta, stride=(1, 1, 1), shift_size=5):
-    """unetpp_d.py:102-111 for kernel (1,3,3)."""
-    x = depth_shift(x, shift_size)
-    y = F.conv3d(x, w, b, stride=stride, padding=(0, 1, 1))
+    """unetpp_d.py:102-111 for kernel (1,3,3); unetpp_d_313.py / unetpp_d_331.py:101-110 for the other two kernel
+    shapes (their shift is switched off in the source: ``if self.conv.kernel_size == (3, 1, 3) and False``)."""
+    k = tuple(w.shape[2:])
+    if k == (1, 3, 3):
+        x = depth_shift(x, shift_size)
+    y = F.conv3d(x, w, b, stride=stride, padding=tuple(1 if v == 3 else 0 for v in k))
     y = F.instance_norm(y, weight=gamma, bias=beta, eps=1e-5)
     return F.leaky_relu(y, 0.01)
 

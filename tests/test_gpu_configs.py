@@ -373,3 +373,100 @@ def test_whole_net_fixed_seed_sweep(idx, cfg):
         assert (o.cpu() - r.detach()).abs().max() <= 1e-4
     assert abs(loss.item() - ref_loss.item()) < 5e-5
     _check_all_grads(eng, shapes, leaves, tol=2e-3)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# kernel-shape ablation networks unetpp_d_313 / unetpp_d_331 (conv kernel (3,1,3) / (3,3,1), no shift) on
+# the (1,3,3) engine over axis-permuted tensors; anisotropic pooling plan, goldens from the reference's own modules
+VARIANT = dict(patch=(16, 16, 64), cin=2, base=8, k=3, pools=[(2, 2, 2), (2, 2, 2), (1, 2, 2), (2, 1, 2), (1, 1, 2)], max_feat=32)
+
+
+def _variant_net(var):
+    import importlib
+    from torch import nn
+    mod = importlib.import_module("e2enet_medical_amd.network_architecture.unetpp_d_" + var)
+    V = VARIANT
+    net = mod.Generic_UNetPlusPlus(V["patch"], V["cin"], V["base"], V["k"], 5, 2, 2, nn.Conv3d, nn.InstanceNorm3d,
+                                   {'eps': 1e-5, 'affine': True}, nn.Dropout3d, {'p': 0, 'inplace': True}, nn.LeakyReLU,
+                                   {'negative_slope': 1e-2, 'inplace': True}, True, False, lambda x: x,
+                                   mod.InitWeights_He(1e-2), [list(k) for k in V["pools"]], None, False, True, True,
+                                   max_num_features=V["max_feat"]).cuda()
+    spec = oracle.make_spec(V["cin"], V["base"], V["k"], V["pools"], 2, V["max_feat"], conv_variant=var)
+    shapes = oracle.param_shapes(spec)                      # the reference's shapes = the checkpoint wire format
+    params = closed_form_params(shapes)
+    net.load_state_dict({n: p.clone() for n, p in params.items()})
+    return net, spec, shapes, params
+
+
+def _grad_in_reference_layout(net, name):
+    g = net.get_parameter(name).grad
+    return net._up_to_reference(g) if net._is_up_weight(name) else g.view(net.get_parameter(name).shape)
+
+
+@pytest.mark.parametrize("var", ["313", "331"])
+def test_conv_variant_forward_backward_vs_reference_golden(var):
+    g = golden("net_variants.npz")
+    V = VARIANT
+    net, spec, shapes, params = _variant_net(var)
+    x = seeded_input((2, V["cin"]) + V["patch"], seed=121).cuda()
+    outs = net(x)                                          # autograd path, tensors in the reference's axis order
+    for i, o in enumerate(outs):
+        ref = g[var + "_logits%d" % i]
+        got = o.detach().cpu().numpy()
+        got = got[..., ::2, ::2] if i == 0 else got
+        assert np.abs(got - ref).max() <= 1e-4, "logits%d" % i
+    from e2enet_medical_amd.training.loss_functions.dice_loss import DC_and_CE_loss
+    from e2enet_medical_amd.training.loss_functions.deep_supervision import MultipleOutputLoss2
+    targets = [seeded_labels((o.shape[0], 1) + tuple(o.shape[2:]), V["k"], seed=130 + i).cuda() for i, o in enumerate(outs)]
+    loss = MultipleOutputLoss2(DC_and_CE_loss({'batch_dice': False, 'smooth': 1e-5, 'do_bg': False}, {}), oracle.ds_weights(5))(outs, targets)
+    assert abs(loss.item() - float(g[var + "_loss"])) < 2e-5
+    loss.backward()
+    names = [str(s) for s in g[var + "_names"]]
+    got_l2 = np.array([net.get_parameter(n).grad.double().norm().item() for n in names])
+    np.testing.assert_allclose(got_l2, g[var + "_grad_l2"], rtol=5e-3, atol=2e-6)
+    for key in g.files:
+        if key.startswith(var + "_grad::"):
+            n = key.split("::", 1)[1]
+            ref = g[key]
+            got = _grad_in_reference_layout(net, n).cpu().numpy().reshape(ref.shape)
+            assert np.abs(got - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max()), n
+
+
+@pytest.mark.parametrize("var", ["313", "331"])
+def test_conv_variant_engine_fastpath_and_predict_vs_oracle(var):
+    """Trainer fast path (engine layout in, fused loss, backward) against the oracle's autograd for every parameter, then
+    sliding-window predict_3D with mirroring against the oracle's tiled prediction through the variant network."""
+    V = VARIANT
+    net, spec, shapes, params = _variant_net(var)
+    x = seeded_input((2, V["cin"]) + V["patch"], seed=141)
+    xe = net.to_engine_layout(x.cuda())
+    eng = net.engine(xe)
+    outs_e = eng.forward(xe, True)
+    outs = [net.from_engine_layout(o) for o in outs_e]
+    targets = [seeded_labels((o.shape[0], 1) + tuple(o.shape[2:]), V["k"], seed=150 + i) for i, o in enumerate(outs)]
+    w = oracle.ds_weights(5)
+    loss = eng.loss_backward([net.to_engine_layout(t.cuda()) for t in targets], w, batch_dice=False)
+    leaves = {n: p.clone().requires_grad_(True) for n, p in params.items()}
+    ref = oracle.forward(spec, leaves, x)
+    ref_loss = oracle.deep_supervision_loss(ref, targets, w, False)
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < 2e-5
+    for o, r in zip(outs, ref):
+        assert (o.cpu() - r.detach()).abs().max() <= 1e-4
+    for n in shapes:
+        ge = eng.grads[n]
+        got = net._up_to_reference(ge) if net._is_up_weight(n) else ge.reshape(shapes[n])
+        r = leaves[n].grad
+        assert (got.cpu() - r).abs().max().item() <= 2e-4 * max(1.0, r.abs().max().item()), n
+
+    # inference: 24 x 24 x 96 volume, patch = the network's, step 0.5, all 8 mirrors, Gaussian weighting
+    vol = seeded_input((V["cin"], 24, 24, 96), seed=160).numpy()
+    net.eval()
+    seg, probs = net.predict_3D(vol, True, (0, 1, 2), True, 0.5, V["patch"], None, True, "constant", {'constant_values': 0},
+                                False, False)
+    with torch.no_grad():
+        fwd = lambda t: F.softmax(oracle.forward(spec, params, t, do_ds=False), 1)
+        ref_seg, ref_probs = oracle.predict_tiled(fwd, vol, V["k"], V["patch"], step_size=0.5, do_mirroring=True,
+                                                  mirror_axes=(0, 1, 2), use_gaussian=True)
+    assert np.abs(probs - ref_probs).max() <= 2e-5
+    assert (seg != ref_seg).mean() < 1e-3

@@ -344,3 +344,40 @@ def test_predict_cases_fold_ensemble_on_device():
     got = {}
     done = predict_cases(tr, params, [("case0.nii.gz", (vol, props))], lambda seg, fn, dct: got.__setitem__(fn, seg))
     assert done == ["case0.nii.gz"] and np.array_equal(got["case0.nii.gz"], want)
+
+
+# ------------------------------------------------------------------------------------------------ N4: Tconv ablations
+@pytest.mark.parametrize("tconv,variant,shift", [("shiftConvPP_313", "313", 1), ("shiftConvPP_331", "331", 1),
+                                                 ("shiftConvPP_noshift", "133", 1)])
+def test_trainer_builds_and_steps_the_tconv_ablations(tmp_path, tconv, variant, shift):
+    """initialize_network dispatches on Tconv like the reference (:303-346); one training iteration on the fast path
+    (data and targets moved to the engine's axis order by run_iteration) gives the loss of the same network evaluated by
+    the oracle in the reference's axis order, and the checkpoint written afterwards has the reference's tensor shapes."""
+    from e2enet_medical_amd.training.network_training.nnUNetTrainer_simple import nnUNetTrainer_simple
+    plans = dict(PLANS)
+    plans['plans_per_stage'] = {0: dict(PLANS['plans_per_stage'][0], patch_size=[16, 16, 64],
+                                        pool_op_kernel_sizes=[[2, 2, 2], [2, 2, 2], [1, 2, 2], [2, 1, 2], [1, 1, 2]])}
+    tr = nnUNetTrainer_simple(plans, 0, output_folder=str(tmp_path), Tconv=tconv, max_num_epochs=1, num_batches_per_epoch=1)
+    tr.base_num_features_override = 8
+    torch.manual_seed(0)
+    net, opt = tr.initialize(True)
+    assert net.conv_variant == variant and net._cfg.shift_size == shift
+    pools = [tuple(k) for k in plans['plans_per_stage'][0]['pool_op_kernel_sizes']]
+    spec = oracle.make_spec(1, 8, 3, pools, 2, 320, shift_size=shift, conv_variant=variant)
+    sd = {n: v.detach().cpu().clone() for n, v in net.state_dict().items()}
+    assert {n: tuple(v.shape) for n, v in sd.items()} == oracle.param_shapes(spec)
+    x = seeded_input((2, 1, 16, 16, 64), seed=171)
+    with torch.no_grad():
+        ref_outs = oracle.forward(spec, sd, x)
+    targets = [seeded_labels((2, 1) + tuple(o.shape[2:]), 3, seed=180 + i) for i, o in enumerate(ref_outs)]
+    ref_loss = oracle.deep_supervision_loss(ref_outs, targets, oracle.ds_weights(5), tr.batch_dice).item()
+
+    def gen():
+        while True:
+            yield {'data': x.clone(), 'target': [t.clone() for t in targets]}
+    loss = tr.run_iteration(gen(), do_backprop=True, run_online_evaluation=False)
+    assert abs(float(loss) - ref_loss) < 2e-5
+    fname = os.path.join(tr.output_folder, "ck.model")
+    tr.save_checkpoint(fname)
+    saved = torch.load(fname, map_location="cpu", weights_only=False)['state_dict']
+    assert {n: tuple(v.shape) for n, v in saved.items()} == oracle.param_shapes(spec)

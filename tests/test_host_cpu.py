@@ -219,3 +219,51 @@ def test_world_size_2_tile_sharding_and_dp_exchange_gloo(tmp_path):
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, se[-2000:]
     assert "WORKER_OK" in outs[0][0]
+
+
+# kernel-shape ablation networks (reference unetpp_d_313.py / unetpp_d_331.py)
+VARIANT = dict(patch=(16, 16, 64), cin=2, base=8, k=3, pools=[[2, 2, 2], [2, 2, 2], [1, 2, 2], [2, 1, 2], [1, 1, 2]], max_feat=32)
+
+
+def _build_variant(var, seed=None):
+    import importlib
+    mod = importlib.import_module("e2enet_medical_amd.network_architecture.unetpp_d_" + var)
+    if seed is not None:
+        torch.manual_seed(seed)
+    V = VARIANT
+    return mod.Generic_UNetPlusPlus(V["patch"], V["cin"], V["base"], V["k"], len(V["pools"]), 2, 2, nn.Conv3d, nn.InstanceNorm3d,
+                                    {'eps': 1e-5, 'affine': True}, nn.Dropout3d, {'p': 0, 'inplace': True}, nn.LeakyReLU,
+                                    {'negative_slope': 1e-2, 'inplace': True}, True, False, lambda x: x,
+                                    mod.InitWeights_He(1e-2), V["pools"], None, False, True, True, max_num_features=V["max_feat"])
+
+
+@pytest.mark.parametrize("var", ["313", "331"])
+def test_conv_variant_modules_state_dict_and_init_match_reference(var):
+    """The ablation networks keep the reference's module path, class name, state_dict names AND shapes (conv weights
+    [o,i,3,1,3] / [o,i,3,3,1], transposed-conv weights in the reference's axis order) and its He-init draws, although
+    the engine runs them on axis-permuted tensors; position-weighted checksums catch a permuted tensor."""
+    g = golden("net_variants.npz")
+    net = _build_variant(var, seed=1234)
+    sd = net.state_dict()
+    assert list(sd.keys()) == [str(s) for s in g[var + "_init_names"]]
+    shapes = {str(n): str(s) for n, s in zip(g[var + "_names"], g[var + "_shapes"])}
+    for n, v in sd.items():
+        assert str(tuple(v.shape)) == shapes[n], n
+    assert np.array_equal(np.array([v.double().sum().item() for v in sd.values()]), g[var + "_init_sum"])
+    assert np.array_equal(np.array([v.double().abs().sum().item() for v in sd.values()]), g[var + "_init_abs"])
+    pos = np.array([(v.double().flatten() * (torch.arange(v.numel(), dtype=torch.float64) + 1)).sum().item() / v.numel()
+                    for v in sd.values()])
+    assert np.array_equal(pos, g[var + "_init_pos"])
+    # round trip through the checkpoint format leaves the engine-order parameters untouched
+    before = {n: p.detach().clone() for n, p in net.named_parameters()}
+    net.load_state_dict({k: v.clone() for k, v in sd.items()})
+    for n, p in net.named_parameters():
+        assert torch.equal(p, before[n]), n
+    # the engine's pooling plan is the reference's with the axes permuted; divisibility stays in the reference's order
+    perm = {"313": (1, 0, 2), "331": (2, 0, 1)}[var]
+    assert net._cfg.pool_kernels == [tuple(k[a] for a in perm) for k in VARIANT["pools"]]
+    assert list(net.input_shape_must_be_divisible_by) == [8, 8, 32]
+    assert net._cfg.shift_size == 1
+    x = torch.arange(2 * 3 * 4 * 5 * 6, dtype=torch.float32).view(2, 3, 4, 5, 6)
+    assert torch.equal(net.from_engine_layout(net.to_engine_layout(x)), x)
+    assert tuple(net.to_engine_layout(x).shape[2:]) == tuple(x.shape[2 + a] for a in perm)

@@ -428,3 +428,37 @@ def test_export_matches_reference(tag):
     regions = tuple(int(v) for v in g[tag + "_regions"]) if tag + "_regions" in g.files else None
     seg = oracle.export_segmentation(total, props, tb, regions)
     assert seg.dtype == np.uint8 and np.array_equal(seg, g[tag + "_seg"])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# ablation networks unetpp_d_313 / unetpp_d_331 (conv kernel (3,1,3) / (3,3,1), no shift)
+VARIANT = dict(patch=(16, 16, 64), cin=2, base=8, k=3, pools=[(2, 2, 2), (2, 2, 2), (1, 2, 2), (2, 1, 2), (1, 1, 2)], max_feat=32)
+
+
+@pytest.mark.parametrize("var", ["313", "331"])
+def test_conv_variants_vs_reference(var):
+    g = golden("net_variants.npz")
+    V = VARIANT
+    spec = oracle.make_spec(V["cin"], V["base"], V["k"], V["pools"], 2, V["max_feat"], conv_variant=var)
+    shapes = oracle.param_shapes(spec)
+    assert list(shapes.keys()) == [str(n) for n in g[var + "_names"]]
+    assert [str(shapes[n]) for n in shapes] == [str(s) for s in g[var + "_shapes"]]
+    params = {n: p.requires_grad_(True) for n, p in closed_form_params(shapes).items()}
+    x = seeded_input((2, V["cin"]) + V["patch"], seed=121)
+    outs = oracle.forward(spec, params, x)
+    for i, o in enumerate(outs):
+        ref = torch.from_numpy(g[var + "_logits%d" % i])
+        got = o.detach()[..., ::2, ::2] if i == 0 else o.detach()
+        assert (got - ref).abs().max().item() < 1e-5, "logits %d" % i
+    targets = [seeded_labels((o.shape[0], 1) + tuple(o.shape[2:]), V["k"], seed=130 + i) for i, o in enumerate(outs)]
+    loss = oracle.deep_supervision_loss(outs, targets, oracle.ds_weights(5))
+    assert abs(loss.item() - float(g[var + "_loss"])) < 1e-5
+    loss.backward()
+    for n, ref in zip(shapes, g[var + "_grad_l2"]):
+        got = params[n].grad.double().norm().item()
+        assert abs(got - ref) <= 2e-4 * max(ref, 1e-3), n
+    for key in g.files:
+        if key.startswith(var + "_grad::"):
+            n = key.split("::", 1)[1]
+            ref = torch.from_numpy(g[key])
+            assert (params[n].grad - ref).abs().max().item() <= 2e-4 * max(ref.abs().max().item(), 1e-3), n

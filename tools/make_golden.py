@@ -469,6 +469,57 @@ def gen_init():
     np.savez_compressed(os.path.join(OUT, "init.npz"), **out)
 
 
+
+VARIANT = dict(patch=(16, 16, 64), cin=2, base=8, k=3, pools=[[2, 2, 2], [2, 2, 2], [1, 2, 2], [2, 1, 2], [1, 1, 2]], max_feat=32)
+
+
+def gen_net_variants():
+    """the ablation networks unetpp_d_313.py / unetpp_d_331.py (conv kernel (3,1,3) / (3,3,1), shift switched
+    off in their source).  Anisotropic pooling plan so that a wrong axis permutation cannot hide; B = 2; closed-form
+    weights: forward + deep-supervision loss + backward; plus the He-init checksums under torch.manual_seed(1234)."""
+    import importlib
+    out = {}
+    V = VARIANT
+    for var in ("313", "331"):
+        mod = importlib.import_module("e2enet.network_architecture.unetpp_d_" + var)
+
+        def build(seed=None):
+            if seed is not None:
+                torch.manual_seed(seed)
+            return mod.Generic_UNetPlusPlus(V["patch"], V["cin"], V["base"], V["k"], len(V["pools"]), 2, 2, nn.Conv3d,
+                                            nn.InstanceNorm3d, {'eps': 1e-5, 'affine': True}, nn.Dropout3d,
+                                            {'p': 0, 'inplace': True}, nn.LeakyReLU, {'negative_slope': 1e-2, 'inplace': True},
+                                            True, False, lambda x: x, mod.InitWeights_He(1e-2), V["pools"], None, False, True,
+                                            True, max_num_features=V["max_feat"])
+        net = build()
+        shapes = load_closed_form(net)
+        x = seeded_input((2, V["cin"]) + V["patch"], seed=121)
+        outs = net(x)
+        targets = [seeded_labels((o.shape[0], 1) + tuple(o.shape[2:]), V["k"], seed=130 + i) for i, o in enumerate(outs)]
+        loss = _ds_loss()(outs, targets)
+        loss.backward()
+        out[var + "_loss"] = np.float64(loss.item())
+        for i, o in enumerate(outs):
+            od = o.detach()
+            out[var + "_sum%d" % i] = np.float64(od.double().sum().item())
+            out[var + "_logits%d" % i] = od.numpy()[..., ::2, ::2] if i == 0 else od.numpy()
+        names = list(shapes.keys())
+        out[var + "_names"] = np.array(names)
+        out[var + "_shapes"] = np.array([str(shapes[n]) for n in names])
+        out[var + "_grad_l2"] = np.array([net.get_parameter(n).grad.double().norm().item() for n in names])
+        for n in ("conv_blocks_context.0.blocks.0.conv.weight", "loc0.4.1.blocks.0.conv.weight", "up0.0.weight", "up2.1.weight",
+                  "up4.0.weight", "seg_outputs.0.weight", "loc3.0.0.blocks.0.instnorm.weight", "loc0.0.0.blocks.0.conv.weight"):
+            out[var + "_grad::" + n] = net.get_parameter(n).grad.numpy()
+        sd = build(seed=1234).state_dict()
+        out[var + "_init_names"] = np.array(list(sd.keys()))
+        out[var + "_init_sum"] = np.array([v.double().sum().item() for v in sd.values()])
+        out[var + "_init_abs"] = np.array([v.double().abs().sum().item() for v in sd.values()])
+        # position-sensitive checksum (a permuted tensor has the same sum): sum of value * (flat index + 1) / numel
+        out[var + "_init_pos"] = np.array([(v.double().flatten() * (torch.arange(v.numel(), dtype=torch.float64) + 1)).sum().item() / v.numel()
+                                           for v in sd.values()])
+    np.savez_compressed(os.path.join(OUT, "net_variants.npz"), **out)
+
+
 def gen_export():
     """save_segmentation_nifti_from_softmax (segmentation_export.py:27-160) on volumes that need no resampling, with the
     SimpleITK writer, skimage and the batchgenerators file helpers stubbed (absent here): the uint8 array handed to the
@@ -528,7 +579,7 @@ def gen_export():
 
 ALL = dict(export=gen_export, shift=gen_shift, block=gen_block, net=gen_net_tiny, sparse=gen_net_sparse_tiny, net64=gen_net64,
            hippo=gen_net_hippo, amos=gen_net_amos,
-           masks=gen_masks, loss=gen_loss, sliding=gen_sliding, dice=gen_dice, init=gen_init)
+           variants=gen_net_variants, masks=gen_masks, loss=gen_loss, sliding=gen_sliding, dice=gen_dice, init=gen_init)
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
