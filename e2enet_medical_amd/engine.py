@@ -369,6 +369,7 @@ class Engine:
         self.loss_ws = None
         self.loss_val = None
         self.generation = 0                # bumped by every forward(): activations are reused in place
+        self.pre_forward_hook = None       # callable(): set by the owning network, brings masks / parameters up to date
         self._eval_counts = None
 
     def _add_conv(self, prefix, sources, cout, stride):
@@ -419,6 +420,11 @@ class Engine:
     def forward(self, x: torch.Tensor, deep_supervision: bool = True):
         assert x.is_cuda and x.dtype == torch.float32, "engine input must be a float32 GPU tensor"
         assert tuple(x.shape) == self.input.shape, "engine built for %s, got %s" % (self.input.shape, tuple(x.shape))
+        if self.pre_forward_hook is not None:
+            # a plan that is held across iterations (benchmark loop, tests) must see the kernel maps of a prune/grow that
+            # happened since it was handed out: with stale maps the regrown kernels stay skipped although their weights
+            # have started to move (found by the nine-iteration trajectory test)
+            self.pre_forward_hook()
         self.input.data.copy_(x)
         self.generation += 1
         for op in self.ops:

@@ -10,6 +10,7 @@ shift, concat, conv, InstanceNorm, LeakyReLU, transposed conv, pooling and heads
 kernels behind the C ABI of libe2e_hip.so.  There is no CPU / eager fallback: a CPU tensor raises.
 """
 import os
+import weakref
 from copy import deepcopy
 
 import numpy as np
@@ -347,6 +348,13 @@ class Generic_UNetPlusPlus(SegmentationNetwork):
                 raise ValueError("input spatial shape %s must be divisible by %s" % (tuple(x.shape[2:]), tuple(div)))
             eng = Engine(self._cfg, self._live_params(), x.shape[0], tuple(x.shape[2:]), x.device)
             eng._sparsity_version = -1
+            ref = weakref.ref(self)
+
+            def _refresh(eng_ref=weakref.ref(eng)):
+                net, e = ref(), eng_ref()
+                if net is not None and e is not None:
+                    net._sync_sparsity(e)          # (a version compare unless the masks changed)
+            eng.pre_forward_hook = _refresh
             self._engines[key] = eng
             # plans are kept per (batch, patch) shape, least recently used first out, inside a byte budget (288 GB of HBM:
             # a training plan at 2 x 128^3 holds 8.6 GB, the 8-mirror inference plan 17 GB; alternating between them must

@@ -516,3 +516,110 @@ def test_full_size_128_properties():
         flipped = net(torch.flip(x, (2,)))
         assert (torch.flip(flipped[0], (2,)) - dense[0]).abs().max().item() > 1e-3                   # (e)
     assert all(torch.isfinite(o).all() for o in a)
+
+
+def test_training_trajectory_nine_iterations_vs_oracle():
+    """Nine full training iterations (forward, DS loss, backward, clip 12, SGD-Nesterov, mask step) with prune/grow events
+    at iterations 3, 6 and 9, engine against the CPU oracle run side by side from the same start: per-iteration losses,
+    clip norms and death rates, mask indices after every update (bit exact), weights at the end.  (The two-iteration
+    fixture from the reference pins the oracle; this pins the engine's drift over a longer run with three updates.)"""
+    from e2enet_medical_amd.training.network_training.sparselearning.core_channel import Masking, CosineDecay
+    from e2enet_medical_amd.training.fused_optim import FusedClipSGD
+    net, shapes, params0 = tiny_net(SPARSE_PATCH)
+    opt = torch.optim.SGD(net.parameters(), 1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)
+
+    class A:
+        adv = False
+        fix = False
+        update_frequency = 3
+        final_density = 0.05
+    spec = oracle.make_spec(TINY["cin"], TINY["base"], TINY["k"], TINY["pools"], 2, TINY["max_feat"])
+    names = oracle.masked_names(spec)
+    # engine side and oracle side consume the same Python `random` stream: seed before each side's draws
+    random.seed(11)
+    mask = Masking(opt, death_rate=0.5, death_mode='magnitude', death_rate_decay=CosineDecay(0.5, 12), growth_mode='random',
+                   redistribution_mode='none', args=A())
+    mask.add_module(net, sparse_init='uniform', density=0.4)
+    rs_engine = random.getstate()
+    random.seed(11)
+    oparams = {n: p.clone() for n, p in params0.items()}
+    mom = {}
+    ostate = oracle.DsffState(oparams, names, 0.4, 0.5, 12, 3, momentum_buffers=mom)
+    rs_oracle = random.getstate()
+    for n in names:
+        assert torch.equal(mask.masks[n].cpu(), ostate.masks[n]), n
+
+    x = seeded_input((2, TINY["cin"]) + SPARSE_PATCH, seed=21)
+    xg = x.cuda()
+    w = oracle.ds_weights(5)
+    fused = FusedClipSGD(opt, list(net.named_parameters()), 12.0)
+    eng = net.engine(xg)
+    targets = None
+    for it in range(9):
+        outs = eng.forward(xg, True)
+        if targets is None:
+            targets = [seeded_labels((o.shape[0], 1) + tuple(o.shape[2:]), TINY["k"], seed=30 + i) for i, o in enumerate(outs)]
+            tg = [t.cuda() for t in targets]
+        loss = eng.loss_backward(tg, w, batch_dice=False).item()
+        fused.step(eng.grads, mask.masks)
+        tn = fused.total_norm()
+        will_update = (it + 1) % 3 == 0
+        if will_update:
+            pre_w = {n: net.get_parameter(n).detach().cpu().clone() for n in names}
+            pre_m = {n: mask.masks[n].cpu().clone() for n in names}
+        random.setstate(rs_engine)
+        updated = mask.step(masks_already_applied=True)
+        rs_after = random.getstate()
+        if will_update:
+            # the engine's prune/grow decision replayed by the oracle's algorithm on the engine's OWN pre-update weights
+            # and the same random stream: bit-identical mask indices at every update
+            random.setstate(rs_engine)
+            rep, nd = {}, {}
+            for n in names:
+                rep[n], nd[n] = oracle.kernel_death(pre_m[n], pre_w[n] * pre_m[n], mask.death_rate)
+            for n in names:
+                rep[n] = oracle.kernel_growth(rep[n], nd[n])
+            for n in names:
+                assert torch.equal(mask.masks[n].cpu(), rep[n]), "replayed update at iteration %d: %s" % (it, n)
+        rs_engine = rs_after
+
+        leaves = {n: p.detach().clone().requires_grad_(True) for n, p in oparams.items()}
+        ref_loss = oracle.deep_supervision_loss(oracle.forward(spec, leaves, x), targets, w, False)
+        ref_loss.backward()
+        ref_tn = oracle.clip_and_sgd_step(oparams, {n: leaves[n].grad for n in leaves}, mom, 1e-2).item()
+        ostate.params = oparams
+        random.setstate(rs_oracle)
+        ref_updated = ostate.step()
+        rs_oracle = random.getstate()
+
+        assert abs(loss - ref_loss.item()) <= 2e-4 * max(1.0, abs(ref_loss.item())), "loss at iteration %d: %g vs %g" % (it, loss, ref_loss.item())
+        assert abs(tn - ref_tn) <= 2e-3 * ref_tn, "clip norm at iteration %d" % it
+        assert mask.death_rate == ostate.death_rate
+        assert bool(updated) == bool(ref_updated) == ((it + 1) % 3 == 0)
+        if updated:
+            # Engine run against oracle run.  Kernels regrown at the previous update carry tiny, similar weights: at later
+            # updates the magnitude threshold can fall between two of them that differ by less than fp32 noise, and the two
+            # runs then kill a different one.  The first update has no such ties and must agree bit for bit; after a later
+            # one the runs may be legitimately different networks and the side-by-side comparison ends (the replay above
+            # still pins every update of the engine).
+            diff = {n: int((mask.masks[n].cpu()[:, :, 0, 0, 0] != ostate.masks[n][:, :, 0, 0, 0]).sum().item()) for n in names}
+            total = sum(diff.values())
+            if it < 3:
+                assert total == 0, "mask indices after the first update: %s" % {n: d for n, d in diff.items() if d}
+            else:
+                # (one swapped pair in the death set shifts the candidate list the growth draws index into, so a tensor
+                #  that differs at all differs in tens of entries; most tensors must still agree)
+                assert sum(1 for d in diff.values() if d) <= len(names) // 4, "update at iteration %d: %s" % (it, diff)
+                for n in names:          # same number of live kernels either way
+                    assert int(mask.masks[n].sum().item()) == int(ostate.masks[n].sum().item()), n
+                if total:
+                    compared_until = it
+                    break
+    else:
+        compared_until = 8
+    assert compared_until >= 5, "the runs must agree at least through the second update"
+    if compared_until < 8:
+        return
+    for n, p in net.named_parameters():
+        ref = oparams[n]
+        assert (p.detach().cpu() - ref).abs().max().item() <= 5e-4 * max(1e-2, ref.abs().max().item()), n
