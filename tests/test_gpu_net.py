@@ -623,3 +623,77 @@ def test_training_trajectory_nine_iterations_vs_oracle():
     for n, p in net.named_parameters():
         ref = oparams[n]
         assert (p.detach().cpu() - ref).abs().max().item() <= 5e-4 * max(1e-2, ref.abs().max().item()), n
+
+
+def test_full_size_128_training_properties():
+    """BASELINE training workload (2 x 4 x 128^3, base 32, K 4, density 0.2), properties that need no oracle run:
+    (a) backward is exactly linear in the logit gradients under scaling by a power of two (bit-identical x 0.5), and
+        run-to-run deterministic;
+    (b) the data gradient with dead kernels skipped == dense execution of the same masked weights;
+    (c) ten iterations on one batch with two prune/grow events: finite, decreasing loss; live-kernel counts preserved;
+        weights and momentum outside the masks exactly zero after every step."""
+    from e2enet_medical_amd.training.network_training.sparselearning.core_channel import Masking, CosineDecay
+    from e2enet_medical_amd.training.fused_optim import FusedClipSGD
+    torch.manual_seed(0)
+    net = build_net((128, 128, 128), 4, 32, 4, [(2, 2, 2)] * 5)
+    opt = torch.optim.SGD(net.parameters(), 1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)
+
+    class A:
+        adv = False
+        fix = False
+        update_frequency = 4
+        final_density = 0.05
+    random.seed(0)
+    mask = Masking(opt, death_rate=0.5, death_mode='magnitude', death_rate_decay=CosineDecay(0.5, 10), growth_mode='random',
+                   redistribution_mode='none', args=A())
+    mask.add_module(net, sparse_init='uniform', density=0.2)
+    names = list(mask.masks.keys())
+    x = seeded_input((2, 4, 128, 128, 128), seed=5).cuda()
+    eng = net.engine(x)
+    outs = eng.forward(x, True)
+    targets = [seeded_labels((o.shape[0], 1) + tuple(o.shape[2:]), 4, seed=40 + i).cuda() for i, o in enumerate(outs)]
+    w = oracle.ds_weights(5)
+
+    # (a) explicit logit gradients g, then g / 2
+    eng.prepare_backward()
+    gl = [torch.from_numpy(np.random.RandomState(7 + i).standard_normal(tuple(o.shape)).astype(np.float32)).cuda() * 1e-3 for i, o in enumerate(outs)]
+    eng.backward(gl)
+    g1 = {n: v.clone() for n, v in eng.grads.items()}
+    eng.forward(x, True)
+    eng.backward(gl)
+    for n in g1:
+        assert torch.equal(g1[n], eng.grads[n]), "determinism: " + n
+    eng.forward(x, True)
+    eng.backward([g * 0.5 for g in gl])
+    for n in g1:
+        assert torch.equal(g1[n] * 0.5, eng.grads[n]), "linearity: " + n
+
+    # (b) liveness-skipping data gradient against dense execution of the same (masked) weights
+    eng.forward(x, True)
+    eng.backward(gl)
+    sparse = {n: v.clone() for n, v in eng.grads.items()}
+    net.set_kernel_masks(None)
+    eng.forward(x, True)
+    eng.backward(gl)
+    for n, v in eng.grads.items():
+        ref = v
+        assert (sparse[n] - ref).abs().max().item() <= 2e-4 * max(ref.abs().max().item(), 1e-6), "sparse vs dense backward: " + n
+    mask._push_liveness()
+
+    # (c) ten iterations
+    fused = FusedClipSGD(opt, list(net.named_parameters()), 12.0)
+    nnz0 = {n: int(mask.masks[n].sum().item()) for n in names}
+    losses = []
+    for it in range(10):
+        eng.forward(x, True)
+        loss = eng.loss_backward(targets, w, batch_dice=False)
+        fused.step(eng.grads, mask.masks)
+        updated = mask.step(masks_already_applied=True)
+        assert bool(updated) == ((it + 1) % 4 == 0)
+        losses.append(loss.item())
+        for n in names[::5]:
+            m = mask.masks[n]
+            assert int(m.sum().item()) == nnz0[n], n
+            assert float((net.get_parameter(n).detach() * (1 - m)).abs().max()) == 0.0, n
+    assert all(np.isfinite(losses)), losses
+    assert losses[-1] < losses[0] - 0.02, losses
