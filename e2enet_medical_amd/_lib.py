@@ -59,6 +59,7 @@ SIGNATURES = {
     "e2e_dc_ce_grad": (I, [P, P, P, F, I, F, P, P, I, I, LL, P]),
     "e2e_dc_ce_fold_batch": (I, [P, I, I, P]),
     "e2e_online_eval_counts": (I, [P, P, P, I, I, LL, P]),
+    "e2e_ds_target_gather": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "e2e_grad_sqnorm": (I, [P, I, P, P]),
     "e2e_sgd_clip_mask_step": (I, [P, I, P, F, F, F, F, I, I, P]),
     "e2e_apply_mask": (I, [P, I, P]),
@@ -115,7 +116,7 @@ class _Lib:
 _lib = None
 
 
-ABI_VERSION = 5          # e2e_abi_version() of the library this binding was written against
+ABI_VERSION = 6          # e2e_abi_version() of the library this binding was written against
 
 
 def lib() -> _Lib:

@@ -281,3 +281,32 @@ extern "C" int e2e_online_eval_counts(const float* logits, const float* target, 
                                     (unsigned long long*)counts, K, spatial));
   return e2e::check_launch("online_eval_kernel");
 }
+
+
+// ---- deep-supervision targets: nearest-neighbour gather through per-axis index vectors (downsampling.py:87-107) ----
+namespace {
+__global__ __launch_bounds__(256) void ds_target_gather_kernel(const float* __restrict__ seg, float* __restrict__ out,
+                                                               const int* __restrict__ idx_d, const int* __restrict__ idx_h,
+                                                               const int* __restrict__ idx_w, int D, int H, int W, int d, int h,
+                                                               int w, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int x = (int)(i % w);
+  long long t = i / w;
+  const int y = (int)(t % h);
+  t /= h;
+  const int z = (int)(t % d);
+  const long long bc = t / d;
+  out[i] = seg[((bc * D + idx_d[z]) * H + idx_h[y]) * W + idx_w[x]];
+}
+}  // namespace
+
+extern "C" int e2e_ds_target_gather(const float* seg, float* out, const int* idx_d, const int* idx_h, const int* idx_w,
+                                    int BC, int D, int H, int W, int d, int h, int w, void* stream) {
+  E2E_REQUIRE(seg && out && idx_d && idx_h && idx_w, "ds_target_gather: null pointer");
+  E2E_REQUIRE(BC > 0 && D > 0 && H > 0 && W > 0 && d > 0 && h > 0 && w > 0, "ds_target_gather: bad dims");
+  const long long total = (long long)BC * d * h * w;
+  hipLaunchKernelGGL(ds_target_gather_kernel, dim3((unsigned)e2e::cdivll(total, 256)), dim3(256), 0, (hipStream_t)stream, seg, out,
+                     idx_d, idx_h, idx_w, D, H, W, d, h, w, total);
+  return e2e::check_launch("ds_target_gather_kernel");
+}

@@ -305,6 +305,11 @@ class nnUNetTrainer_simple(object):
         if not isinstance(target, (list, tuple)):
             target = [target]
         target = [torch.as_tensor(t).float().to(dev, non_blocking=True).contiguous() for t in target]
+        if len(target) == 1 and self.deep_supervision_scales is not None and len(self.deep_supervision_scales) > 1:
+            # a generator that yields the full-resolution labels only: the deep-supervision scales are gathered on the
+            # device (the reference's DownsampleSegForDSTransform2 step of the CPU augmentation pipeline, N3)
+            from ..data_augmentation.downsampling import downsample_seg_for_ds_transform2
+            target = downsample_seg_for_ds_transform2(target[0], self.deep_supervision_scales[:4], order=0)
         if getattr(self.network, "conv_variant", "133") != "133":     # kernel-shape ablations run on axis-permuted tensors
             data = self.network.to_engine_layout(data)
             target = [self.network.to_engine_layout(t) for t in target]

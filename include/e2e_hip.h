@@ -173,6 +173,16 @@ int e2e_dc_ce_fold_batch(void* acc, int B, int K, void* stream);
 int e2e_online_eval_counts(const float* logits, const float* target, long long* counts, int B, int K,
                            long long spatial, void* stream);
 
+/* Deep-supervision targets (the loss-side end of the input feed): reference
+ * e2enet/training/data_augmentation/downsampling.py:87-107 (downsample_seg_for_ds_transform2, order 0) resizes the label
+ * map to every deep-supervision scale with batchgenerators' resize_segmentation -> skimage.transform.resize(order=0,
+ * mode="edge", anti_aliasing=False), which in scikit-image 0.19.3 is scipy.ndimage.zoom(order=0, mode="nearest",
+ * grid_mode=True): out[j] = in[floor((j + 0.5) * in_size / out_size)] per axis.  The host computes the three index vectors
+ * in float64 exactly like scipy's zoom; this kernel gathers.  seg [BC][D][H][W] -> out [BC][d][h][w].                 */
+int e2e_ds_target_gather(const float* seg, float* out, const int* idx_d, const int* idx_h, const int* idx_w,
+                         int BC, int D, int H, int W, int d, int h, int w, void* stream);
+
+
 /* ---- K10: clip_grad_norm_ + SGD(nesterov) + DSFF mask, multi-tensor ---------------------
  * Replaces: torch.nn.utils.clip_grad_norm_(params, 12) + torch.optim.SGD.step (nnUNetTrainer_simple.py:573-574,
  * :369-370) + Masking.apply_mask (core_channel.py:427-434).

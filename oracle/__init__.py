@@ -29,3 +29,4 @@ from .sliding_window import (compute_steps, gaussian_map, pad_to_patch,  # noqa:
 from .loss import dc_ce_loss, deep_supervision_loss, ds_weights, hard_dice  # noqa: F401
 from .optim import clip_and_sgd_step, poly_lr                          # noqa: F401
 from .export import ensemble_softmax, export_segmentation                  # noqa: F401
+from .ds_targets import downsample_seg_for_ds                              # noqa: F401  (parity unpinned: see its header)

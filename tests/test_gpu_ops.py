@@ -466,3 +466,21 @@ def test_conv133_persistent_run_loop_forced():
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "passed" in r.stdout
+
+
+@pytest.mark.parametrize("shape", [(2, 1, 16, 32, 32), (1, 1, 40, 56, 40), (2, 2, 7, 9, 13)])
+def test_ds_target_gather_vs_oracle(shape):
+    """Deep-supervision targets gathered on the device against the oracle (scipy's zoom, order 0): bit exact."""
+    from e2enet_medical_amd.training.data_augmentation.downsampling import downsample_seg_for_ds_transform2
+    scales = [[1, 1, 1], [0.5, 0.5, 0.5], [0.25, 0.25, 0.25], [1, 0.5, 0.5], [0.5, 1, 0.25], [0.125, 0.0625, 0.0625]]
+    seg = np.random.RandomState(5).randint(0, 14, size=shape).astype(np.float32)
+    ref = oracle.downsample_seg_for_ds(seg, scales)
+    got = downsample_seg_for_ds_transform2(torch.from_numpy(seg).cuda(), scales, order=0)
+    assert len(got) == len(ref)
+    for g, r in zip(got, ref):
+        assert tuple(g.shape) == r.shape
+        assert np.array_equal(g.cpu().numpy(), r)
+    with pytest.raises(NotImplementedError):
+        downsample_seg_for_ds_transform2(torch.from_numpy(seg).cuda(), scales, order=1)
+    with pytest.raises(RuntimeError):
+        downsample_seg_for_ds_transform2(torch.from_numpy(seg), scales, order=0)

@@ -381,3 +381,20 @@ def test_trainer_builds_and_steps_the_tconv_ablations(tmp_path, tconv, variant, 
     tr.save_checkpoint(fname)
     saved = torch.load(fname, map_location="cpu", weights_only=False)['state_dict']
     assert {n: tuple(v.shape) for n, v in saved.items()} == oracle.param_shapes(spec)
+
+
+def test_trainer_builds_ds_targets_on_device_from_full_resolution_labels(tmp_path):
+    """A generator that yields only the full-resolution label map (N3: the DownsampleSegForDSTransform2 step moved to the
+    device) gives the same iteration loss as one that yields the oracle's list of downsampled targets."""
+    tr, net, opt = _trainer(str(tmp_path), epochs=1)
+    x = seeded_input((2, 1, 16, 32, 32), seed=191)
+    full = seeded_labels((2, 1, 16, 32, 32), 3, seed=192)
+    scales = tr.deep_supervision_scales[:4]
+    lists = [torch.from_numpy(a) for a in oracle.downsample_seg_for_ds(full.numpy(), scales)]
+
+    def gen(targets):
+        while True:
+            yield {'data': x.clone(), 'target': targets}
+    a = tr.run_iteration(gen(full.clone()), do_backprop=False)
+    b = tr.run_iteration(gen([t.clone() for t in lists]), do_backprop=False)
+    assert float(a) == float(b)

@@ -267,3 +267,24 @@ def test_conv_variant_modules_state_dict_and_init_match_reference(var):
     x = torch.arange(2 * 3 * 4 * 5 * 6, dtype=torch.float32).view(2, 3, 4, 5, 6)
     assert torch.equal(net.from_engine_layout(net.to_engine_layout(x)), x)
     assert tuple(net.to_engine_layout(x).shape[2:]) == tuple(x.shape[2 + a] for a in perm)
+
+
+def test_ds_target_index_formula_is_scipy_zoom_order0():
+    """The per-axis source indices the device gather uses are exactly scipy.ndimage.zoom(order=0, mode='nearest',
+    grid_mode=True) -- the routine scikit-image 0.19.3's resize(order=0) delegates to (oracle/ds_targets.py header: parity
+    for this step is anchored on that third-party routine, the reference's own resize could not be run here)."""
+    from scipy import ndimage
+    from e2enet_medical_amd.training.data_augmentation.downsampling import zoom_nearest_indices
+    import oracle
+    for n_in in (1, 2, 3, 5, 7, 8, 20, 33, 40, 56, 96, 128, 160):
+        for n_out in sorted({max(1, int(np.round(n_in * s))) for s in (1.0, 0.5, 0.25, 0.125, 0.0625, 0.75)}):
+            ramp = np.arange(n_in, dtype=float)
+            ref = ndimage.zoom(ramp, n_out / n_in, order=0, mode="nearest", grid_mode=True)
+            assert ref.shape == (n_out,)
+            assert np.array_equal(zoom_nearest_indices(n_in, n_out), ref.astype(np.int32)), (n_in, n_out)
+    assert np.array_equal(zoom_nearest_indices(128, 64), np.arange(64) * 2 + 1)          # scale 1/2 keeps the odd voxels
+    assert np.array_equal(zoom_nearest_indices(128, 32), np.arange(32) * 4 + 2)
+    seg = np.random.RandomState(0).randint(0, 4, size=(2, 1, 6, 10, 12)).astype(np.float32)
+    outs = oracle.downsample_seg_for_ds(seg, [[1, 1, 1], [0.5, 0.5, 0.5], [1, 0.5, 0.25]])
+    assert outs[0] is seg and outs[1].shape == (2, 1, 3, 5, 6) and outs[2].shape == (2, 1, 6, 5, 3)
+    assert np.array_equal(outs[1], seg[:, :, 1::2, 1::2, 1::2])
