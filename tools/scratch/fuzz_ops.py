@@ -5,6 +5,8 @@
    which shifts the InstanceNorm-backward sums for that (n, c) -- not a kernel bug; all-shifted-out inputs (Cin small,
    D <= 2) make the InstanceNorm degenerate (constant channel) and are not generated.  Real find so far: planes with
    4 rows and wide columns picked the (4, 8, 8) weight-gradient kernel with a (16, 4, 4) tile plan (fixed).
+   Masks that leave an output plane without any live kernel are skipped: the plane is constant, its InstanceNorm has
+   rstd = 1/sqrt(eps) = 316 and the (analytically zero) conv-bias gradient is amplified rounding noise on both sides.
    python tools/scratch/fuzz_ops.py [n_cases] [seed]"""
 import os, sys, math, random
 import torch
@@ -32,6 +34,9 @@ def main():
         stride = rng.choice([(1, 1, 1)] * 4 + [(2, 2, 2), (1, 2, 2)])
         density = rng.choice([1.0, 0.2, 0.5])
         case = (B, srcs, cout, dims, stride, density)
+        km = T._kmask(cout, sum(c for c, _ in srcs), density, 5)
+        if km is not None and bool((km.sum(1) == 0).any()):
+            continue          # an output plane without a live kernel is a constant channel: degenerate InstanceNorm (rstd = 316)
         try:
             T.test_conv133_fwd_bwd(case)
         except AssertionError as e:
