@@ -39,6 +39,8 @@ SIGNATURES = {
     "e2e_last_kernel": (C.c_char_p, []),
     "e2e_conv133_num_partials": (I, [I, I, I, I, I]),
     "e2e_conv133_fwd": (I, [P, I, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "e2e_conv133_fwd_ws_bytes": (LL, [I, I, I, I, I, I, I, I, I]),
+    "e2e_conv133_fwd_splitk": (I, [P, I, P, P, P, P, P, I, I, I, I, I, I, I, I, P, LL, P]),
     "e2e_conv133_dgrad": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "e2e_conv133_wgrad_ws_bytes": (LL, [I, I, I, I, I, I, I, I, I]),
     "e2e_conv133_wgrad": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
@@ -77,7 +79,7 @@ SIGNATURES = {
     "e2e_export_argmax_u8": (I, [P, P, I, LL, I, I, I, LL, LL, LL, I, I, I, I, I, I, P, I, P]),
 }
 
-_NO_STATUS = {"e2e_last_error", "e2e_abi_version", "e2e_last_kernel", "e2e_conv133_num_partials", "e2e_conv133_wgrad_ws_bytes",
+_NO_STATUS = {"e2e_last_error", "e2e_abi_version", "e2e_last_kernel", "e2e_conv133_num_partials", "e2e_conv133_wgrad_ws_bytes", "e2e_conv133_fwd_ws_bytes",
               "e2e_convT_wgrad_ws_bytes", "e2e_head1x1_wgrad_ws_bytes", "e2e_loss_ws_bytes"}
 
 
@@ -116,7 +118,7 @@ class _Lib:
 _lib = None
 
 
-ABI_VERSION = 6          # e2e_abi_version() of the library this binding was written against
+ABI_VERSION = 7          # e2e_abi_version() of the library this binding was written against
 
 
 def lib() -> _Lib:

@@ -57,6 +57,8 @@ struct ConvParams {
   int total;                           // B * tiles_per_n * groups (logical work items)
   int padded_total;
   int items_per_wg;
+  int ksplit;                          // fwd: the input-plane chunks of a tile are split over ksplit workgroups (deep levels)
+  float* kpart;                        // ... which store raw partial sums here: [ksplit][B][Q][Do][Ho][Wo]
   int dbg;                             // diagnostics (E2E_CONV_DBG): 1 = no staging, 2 = no FMA phase, 4 = no barriers
 };
 
@@ -195,9 +197,11 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
                               : (item_lo < p.total ? item_lo + 1 : item_lo);
   if (item_lo >= item_hi) return;
 
-  struct Item { int g, n, d, tile_in_n, h0, w0; };
+  struct Item { int g, n, d, tile_in_n, h0, w0, ks; };
   auto decode = [&](int item) {
     Item it;
+    it.ks = item % p.ksplit;              // split fastest: the parts of one tile run side by side
+    item /= p.ksplit;
     it.g = item % p.groups;
     int t = item / p.groups;
     it.n = t / p.tiles_per_n;
@@ -212,7 +216,16 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
     return it;
   };
   // data gradient of a depth-strided conv: only every sd-th slice of the (shifted) input received anything
-  auto chunks_of = [&](const Item& it) { return ((MODE != 0) && (it.d % p.sd != 0)) ? 0 : (p.P + CK - 1) / CK; };
+  // (split-K: part ks of a tile takes the chunks [ks * per, (ks + 1) * per) of the ceil(P / CK) chunks)
+  const int chunks_all = (p.P + CK - 1) / CK;
+  const int chunks_per = (chunks_all + p.ksplit - 1) / p.ksplit;
+  auto chunk_lo = [&](const Item& it) { return it.ks * chunks_per; };
+  auto chunks_of = [&](const Item& it) {
+    if ((MODE != 0) && (it.d % p.sd != 0)) return 0;
+    const int lo = it.ks * chunks_per;
+    const int left = chunks_all - lo;
+    return left < 0 ? 0 : (left < chunks_per ? left : chunks_per);
+  };
 
   // ---- descriptor of plane `pl` for the (n, d) of an item ------------------------------------------------------
   auto make_desc = [&](int pl, int n, int d) {
@@ -534,6 +547,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
     const int qgroup = cur.g * C::OCG;
     const int qbase = qgroup + wave * OPW;
     const int nchunks = chunks_of(cur);
+    const int cbase = chunk_lo(cur) * CK;           // first input plane of this item's chunk window
     const bool has_next = PERSIST && item + 1 < item_hi;
     Item nxt = cur;
     if (has_next) nxt = decode(item + 1);
@@ -541,7 +555,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
       set_geometry(cur);
       if (nchunks > 0) {
         ensure_table(cur);
-        if (!CDBG(1)) prefetch(0, qgroup);
+        if (!CDBG(1)) prefetch(cbase, qgroup);
       }
     }
     requested = false;
@@ -577,12 +591,12 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
 
     unsigned long long m_cur[NQD];
 #pragma unroll
-    for (int j = 0; j < NQD; ++j) m_cur[j] = nchunks > 0 ? chunk_mask(0, j, qbase) : 0ull;
+    for (int j = 0; j < NQD; ++j) m_cur[j] = nchunks > 0 ? chunk_mask(cbase, j, qbase) : 0ull;
     STAMP(t_pro);
     STAMP_ADD(0, t_begin, t_pro);
 
     for (int ci = 0; ci < nchunks; ++ci) {
-      const int c0 = ci * CK;
+      const int c0 = cbase + ci * CK;
       unsigned long long m_next[NQD];                      // scalar loads, in flight during commit
 #pragma unroll
       for (int j = 0; j < NQD; ++j) m_next[j] = ci + 1 < nchunks ? chunk_mask(c0 + CK, j, qbase) : 0ull;
@@ -597,7 +611,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
       bool pf = ci + 1 < nchunks;
       if (!pf && has_next && nxt.n == n && nxt.d == d && !CDBG(128)) {
         set_geometry(nxt);          // travels under this item's last walk and epilogue
-        pf_c0 = 0; pf_qg = nxt.g * C::OCG;
+        pf_c0 = chunk_lo(nxt) * CK; pf_qg = nxt.g * C::OCG;
         pf = true; requested = true;
       }
       if constexpr (UNROLL) {
@@ -698,8 +712,9 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
       const int q = qbase + a;
       if (q >= p.Q || CDBG(64)) continue;
       if (MODE == 0) {
-        const float bq = bqs[a];
-        float* yp = p.y + (((long long)n * p.Q + q) * p.Do + d) * out_plane;
+        const float bq = p.ksplit > 1 ? 0.f : bqs[a];          // split-K parts store raw sums: bias, statistics in conv133_ksum_kernel
+        float* yp = (p.ksplit > 1 ? p.kpart + (long long)cur.ks * p.B * p.Q * p.Do * out_plane : p.y) +
+                    (((long long)n * p.Q + q) * p.Do + d) * out_plane;
         float s = 0.f;
         const bool vec_store = (C::PW == 4) && (p.Wo % 4 == 0);      // lane rows are 16-byte aligned
         const bool vec2_store = (C::PW == 2) && (p.Wo % 2 == 0);     // ... or 8-byte aligned pairs
@@ -843,6 +858,57 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
   }
 }
 
+// ---- split-K tail (deep levels): y = bias + sum over the parts (fixed order), per-tile (count, mean, M2) partials ----
+// The deep levels have tiny planes and hundreds of input planes: a tile's workgroup walks 40-112 chunks one after the
+// other (a chain of load and LDS latencies, 130-160 us for a few MFLOP) while most CUs have nothing to do.  Splitting the
+// chunks over ksplit workgroups shortens the chain; this kernel adds the parts up.  One wave per (n, q, tile).
+__global__ __launch_bounds__(64) void conv133_ksum_kernel(const float* __restrict__ kpart, const float* __restrict__ bias,
+                                                          float* __restrict__ y, float* __restrict__ part, int ksplit, int B,
+                                                          int Q, int Do, int Ho, int Wo, int TH, int TW, int tiles_x,
+                                                          int tiles_y) {
+  const int tiles_per_n = Do * tiles_y * tiles_x;
+  int t = blockIdx.x;
+  const int tile_in_n = t % tiles_per_n;
+  t /= tiles_per_n;
+  const int q = t % Q, n = t / Q;
+  int u = tile_in_n;
+  const int tx = u % tiles_x;
+  u /= tiles_x;
+  const int ty = u % tiles_y, d = u / tiles_y;
+  const int h0 = ty * TH, w0 = tx * TW;
+  const int vr = Ho - h0 < TH ? Ho - h0 : TH, vc = Wo - w0 < TW ? Wo - w0 : TW;
+  const long long plane = (long long)Ho * Wo;
+  const long long base = (((long long)n * Q + q) * Do + d) * plane;
+  const long long kstride = (long long)B * Q * Do * plane;
+  const float bq = bias ? bias[q] : 0.f;
+  const int lane = threadIdx.x;
+  const int npx = vr * vc;
+  float s = 0.f;
+  for (int i = lane; i < npx; i += 64) {
+    const int r = i / vc, c = i - r * vc;
+    const long long off = base + (long long)(h0 + r) * Wo + (w0 + c);
+    float v = bq;
+    for (int k = 0; k < ksplit; ++k) v += kpart[(long long)k * kstride + off];
+    y[off] = v;
+    s += v;
+  }
+  const float tcnt = (float)npx;
+  const float mean = e2e::wave_sum_dpp(s) / tcnt;
+  float m2 = 0.f;
+  for (int i = lane; i < npx; i += 64) {
+    const int r = i / vc, c = i - r * vc;
+    const float dlt = y[base + (long long)(h0 + r) * Wo + (w0 + c)] - mean;     // (this lane's own store above)
+    m2 = fmaf(dlt, dlt, m2);
+  }
+  m2 = e2e::wave_sum_dpp(m2);
+  if (lane == 0 && part != nullptr) {
+    float* pp = part + (((long long)n * Q + q) * tiles_per_n + tile_in_n) * 3;
+    pp[0] = tcnt;
+    pp[1] = mean;
+    pp[2] = m2;
+  }
+}
+
 // ---- strided data gradient (encoder "convolutional pooling" convs, 5 layers, dense): gather form ------------
 // dx[c][di][hi][wi] = sum_o sum_{kh,kw : (hi+1-kh) % sh == 0, (wi+1-kw) % sw == 0} dy[o][ds][(hi+1-kh)/sh][(wi+1-kw)/sw] w[o][c][kh][kw]
 // where the shifted depth ds*sd = di + s(c).
@@ -926,7 +992,10 @@ int launch_cfg_impl(ConvParams p, hipStream_t st) {
   p.tiles_y = e2e::cdiv(p.Ho, TH);
   p.tiles_per_n = p.Do * p.tiles_y * p.tiles_x;
   p.groups = e2e::cdiv(p.Q, C::OCG);
-  p.total = p.B * p.tiles_per_n * p.groups;
+  if (p.ksplit < 1 || MODE != 0 || PERSIST) p.ksplit = 1;
+  float* const part_out = p.part;
+  if (p.ksplit > 1) p.part = nullptr;                 // raw partial sums: statistics come from conv133_ksum_kernel
+  p.total = p.B * p.tiles_per_n * p.groups * p.ksplit;
   p.padded_total = (p.total + 7) & ~7;
   static const int dbg_knob = getenv("E2E_CONV_DBG") ? atoi(getenv("E2E_CONV_DBG")) : 0;
   p.dbg = dbg_knob;
@@ -934,10 +1003,13 @@ int launch_cfg_impl(ConvParams p, hipStream_t st) {
   if (wgs > p.total) wgs = p.total;
   p.items_per_wg = e2e::cdiv(p.total, wgs);
   wgs = (e2e::cdiv(p.total, p.items_per_wg) + 7) & ~7;
-  e2e::note_kernel("conv133_kernel<mode=%d,s=%dx%d,dil=%dx%d,tile=%dx%d,opw=%d,nw=%d,ck=%d,stg=%d,persist=%d> wgs=%d", MODE, SH, SW, DH, DW,
-                   TH, TW, OPW, NW, CK, STG, PERSIST, wgs);
+  e2e::note_kernel("conv133_kernel<mode=%d,s=%dx%d,dil=%dx%d,tile=%dx%d,opw=%d,nw=%d,ck=%d,stg=%d,persist=%d> wgs=%d ksplit=%d", MODE, SH, SW, DH, DW,
+                   TH, TW, OPW, NW, CK, STG, PERSIST, wgs, p.ksplit);
   hipLaunchKernelGGL((conv133_kernel<MODE, SH, SW, DH, DW, TH, TW, LY, LX, OPW, NW, CK, STG, MINW, PIPE, PERSIST>), dim3(wgs),
                      dim3(C::NT), (size_t)p.P * sizeof(PlaneDesc), st, p);
+  if (p.ksplit > 1)
+    hipLaunchKernelGGL(conv133_ksum_kernel, dim3(p.B * p.Q * p.tiles_per_n), dim3(64), 0, st, p.kpart, p.bias, p.y, part_out,
+                       p.ksplit, p.B, p.Q, p.Do, p.Ho, p.Wo, TH, TW, p.tiles_x, p.tiles_y);
 #ifdef E2E_CONV_DEBUG
   if (p.dbg & 8) {
     hipStreamSynchronize(st);
@@ -1024,9 +1096,33 @@ extern "C" int e2e_conv133_num_partials(int Do, int Ho, int Wo, int sh, int sw) 
   return Do * e2e::cdiv(Ho, th) * e2e::cdiv(Wo, tw);
 }
 
-extern "C" int e2e_conv133_fwd(const e2e_in_chan_t* chans, int Cin, const float* w, const float* bias,
-                               const unsigned* live, float* y, float* part, int B, int Cout, int Di, int Hi, int Wi,
-                               int sd, int sh, int sw, void* stream) {
+// split-K plan of the forward (deep levels only: planes no larger than a 16 x 16 tile): number of parts, 1 = off
+static int plan_fwd_ksplit(int B, int Cin, int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw) {
+  static const int knob = getenv("E2E_CONV_KSPLIT") ? atoi(getenv("E2E_CONV_KSPLIT")) : -1;   // 0/1 = off, n = force n (A/B)
+  const int Do = (Di - 1) / sd + 1, Ho = (Hi - 1) / sh + 1, Wo = (Wi - 1) / sw + 1;
+  const TileKind k = pick_tile(Ho, Wo, sh, sw);
+  if (k == T32 || k == T16x32S) return 1;
+  int th, tw;
+  tile_dims(k, th, tw);
+  const int chunks = e2e::cdiv(Cin, 16);                   // (these configurations stage 16 planes per chunk)
+  const long long base = (long long)B * Do * e2e::cdiv(Ho, th) * e2e::cdiv(Wo, tw) * e2e::cdiv(Cout, 32);
+  if (knob == 0 || knob == 1) return 1;
+  long long ks = knob > 1 ? knob : 1024 / (base > 0 ? base : 1);
+  if (ks > 8) ks = 8;
+  if (ks > chunks / 2) ks = chunks / 2;
+  return ks < 2 ? 1 : (int)ks;
+}
+
+extern "C" long long e2e_conv133_fwd_ws_bytes(int B, int Cin, int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw) {
+  const int ks = plan_fwd_ksplit(B, Cin, Cout, Di, Hi, Wi, sd, sh, sw);
+  if (ks <= 1) return 0;
+  const long long Do = (Di - 1) / sd + 1, Ho = (Hi - 1) / sh + 1, Wo = (Wi - 1) / sw + 1;
+  return (long long)ks * B * Cout * Do * Ho * Wo * 4;
+}
+
+static int conv133_fwd_impl(const e2e_in_chan_t* chans, int Cin, const float* w, const float* bias, const unsigned* live, float* y,
+                            float* part, int B, int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw, float* ws,
+                            long long ws_bytes, void* stream) {
   E2E_REQUIRE(chans && w && y, "conv133_fwd: null pointer");
   E2E_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Di > 0 && Hi > 0 && Wi > 0, "conv133_fwd: bad dims");
   E2E_REQUIRE((sd == 1 || sd == 2) && (sh == 1 || sh == 2) && (sw == 1 || sw == 2), "conv133_fwd: stride must be 1 or 2");
@@ -1036,6 +1132,15 @@ extern "C" int e2e_conv133_fwd(const e2e_in_chan_t* chans, int Cin, const float*
   p.B = B; p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.sd = sd;
   p.Do = (Di - 1) / sd + 1; p.Ho = (Hi - 1) / sh + 1; p.Wo = (Wi - 1) / sw + 1;
   p.Ds = Di; p.Hs = Hi; p.Ws = Wi;
+  p.ksplit = 1; p.kpart = nullptr;
+  if (ws != nullptr) {
+    const long long need = e2e_conv133_fwd_ws_bytes(B, Cin, Cout, Di, Hi, Wi, sd, sh, sw);
+    if (need > 0) {
+      E2E_REQUIRE(ws_bytes >= need, "conv133_fwd: workspace too small (%lld < %lld bytes)", ws_bytes, need);
+      p.ksplit = plan_fwd_ksplit(B, Cin, Cout, Di, Hi, Wi, sd, sh, sw);
+      p.kpart = ws;
+    }
+  }
   hipStream_t st = (hipStream_t)stream;
   const TileKind k = pick_tile(p.Ho, p.Wo, sh, sw);
   if (sh == 1 && sw == 1) return launch_s1<0, 1, 1>(p, k == T32 ? 0 : (k == T16 ? 1 : 2), st);
@@ -1051,6 +1156,18 @@ extern "C" int e2e_conv133_fwd(const e2e_in_chan_t* chans, int Cin, const float*
   }
   if (k == T16x32S) return launch_cfg<0, 2, 1, 1, 1, 16, 32, 4, 16, 4, 8, 8, 0>(p, st);
   return launch_cfg<0, 2, 1, 1, 1, 8, 8, 8, 8, 4, 8, 16, 0>(p, st);
+}
+
+extern "C" int e2e_conv133_fwd(const e2e_in_chan_t* chans, int Cin, const float* w, const float* bias,
+                               const unsigned* live, float* y, float* part, int B, int Cout, int Di, int Hi, int Wi,
+                               int sd, int sh, int sw, void* stream) {
+  return conv133_fwd_impl(chans, Cin, w, bias, live, y, part, B, Cout, Di, Hi, Wi, sd, sh, sw, nullptr, 0, stream);
+}
+
+extern "C" int e2e_conv133_fwd_splitk(const e2e_in_chan_t* chans, int Cin, const float* w, const float* bias,
+                                      const unsigned* live, float* y, float* part, int B, int Cout, int Di, int Hi, int Wi,
+                                      int sd, int sh, int sw, float* ws, long long ws_bytes, void* stream) {
+  return conv133_fwd_impl(chans, Cin, w, bias, live, y, part, B, Cout, Di, Hi, Wi, sd, sh, sw, ws, ws_bytes, stream);
 }
 
 extern "C" int e2e_conv133_dgrad(const float* dy, const float* w, const unsigned* live_t, const e2e_out_chan_t* outs,

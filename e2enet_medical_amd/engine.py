@@ -144,9 +144,16 @@ class ConvOp:
         di, hi, wi = self.in_dims
         sd, sh, sw = self.stride
         L = lib()
-        L.conv133_fwd(self.chans.data_ptr(), self.cin, p[self.w_name].data_ptr(), p[self.prefix + ".conv.bias"].data_ptr(),
-                      _ptr(self.live), self.out.data.data_ptr(), self.part.data_ptr(), b, self.cout, di, hi, wi,
-                      sd, sh, sw, _stream())
+        ws = getattr(e, "fwd_ws", None)
+        if ws is not None and self.fwd_ws_bytes > 0:      # deep levels: input-plane chunks split over several workgroups
+            L.conv133_fwd_splitk(self.chans.data_ptr(), self.cin, p[self.w_name].data_ptr(),
+                                 p[self.prefix + ".conv.bias"].data_ptr(), _ptr(self.live), self.out.data.data_ptr(),
+                                 self.part.data_ptr(), b, self.cout, di, hi, wi, sd, sh, sw, ws.data_ptr(), ws.numel() * 4,
+                                 _stream())
+        else:
+            L.conv133_fwd(self.chans.data_ptr(), self.cin, p[self.w_name].data_ptr(), p[self.prefix + ".conv.bias"].data_ptr(),
+                          _ptr(self.live), self.out.data.data_ptr(), self.part.data_ptr(), b, self.cout, di, hi, wi,
+                          sd, sh, sw, _stream())
         L.in_stats_finalize(self.part.data_ptr(), self.np, p[self.prefix + ".instnorm.weight"].data_ptr(),
                             p[self.prefix + ".instnorm.bias"].data_ptr(), IN_EPS, self.out.scale.data_ptr(),
                             self.out.shift.data_ptr(), self.out.mean.data_ptr(), self.out.rstd.data_ptr(), b,
@@ -175,6 +182,13 @@ class ConvOp:
     def wgrad_ws_bytes(self):
         di, hi, wi = self.in_dims
         return lib().conv133_wgrad_ws_bytes(self.out.shape[0], self.cin, self.cout, di, hi, wi, *self.stride)
+
+    @property
+    def fwd_ws_bytes(self):
+        if not hasattr(self, "_fwd_ws_bytes"):
+            di, hi, wi = self.in_dims
+            self._fwd_ws_bytes = int(lib().conv133_fwd_ws_bytes(self.out.shape[0], self.cin, self.cout, di, hi, wi, *self.stride))
+        return self._fwd_ws_bytes
 
 
 class UpOp:
@@ -369,6 +383,8 @@ class Engine:
         self.loss_ws = None
         self.loss_val = None
         self.generation = 0                # bumped by every forward(): activations are reused in place
+        fws = max([op.fwd_ws_bytes for op in self.conv_ops.values()] + [0])
+        self.fwd_ws = torch.empty(fws // 4, dtype=torch.float32, device=self.device) if fws > 0 else None   # split-K partial sums (deep levels)
         self.pre_forward_hook = None       # callable(): set by the owning network, brings masks / parameters up to date
         self._eval_counts = None
 

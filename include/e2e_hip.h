@@ -75,6 +75,17 @@ int e2e_conv133_fwd(const e2e_in_chan_t* chans, int Cin, const float* w, const f
                     const unsigned* live, float* y, float* part, int B, int Cout, int Di, int Hi,
                     int Wi, int sd, int sh, int sw, void* stream);
 
+/* Forward with a workspace: on the deep levels (planes no larger than a 16 x 16 tile, hundreds of input planes) the
+ * input-plane chunks of a tile are split over several workgroups that store raw partial sums in `ws`
+ * ([parts][B][Cout][Do][Ho][Wo]); a second kernel adds them up in a fixed order (deterministic), adds the bias and
+ * writes the InstanceNorm partials.  e2e_conv133_fwd_ws_bytes returns the bytes this shape wants (0: it does not
+ * split and e2e_conv133_fwd_splitk behaves exactly like e2e_conv133_fwd).                                              */
+long long e2e_conv133_fwd_ws_bytes(int B, int Cin, int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw);
+int e2e_conv133_fwd_splitk(const e2e_in_chan_t* chans, int Cin, const float* w, const float* bias,
+                           const unsigned* live, float* y, float* part, int B, int Cout, int Di, int Hi, int Wi,
+                           int sd, int sh, int sw, float* ws, long long ws_bytes, void* stream);
+
+
 /* ---- K6a: 1x3x3 convolution, data gradient ------------------------------------------
  * Replaces: autograd of the Conv3d + cat + torch_shift chain w.r.t. its inputs
  * (nnUNetTrainer_simple.py:572 l.backward()).

@@ -484,3 +484,57 @@ def test_ds_target_gather_vs_oracle(shape):
         downsample_seg_for_ds_transform2(torch.from_numpy(seg).cuda(), scales, order=1)
     with pytest.raises(RuntimeError):
         downsample_seg_for_ds_transform2(torch.from_numpy(seg), scales, order=0)
+
+
+@pytest.mark.parametrize("B,src_desc,cout,dims,stride,density", [
+    (2, [(320, True), (320, False), (256, False)], 320, (8, 8, 8), (1, 1, 1), 0.2),      # BASELINE level 4: 896 -> 320 @8^3
+    (2, [(256, True), (256, False), (128, False)], 256, (4, 16, 16), (1, 1, 1), 0.2),    # level 3 planes (16 x 16 tile)
+    (1, [(100, True), (28, False)], 70, (5, 7, 5), (1, 1, 1), 0.5),                      # Hippocampus-like ragged planes
+    (2, [(256, True)], 320, (4, 16, 16), (2, 2, 2), 1.0),                                # strided onto 8 x 8 planes
+    (1, [(320, True)], 320, (2, 4, 4), (1, 1, 1), 1.0),                                  # 4 x 4 planes in an 8 x 8 tile
+])
+def test_conv133_forward_split_k_matches_unsplit(B, src_desc, cout, dims, stride, density):
+    """Deep levels: the forward with its input-plane chunks split over several workgroups (+ the sum kernel: fixed order,
+    bias, InstanceNorm partials) against the unsplit forward of the same operands and against torch; deterministic."""
+    from e2enet_medical_amd.engine import ConvOp
+    from e2enet_medical_amd._lib import lib
+    L = lib()
+    srcs = [_make_act((B, c) + dims, normed, 40 + i) for i, (c, normed) in enumerate(src_desc)]
+    cin = sum(c for c, _ in src_desc)
+    w = seeded_input((cout, cin, 1, 3, 3), seed=3) * (1.0 / math.sqrt(cin * 9))
+    km = _kmask(cout, cin, density, 5)
+    if km is not None:
+        w = w * km.view(cout, cin, 1, 1, 1)
+    params = {"blk.conv.weight": w, "blk.conv.bias": seeded_input((cout,), seed=4) * 0.1,
+              "blk.instnorm.weight": 1 + 0.2 * seeded_input((cout,), seed=6), "blk.instnorm.bias": 0.2 * seeded_input((cout,), seed=7)}
+    e = _eng_stub(params)
+    e.batch = B
+    op = ConvOp(e, "blk", srcs, cout, stride)
+    if km is not None:
+        rows = torch.empty(((cout + 3) // 4) * ((cin + 7) // 8), dtype=torch.int32, device=e.device)
+        cols = torch.empty(((cin + 3) // 4) * ((cout + 7) // 8), dtype=torch.int32, device=e.device)
+        L.dsff_expand_quads(km.to(e.device).data_ptr(), rows.data_ptr(), cols.data_ptr(), cout, cin, 0)
+        op.live, op.live_t = rows, cols
+    assert op.fwd_ws_bytes > 0, "this shape is expected to split"
+    op.forward()                                            # no workspace on the stub engine: unsplit
+    assert b"ksplit=1" in L.last_kernel()
+    y0, sc0, sh0 = op.out.data.clone(), op.out.scale.clone(), op.out.shift.clone()
+    e.fwd_ws = torch.empty(op.fwd_ws_bytes // 4, dtype=torch.float32, device=e.device)
+    op.out.data.fill_(float("nan"))
+    op.forward()
+    name = L.last_kernel().decode()
+    assert "ksplit=" in name and int(name.rsplit("ksplit=", 1)[1]) > 1, name
+    y1, sc1, sh1 = op.out.data.clone(), op.out.scale.clone(), op.out.shift.clone()
+    assert torch.isfinite(y1).all()
+    assert (y1 - y0).abs().max().item() <= 2e-5 * max(1.0, y0.abs().max().item())
+    assert (sc1 - sc0).abs().max().item() <= 1e-4 * max(1.0, sc0.abs().max().item())
+    assert (sh1 - sh0).abs().max().item() <= 1e-4 * max(1.0, sh0.abs().max().item())
+    op.forward()
+    assert torch.equal(op.out.data, y1) and torch.equal(op.out.scale, sc1)       # fixed summation order
+    ref = _ref_conv(srcs, params["blk.conv.weight"], params["blk.conv.bias"], stride)
+    assert (y1.cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    with pytest.raises(RuntimeError):                        # a workspace that is too small is an argument error
+        small = torch.empty(16, dtype=torch.float32, device=e.device)
+        L.conv133_fwd_splitk(op.chans.data_ptr(), cin, e.params["blk.conv.weight"].data_ptr(), e.params["blk.conv.bias"].data_ptr(),
+                             op.live.data_ptr() if op.live is not None else None, op.out.data.data_ptr(), op.part.data_ptr(), B,
+                             cout, *dims, *stride, small.data_ptr(), 64, 0)
