@@ -301,7 +301,7 @@ def main():
         dt = float(tt.item())
 
     # ---- instrumented steps (outside the timed region): HIP events around the conv entry points --------------------
-    names = ["conv133_fwd", "conv133_fwd_splitk", "conv133_dgrad", "conv133_wgrad"]    # (_splitk: the deep levels' forward, same kernel + a sum kernel)
+    names = ["conv133_fwd", "conv133_fwd_splitk", "conv133_dgrad", "conv133_dgrad_splitk", "conv133_wgrad"]    # (_splitk: the deep levels' forward, same kernel + a sum kernel)
     if args.op_profile:
         names += ["in_stats_finalize", "in_lrelu_bwd", "convT_fwd", "convT_dgrad", "convT_wgrad", "maxpool_fwd", "maxpool_bwd",
                   "head1x1_fwd", "head1x1_dgrad", "head1x1_wgrad", "dc_ce_reduce", "dc_ce_grad", "grad_sqnorm", "sgd_clip_mask_step"]
@@ -337,7 +337,7 @@ def main():
             out["metric"] = "voxels/sec (inference forward only), 128^3 patch 32ch density=0.2"
         work = conv_work(eng, mask)
         ev = [(e0.elapsed_time(e1), work[a[0]]) for e0, e1, a in timers["conv133_fwd"].events + timers["conv133_fwd_splitk"].events]
-        ev += [(e0.elapsed_time(e1), work[a[3]]) for e0, e1, a in timers["conv133_dgrad"].events]
+        ev += [(e0.elapsed_time(e1), work[a[3]]) for e0, e1, a in timers["conv133_dgrad"].events + timers["conv133_dgrad_splitk"].events]
         if ev:
             ms = sum(t for t, _ in ev)
             byt = sum(w["bytes"] for _, w in ev)

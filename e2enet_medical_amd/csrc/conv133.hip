@@ -586,7 +586,15 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
     for (int a = 0; a < OPW; ++a) {
       const int q = qbase + a < p.Q ? qbase + a : p.Q - 1;
       if (MODE == 0) bqs[a] = p.bias ? load_uniform(p.bias + q) : 0.f;
-      else ocs[a] = load_uniform(p.outs + q);
+      else if (p.ksplit > 1) {   // split-K part: raw sums into the workspace as a plain [n][Q][Do] tensor; conv133_dsum_kernel scatters
+        e2e_out_chan_t oc{};
+        const long long vol = (long long)p.Do * p.Ho * p.Wo;
+        oc.ptr = p.kpart + ((long long)cur.ks * p.B * p.Q + q) * vol;
+        oc.nstride = (long long)p.Q * vol;
+        oc.dshift = 0;
+        oc.accumulate = 0;
+        ocs[a] = oc;
+      } else ocs[a] = load_uniform(p.outs + q);
     }
 
     unsigned long long m_cur[NQD];
@@ -909,6 +917,53 @@ __global__ __launch_bounds__(64) void conv133_ksum_kernel(const float* __restric
   }
 }
 
+// ---- split-K tail of the data gradient: sum of the parts (fixed order), then the scatter epilogue of conv133_kernel
+// (un-shift on store, zero-fill of the slices that receive nothing, accumulate flag).  One wave per (n, q, tile).
+__global__ __launch_bounds__(64) void conv133_dsum_kernel(const float* __restrict__ kpart, const e2e_out_chan_t* __restrict__ outs,
+                                                          int ksplit, int B, int Q, int Do, int Ho, int Wo, int TH, int TW,
+                                                          int tiles_x, int tiles_y) {
+  const int tiles_per_n = Do * tiles_y * tiles_x;
+  int t = blockIdx.x;
+  const int tile_in_n = t % tiles_per_n;
+  t /= tiles_per_n;
+  const int q = t % Q, n = t / Q;
+  int u = tile_in_n;
+  const int tx = u % tiles_x;
+  u /= tiles_x;
+  const int ty = u % tiles_y, d = u / tiles_y;
+  const e2e_out_chan_t oc = outs[q];
+  if (oc.ptr == nullptr) return;
+  int dd = d - oc.dshift;
+  bool zero_fill = false;
+  if (dd < 0) {
+    const int lo = Do - oc.dshift > 0 ? Do - oc.dshift : 0;
+    dd = lo + d;
+    zero_fill = true;
+  } else if (dd >= Do) {
+    const int lo = Do + oc.dshift > 0 ? Do + oc.dshift : 0;
+    dd = d - lo;
+    zero_fill = true;
+  }
+  if (zero_fill && oc.accumulate) return;
+  const int h0 = ty * TH, w0 = tx * TW;
+  const int vr = Ho - h0 < TH ? Ho - h0 : TH, vc = Wo - w0 < TW ? Wo - w0 : TW;
+  const long long plane = (long long)Ho * Wo;
+  const long long src = (((long long)n * Q + q) * Do + d) * plane;
+  const long long kstride = (long long)B * Q * Do * plane;
+  float* xp = oc.ptr + (long long)n * oc.nstride + (long long)dd * plane;
+  const int npx = vr * vc;
+  for (int i = threadIdx.x; i < npx; i += 64) {
+    const int r = i / vc, c = i - r * vc;
+    const long long po = (long long)(h0 + r) * Wo + (w0 + c);
+    float v = 0.f;
+    if (!zero_fill) {
+      for (int k = 0; k < ksplit; ++k) v += kpart[(long long)k * kstride + src + po];
+      if (oc.accumulate) v += xp[po];
+    }
+    xp[po] = v;
+  }
+}
+
 // ---- strided data gradient (encoder "convolutional pooling" convs, 5 layers, dense): gather form ------------
 // dx[c][di][hi][wi] = sum_o sum_{kh,kw : (hi+1-kh) % sh == 0, (wi+1-kw) % sw == 0} dy[o][ds][(hi+1-kh)/sh][(wi+1-kw)/sw] w[o][c][kh][kw]
 // where the shifted depth ds*sd = di + s(c).
@@ -992,7 +1047,7 @@ int launch_cfg_impl(ConvParams p, hipStream_t st) {
   p.tiles_y = e2e::cdiv(p.Ho, TH);
   p.tiles_per_n = p.Do * p.tiles_y * p.tiles_x;
   p.groups = e2e::cdiv(p.Q, C::OCG);
-  if (p.ksplit < 1 || MODE != 0 || PERSIST) p.ksplit = 1;
+  if (p.ksplit < 1 || PERSIST) p.ksplit = 1;
   float* const part_out = p.part;
   if (p.ksplit > 1) p.part = nullptr;                 // raw partial sums: statistics come from conv133_ksum_kernel
   p.total = p.B * p.tiles_per_n * p.groups * p.ksplit;
@@ -1007,9 +1062,12 @@ int launch_cfg_impl(ConvParams p, hipStream_t st) {
                    TH, TW, OPW, NW, CK, STG, PERSIST, wgs, p.ksplit);
   hipLaunchKernelGGL((conv133_kernel<MODE, SH, SW, DH, DW, TH, TW, LY, LX, OPW, NW, CK, STG, MINW, PIPE, PERSIST>), dim3(wgs),
                      dim3(C::NT), (size_t)p.P * sizeof(PlaneDesc), st, p);
-  if (p.ksplit > 1)
+  if (p.ksplit > 1 && MODE == 0)
     hipLaunchKernelGGL(conv133_ksum_kernel, dim3(p.B * p.Q * p.tiles_per_n), dim3(64), 0, st, p.kpart, p.bias, p.y, part_out,
                        p.ksplit, p.B, p.Q, p.Do, p.Ho, p.Wo, TH, TW, p.tiles_x, p.tiles_y);
+  if (p.ksplit > 1 && MODE != 0)
+    hipLaunchKernelGGL(conv133_dsum_kernel, dim3(p.B * p.Q * p.tiles_per_n), dim3(64), 0, st, p.kpart, p.outs, p.ksplit, p.B,
+                       p.Q, p.Do, p.Ho, p.Wo, TH, TW, p.tiles_x, p.tiles_y);
 #ifdef E2E_CONV_DEBUG
   if (p.dbg & 8) {
     hipStreamSynchronize(st);
@@ -1170,9 +1228,32 @@ extern "C" int e2e_conv133_fwd_splitk(const e2e_in_chan_t* chans, int Cin, const
   return conv133_fwd_impl(chans, Cin, w, bias, live, y, part, B, Cout, Di, Hi, Wi, sd, sh, sw, ws, ws_bytes, stream);
 }
 
-extern "C" int e2e_conv133_dgrad(const float* dy, const float* w, const unsigned* live_t, const e2e_out_chan_t* outs,
-                                 int B, int Cin, int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw,
-                                 void* stream) {
+// split-K plan of the data gradient (deep levels; the tiled paths only)
+static int plan_dgrad_ksplit(int B, int Cin, int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw) {
+  static const int knob = getenv("E2E_CONV_KSPLIT") ? atoi(getenv("E2E_CONV_KSPLIT")) : -1;
+  if (knob == 0 || knob == 1) return 1;
+  const bool tiled = (sh == 1 && sw == 1) || (sh == 2 && sw == 2);
+  if (!tiled) return 1;
+  const TileKind k = pick_tile(Hi, Wi, 1, 1);
+  if (k == T32) return 1;
+  int th, tw;
+  tile_dims(k, th, tw);
+  const int chunks = e2e::cdiv(Cout, 16);
+  const long long base = (long long)B * Di * e2e::cdiv(Hi, th) * e2e::cdiv(Wi, tw) * e2e::cdiv(Cin, 32);
+  long long ks = knob > 1 ? knob : 1024 / (base > 0 ? base : 1);
+  if (ks > 8) ks = 8;
+  if (ks > chunks / 2) ks = chunks / 2;
+  return ks < 2 ? 1 : (int)ks;
+}
+
+extern "C" long long e2e_conv133_dgrad_ws_bytes(int B, int Cin, int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw) {
+  const int ks = plan_dgrad_ksplit(B, Cin, Cout, Di, Hi, Wi, sd, sh, sw);
+  return ks <= 1 ? 0 : (long long)ks * B * Cin * Di * Hi * Wi * 4;
+}
+
+static int conv133_dgrad_impl(const float* dy, const float* w, const unsigned* live_t, const e2e_out_chan_t* outs,
+                              int B, int Cin, int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw, float* ws,
+                              long long ws_bytes, void* stream) {
   E2E_REQUIRE(dy && w && outs, "conv133_dgrad: null pointer");
   E2E_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Di > 0 && Hi > 0 && Wi > 0, "conv133_dgrad: bad dims");
   E2E_REQUIRE((sd == 1 || sd == 2) && (sh == 1 || sh == 2) && (sw == 1 || sw == 2), "conv133_dgrad: stride must be 1 or 2");
@@ -1196,6 +1277,15 @@ extern "C" int e2e_conv133_dgrad(const float* dy, const float* w, const unsigned
   p.P = Cout; p.Q = Cin; p.wq_stride = 9; p.wp_stride = Cin * 9; p.live_words = e2e::cdiv(Cout, 32);
   p.B = B; p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.sd = sd; p.Do = Di; p.Ho = Hi; p.Wo = Wi;
   p.Ds = Do; p.Hs = Ho; p.Ws = Wo;
+  p.ksplit = 1; p.kpart = nullptr;
+  if (ws != nullptr) {
+    const long long need = e2e_conv133_dgrad_ws_bytes(B, Cin, Cout, Di, Hi, Wi, sd, sh, sw);
+    if (need > 0) {
+      E2E_REQUIRE(ws_bytes >= need, "conv133_dgrad: workspace too small (%lld < %lld bytes)", ws_bytes, need);
+      p.ksplit = plan_dgrad_ksplit(B, Cin, Cout, Di, Hi, Wi, sd, sh, sw);
+      p.kpart = ws;
+    }
+  }
   const TileKind k = pick_tile(Hi, Wi, 1, 1);
   const int kind = k == T32 ? 0 : (k == T16 ? 1 : 2);
   if (sh == 1) return launch_s1<1, 1, 1>(p, kind, st);
@@ -1204,4 +1294,16 @@ extern "C" int e2e_conv133_dgrad(const float* dy, const float* w, const unsigned
     return launch_sub(p, kind, st);
   }
   return launch_s1<1, 2, 2>(p, kind, st);
+}
+
+extern "C" int e2e_conv133_dgrad(const float* dy, const float* w, const unsigned* live_t, const e2e_out_chan_t* outs,
+                                 int B, int Cin, int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw,
+                                 void* stream) {
+  return conv133_dgrad_impl(dy, w, live_t, outs, B, Cin, Cout, Di, Hi, Wi, sd, sh, sw, nullptr, 0, stream);
+}
+
+extern "C" int e2e_conv133_dgrad_splitk(const float* dy, const float* w, const unsigned* live_t, const e2e_out_chan_t* outs,
+                                        int B, int Cin, int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw, float* ws,
+                                        long long ws_bytes, void* stream) {
+  return conv133_dgrad_impl(dy, w, live_t, outs, B, Cin, Cout, Di, Hi, Wi, sd, sh, sw, ws, ws_bytes, stream);
 }

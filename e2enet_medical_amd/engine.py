@@ -176,12 +176,24 @@ class ConvOp:
         L.conv133_wgrad(self.chans.data_ptr(), o.grad.data_ptr(), g[self.w_name].data_ptr(), e.wgrad_ws.data_ptr(),
                         b, self.cin, self.cout, di, hi, wi, sd, sh, sw, _stream())
         if self.do_dgrad:
-            L.conv133_dgrad(o.grad.data_ptr(), p[self.w_name].data_ptr(), _ptr(self.live_t), self.outs.data_ptr(),
-                            b, self.cin, self.cout, di, hi, wi, sd, sh, sw, _stream())
+            ws = getattr(e, "fwd_ws", None)
+            if ws is not None and self.dgrad_ws_bytes > 0:        # deep levels: split-K (the workspace is idle during backward)
+                L.conv133_dgrad_splitk(o.grad.data_ptr(), p[self.w_name].data_ptr(), _ptr(self.live_t), self.outs.data_ptr(),
+                                       b, self.cin, self.cout, di, hi, wi, sd, sh, sw, ws.data_ptr(), ws.numel() * 4, _stream())
+            else:
+                L.conv133_dgrad(o.grad.data_ptr(), p[self.w_name].data_ptr(), _ptr(self.live_t), self.outs.data_ptr(),
+                                b, self.cin, self.cout, di, hi, wi, sd, sh, sw, _stream())
 
     def wgrad_ws_bytes(self):
         di, hi, wi = self.in_dims
         return lib().conv133_wgrad_ws_bytes(self.out.shape[0], self.cin, self.cout, di, hi, wi, *self.stride)
+
+    @property
+    def dgrad_ws_bytes(self):
+        if not hasattr(self, "_dgrad_ws_bytes"):
+            di, hi, wi = self.in_dims
+            self._dgrad_ws_bytes = int(lib().conv133_dgrad_ws_bytes(self.out.shape[0], self.cin, self.cout, di, hi, wi, *self.stride))
+        return self._dgrad_ws_bytes
 
     @property
     def fwd_ws_bytes(self):
@@ -383,7 +395,7 @@ class Engine:
         self.loss_ws = None
         self.loss_val = None
         self.generation = 0                # bumped by every forward(): activations are reused in place
-        fws = max([op.fwd_ws_bytes for op in self.conv_ops.values()] + [0])
+        fws = max([max(op.fwd_ws_bytes, op.dgrad_ws_bytes if op.do_dgrad else 0) for op in self.conv_ops.values()] + [0])
         self.fwd_ws = torch.empty(fws // 4, dtype=torch.float32, device=self.device) if fws > 0 else None   # split-K partial sums (deep levels)
         self.pre_forward_hook = None       # callable(): set by the owning network, brings masks / parameters up to date
         self._eval_counts = None

@@ -96,6 +96,15 @@ int e2e_conv133_fwd_splitk(const e2e_in_chan_t* chans, int Cin, const float* w, 
 int e2e_conv133_dgrad(const float* dy, const float* w, const unsigned* live_t, const e2e_out_chan_t* outs,
                       int B, int Cin, int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw, void* stream);
 
+/* Data gradient with a workspace: the split-K form of the deep levels (see e2e_conv133_fwd_splitk); the parts hold raw
+ * sums per virtual-concat channel, a second kernel adds them in a fixed order and applies the scatter epilogue (un-shift
+ * on store, zero-fill, accumulate flag).  ws_bytes from e2e_conv133_dgrad_ws_bytes (0: this shape does not split).      */
+long long e2e_conv133_dgrad_ws_bytes(int B, int Cin, int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw);
+int e2e_conv133_dgrad_splitk(const float* dy, const float* w, const unsigned* live_t, const e2e_out_chan_t* outs,
+                             int B, int Cin, int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw, float* ws,
+                             long long ws_bytes, void* stream);
+
+
 /* ---- K6b: 1x3x3 convolution, weight gradient (dense: also for dead kernels, because the
  * reference's clip_grad_norm_ runs over all gradients, nnUNetTrainer_simple.py:573) ----
  *   dw   [Cout,Cin,1,3,3] (overwritten)

@@ -538,3 +538,67 @@ def test_conv133_forward_split_k_matches_unsplit(B, src_desc, cout, dims, stride
         L.conv133_fwd_splitk(op.chans.data_ptr(), cin, e.params["blk.conv.weight"].data_ptr(), e.params["blk.conv.bias"].data_ptr(),
                              op.live.data_ptr() if op.live is not None else None, op.out.data.data_ptr(), op.part.data_ptr(), B,
                              cout, *dims, *stride, small.data_ptr(), 64, 0)
+
+
+@pytest.mark.parametrize("B,src_desc,cout,dims,stride,density", [
+    (2, [(320, True), (320, False), (256, False)], 320, (8, 8, 8), (1, 1, 1), 0.2),      # level 4
+    (2, [(256, True), (256, False), (128, False)], 256, (4, 16, 16), (1, 1, 1), 0.2),    # level 3 (16 x 16 tile)
+    (1, [(100, True), (28, False)], 70, (5, 7, 5), (1, 1, 1), 0.5),                      # ragged planes, shifted groups
+    (2, [(256, True)], 320, (4, 16, 16), (2, 2, 2), 1.0),                                # strided: sub-pixel data gradient
+    (1, [(320, True)], 320, (2, 4, 4), (1, 1, 1), 1.0),
+])
+def test_conv133_data_gradient_split_k_matches_unsplit(B, src_desc, cout, dims, stride, density):
+    """Deep levels: data gradient with the dy-plane chunks split over several workgroups (+ the sum / scatter kernel:
+    un-shift, zero-fill, accumulate) against the unsplit kernel, in overwrite and in accumulate mode; deterministic."""
+    from e2enet_medical_amd.engine import ConvOp
+    from e2enet_medical_amd._lib import lib
+    L = lib()
+    srcs = [_make_act((B, c) + dims, normed, 50 + i) for i, (c, normed) in enumerate(src_desc)]
+    cin = sum(c for c, _ in src_desc)
+    w = seeded_input((cout, cin, 1, 3, 3), seed=3) * (1.0 / math.sqrt(cin * 9))
+    km = _kmask(cout, cin, density, 5)
+    if km is not None:
+        w = w * km.view(cout, cin, 1, 1, 1)
+    params = {"blk.conv.weight": w, "blk.conv.bias": seeded_input((cout,), seed=4) * 0.1,
+              "blk.instnorm.weight": 1 + 0.2 * seeded_input((cout,), seed=6), "blk.instnorm.bias": 0.2 * seeded_input((cout,), seed=7)}
+    e = _eng_stub(params)
+    e.batch = B
+    op = ConvOp(e, "blk", srcs, cout, stride)
+    if km is not None:
+        rows = torch.empty(((cout + 3) // 4) * ((cin + 7) // 8), dtype=torch.int32, device=e.device)
+        cols = torch.empty(((cin + 3) // 4) * ((cout + 7) // 8), dtype=torch.int32, device=e.device)
+        L.dsff_expand_quads(km.to(e.device).data_ptr(), rows.data_ptr(), cols.data_ptr(), cout, cin, 0)
+        op.live, op.live_t = rows, cols
+    assert op.dgrad_ws_bytes > 0, "this shape is expected to split"
+    op.forward()
+    dy = seeded_input(tuple(op.out.shape), seed=8).cuda()
+    for s in srcs:
+        s._grad_written = False
+    op.out.alloc_grad()
+    op.plan_backward()
+    di, hi, wi = dims
+
+    def run(ws, accumulate):
+        for s in srcs:
+            s._grad_written = accumulate
+        op.plan_backward()
+        for s in srcs:
+            s.grad.copy_(s.data * 0.25) if accumulate else s.grad.fill_(float("nan"))
+        args = (dy.data_ptr(), e.params["blk.conv.weight"].data_ptr(), op.live_t.data_ptr() if op.live_t is not None else None,
+                op.outs.data_ptr(), B, cin, cout, di, hi, wi, *stride)
+        if ws is None:
+            L.conv133_dgrad(*args, 0)
+        else:
+            L.conv133_dgrad_splitk(*args, ws.data_ptr(), ws.numel() * 4, 0)
+        name = L.last_kernel().decode()
+        return [s.grad.clone() for s in srcs], name
+    ws = torch.empty(op.dgrad_ws_bytes // 4, dtype=torch.float32, device=e.device)
+    for accumulate in (False, True):
+        ref, n0 = run(None, accumulate)
+        got, n1 = run(ws, accumulate)
+        again, _ = run(ws, accumulate)
+        assert n0.endswith("ksplit=1") and int(n1.rsplit("ksplit=", 1)[1]) > 1, (n0, n1)
+        for r, g, a in zip(ref, got, again):
+            assert torch.isfinite(g).all()
+            assert (g - r).abs().max().item() <= 2e-5 * max(1.0, r.abs().max().item())
+            assert torch.equal(g, a)
