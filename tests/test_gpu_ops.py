@@ -492,6 +492,7 @@ def test_ds_target_gather_vs_oracle(shape):
     (1, [(100, True), (28, False)], 70, (5, 7, 5), (1, 1, 1), 0.5),                      # Hippocampus-like ragged planes
     (2, [(256, True)], 320, (4, 16, 16), (2, 2, 2), 1.0),                                # strided onto 8 x 8 planes
     (1, [(320, True)], 320, (2, 4, 4), (1, 1, 1), 1.0),                                  # 4 x 4 planes in an 8 x 8 tile
+    (1, [(100, True), (60, False)], 40, (3, 12, 40), (1, 1, 1), 0.3),                    # three ragged 16 x 16 tiles per slice
 ])
 def test_conv133_forward_split_k_matches_unsplit(B, src_desc, cout, dims, stride, density):
     """Deep levels: the forward with its input-plane chunks split over several workgroups (+ the sum kernel: fixed order,
@@ -546,6 +547,7 @@ def test_conv133_forward_split_k_matches_unsplit(B, src_desc, cout, dims, stride
     (1, [(100, True), (28, False)], 70, (5, 7, 5), (1, 1, 1), 0.5),                      # ragged planes, shifted groups
     (2, [(256, True)], 320, (4, 16, 16), (2, 2, 2), 1.0),                                # strided: sub-pixel data gradient
     (1, [(320, True)], 320, (2, 4, 4), (1, 1, 1), 1.0),
+    (1, [(100, True), (60, False)], 128, (3, 12, 40), (1, 1, 1), 0.3),                    # three ragged 16 x 16 tiles per slice
 ])
 def test_conv133_data_gradient_split_k_matches_unsplit(B, src_desc, cout, dims, stride, density):
     """Deep levels: data gradient with the dy-plane chunks split over several workgroups (+ the sum / scatter kernel:
