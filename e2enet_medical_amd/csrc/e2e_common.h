@@ -72,4 +72,19 @@ __device__ __forceinline__ int xcd_remap(int id, int padded_total) {
   return (id & 7) * per + (id >> 3);
 }
 
+// Zero `bytes` (a multiple of 4) on the stream with a kernel.  Not hipMemsetAsync: captured into a HIP graph (ROCm 7.0) the
+// memset nodes of the small accumulator buffers that several ops reuse one after the other were not reliably ordered
+// against the neighbouring kernel nodes once eager work ran between two replays (NaN sums; tests/test_gpu_net.py graph
+// test); a kernel node is ordered like every other kernel.
+__global__ inline void zero_words_kernel(unsigned* p, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = 0u;
+}
+inline void zero_async(void* p, size_t bytes, hipStream_t st) {
+  const long long n = (long long)(bytes / 4);
+  long long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (unsigned*)p, n);
+}
+
 }  // namespace e2e

@@ -213,10 +213,7 @@ extern "C" int e2e_in_lrelu_bwd(float* dz_dy, const float* y, const float* mean,
   E2E_REQUIRE(B > 0 && C > 0 && spatial > 0, "in_lrelu_bwd: bad dims");
   hipStream_t st = (hipStream_t)stream;
   double* ds = reinterpret_cast<double*>(sums);
-  if (hipMemsetAsync(ds, 0, (size_t)B * C * 3 * sizeof(double), st) != hipSuccess) {
-    e2e::set_error("in_lrelu_bwd: memset failed");
-    return E2E_ERR_LAUNCH;
-  }
+  e2e::zero_async(ds, (size_t)B * C * 3 * sizeof(double), st);
   long long blocks = e2e::cdivll(spatial, 256 * 4 * 4);
   if (blocks > 256) blocks = 256;
   if (blocks < 1) blocks = 1;

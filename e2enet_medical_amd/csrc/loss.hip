@@ -240,10 +240,7 @@ extern "C" int e2e_dc_ce_reduce(const float* logits, const float* target, void* 
   E2E_REQUIRE(logits && target && acc, "dc_ce_reduce: null pointer");
   E2E_REQUIRE(B > 0 && K > 1 && K <= KMAX && spatial > 0, "dc_ce_reduce: need 2 <= K <= 32");
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(acc, 0, (size_t)e2e_loss_ws_bytes(B, K), st) != hipSuccess) {
-    e2e::set_error("dc_ce_reduce: memset failed");
-    return E2E_ERR_LAUNCH;
-  }
+  e2e::zero_async(acc, (size_t)e2e_loss_ws_bytes(B, K), st);
   dim3 grid(loss_blocks(spatial), B);
   DISPATCH_LK(K, hipLaunchKernelGGL((dc_ce_reduce_kernel<KB>), grid, dim3(256), 0, st, logits, target, (double*)acc, K, spatial));
   return e2e::check_launch("dc_ce_reduce_kernel");
@@ -272,10 +269,7 @@ extern "C" int e2e_online_eval_counts(const float* logits, const float* target, 
   E2E_REQUIRE(logits && target && counts, "online_eval_counts: null pointer");
   E2E_REQUIRE(B > 0 && K > 1 && K <= KMAX && spatial > 0, "online_eval_counts: need 2 <= K <= 32");
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(counts, 0, (size_t)K * 3 * sizeof(long long), st) != hipSuccess) {
-    e2e::set_error("online_eval_counts: memset failed");
-    return E2E_ERR_LAUNCH;
-  }
+  e2e::zero_async(counts, (size_t)K * 3 * sizeof(long long), st);
   dim3 grid(loss_blocks(spatial), B);
   DISPATCH_LK(K, hipLaunchKernelGGL((online_eval_kernel<KB>), grid, dim3(256), 0, st, logits, target,
                                     (unsigned long long*)counts, K, spatial));

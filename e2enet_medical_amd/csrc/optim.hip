@@ -87,10 +87,7 @@ __global__ __launch_bounds__(256) void apply_mask_kernel(const e2e_param_t* __re
 extern "C" int e2e_grad_sqnorm(const e2e_param_t* table, int n, double* sq_out, void* stream) {
   E2E_REQUIRE(table && sq_out && n > 0, "grad_sqnorm: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(sq_out, 0, sizeof(double), st) != hipSuccess) {
-    e2e::set_error("grad_sqnorm: memset failed");
-    return E2E_ERR_LAUNCH;
-  }
+  e2e::zero_async(sq_out, sizeof(double), st);
   hipLaunchKernelGGL(sqnorm_kernel, dim3(128, n), dim3(256), 0, st, table, sq_out);
   return e2e::check_launch("sqnorm_kernel");
 }

@@ -398,10 +398,7 @@ extern "C" int e2e_maxpool_bwd(const float* x, const float* scale, const float* 
   hipStream_t st = (hipStream_t)stream;
   const int Do = D / kd, Ho = H / kh, Wo = W / kw;
   if (!accumulate && (D % kd || H % kh || W % kw)) {   // cells outside every window receive no gradient
-    if (hipMemsetAsync(dx, 0, (size_t)B * C * D * H * W * sizeof(float), st) != hipSuccess) {
-      e2e::set_error("maxpool_bwd: memset failed");
-      return E2E_ERR_LAUNCH;
-    }
+    e2e::zero_async(dx, (size_t)B * C * D * H * W * sizeof(float), st);
   }
   if (kw == 2 && (W % 4) == 0) {
     dim3 grid2((unsigned)e2e::cdivll((long long)Do * Ho * (Wo / 2), 256), B * C);
@@ -462,10 +459,7 @@ extern "C" int e2e_head1x1_wgrad(const float* x, const float* scale, const float
   E2E_REQUIRE(x && dlogits && dw && ws, "head1x1_wgrad: null pointer");
   hipStream_t st = (hipStream_t)stream;
   double* acc = reinterpret_cast<double*>(ws);
-  if (hipMemsetAsync(acc, 0, (size_t)C * K * sizeof(double), st) != hipSuccess) {
-    e2e::set_error("head1x1_wgrad: memset failed");
-    return E2E_ERR_LAUNCH;
-  }
+  e2e::zero_async(acc, (size_t)C * K * sizeof(double), st);
   long long blocks = e2e::cdivll(spatial, 256 * 16);
   if (blocks > 128) blocks = 128;
   if (blocks < 1) blocks = 1;

@@ -697,3 +697,58 @@ def test_full_size_128_training_properties():
             assert float((net.get_parameter(n).detach() * (1 - m)).abs().max()) == 0.0, n
     assert all(np.isfinite(losses)), losses
     assert losses[-1] < losses[0] - 0.02, losses
+
+
+@pytest.mark.parametrize("mode", ["explicit", "loss"])
+def test_engine_forward_and_backward_are_graph_capturable(mode):
+    """include/e2e_hip.h promises asynchronous, allocation-free, graph-capturable entry points: capture a whole forward
+    and backward pass of the tiny net into a HIP graph through torch.cuda.CUDAGraph and replay it on new input.
+    "explicit": backward from given logit gradients -- logits and every parameter gradient bit-identical to the eager
+    launches.  "loss": forward + fused loss kernels + backward -- logits bit-identical, loss and gradients at 1e-6 (the
+    Dice sums are fp64 atomics whose order is not fixed, eager or not).  This test is why the library zeroes its small
+    accumulators with a kernel (e2e::zero_async) and not with hipMemsetAsync: with memset nodes in the graph the second
+    replay returned NaN gradients whenever eager work ran between two replays (tools/scratch/graph_dbg3.py)."""
+    net, shapes, _ = tiny_net()
+    xa = seeded_input((2, TINY["cin"]) + TINY["patch"], seed=61).cuda()
+    xb = seeded_input((2, TINY["cin"]) + TINY["patch"], seed=62).cuda()
+    eng = net.engine(xa)
+    outs = eng.forward(xa, True)
+    targets = [seeded_labels((o.shape[0], 1) + tuple(o.shape[2:]), TINY["k"], seed=70 + i).cuda() for i, o in enumerate(outs)]
+    gl = [torch.from_numpy(np.random.RandomState(9 + i).standard_normal(tuple(o.shape)).astype(np.float32)).cuda() * 1e-2
+          for i, o in enumerate(outs)]
+    w = oracle.ds_weights(5)
+
+    def body(x):
+        o = eng.forward(x, True)
+        if mode == "loss":
+            return o, eng.loss_backward(targets, w, batch_dice=False)
+        eng.backward(gl)
+        return o, None
+    eng.loss_backward(targets, w, batch_dice=False)            # eager warm-up: every buffer exists before the capture
+    eager = {}
+    for tag, x in (("a", xa), ("b", xb)):
+        o, loss = body(x)
+        eager[tag] = ([t.clone() for t in o], None if loss is None else loss.clone(), {n: g.clone() for n, g in eng.grads.items()})
+    xin = xa.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        body(xin)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        gouts, gloss = body(xin)
+    for tag, x in (("a", xa), ("b", xb), ("a", xa)):
+        o_ref, l_ref, g_ref = eager[tag]
+        xin.copy_(x)
+        graph.replay()
+        torch.cuda.synchronize()
+        for a, b in zip(gouts, o_ref):
+            assert torch.equal(a, b)
+        if mode == "loss":
+            assert abs(gloss.item() - l_ref.item()) <= 1e-6
+        for n in g_ref:
+            if mode == "explicit":
+                assert torch.equal(eng.grads[n], g_ref[n]), n
+            else:
+                assert (eng.grads[n] - g_ref[n]).abs().max().item() <= 1e-6 * max(1.0, g_ref[n].abs().max().item()), (tag, n)
