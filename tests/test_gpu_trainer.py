@@ -398,3 +398,36 @@ def test_trainer_builds_ds_targets_on_device_from_full_resolution_labels(tmp_pat
     a = tr.run_iteration(gen(full.clone()), do_backprop=False)
     b = tr.run_iteration(gen([t.clone() for t in lists]), do_backprop=False)
     assert float(a) == float(b)
+
+
+def test_run_iteration_prefetches_the_next_batch_without_changing_the_sequence(tmp_path):
+    """run_iteration fetches batch i+1 and uploads it on a copy stream under the kernels of batch i: the losses are those
+    of the synchronous path batch for batch, the generator is consumed exactly one batch ahead, a second generator does
+    not see the first one's batch, and an exhausted generator ends cleanly."""
+    batches = []
+    for i in range(4):
+        x = seeded_input((2, 1, 16, 32, 32), seed=300 + i)
+        t = [seeded_labels((2, 1) + s, 3, seed=310 + i) for s in ((16, 32, 32), (8, 16, 16), (4, 8, 8), (2, 4, 4))]
+        batches.append({'data': x.numpy(), 'target': [v.numpy() for v in t]})     # numpy, like the reference's augmenters
+
+    def run(prefetch):
+        tr, net, opt = _trainer(str(tmp_path / ("p%d" % prefetch)), epochs=1)
+        tr.prefetch_batches = bool(prefetch)
+        taken = []
+
+        def gen(tag):
+            for i, b in enumerate(batches):
+                taken.append((tag, i))
+                yield b
+        g1, g2 = gen("a"), gen("b")
+        out = [float(tr.run_iteration(g1, do_backprop=True)) for _ in range(2)]
+        n_after_two = len([t for t in taken if t[0] == "a"])
+        out.append(float(tr.run_iteration(g2, do_backprop=False)))          # another generator: its own first batch
+        out += [float(tr.run_iteration(g1, do_backprop=True)) for _ in range(2)]
+        with pytest.raises(StopIteration):
+            tr.run_iteration(g1, do_backprop=True)                           # 4 batches consumed, nothing prefetched
+        return out, n_after_two
+    sync, n_sync = run(0)
+    pre, n_pre = run(1)
+    assert sync == pre
+    assert n_sync == 2 and n_pre == 3
