@@ -20,6 +20,8 @@ bucketed RCCL all-reduce of the gradients overlapped with the backward pass.  Pr
                          step 0.5, 8 mirrors, everything device resident
   dsff_update            BASELINE config 3: one Masking.truncate_weights() (prune + grow of all 35 masked tensors)
   cpu_baseline           the CPU oracle on the same 128^3 patch (B = 1: fwd + loss + bwd), 1 warm-up + up to 3 timed
+  parity                 the metric's "Dice vs CPU ref" half: engine vs that oracle on the IDENTICAL patch (the GPU network's
+                         weights and masks): Dice of the argmax maps, max |dlogit| per head, loss difference
 """
 import argparse
 import contextlib
@@ -148,33 +150,43 @@ def host_threads():
     return max(1, min(avail, int(os.environ.get("E2E_CPU_THREADS", "16"))))
 
 
-def cpu_baseline(patch_edge=128, budget_s=150.0):
+def parity_sample(net, device, patch, ds_w):
+    """GPU side of the metric's "Dice vs CPU ref" half: ONE patch (B = 1, seed 0) through the engine with
+    the network's current weights and DSFF masks -- logits of the four heads and the deep-supervision loss -- plus everything
+    the CPU oracle needs to evaluate the identical patch (cpu_baseline)."""
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((1, CIN) + tuple(patch), generator=g)
+    full = torch.randint(0, K, (1, 1) + tuple(patch), generator=g).float()
+    targets = [full[:, :, ::s, ::s, ::s].contiguous() for s in (1, 2, 4, 8)]
+    xd = x.to(device)
+    eng1 = net.engine(xd)
+    outs = eng1.forward(xd, True)
+    loss = eng1.loss_backward([t.to(device) for t in targets], ds_w, batch_dice=False)
+    return {"x": x, "targets": targets, "logits": [o.detach().cpu() for o in outs], "loss": float(loss.item()),
+            "params": {n: p.detach().cpu().clone() for n, p in net.named_parameters()}}
+
+
+def cpu_baseline(sample, patch_edge=128, budget_s=150.0):
     """The oracle (CPU restatement, kind "port") on the host cores: fwd + loss + bwd of ONE patch of the benchmarked
-    network (B = 1, 4 x 128^3, 32 ch, density 0.2; dense masked weights like the reference), 1 warm-up + up to 3 timed
-    steps; the loop stops early when the projected time leaves the budget."""
+    network (B = 1, 4 x 128^3, 32 ch, density 0.2; dense masked weights like the reference) with the GPU network's own
+    weights, masks, input and targets (`sample`), 1 warm-up + up to 3 timed steps; the loop stops
+    early when the projected time leaves the budget.  The warm-up step's logits and loss are compared with the engine's
+    on the identical patch: returns (cpu_baseline record, parity record)."""
     import oracle
-    from oracle import network as onet
     threads = host_threads()
     torch.set_num_threads(threads)
     spec = oracle.make_spec(CIN, BASE, K, POOLS)
-    params = oracle.init_params(spec, seed=0)
-    names = oracle.masked_names(spec)
-    random.seed(0)
-    masks = oracle.uniform_kernel_masks(onet.param_shapes(spec), names, DENSITY)
-    for n in names:
-        params[n] = params[n] * masks[n]
-    patch = (patch_edge,) * 3
-    g = torch.Generator().manual_seed(0)
-    x = torch.randn((1, CIN) + patch, generator=g)
-    full = torch.randint(0, K, (1, 1) + patch, generator=g).float()
-    targets = [full[:, :, ::s, ::s, ::s].contiguous() for s in (1, 2, 4, 8)]
+    params, x, targets = sample["params"], sample["x"], sample["targets"]
     w = oracle.ds_weights(5)
+    keep = {}
 
     def step():
         leaves = {n: p.detach().clone().requires_grad_(True) for n, p in params.items()}
         outs = oracle.forward(spec, leaves, x)
         loss = oracle.deep_supervision_loss(outs, targets, w)
         loss.backward()
+        if not keep:
+            keep["logits"], keep["loss"] = [o.detach() for o in outs], float(loss.detach())
         return float(loss.detach())
     t0 = time.time()
     step()                                     # warm-up
@@ -184,9 +196,18 @@ def cpu_baseline(patch_edge=128, budget_s=150.0):
         step()
         n += 1
     dt = time.time() - t1
-    return {"value": n * patch_edge ** 3 / dt, "unit": "voxels/s", "cores": threads, "kind": "port",
+    base = {"value": n * patch_edge ** 3 / dt, "unit": "voxels/s", "cores": threads, "kind": "port",
             "sample": "%d timed fwd+loss+bwd steps (+1 warm-up of %.1f s) of one 4 x %d^3 patch (B=1, 32 ch, density 0.2, dense "
-                      "masked weights), torch-CPU oracle, %d threads, %.1f s" % (n, first, patch_edge, threads, dt)}
+                      "masked weights: the GPU network's own), torch-CPU oracle, %d threads, %.1f s" % (n, first, patch_edge, threads, dt)}
+    # ---- Dice(GPU argmax, CPU argmax) and max |dlogit| on the identical patch (metrics.py:106-121)
+    dl = [float((a - b).abs().max()) for a, b in zip(sample["logits"], keep["logits"])]
+    seg_g, seg_c = sample["logits"][0].argmax(1).numpy(), keep["logits"][0].argmax(1).numpy()
+    dices = [oracle.hard_dice(seg_g, seg_c, label) for label in range(K)]
+    parity = {"what": "engine vs the fp32 CPU oracle on the identical patch (B=1, 4 x %d^3), same weights, masks and targets" % patch_edge,
+              "max_abs_dlogit": max(dl), "max_abs_dlogit_per_head": dl, "dice_vs_cpu": min(dices), "dice_vs_cpu_per_label": dices,
+              "argmax_mismatch_voxels": int((seg_g != seg_c).sum()), "loss_gpu": sample["loss"], "loss_cpu": keep["loss"],
+              "loss_abs_diff": abs(sample["loss"] - keep["loss"]), "tolerance": "1e-4 logit / 1e-3 Dice (BASELINE.json north_star)"}
+    return base, parity
 
 
 def sliding_window_record(device):
@@ -257,6 +278,7 @@ def main():
     eng = net.engine(x)
     ds_w = np.array([8, 4, 2, 1, 0], dtype=np.float64) / 15.0
     overlap = None
+    sample = None
 
     def train_step():
         nonlocal overlap
@@ -393,12 +415,15 @@ def main():
                                   "what": "Masking.truncate_weights(): kernel L1 + exact k-th value + death on device, one packed D2H, "
                                           "growth draws on the host (Python random), masks and liveness tables re-expanded",
                                   "amortised_ms_per_step_at_update_frequency_1200": (time.perf_counter() - t0) / 3 * 1e3 / 1200}
+            sample = parity_sample(net, device, patch, ds_w) if not args.no_cpu_baseline else None
             del eng
             net._engines.clear()
             torch.cuda.empty_cache()
             out["sliding_window"] = sliding_window_record(device)
         if not args.no_cpu_baseline and world == 1:      # the CPU port is timed on rank 0 of the single-GPU run only
-            out["cpu_baseline"] = cpu_baseline(args.patch)
+            if sample is None:
+                sample = parity_sample(net, device, patch, ds_w)
+            out["cpu_baseline"], out["parity"] = cpu_baseline(sample, args.patch)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()

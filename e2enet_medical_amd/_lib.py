@@ -7,7 +7,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libe2e_hip.so")
+# E2E_LIB_PATH: A/B runs against a diagnostic build of the same sources (e.g. `make DEFS=-D... LIB=...`); still the HIP
+# library, still no fallback
+LIB_PATH = os.environ.get("E2E_LIB_PATH") or os.path.join(_HERE, "csrc", "libe2e_hip.so")
 
 
 class InChan(C.Structure):
@@ -120,7 +122,7 @@ class _Lib:
 _lib = None
 
 
-ABI_VERSION = 8          # e2e_abi_version() of the library this binding was written against
+ABI_VERSION = 9          # e2e_abi_version() of the library this binding was written against
 
 
 def lib() -> _Lib:

@@ -21,6 +21,7 @@
 #include "e2e_common.h"
 #include <cstdlib>
 #include <cstdio>
+#include <type_traits>
 
 // phase-split diagnostics (tools/kbench.py): build with -DE2E_CONV_DEBUG, then E2E_CONV_DBG=1|2|4 at run time
 #ifdef E2E_CONV_DEBUG
@@ -45,7 +46,7 @@ struct ConvParams {
   const float* bias;            // fwd only (may be null)
   const unsigned* live;         // quad words [ceil(Q/4)][ceil(P/8)], bit (p % 8) * 4 + q % 4, or null (dense)
   float* y;                     // fwd
-  float* part;                  // fwd, may be null
+  double* part;                 // fwd, may be null: per-tile (count, mean, M2) of the stored values, fp64
   const e2e_out_chan_t* outs;   // dgrad
   int P, Q;                     // input planes, output planes
   int wq_stride, wp_stride;     // element strides of the weight tensor for (q, p)
@@ -525,14 +526,19 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
     return m;
   };
 
-  // small tiles serve the deep levels, where a sum runs over up to 896 x 9 products: one sequential fp32 chain of that
-  // length is 3-6x noisier than the blocked summation of a CPU conv (measured against fp64, tools/scratch/conv_err.py).
-  // Two-level summation: the chunk's partial sum (CK x 9 terms) is flushed into an outer accumulator after every chunk;
-  // the extra registers are free here (4 or 16 accumulators per plane), the large 16x32 tile (Cin <= 160) keeps one level.
-#ifdef E2E_TWOLVL_ALL
-  constexpr bool TWOLVL = true;          // diagnostic build (tools/scratch/node_err.py): every tile shape, spills allowed
+  // Two-level summation.  One sequential fp32 FMA chain over up to 896 x 9 products is 2-6x noisier than the blocked
+  // summation of a CPU conv (measured against fp64, tools/scratch/conv_err.py), and the network amplifies that noise 3-5x per
+  // level: with single chains the logits of BASELINE configs 1 and 5 sat 2-4x further from an fp64 evaluation than the fp32
+  // CPU path does (profiles/r03_parity.json, "default" vs "twolvl_all").  Every tile shape therefore flushes the chunk's
+  // partial sum (CK x 9 terms) into an outer accumulator after each chunk: +32 VGPRs in the 16x32 tile (128, still four
+  // waves per SIMD), +1.7 % on the conv walk, +0.6 % on the 128^3 training step.  The small tiles of the deep levels (sums
+  // over 320..896 planes in front of InstanceNorms over 8..175 voxels) keep the outer accumulator in fp64: 4 or 16 values
+  // per wave, free in these latency-bound launches.  A single-chunk layer (PERSIST: Cin <= CK) has nothing to flush.
+  constexpr bool TWOLVL = (PERSIST == 0) || (C::PH * C::PW <= 4);
+#ifdef E2E_ACC2_F32
+  using acc2_t = float;
 #else
-  constexpr bool TWOLVL = (C::PH * C::PW <= 4);
+  using acc2_t = typename std::conditional<(C::PH * C::PW <= 4), double, float>::type;
 #endif
 
   // ================= the run of items =============================================================================
@@ -567,14 +573,14 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
       for (int i = 0; i < C::PH; ++i)
 #pragma unroll
         for (int j = 0; j < C::PW; ++j) acc[a][i][j] = 0.f;
-    float acc2[TWOLVL ? OPW : 1][TWOLVL ? C::PH : 1][TWOLVL ? C::PW : 1];
+    acc2_t acc2[TWOLVL ? OPW : 1][TWOLVL ? C::PH : 1][TWOLVL ? C::PW : 1];
     if constexpr (TWOLVL) {
 #pragma unroll
       for (int a = 0; a < OPW; ++a)
 #pragma unroll
         for (int i = 0; i < C::PH; ++i)
 #pragma unroll
-          for (int j = 0; j < C::PW; ++j) acc2[a][i][j] = 0.f;
+          for (int j = 0; j < C::PW; ++j) acc2[a][i][j] = (acc2_t)0;
     }
 
     // epilogue operands, requested before the main loop so that their (dependent) global loads are long done when the
@@ -683,7 +689,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
 #pragma unroll
           for (int i = 0; i < C::PH; ++i)
 #pragma unroll
-            for (int j = 0; j < C::PW; ++j) { acc2[a][i][j] += acc[a][i][j]; acc[a][i][j] = 0.f; }
+            for (int j = 0; j < C::PW; ++j) { acc2[a][i][j] += (acc2_t)acc[a][i][j]; acc[a][i][j] = 0.f; }
       }
       STAMP(t4);
       if (!CDBG(4)) __syncthreads();
@@ -697,7 +703,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
 #pragma unroll
         for (int i = 0; i < C::PH; ++i)
 #pragma unroll
-          for (int j = 0; j < C::PW; ++j) acc[a][i][j] = acc2[a][i][j];
+          for (int j = 0; j < C::PW; ++j) acc[a][i][j] = (float)acc2[a][i][j];
     }
 
     // ---------------- epilogue ------------------------------------------------------------------------------
@@ -820,38 +826,62 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
     }
     if (MODE == 0 && p.part != nullptr && !CDBG(32)) {
       // per-tile (count, mean, M2) partials of the 4 output planes: the count is known from the tile geometry, the four
-      // sums (and then the four M2) are reduced side by side so their cross-lane steps overlap
+      // sums (and then the four M2) are reduced side by side so their cross-lane steps overlap.  The record is fp64.  The
+      // small tiles (deep levels: InstanceNorms over 8..175 voxels) also FORM it in fp64: an fp32 rounding of a plane's mean
+      // is an error common to every voxel of the plane, which the 9 taps of the next conv add up linearly -- as large as the
+      // conv's own rounding noise there (tools/scratch/node_err.py: 1.3-1.4x the CPU path's noise at the 5x7x5 nodes).
       const int vr = p.Ho - h0 < TH ? p.Ho - h0 : TH, vc = p.Wo - w0 < TW ? p.Wo - w0 : TW;
       const float tcnt = (float)(vr * vc);
-      float mean[OPW], m2[OPW];
+      constexpr bool STAT64 = (C::PH * C::PW <= 4);
+      using st_t = typename std::conditional<STAT64, double, float>::type;
+      st_t mean[OPW], m2[OPW];
+      if constexpr (STAT64) {
 #pragma unroll
-      for (int a = 0; a < OPW; ++a) mean[a] = e2e::wave_sum_dpp(psum[a]) / tcnt;
+        for (int a = 0; a < OPW; ++a) {
+          double sd = 0.0;
+#pragma unroll
+          for (int i = 0; i < C::PH; ++i)
+#pragma unroll
+            for (int j = 0; j < C::PW; ++j)
+              if (oh0 + i < p.Ho && ow0 + j < p.Wo) sd += (double)acc[a][i][j];
+          mean[a] = sd;
+        }
+#pragma unroll
+        for (int a = 0; a < OPW; ++a) mean[a] = e2e::wave_sum_dpp_d(mean[a]) / (double)tcnt;
+      } else {
+#pragma unroll
+        for (int a = 0; a < OPW; ++a) mean[a] = e2e::wave_sum_dpp(psum[a]) / tcnt;
+      }
 #pragma unroll
       for (int a = 0; a < OPW; ++a) {
-        float t = 0.f;
+        st_t t = 0;
 #pragma unroll
         for (int i = 0; i < C::PH; ++i)
 #pragma unroll
           for (int j = 0; j < C::PW; ++j) {
             const int oh = oh0 + i, ow = ow0 + j;
             if (oh < p.Ho && ow < p.Wo) {
-              const float dlt = acc[a][i][j] - mean[a];
-              t = fmaf(dlt, dlt, t);
+              const st_t dlt = (st_t)acc[a][i][j] - mean[a];
+              if constexpr (STAT64) t = fma(dlt, dlt, t);
+              else t = fmaf(dlt, dlt, t);
             }
           }
         m2[a] = t;
       }
 #pragma unroll
-      for (int a = 0; a < OPW; ++a) m2[a] = e2e::wave_sum_dpp(m2[a]);
+      for (int a = 0; a < OPW; ++a) {
+        if constexpr (STAT64) m2[a] = e2e::wave_sum_dpp_d(m2[a]);
+        else m2[a] = e2e::wave_sum_dpp(m2[a]);
+      }
       if (lane < OPW && qbase + lane < p.Q) {
-        float mm = mean[0], vv = m2[0];
+        st_t mm = mean[0], vv = m2[0];
 #pragma unroll
         for (int a = 1; a < OPW; ++a)
           if (lane == a) { mm = mean[a]; vv = m2[a]; }
-        float* pp = p.part + (((long long)n * p.Q + qbase + lane) * p.tiles_per_n + tile_in_n) * 3;
-        pp[0] = tcnt;
-        pp[1] = mm;
-        pp[2] = vv;
+        double* pp = p.part + (((long long)n * p.Q + qbase + lane) * p.tiles_per_n + tile_in_n) * 3;
+        pp[0] = (double)tcnt;
+        pp[1] = (double)mm;
+        pp[2] = (double)vv;
       }
     }
     STAMP(t_end);
@@ -871,7 +901,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv133_kernel(ConvParams p) {
 // other (a chain of load and LDS latencies, 130-160 us for a few MFLOP) while most CUs have nothing to do.  Splitting the
 // chunks over ksplit workgroups shortens the chain; this kernel adds the parts up.  One wave per (n, q, tile).
 __global__ __launch_bounds__(64) void conv133_ksum_kernel(const float* __restrict__ kpart, const float* __restrict__ bias,
-                                                          float* __restrict__ y, float* __restrict__ part, int ksplit, int B,
+                                                          float* __restrict__ y, double* __restrict__ part, int ksplit, int B,
                                                           int Q, int Do, int Ho, int Wo, int TH, int TW, int tiles_x,
                                                           int tiles_y) {
   const int tiles_per_n = Do * tiles_y * tiles_x;
@@ -891,26 +921,27 @@ __global__ __launch_bounds__(64) void conv133_ksum_kernel(const float* __restric
   const float bq = bias ? bias[q] : 0.f;
   const int lane = threadIdx.x;
   const int npx = vr * vc;
-  float s = 0.f;
+  double s = 0.0;
   for (int i = lane; i < npx; i += 64) {
     const int r = i / vc, c = i - r * vc;
     const long long off = base + (long long)(h0 + r) * Wo + (w0 + c);
-    float v = bq;
-    for (int k = 0; k < ksplit; ++k) v += kpart[(long long)k * kstride + off];
+    double vs = 0.0;                    // (the parts are two-level sums themselves; their sum is formed in fp64)
+    for (int k = 0; k < ksplit; ++k) vs += (double)kpart[(long long)k * kstride + off];
+    const float v = (float)(vs + (double)bq);
     y[off] = v;
-    s += v;
+    s += (double)v;
   }
-  const float tcnt = (float)npx;
-  const float mean = e2e::wave_sum_dpp(s) / tcnt;
-  float m2 = 0.f;
+  const double tcnt = (double)npx;
+  const double mean = e2e::wave_sum_dpp_d(s) / tcnt;      // fp64 statistics: see the epilogue of conv133_kernel
+  double m2 = 0.0;
   for (int i = lane; i < npx; i += 64) {
     const int r = i / vc, c = i - r * vc;
-    const float dlt = y[base + (long long)(h0 + r) * Wo + (w0 + c)] - mean;     // (this lane's own store above)
-    m2 = fmaf(dlt, dlt, m2);
+    const double dlt = (double)y[base + (long long)(h0 + r) * Wo + (w0 + c)] - mean;     // (this lane's own store above)
+    m2 = fma(dlt, dlt, m2);
   }
-  m2 = e2e::wave_sum_dpp(m2);
+  m2 = e2e::wave_sum_dpp_d(m2);
   if (lane == 0 && part != nullptr) {
-    float* pp = part + (((long long)n * Q + q) * tiles_per_n + tile_in_n) * 3;
+    double* pp = part + (((long long)n * Q + q) * tiles_per_n + tile_in_n) * 3;
     pp[0] = tcnt;
     pp[1] = mean;
     pp[2] = m2;
@@ -957,7 +988,9 @@ __global__ __launch_bounds__(64) void conv133_dsum_kernel(const float* __restric
     const long long po = (long long)(h0 + r) * Wo + (w0 + c);
     float v = 0.f;
     if (!zero_fill) {
-      for (int k = 0; k < ksplit; ++k) v += kpart[(long long)k * kstride + src + po];
+      double vs = 0.0;
+      for (int k = 0; k < ksplit; ++k) vs += (double)kpart[(long long)k * kstride + src + po];
+      v = (float)vs;
       if (oc.accumulate) v += xp[po];
     }
     xp[po] = v;
@@ -1048,7 +1081,7 @@ int launch_cfg_impl(ConvParams p, hipStream_t st) {
   p.tiles_per_n = p.Do * p.tiles_y * p.tiles_x;
   p.groups = e2e::cdiv(p.Q, C::OCG);
   if (p.ksplit < 1 || PERSIST) p.ksplit = 1;
-  float* const part_out = p.part;
+  double* const part_out = p.part;
   if (p.ksplit > 1) p.part = nullptr;                 // raw partial sums: statistics come from conv133_ksum_kernel
   p.total = p.B * p.tiles_per_n * p.groups * p.ksplit;
   p.padded_total = (p.total + 7) & ~7;
@@ -1179,7 +1212,7 @@ extern "C" long long e2e_conv133_fwd_ws_bytes(int B, int Cin, int Cout, int Di, 
 }
 
 static int conv133_fwd_impl(const e2e_in_chan_t* chans, int Cin, const float* w, const float* bias, const unsigned* live, float* y,
-                            float* part, int B, int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw, float* ws,
+                            double* part, int B, int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw, float* ws,
                             long long ws_bytes, void* stream) {
   E2E_REQUIRE(chans && w && y, "conv133_fwd: null pointer");
   E2E_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Di > 0 && Hi > 0 && Wi > 0, "conv133_fwd: bad dims");
@@ -1217,13 +1250,13 @@ static int conv133_fwd_impl(const e2e_in_chan_t* chans, int Cin, const float* w,
 }
 
 extern "C" int e2e_conv133_fwd(const e2e_in_chan_t* chans, int Cin, const float* w, const float* bias,
-                               const unsigned* live, float* y, float* part, int B, int Cout, int Di, int Hi, int Wi,
+                               const unsigned* live, float* y, double* part, int B, int Cout, int Di, int Hi, int Wi,
                                int sd, int sh, int sw, void* stream) {
   return conv133_fwd_impl(chans, Cin, w, bias, live, y, part, B, Cout, Di, Hi, Wi, sd, sh, sw, nullptr, 0, stream);
 }
 
 extern "C" int e2e_conv133_fwd_splitk(const e2e_in_chan_t* chans, int Cin, const float* w, const float* bias,
-                                      const unsigned* live, float* y, float* part, int B, int Cout, int Di, int Hi, int Wi,
+                                      const unsigned* live, float* y, double* part, int B, int Cout, int Di, int Hi, int Wi,
                                       int sd, int sh, int sw, float* ws, long long ws_bytes, void* stream) {
   return conv133_fwd_impl(chans, Cin, w, bias, live, y, part, B, Cout, Di, Hi, Wi, sd, sh, sw, ws, ws_bytes, stream);
 }

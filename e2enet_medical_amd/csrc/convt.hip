@@ -57,6 +57,13 @@ __global__ __launch_bounds__(256) void convT_fwd_kernel(const float* __restrict_
     const int remain = Cin - wd * 32;
     if (remain < 32) bits &= (1u << remain) - 1u;
     bits = __builtin_amdgcn_readfirstlane(bits);
+    // two-level summation (as in conv133_kernel): the live planes of one 32-plane word form a partial sum that is flushed
+    // into the outer accumulator -- one fp32 chain over up to 320 planes is noisier than the CPU path's blocked sum
+    float part[VPL][KT];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+      for (int t = 0; t < KT; ++t) part[v][t] = 0.f;
     while (bits) {
       const int c = wd * 32 + __builtin_ctz(bits);
       bits &= bits - 1;
@@ -79,9 +86,13 @@ __global__ __launch_bounds__(256) void convT_fwd_kernel(const float* __restrict_
       for (int v = 0; v < VPL; ++v) {
         const float z = e2e::in_act(xv[v], a, b, sl);
 #pragma unroll
-        for (int t = 0; t < KT; ++t) acc[v][t] = fmaf(wt[t], z, acc[v][t]);
+        for (int t = 0; t < KT; ++t) part[v][t] = fmaf(wt[t], z, part[v][t]);
       }
     }
+#pragma unroll
+    for (int v = 0; v < VPL; ++v)
+#pragma unroll
+      for (int t = 0; t < KT; ++t) acc[v][t] += part[v][t];
   }
   const int Ho = H * kh, Wo = W * kw;
   float* yp = y + ((long long)n * Cout + o) * spatial * KT;

@@ -52,6 +52,29 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
   return v;
 }
 
+// the same for a double (two DPP moves per step); used where a sum must not carry an fp32 rounding that is coherent over
+// a whole plane (InstanceNorm statistics of the deep levels)
+__device__ __forceinline__ double dpp_move_d(double v, const int ctrl_sel) {
+  const long long b = __builtin_bit_cast(long long, v);
+  int lo = (int)b, hi = (int)(b >> 32);
+  switch (ctrl_sel) {
+    case 0: lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true); break;
+    case 1: lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true); break;
+    case 2: lo = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, true); break;
+    default: lo = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xF, 0xF, true); break;
+  }
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double wave_sum_dpp_d(double v) {
+  v += dpp_move_d(v, 0);
+  v += dpp_move_d(v, 1);
+  v += dpp_move_d(v, 2);
+  v += dpp_move_d(v, 3);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
 // full-wave (64 lane) sum, result valid in every lane
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -20,7 +20,7 @@ __device__ __forceinline__ Stat combine(const Stat a, const Stat b) {
   return r;
 }
 
-__global__ __launch_bounds__(256) void in_finalize_kernel(const float* __restrict__ part, int np,
+__global__ __launch_bounds__(256) void in_finalize_kernel(const double* __restrict__ part, int np,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps,
                                                           float* __restrict__ scale, float* __restrict__ shift,
@@ -28,10 +28,10 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const float* __restric
                                                           int C) {
   const int nc = blockIdx.x;
   const int c = nc % C;
-  const float* pp = part + (long long)nc * np * 3;
+  const double* pp = part + (long long)nc * np * 3;
   Stat s{0.0, 0.0, 0.0};
   for (int i = threadIdx.x; i < np; i += 256) {
-    Stat t{(double)pp[i * 3], (double)pp[i * 3 + 1], (double)pp[i * 3 + 2]};
+    Stat t{pp[i * 3], pp[i * 3 + 1], pp[i * 3 + 2]};
     s = combine(s, t);
   }
   __shared__ double sh[3][256];
@@ -196,7 +196,7 @@ __global__ void in_bwd_params_kernel(const double* __restrict__ sums, float* __r
 
 }  // namespace
 
-extern "C" int e2e_in_stats_finalize(const float* part, int np, const float* gamma, const float* beta, float eps,
+extern "C" int e2e_in_stats_finalize(const double* part, int np, const float* gamma, const float* beta, float eps,
                                      float* scale, float* shift, float* mean, float* rstd, int B, int C,
                                      void* stream) {
   E2E_REQUIRE(part && gamma && beta && scale && shift && mean && rstd, "in_stats_finalize: null pointer");

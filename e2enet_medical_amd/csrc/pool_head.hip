@@ -150,13 +150,21 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     float acc[KB];
 #pragma unroll
     for (int k = 0; k < KB; ++k) acc[k] = 0.f;
-    for (int c = 0; c < C; ++c) {
-      float a = 1.f, b = 0.f, sl = 1.f;
-      if (scale) { a = scale[(long long)n * C + c]; b = shift[(long long)n * C + c]; sl = slope; }
-      const float z = e2e::in_act(x[((long long)n * C + c) * spatial + v], a, b, sl);
+    for (int cb = 0; cb < C; cb += 16) {          // two-level summation: blocks of 16 channels (see conv133_kernel)
+      float part[KB];
 #pragma unroll
-      for (int k = 0; k < KB; ++k)
-        if (k0 + k < K) acc[k] = fmaf(w[(long long)(k0 + k) * C + c], z, acc[k]);
+      for (int k = 0; k < KB; ++k) part[k] = 0.f;
+      const int ce = cb + 16 < C ? cb + 16 : C;
+      for (int c = cb; c < ce; ++c) {
+        float a = 1.f, b = 0.f, sl = 1.f;
+        if (scale) { a = scale[(long long)n * C + c]; b = shift[(long long)n * C + c]; sl = slope; }
+        const float z = e2e::in_act(x[((long long)n * C + c) * spatial + v], a, b, sl);
+#pragma unroll
+        for (int k = 0; k < KB; ++k)
+          if (k0 + k < K) part[k] = fmaf(w[(long long)(k0 + k) * C + c], z, part[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < KB; ++k) acc[k] += part[k];
     }
 #pragma unroll
     for (int k = 0; k < KB; ++k)
@@ -248,20 +256,32 @@ __global__ __launch_bounds__(256) void head_fwd_v4_kernel(const float* __restric
     for (int k = 0; k < KB; ++k)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[k][j] = 0.f;
-#pragma unroll 8
-    for (int c = 0; c < C; ++c) {
-      float a = 1.f, b = 0.f, sl = 1.f;
-      if (scale) { a = scale[(long long)n * C + c]; b = shift[(long long)n * C + c]; sl = slope; }
-      const float4 q = *reinterpret_cast<const float4*>(x + ((long long)n * C + c) * spatial + v);
-      const float z[4] = {e2e::in_act(q.x, a, b, sl), e2e::in_act(q.y, a, b, sl), e2e::in_act(q.z, a, b, sl),
-                          e2e::in_act(q.w, a, b, sl)};
+    for (int cb = 0; cb < C; cb += 16) {          // two-level summation: blocks of 16 channels (see conv133_kernel)
+      float part[KB][4];
 #pragma unroll
       for (int k = 0; k < KB; ++k)
-        if (k0 + k < K) {
-          const float wk = w[(long long)(k0 + k) * C + c];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[k][j] = fmaf(wk, z[j], acc[k][j]);
-        }
+        for (int j = 0; j < 4; ++j) part[k][j] = 0.f;
+      const int ce = cb + 16 < C ? cb + 16 : C;
+#pragma unroll 8
+      for (int c = cb; c < ce; ++c) {
+        float a = 1.f, b = 0.f, sl = 1.f;
+        if (scale) { a = scale[(long long)n * C + c]; b = shift[(long long)n * C + c]; sl = slope; }
+        const float4 q = *reinterpret_cast<const float4*>(x + ((long long)n * C + c) * spatial + v);
+        const float z[4] = {e2e::in_act(q.x, a, b, sl), e2e::in_act(q.y, a, b, sl), e2e::in_act(q.z, a, b, sl),
+                            e2e::in_act(q.w, a, b, sl)};
+#pragma unroll
+        for (int k = 0; k < KB; ++k)
+          if (k0 + k < K) {
+            const float wk = w[(long long)(k0 + k) * C + c];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part[k][j] = fmaf(wk, z[j], part[k][j]);
+          }
+      }
+#pragma unroll
+      for (int k = 0; k < KB; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[k][j] += part[k][j];
     }
 #pragma unroll
     for (int k = 0; k < KB; ++k)

@@ -96,7 +96,7 @@ class ConvOp:
         self.out_dims = ((di - 1) // sd + 1, (hi - 1) // sh + 1, (wi - 1) // sw + 1)
         self.out = Act(prefix, (b, cout) + self.out_dims, True, eng.device)
         self.np = lib().conv133_num_partials(*self.out_dims, sh, sw)
-        self.part = torch.empty(b * cout * self.np * 3, dtype=torch.float32, device=eng.device)
+        self.part = torch.empty(b * cout * self.np * 3, dtype=torch.float64, device=eng.device)      # (count, mean, M2), fp64
         self.w_name = prefix + ".conv.weight"
         self.live = None        # quad words [ceil(Cout/4), ceil(Cin/8)] int32 (e2e_dsff_expand_quads)
         self.live_t = None      # quad words [ceil(Cin/4), ceil(Cout/8)] int32

@@ -230,7 +230,7 @@ class nnUNetTrainer_simple(object):
             self.initialize_network()
             self.initialize_optimizer_and_scheduler()
             if training and self.tr_gen is None:
-                scales = self.deep_supervision_scales[:4]
+                scales = self.deep_supervision_scales[:self._num_ds_outputs()]
                 dev = "cuda" if torch.cuda.is_available() else "cpu"
                 self.tr_gen = SyntheticGenerator(self.batch_size, self.num_input_channels, self.patch_size,
                                                  self.num_classes, scales, seed=0, device=dev)
@@ -285,6 +285,33 @@ class nnUNetTrainer_simple(object):
         force = os.environ.get("E2E_FORCE_DIST") == "1"
         return dist.get_world_size(self.process_group) > 1 or force, self.process_group
 
+    def _num_ds_outputs(self):
+        """deep-supervision outputs the network emits = targets the loss consumes (one per segmentation head; the
+        reference's plans give num_pool scales, of which the heads cover the first num_pool - 1, unetpp_d.py:394-401)"""
+        heads = getattr(self.network, "seg_outputs", None)
+        n = len(heads) if heads is not None else len(self.deep_supervision_scales)
+        assert self.ds_loss_weights is None or all(w == 0 for w in self.ds_loss_weights[n:]), \
+            "non-zero deep-supervision loss weight beyond the network's %d heads" % n
+        return min(n, len(self.deep_supervision_scales))
+
+    def _rank(self):
+        """(rank, world, group) of the data-parallel job; (0, 1, None) for a single process"""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return 0, 1, None
+        return dist.get_rank(self.process_group), dist.get_world_size(self.process_group), self.process_group
+
+    def _rank_mean(self, value):
+        """mean of a host scalar over the data-parallel ranks: epoch losses feed the moving averages and the patience
+        decision, which every rank must take identically (reference nnUNetTrainerV2_DDP keeps them on rank 0's view)"""
+        rank, world, group = self._rank()
+        if world == 1:
+            return float(value)
+        import torch.distributed as dist
+        t = torch.tensor([float(value)], dtype=torch.float64, device=next(self.network.parameters()).device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return float(t.item()) / world
+
     def _dp_for(self, eng, group):
         from ... import parallel
         dp = self._dp.get(id(eng))
@@ -312,7 +339,7 @@ class nnUNetTrainer_simple(object):
             # a generator that yields the full-resolution labels only: the deep-supervision scales are gathered on the
             # device (the reference's DownsampleSegForDSTransform2 step of the CPU augmentation pipeline, N3)
             from ..data_augmentation.downsampling import downsample_seg_for_ds_transform2
-            target = downsample_seg_for_ds_transform2(target[0], self.deep_supervision_scales[:4], order=0)
+            target = downsample_seg_for_ds_transform2(target[0], self.deep_supervision_scales[:self._num_ds_outputs()], order=0)
         if getattr(self.network, "conv_variant", "133") != "133":     # kernel-shape ablations run on axis-permuted tensors
             data = self.network.to_engine_layout(data)
             target = [self.network.to_engine_layout(t) for t in target]
@@ -496,12 +523,12 @@ class nnUNetTrainer_simple(object):
             epoch_start_time = time()
             self.network.train()
             train_losses_epoch = [self.run_iteration(self.tr_gen, True, mask=mask) for _ in range(self.num_batches_per_epoch)]
-            self.all_tr_losses.append(np.mean(train_losses_epoch))
+            self.all_tr_losses.append(self._rank_mean(np.mean(train_losses_epoch)))
             self.print_to_log_file("train loss : %.4f" % self.all_tr_losses[-1])
             with torch.no_grad():
                 self.network.eval()
                 val_losses = [self.run_iteration(self.val_gen, False, True) for _ in range(self.num_val_batches_per_epoch)]
-                self.all_val_losses.append(np.mean(val_losses))
+                self.all_val_losses.append(self._rank_mean(np.mean(val_losses)))
                 self.print_to_log_file("validation loss: %.4f" % self.all_val_losses[-1])
             self.update_train_loss_MA()
             continue_training = self.on_epoch_end()
@@ -513,13 +540,16 @@ class nnUNetTrainer_simple(object):
         if self.output_folder:
             if self.save_final_checkpoint:
                 self.save_checkpoint(join(self.output_folder, "%s_model_final_checkpoint.model" % self.Tconv), mask=mask)
-            for f in ("%s_model_latest.model" % self.Tconv, "%s_model_latest.model.pkl" % self.Tconv):
-                if isfile(join(self.output_folder, f)):          # identical with final (reference :1022-1025)
-                    os.remove(join(self.output_folder, f))
+            if self._rank()[0] == 0:
+                for f in ("%s_model_latest.model" % self.Tconv, "%s_model_latest.model.pkl" % self.Tconv):
+                    if isfile(join(self.output_folder, f)):          # identical with final (reference :1022-1025)
+                        os.remove(join(self.output_folder, f))
         self.network.do_ds = ds
 
     def print_to_log_file(self, *args, also_print_to_console=True, add_timestamp=True):
         """reference :1106-1138 (timestamped text log next to the checkpoints)."""
+        if self._rank()[0] != 0:                   # data parallel: one log, written by rank 0 (nnUNetTrainerV2_DDP.py: local_rank == 0)
+            return
         if self.output_folder and self.log_file is None:
             ts = datetime.now()
             self.log_file = join(self.output_folder, "training_log_%d_%d_%d_%02.0d_%02.0d_%02.0d.txt" %
@@ -541,6 +571,14 @@ class nnUNetTrainer_simple(object):
         carries 'dsff_state' (packed kernel maps, death-rate schedule position, growth RNG state); reference loaders
         ignore the extra key."""
         mask = mask if mask is not None else self._mask
+        rank, world, group = self._rank()
+        if world > 1:
+            # replicas hold identical weights, optimizer state and masks: rank 0 writes, the others wait until the file is
+            # complete (every rank writing the same path at once can leave a torn .model / .pkl)
+            import torch.distributed as dist
+            if rank != 0:
+                dist.barrier(group=group)
+                return
         state_dict = OrderedDict((k, v.cpu()) for k, v in self.network.state_dict().items())
         save_this = {'epoch': self.epoch + 1, 'state_dict': state_dict,
                      'optimizer_state_dict': self.optimizer.state_dict() if save_optimizer else None,
@@ -556,6 +594,8 @@ class nnUNetTrainer_simple(object):
         info['class'] = str(self.__class__)
         with open(fname + ".pkl", 'wb') as f:
             pickle.dump(info, f)
+        if world > 1:
+            dist.barrier(group=group)
 
     def load_best_checkpoint(self, train=True, mask=None):
         """reference :1178-1186"""

@@ -67,12 +67,12 @@ typedef struct {
  *   live    quad words [ceil(Cout/4), ceil(Cin/8)] (quads_rows of e2e_dsff_expand_quads): bit (c%8)*4 + o%4 of
  *           word [o/4][c/8] set <=> kernel (o,c) is alive; NULL => dense
  *   y       [B,Cout,Do,Ho,Wo] pre-norm output, Do=(Di-1)/sd+1, Ho=(Hi-1)/sh+1, ...
- *   part    [B,Cout,np,3] per-tile (count, mean, M2) partials, np =
+ *   part    [B,Cout,np,3] per-tile (count, mean, M2) partials, fp64 (ABI 9; fp32 before), np =
  *           e2e_conv133_num_partials(Do,Ho,Wo,sh,sw); NULL => no statistics
  */
 int e2e_conv133_num_partials(int Do, int Ho, int Wo, int sh, int sw);
 int e2e_conv133_fwd(const e2e_in_chan_t* chans, int Cin, const float* w, const float* bias,
-                    const unsigned* live, float* y, float* part, int B, int Cout, int Di, int Hi,
+                    const unsigned* live, float* y, double* part, int B, int Cout, int Di, int Hi,
                     int Wi, int sd, int sh, int sw, void* stream);
 
 /* Forward with a workspace: on the deep levels (planes no larger than a 16 x 16 tile, hundreds of input planes) the
@@ -82,7 +82,7 @@ int e2e_conv133_fwd(const e2e_in_chan_t* chans, int Cin, const float* w, const f
  * split and e2e_conv133_fwd_splitk behaves exactly like e2e_conv133_fwd).                                              */
 long long e2e_conv133_fwd_ws_bytes(int B, int Cin, int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw);
 int e2e_conv133_fwd_splitk(const e2e_in_chan_t* chans, int Cin, const float* w, const float* bias,
-                           const unsigned* live, float* y, float* part, int B, int Cout, int Di, int Hi, int Wi,
+                           const unsigned* live, float* y, double* part, int B, int Cout, int Di, int Hi, int Wi,
                            int sd, int sh, int sw, float* ws, long long ws_bytes, void* stream);
 
 
@@ -119,7 +119,7 @@ int e2e_conv133_wgrad(const e2e_in_chan_t* chans, const float* dy, float* dw, vo
  * combines the per-tile partials (Chan) in fp64 and emits per-(n,c)
  *   scale = gamma * rstd, shift = beta - mean * gamma * rstd   (consumed on load), mean, rstd.
  */
-int e2e_in_stats_finalize(const float* part, int np, const float* gamma, const float* beta, float eps,
+int e2e_in_stats_finalize(const double* part, int np, const float* gamma, const float* beta, float eps,
                           float* scale, float* shift, float* mean, float* rstd, int B, int C, void* stream);
 
 /* ---- K7: InstanceNorm + LeakyReLU backward -------------------------------------------

@@ -54,34 +54,44 @@ class KernelLog:
 
 # ------------------------------------------------------------------------------------------------ tolerances
 def _logit_bars(spec, params, x):
-    """The 1e-4 logit bar of BASELINE.json, anchored on exact arithmetic.  These nets normalise over as few as 175 (config
-    1) or 8 (config 5) voxels per channel and amplify rounding noise 3-5x per level: the reference's own fp32 CPU result
-    sits up to 2.6e-4 away from an fp64 evaluation of the same graph (tools/scratch/node_err.py), so
-    'within 1e-4 of the CPU path' is not defined better than that.  Returns (fp64 logits, per-output bars): the engine
-    must be in the noise class of the fp32 CPU path, i.e. its RMS distance from the fp64 logits at most 3x the CPU's (the
-    robust statistic; measured 0.7-2.2x over seeds, tools/scratch/hippo_noise.py) and its largest single deviation at most
-    max(1e-4, 5 x the CPU's largest) -- the maximum over 10^5 logits is a tail statistic (engine max / rms ~ 26, CPU ~ 13)
-    and moves by +-50 % with the summation order (3.7x was seen for one seed with the split-K forward, 2.7x without)."""
+    """The 1e-4 logit bar of BASELINE.json's north_star, anchored on an fp64 evaluation of the same graph.
+
+    Per output head, with c = the fp32 CPU oracle's own largest distance from fp64 (the oracle is bit-identical to the
+    reference on these configurations, tests/test_oracle_golden.py):
+      * heads 0-2 (full, 1/2, 1/4 resolution) where c <= 1e-4, i.e. where fp32 defines the logits that well:
+        engine within 1e-4 of fp64 (max norm), within 2e-4 of the reference golden, RMS distance <= 1.5x the CPU's;
+      * the 1/8 head, and any head whose CPU evaluation is itself further than 1e-4 from fp64 (InstanceNorms over 8..175
+        voxels amplify rounding noise 3-5x per level): same noise class as the CPU path -- max <= 2 c, RMS <= 2x the CPU's,
+        within 3 c of the golden.
+    Measured values of every quantity for this build: profiles/r03_parity.json (tools/parity_report.py).  Returns
+    (fp64 logits, bars)."""
     with torch.no_grad():
         ref32 = oracle.forward(spec, params, x)
         ref64 = oracle.forward(spec, {n: p.detach().double() for n, p in params.items()}, x.double())
-    bars = [_Bar(max(1e-4, 5.0 * (a.double() - b).abs().max().item()), 3.0 * (a.double() - b).pow(2).mean().sqrt().item())
-            for a, b in zip(ref32, ref64)]
+    bars = []
+    for i, (a, b) in enumerate(zip(ref32, ref64)):
+        d = (a.double() - b).abs()
+        c_max, c_rms = d.max().item(), d.pow(2).mean().sqrt().item()
+        if i < 3 and c_max <= 1e-4:
+            bars.append(_Bar(1e-4, 1.5 * c_rms, 2e-4))
+        else:
+            bars.append(_Bar(2.0 * c_max, 2.0 * c_rms, 3.0 * c_max))
     return ref64, bars
 
 
 class _Bar(float):
-    """max-norm bar (the float) that also carries the RMS bar; `check(got, ref64)` asserts both"""
+    """max-norm bar against fp64 (the float) that also carries the RMS bar and the bar against the reference golden"""
 
-    def __new__(cls, mx, rms):
+    def __new__(cls, mx, rms, gold):
         o = super().__new__(cls, mx)
-        o.rms = rms
+        o.rms, o.gold = rms, gold
         return o
 
     def check(self, got, ref64):
         d = (got.double() - ref64).abs()
-        assert d.pow(2).mean().sqrt().item() <= max(self.rms, 2e-6), "rms distance from fp64 %.3e > %.3e" % (d.pow(2).mean().sqrt().item(), self.rms)
-        assert d.max().item() <= float(self), "max distance from fp64 %.3e > %.3e" % (d.max().item(), float(self))
+        rms, mx = d.pow(2).mean().sqrt().item(), d.max().item()
+        assert rms <= self.rms, "rms distance from fp64 %.3e > %.3e" % (rms, self.rms)
+        assert mx <= float(self), "max distance from fp64 %.3e > %.3e" % (mx, float(self))
         return True
 
 
@@ -93,8 +103,9 @@ def _check_all_grads(eng, shapes, leaves, tol=2e-4, leaves64=None):
     the fp32 noise of u) that take either branch in any fp32 evaluation, and InstanceNorms over 8..175 voxels amplify
     that: the reference's own fp32 encoder gradients sit 3-17 % (relative L2) away from the fp64 gradients of the same
     graph, and which tensor a flipped element lands in is a matter of chance.  The engine must be in that noise class:
-      * relative L2 over ALL gradients together <= 8x, median per-tensor relative L2 <= 3x the fp32 oracle's (or `tol`);
-      * no single tensor further than 0.5 (relative L2) from fp64: a gross-error bound, single tensors are heavy-tailed;
+      * every tensor: relative L2 distance from fp64 <= 3x the fp32 oracle's WORST tensor (measured 0.55-1.4x);
+      * all gradients together: relative L2 <= 3x the fp32 oracle's (measured 0.3-1.2x);
+      * median per-tensor relative L2 <= 3x the fp32 oracle's median (measured 0.8-2.0x);
       * max norm per tensor <= max(tol x scale, 10 x the fp32 oracle's worst max-norm error relative to scale).
     A wrong tap, shift or mask is O(1) in relative L2; the operator tests at small sizes are exact to 2e-4."""
     if leaves64 is None:
@@ -115,28 +126,25 @@ def _check_all_grads(eng, shapes, leaves, tol=2e-4, leaves64=None):
         nrm = r64.norm().item()
         if nrm > 1e-6:                     # conv biases in front of an InstanceNorm have an exactly-zero gradient
             l2_gpu[n], l2_cpu[n] = (got - r64).norm().item() / nrm, (rg - r64).norm().item() / nrm
-    # (which tensor a flipped kink element lands in is chance, and an ulp anywhere upstream -- e.g. the order of the fp64
-    #  atomics of the loss sums -- moves the flips: rank-by-rank comparisons proved flaky, aggregates are not)
     import statistics
     names = list(l2_gpu.keys())
     num_g = sum((eng.grads[n].cpu().double() - leaves64[n].grad).pow(2).sum().item() for n in names)
     num_c = sum((leaves[n].grad.double() - leaves64[n].grad).pow(2).sum().item() for n in names)
     den = sum(leaves64[n].grad.pow(2).sum().item() for n in names)
     glob_g, glob_c = (num_g / den) ** 0.5, (num_c / den) ** 0.5
-    # measured over configs 1 / 5 and two summation orders of the deep levels (split-K forward on / off): global 0.65-5.2x
-    # (a single flipped kink element in a large tensor dominates this sum: it is the gross-error bound), median per
-    # tensor 1.1-1.9x (the robust statistic).  Forward noise is 1.5-2x the CPU's (sequential fp32 FMA chains of the
-    # 16x32-tile conv kernel), compounded through the kink flips of the backward pass.
     med_g, med_c = statistics.median(l2_gpu.values()), statistics.median(l2_cpu.values())
-    print("[grad noise] global rel-L2 engine %.4f cpu32 %.4f (x%.2f); median per tensor engine %.4f cpu32 %.4f (x%.2f)" % (glob_g, glob_c, glob_g / max(glob_c, 1e-12), med_g, med_c, med_g / max(med_c, 1e-12)))
-    assert glob_g <= max(tol, 8.0 * glob_c), ("global relative L2", glob_g, glob_c)
+    worst_c = max(l2_cpu.values())
+    n_worst = max(l2_gpu, key=l2_gpu.get)
+    print("[grad noise] global rel-L2 engine %.4f cpu32 %.4f (x%.2f); median per tensor engine %.4f cpu32 %.4f (x%.2f); worst tensor "
+          "engine %.4f (%s) cpu32 %.4f" % (glob_g, glob_c, glob_g / max(glob_c, 1e-12), med_g, med_c, med_g / max(med_c, 1e-12),
+                                          l2_gpu[n_worst], n_worst, worst_c))
+    assert glob_g <= max(tol, 3.0 * glob_c), ("global relative L2", glob_g, glob_c)
     assert med_g <= max(tol, 3.0 * med_c), ("median relative L2", med_g, med_c)
-    for n in names:                       # single tensors are heavy-tailed (one flipped element): gross-error bound only
-        assert l2_gpu[n] <= 0.5, (n, "relative L2", l2_gpu[n])
+    for n in names:
+        assert l2_gpu[n] <= max(tol, 3.0 * worst_c), (n, "relative L2", l2_gpu[n], "cpu32 worst tensor", worst_c)
     worst_cpu = max(mx_cpu.values())
     for n in shapes:
         assert mx_gpu[n] <= max(tol, 10.0 * worst_cpu), (n, "max norm", mx_gpu[n], worst_cpu)
-    n_worst = max(l2_gpu, key=l2_gpu.get)
     return l2_gpu[n_worst], n_worst
 
 
@@ -170,11 +178,11 @@ def test_config1_hippocampus_whole_net(B):
     loss = eng.loss_backward([t.cuda() for t in targets], w, batch_dice=False)
     ref64, bars = _logit_bars(spec, params, x)
     for o, r, bar in zip(outs, ref64, bars):
-        assert o.shape == r.shape and (o.cpu().double() - r).abs().max().item() <= bar
-    if B == 1:                                      # the reference itself (its fp32 noise is inside `bars`)
+        assert o.shape == r.shape and bar.check(o.cpu(), r)
+    if B == 1:                                      # the reference itself
         for i, o in enumerate(outs):
             od = o.cpu().numpy()
-            assert np.abs((od[:, :, ::2, ::2, ::2] if i == 0 else od) - g["b32_logits%d" % i]).max() <= bars[i] + bars[i] / 3
+            assert np.abs((od[:, :, ::2, ::2, ::2] if i == 0 else od) - g["b32_logits%d" % i]).max() <= bars[i].gold
         assert abs(loss.item() - float(g["loss"])) < 5e-5
         # (the reference's gradients are pinned to the oracle's by tests/test_oracle_golden.py; the engine's are checked
         #  against the oracle below, anchored on fp64)
@@ -198,7 +206,7 @@ def test_config1_hippocampus_width48_forward_and_predict():
     spec = oracle.make_spec(HIPPO["cin"], 48, HIPPO["k"], HIPPO["pools"])
     ref64, bars = _logit_bars(spec, params, x)
     assert bars[0].check(o.cpu(), ref64[0])
-    assert np.abs(o.cpu().numpy()[:, :, ::2, ::2, ::2] - g["b48_logits"]).max() <= bars[0] + bars[0] / 3
+    assert np.abs(o.cpu().numpy()[:, :, ::2, ::2, ::2] - g["b48_logits"]).max() <= bars[0].gold
     net.inference_apply_nonlin = lambda t: F.softmax(t, 1)
     vol = x[0].numpy()
     seg, probs = net.predict_3D(vol, do_mirroring=True, mirror_axes=(0, 1, 2), use_sliding_window=True, step_size=0.5,
@@ -246,10 +254,10 @@ def test_config5_amos_density_whole_net(dens):
     ref64, bars = _logit_bars(spec, masked_params, x)
     for o, r, bar in zip(outs, ref64, bars):
         assert bar.check(o.cpu(), r)
-    # --- the reference itself (its fp32 noise is inside `bars`)
+    # --- the reference itself
     assert abs(loss.item() - float(g[tag + "_loss"])) < 5e-5
-    assert np.abs(outs[0].cpu().numpy()[0, :, 31, ::2, ::2] - g[tag + "_slice_d31"]).max() <= bars[0] + bars[0] / 3
-    assert np.abs(outs[3].cpu().numpy() - g[tag + "_logits3"]).max() <= bars[3] + bars[3] / 3
+    assert np.abs(outs[0].cpu().numpy()[0, :, 31, ::2, ::2] - g[tag + "_slice_d31"]).max() <= bars[0].gold
+    assert np.abs(outs[3].cpu().numpy() - g[tag + "_logits3"]).max() <= bars[3].gold
     for i, o in enumerate(outs):
         assert abs(o.double().abs().sum().item() - float(g[tag + "_abs%d" % i])) <= 2e-5 * float(g[tag + "_abs%d" % i])
     # --- the oracle in fp32 and fp64: loss and all gradients (dead kernels included: dense weight gradient)

@@ -699,6 +699,35 @@ def test_full_size_128_training_properties():
     assert losses[-1] < losses[0] - 0.02, losses
 
 
+def test_whole_net_128_vs_oracle():
+    """BASELINE config 2 at the benchmarked size against the CPU oracle (reference: unetpp_d.py:447-488 at 128^3): B = 1,
+    the benchmark's network (He init under torch.manual_seed(0), DSFF masks at density 0.2 under random.seed(0)), its input
+    and targets: all four logit heads within 1e-4 of the fp32 oracle, loss within 5e-5, Dice of the argmax maps >= 1 - 1e-3
+    (metrics.py:106-121).  One oracle forward + loss at this size takes ~10-20 s on the host."""
+    import bench
+    net, opt, mask, fused = bench.build(torch.device("cuda"))
+    x, targets = bench.synthetic_batch(torch.device("cuda"), bench.PATCH, 1, seed=100)
+    eng = net.engine(x)
+    outs = eng.forward(x, True)
+    w = oracle.ds_weights(5)
+    loss = eng.loss_backward(targets, w, batch_dice=False)
+    spec = oracle.make_spec(bench.CIN, bench.BASE, bench.K, bench.POOLS)
+    params = {n: p.detach().cpu().clone() for n, p in net.named_parameters()}
+    for n, m in mask.masks.items():                 # the weights the engine ran with are the masked ones
+        assert float((params[n] * (1 - m.cpu())).abs().max()) == 0.0
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), 16)))
+    with torch.no_grad():
+        ref = oracle.forward(spec, params, x.cpu())
+        ref_loss = oracle.deep_supervision_loss(ref, [t.cpu() for t in targets], w, False)
+    for i, (o, r) in enumerate(zip(outs, ref)):
+        err = (o.cpu() - r).abs().max().item()
+        assert o.shape == r.shape and err <= 1e-4, "head %d: max|dlogit| %.3e" % (i, err)
+    assert abs(loss.item() - ref_loss.item()) <= 5e-5
+    seg, rseg = outs[0].argmax(1).cpu().numpy(), ref[0].argmax(1).numpy()
+    for label in range(1, bench.K):
+        assert oracle.hard_dice(seg, rseg, label) >= 1 - 1e-3
+
+
 @pytest.mark.parametrize("mode", ["explicit", "loss"])
 def test_engine_forward_and_backward_are_graph_capturable(mode):
     """include/e2e_hip.h promises asynchronous, allocation-free, graph-capturable entry points: capture a whole forward

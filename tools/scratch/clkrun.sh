@@ -1,6 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-tools/scratch/walk_bench 2>&1 | tail -16
+hipcc --offload-arch=gfx950 -O3 -o tools/scratch/walk_bench tools/scratch/walk_bench.hip && tools/scratch/walk_bench 2>&1 | tail -16
 echo "== rocm-smi idle"; rocm-smi --showclocks --showpower 2>&1 | grep -i "sclk\|power\|mclk" | head -6
 echo "== conv kernel loop"
 (timeout 60 python tools/scratch/loop_conv.py > gpurun_out/loop.log 2>&1 &)
