@@ -1127,6 +1127,14 @@ inline int plan_v3(WgParams& p, int pairs) {
   return segs * p.B;
 }
 
+// bf3 (conv133_wgrad_bf3.hip: bf16 matrix pipe, fp32-exact three-piece operands): the shapes v3 serves; E2E_WG_BF3=0 keeps
+// the fp32-MFMA kernels (A/B runs).  32 x 32 channel blocks, chunks planned like v3's.
+inline bool use_bf3(int Cin, int Hi, int Wi, int sh, int sw) {
+  static const int on = getenv("E2E_WG_BF3") ? atoi(getenv("E2E_WG_BF3")) : 1;
+  return on && Cin > 4 && use_v3(Cin, Hi, Wi, sh, sw);
+}
+inline int bf3_pairs(int Cin, int Cout) { return e2e::cdiv(Cin, 32) * e2e::cdiv(Cout, 32); }
+
 // network input layer (Cin <= 4): stride 1, rows multiples of 4 floats, planes at least one 8 x 32 tile
 inline bool use_smallc(int Cin, int Hi, int Wi, int sh, int sw) {
   static const int off = getenv("E2E_WG_NOSMALLC") ? atoi(getenv("E2E_WG_NOSMALLC")) : 0;
@@ -1185,6 +1193,8 @@ extern "C" long long e2e_conv133_wgrad_ws_bytes(int B, int Cin, int Cout, int Di
     nchunks = s2_chunks(p.total_tiles, pairs, &p.tiles_per_chunk);
   } else if (use_smallc(Cin, Hi, Wi, sh, sw)) {
     nchunks = 2 * plan_smallc(p, e2e::cdiv(Cout, 32));
+  } else if (use_bf3(Cin, Hi, Wi, sh, sw)) {
+    nchunks = plan_v3(p, bf3_pairs(Cin, Cout));
   } else if (use_v3(Cin, Hi, Wi, sh, sw)) {
     nchunks = plan_v3(p, v3_pairs(Cin, Cout)) * (v3_ksplit(Cin, Cout) ? 2 : 1);
   } else if (use_v2(Hi, Wi, sh, sw)) {
@@ -1235,6 +1245,21 @@ extern "C" int e2e_conv133_wgrad(const e2e_in_chan_t* chans, const float* dy, fl
     e2e::note_kernel("conv133_wgrad_smallc chunks=%d pairs=%d", wgs, pairs);
     hipLaunchKernelGGL(conv133_wgrad_smallc_kernel, dim3(wgs, pairs), dim3(256), 0, st, p);
     rc = e2e::check_launch("conv133_wgrad_smallc_kernel");
+    if (rc != E2E_OK) return rc;
+    hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)e2e::cdivll(numel, 64)), dim3(256), 0, st, p.slab, dw, numel,
+                       nchunks);
+    return e2e::check_launch("wgrad_slab_reduce_kernel");
+  }
+  if (use_bf3(Cin, Hi, Wi, sh, sw)) {
+    const int pairs = bf3_pairs(Cin, Cout);
+    nchunks = plan_v3(p, pairs);
+    e2e::WgBf3Params q{};
+    q.chans = chans; q.dy = dy; q.slab = p.slab;
+    q.B = B; q.Cin = Cin; q.Cout = Cout; q.Di = Di; q.Hi = Hi; q.Wi = Wi; q.Do = p.Do; q.sd = sd;
+    q.tiles_x = p.tiles_x; q.tiles_y = p.tiles_y; q.tiles_per_n = p.tiles_per_n; q.tiles_per_chunk = p.tiles_per_chunk;
+    q.segs = p.cblocks_segs; q.cblocks = e2e::cdiv(Cin, 32);
+    e2e::note_kernel("conv133_wgrad_bf3 chunks=%d pairs=%d", nchunks, pairs);
+    rc = e2e::launch_wgrad_bf3(q, nchunks, pairs, st);
     if (rc != E2E_OK) return rc;
     hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)e2e::cdivll(numel, 64)), dim3(256), 0, st, p.slab, dw, numel,
                        nchunks);

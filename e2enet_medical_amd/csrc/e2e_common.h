@@ -110,4 +110,17 @@ inline void zero_async(void* p, size_t bytes, hipStream_t st) {
   hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (unsigned*)p, n);
 }
 
+// conv133_wgrad_bf3.hip: dense weight gradient on the bf16 matrix pipe with fp32-exact (three-piece) operands; planned and
+// dispatched by e2e_conv133_wgrad (conv133_wgrad.hip)
+struct WgBf3Params {
+  const e2e_in_chan_t* chans;
+  const float* dy;
+  float* slab;                 // [chunks][Cout][Cin][9]
+  int B, Cin, Cout, Di, Hi, Wi, Do, sd;
+  int tiles_x, tiles_y, tiles_per_n, tiles_per_chunk;
+  int segs;                    // chunks per batch item
+  int cblocks;                 // ceil(Cin / 32)
+};
+int launch_wgrad_bf3(const WgBf3Params& p, int nchunks, int pairs, hipStream_t st);
+
 }  // namespace e2e

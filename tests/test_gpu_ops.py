@@ -468,6 +468,21 @@ def test_conv133_persistent_run_loop_forced():
     assert "passed" in r.stdout
 
 
+def test_conv133_wgrad_fp32_mfma_path_forced():
+    """The dense weight gradient of large stride-1 planes runs on the bf16 matrix pipe with three-piece fp32 operands
+    (conv133_wgrad_bf3_kernel); E2E_WG_BF3=0 selects the fp32-MFMA kernels (v3) it replaced, which stay in the library for
+    A/B runs.  The knob is read once per process: run the operator cases again in a child process."""
+    import subprocess
+    import sys
+    env = dict(os.environ, E2E_WG_BF3="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                        "test_conv133_fwd_bwd", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=900,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "passed" in r.stdout
+
+
 @pytest.mark.parametrize("shape", [(2, 1, 16, 32, 32), (1, 1, 40, 56, 40), (2, 2, 7, 9, 13)])
 def test_ds_target_gather_vs_oracle(shape):
     """Deep-supervision targets gathered on the device against the oracle (scipy's zoom, order 0): bit exact."""

@@ -12,7 +12,8 @@ torch.set_num_threads(16)
 CASES = [(1, [(896, True)], 320, (5, 7, 5), (1, 1, 1)), (1, [(320, True), (320, False), (256, False)], 320, (8, 8, 8), (1, 1, 1)),
          (1, [(160, True)], 64, (20, 28, 20), (1, 1, 1)), (1, [(64, True)], 32, (40, 56, 40), (1, 1, 1)), (1, [(64, True)], 32, (64, 64, 64), (1, 1, 1)),
          (1, [(128, True)], 256, (10, 14, 10), (2, 2, 2)), (1, [(256, True)], 256, (5, 7, 5), (1, 1, 1)), (1, [(64, True)], 128, (20, 28, 20), (2, 2, 2)),
-         (1, [(256, True)], 320, (5, 7, 5), (1, 1, 1))]
+         (1, [(256, True)], 320, (5, 7, 5), (1, 1, 1)), (1, [(320, True)], 320, (4, 4, 4), (2, 2, 2)), (1, [(320, True)], 320, (2, 2, 2), (1, 1, 1)),
+         (1, [(320, True), (320, False), (256, False)], 320, (4, 4, 4), (1, 1, 1))]
 for (B, src_desc, cout, dims, stride) in CASES:
     srcs = [T._make_act((B, c) + dims, normed, 10 + i) for i, (c, normed) in enumerate(src_desc)]
     cin = sum(c for c, _ in src_desc)
