@@ -398,6 +398,8 @@ def main():
                     launches.append((round(ms, 3), k, ints[:12]))
             launches.sort(key=lambda v: -v[0])
             out["top_launches"] = launches[:40]
+            if os.environ.get("E2E_BENCH_ALL_LAUNCHES"):
+                out["all_launches"] = launches
         if world == 1 and not args.no_extras and not args.forward_only:
             for _ in range(2):
                 fwd_step()

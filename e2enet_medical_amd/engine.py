@@ -304,8 +304,11 @@ class NetConfig:
     unetpp_d.py:227-445)."""
 
     def __init__(self, in_channels, base_features, num_classes, pool_kernels, convs_per_stage=2, max_features=320,
-                 shift_size=5):
-        if len(pool_kernels) != 5:
+                 shift_size=5, graph="unetpp"):
+        if graph not in ("unetpp", "unet"):
+            raise ValueError("graph must be 'unetpp' (unetpp_d.py) or 'unet' (unetpp_d_nodff.py)")
+        self.graph = graph
+        if graph == "unetpp" and len(pool_kernels) != 5:
             # reference forward() indexes six levels literally (unetpp_d.py:451-483)
             raise ValueError("shiftConvPP needs exactly 5 pooling stages, got %d" % len(pool_kernels))
         self.in_channels, self.base_features, self.num_classes = in_channels, base_features, num_classes
@@ -315,7 +318,7 @@ class NetConfig:
             raise ValueError("shift_size must be odd and >= 1 (reference unetpp_d.py:89 uses 5; 1 disables the shift)")
         self.shift_size = shift_size      # groups of the restricted depth shift (3/7/11, 1 = 'noshift')
         feats, f = [], base_features
-        for _ in range(6):
+        for _ in range(len(pool_kernels) + 1):
             feats.append(min(f, max_features))
             f = min(int(round(f * 2)), max_features)
         self.feats = feats
@@ -333,6 +336,12 @@ class NetConfig:
         if z != 0:
             return ["loc%d.%d.0.blocks.%d" % (z, m, b) for b in range(n - 1)]
         return ["loc0.%d.0.blocks.%d" % (m, b) for b in range(n - 1)] + ["loc0.%d.1.blocks.0" % m]
+
+    def unet_loc_prefixes(self, u):
+        """unetpp_d_nodff.py:303-311: conv_blocks_localization[u] = Sequential(Stacked(2 skip -> skip, n - 1), Stacked(skip -> skip, 1))"""
+        n = self.convs_per_stage
+        return (["conv_blocks_localization.%d.0.blocks.%d" % (u, b) for b in range(n - 1)] +
+                ["conv_blocks_localization.%d.1.blocks.0" % u])
 
     def encoder_prefixes(self, stage):
         n = self.convs_per_stage
@@ -356,6 +365,26 @@ class Engine:
         self.up_ops: Dict[str, UpOp] = {}
         self.input = Act("input", (batch, cfg.in_channels) + self.patch, False, device)
         self.input.needs_grad = False
+        self.heads: List[HeadOp] = []
+        if cfg.graph == "unet":
+            self._build_unet(cfg)
+        else:
+            self._build_unetpp(cfg)
+        self.grads: Dict[str, torch.Tensor] = {}
+        self.grad_bucket_hook = None       # callable(lo, hi): flat gradient slice [lo, hi) is final (data-parallel overlap)
+        self.batch_dice_hook = None        # callable(fp64 tensor [K*3]): all-reduce of the folded tp/fp/fn (data-parallel batch dice)
+        self._backward_ready = False
+        self.loss_ws = None
+        self.loss_val = None
+        self.generation = 0                # bumped by every forward(): activations are reused in place
+        fws = max([max(op.fwd_ws_bytes, op.dgrad_ws_bytes if op.do_dgrad else 0) for op in self.conv_ops.values()] + [0])
+        self.fwd_ws = torch.empty(fws // 4, dtype=torch.float32, device=self.device) if fws > 0 else None   # split-K partial sums (deep levels)
+        self.pre_forward_hook = None       # callable(): set by the owning network, brings masks / parameters up to date
+        self._eval_counts = None
+
+    def _build_unetpp(self, cfg):
+        """reference Generic_UNetPlusPlus.forward (unetpp_d.py:447-488) and create_nest (:491-550)"""
+        P = cfg.num_pool
         nodes = {}
         cur = self.input
         for st in range(P + 1):
@@ -383,22 +412,40 @@ class Engine:
                     t = op.out
                 nodes[(lvl, j)] = t
         self.nodes = nodes
-        self.heads: List[HeadOp] = []
         for h in range(4):
             head = HeadOp(self, "seg_outputs.%d.weight" % h, nodes[(h, P - h)], cfg.num_classes)
             self.heads.append(head)
             self.ops.append(head)
-        self.grads: Dict[str, torch.Tensor] = {}
-        self.grad_bucket_hook = None       # callable(lo, hi): flat gradient slice [lo, hi) is final (data-parallel overlap)
-        self.batch_dice_hook = None        # callable(fp64 tensor [K*3]): all-reduce of the folded tp/fp/fn (data-parallel batch dice)
-        self._backward_ready = False
-        self.loss_ws = None
-        self.loss_val = None
-        self.generation = 0                # bumped by every forward(): activations are reused in place
-        fws = max([max(op.fwd_ws_bytes, op.dgrad_ws_bytes if op.do_dgrad else 0) for op in self.conv_ops.values()] + [0])
-        self.fwd_ws = torch.empty(fws // 4, dtype=torch.float32, device=self.device) if fws > 0 else None   # split-K partial sums (deep levels)
-        self.pre_forward_hook = None       # callable(): set by the owning network, brings masks / parameters up to date
-        self._eval_counts = None
+
+    def _build_unet(self, cfg):
+        """The 'shiftConvPP_nodff' ablation (reference unetpp_d_nodff.py:356-378): encoder with strided first convs, then per
+        level ConvTranspose3d, cat((up, skip)), two conv blocks, a 1x1x1 head; heads ordered [full res, 1/2, ..., lowest]."""
+        P = cfg.num_pool
+        skips, cur = [], self.input
+        for st in range(P + 1):
+            stride = (1, 1, 1) if st == 0 else cfg.pool_kernels[st - 1]
+            for bi, prefix in enumerate(cfg.encoder_prefixes(st)):
+                op = self._add_conv(prefix, [cur], cfg.feats[st], stride if bi == 0 else (1, 1, 1))
+                cur = op.out
+            if st < P:
+                skips.append(cur)
+        self.nodes = {(st, 0): a for st, a in enumerate(skips)}
+        by_u = []
+        for u in range(P):
+            lvl = P - 1 - u
+            up = UpOp(self, "tu.%d.weight" % u, cur, cfg.feats[lvl], cfg.pool_kernels[lvl])
+            self.ops.append(up)
+            self.up_ops[up.w_name] = up
+            t = None
+            for prefix in cfg.unet_loc_prefixes(u):
+                op = self._add_conv(prefix, [up.out, skips[lvl]] if t is None else [t], cfg.feats[lvl], (1, 1, 1))
+                t = op.out
+            cur = t
+            self.nodes[(lvl, 1)] = t
+            head = HeadOp(self, "seg_outputs.%d.weight" % u, t, cfg.num_classes)
+            self.ops.append(head)
+            by_u.append(head)
+        self.heads = [by_u[-1]] + by_u[:-1][::-1]
 
     def _add_conv(self, prefix, sources, cout, stride):
         op = ConvOp(self, prefix, sources, cout, stride)

@@ -121,7 +121,7 @@ class _EngineFunction(torch.autograd.Function):
             raise RuntimeError("Generic_UNetPlusPlus: backward() after another forward() through the same network: the "
                                "engine reuses its activation buffers in place; call backward() before the next forward "
                                "(gradient accumulation over several forwards is not supported)")
-        dl = list(grad_outputs) + [None] * (4 - len(grad_outputs))
+        dl = list(grad_outputs) + [None] * (len(eng.heads) - len(grad_outputs))
         dl = [g.contiguous() if g is not None else None for g in dl]
         grads = eng.backward(dl)
         names = ctx.net._param_names

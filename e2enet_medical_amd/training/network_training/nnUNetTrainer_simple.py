@@ -242,8 +242,9 @@ class nnUNetTrainer_simple(object):
 
     def initialize_network(self):
         """reference :292-301 (Tconv == 'shiftConvPP') and its kernel-shape ablations 'shiftConvPP_313' / 'shiftConvPP_331'
-        (:303-323, same constructor arguments) and 'shiftConvPP_noshift' (:337-346: the (1,3,3) network without the shift);
-        the other Tconv values ('shiftConvPP_nodff', the non-nested baselines) are different graphs outside this engine."""
+        (:303-323, same constructor arguments), 'shiftConvPP_noshift' (:337-346: the (1,3,3) network without the shift) and
+        'shiftConvPP_nodff' (:326-335: the plain U-Net wiring of the same blocks); the remaining Tconv values are other
+        architectures outside this engine."""
         extra = {}
         if self.Tconv == 'shiftConvPP':
             net_cls = Generic_UNetPlusPlus
@@ -253,9 +254,11 @@ class nnUNetTrainer_simple(object):
             from ...network_architecture.unetpp_d_331 import Generic_UNetPlusPlus as net_cls
         elif self.Tconv == 'shiftConvPP_noshift':
             net_cls, extra = Generic_UNetPlusPlus, {"shift_size": 1}
+        elif self.Tconv == 'shiftConvPP_nodff':
+            from ...network_architecture.unetpp_d_nodff import Generic_UNetPlusPlus as net_cls
         else:
-            raise NotImplementedError("the MI355X engine implements Tconv='shiftConvPP' and its ablations "
-                                      "'shiftConvPP_313', 'shiftConvPP_331', 'shiftConvPP_noshift' (got %r)" % (self.Tconv,))
+            raise NotImplementedError("the MI355X engine implements Tconv='shiftConvPP' and its ablations 'shiftConvPP_313', "
+                                      "'shiftConvPP_331', 'shiftConvPP_noshift', 'shiftConvPP_nodff' (got %r)" % (self.Tconv,))
         base = 48 if self.base_num_features_override is None else self.base_num_features_override
         self.network = net_cls(self.patch_size, self.num_input_channels, base, self.num_classes,
                                             len(self.net_num_pool_op_kernel_sizes), self.conv_per_stage, 2, nn.Conv3d,

@@ -31,6 +31,7 @@ class NetSpec:
     shift_size: int = 5          # reference hard-sets 5 (unetpp_d.py:89; the comment there lists 3/7/11); 1 = 'noshift' ablation
     conv_variant: str = "133"    # "313" / "331": the ablation networks unetpp_d_313.py / unetpp_d_331.py (kernel (3,1,3) /
                                  # (3,3,1), padding on the axes of size 3, and NO shift: their forward has `and False`, :102)
+    graph: str = "unetpp"        # "unet": the 'shiftConvPP_nodff' ablation, unetpp_d_nodff.py (plain U-Net wiring, no nests)
 
     @property
     def num_pool(self):
@@ -41,13 +42,15 @@ CONV_KERNELS = {"133": (1, 3, 3), "313": (3, 1, 3), "331": (3, 3, 1)}
 
 
 def make_spec(in_channels, base_features, num_classes, pool_kernels=None, convs_per_stage=2,
-              max_features=320, shift_size=5, conv_variant="133") -> NetSpec:
+              max_features=320, shift_size=5, conv_variant="133", graph="unetpp") -> NetSpec:
     if conv_variant not in CONV_KERNELS:
         raise ValueError("conv_variant must be one of %s" % sorted(CONV_KERNELS))
     if pool_kernels is None:
         pool_kernels = [(2, 2, 2)] * 5
     pool_kernels = [tuple(int(v) for v in k) for k in pool_kernels]
-    if len(pool_kernels) != 5:
+    if graph not in ("unetpp", "unet"):
+        raise ValueError("graph must be 'unetpp' or 'unet'")
+    if graph == "unetpp" and len(pool_kernels) != 5:
         # reference forward() indexes 6 levels literally (unetpp_d.py:451-483)
         raise ValueError("shiftConvPP needs exactly 5 pooling stages")
     feats = []
@@ -57,7 +60,7 @@ def make_spec(in_channels, base_features, num_classes, pool_kernels=None, convs_
         f = int(round(f * 2))
         f = min(f, max_features)
     return NetSpec(in_channels, base_features, num_classes, pool_kernels, convs_per_stage,
-                   max_features, feats, shift_size, conv_variant)
+                   max_features, feats, shift_size, conv_variant, graph)
 
 
 # --------------------------------------------------------------------------- naming
@@ -94,11 +97,41 @@ def concat_channels(spec: NetSpec, level: int) -> int:
     return 2 * f[level] + (f[level - 1] if level > 0 else 0)
 
 
+def unet_loc_prefixes(spec: NetSpec, u: int):
+    """unetpp_d_nodff.py:303-311: conv_blocks_localization[u] = Sequential(Stacked(2 skip -> skip, n - 1), Stacked(skip -> skip, 1))"""
+    n = spec.convs_per_stage
+    return (["conv_blocks_localization.%d.0.blocks.%d" % (u, b) for b in range(n - 1)] +
+            ["conv_blocks_localization.%d.1.blocks.0" % u])
+
+
 def param_shapes(spec: NetSpec) -> "Dict[str, Tuple[int, ...]]":
     """Ordered like the reference's named_parameters(): loc0..4, conv_blocks_context,
-    up0..4, seg_outputs (module registration order, unetpp_d.py:418-438)."""
+    up0..4, seg_outputs (module registration order, unetpp_d.py:418-438); for graph 'unet'
+    conv_blocks_context, conv_blocks_localization, tu, seg_outputs (unetpp_d_nodff.py:238-242)."""
     f = spec.feats
     shapes: Dict[str, Tuple[int, ...]] = {}
+    if spec.graph == "unet":
+        P = spec.num_pool
+
+        def add(prefix, cin, cout):
+            shapes[prefix + ".conv.weight"] = (cout, cin) + CONV_KERNELS[spec.conv_variant]
+            shapes[prefix + ".conv.bias"] = (cout,)
+            shapes[prefix + ".instnorm.weight"] = (cout,)
+            shapes[prefix + ".instnorm.bias"] = (cout,)
+        for st in range(P + 1):
+            cin = spec.in_channels if st == 0 else f[st - 1]
+            for bi, p in enumerate(encoder_block_prefixes(spec, st)):
+                add(p, cin if bi == 0 else f[st], f[st])
+        for u in range(P):
+            lvl = P - 1 - u
+            for bi, p in enumerate(unet_loc_prefixes(spec, u)):
+                add(p, 2 * f[lvl] if bi == 0 else f[lvl], f[lvl])
+        for u in range(P):
+            lvl = P - 1 - u
+            shapes["tu.%d.weight" % u] = (f[lvl + 1], f[lvl]) + tuple(spec.pool_kernels[lvl])
+        for u in range(P):
+            shapes["seg_outputs.%d.weight" % u] = (spec.num_classes, f[P - 1 - u], 1, 1, 1)
+        return shapes
 
     def add_block(prefix, cin, cout):
         shapes[prefix + ".conv.weight"] = (cout, cin) + CONV_KERNELS[spec.conv_variant]
@@ -140,7 +173,7 @@ def init_params(spec: NetSpec, seed: int = 0, dtype=torch.float32) -> "Dict[str,
     g = torch.Generator().manual_seed(seed)
     params = {}
     for name, shp in param_shapes(spec).items():
-        if name.endswith("conv.weight") or name.startswith("up") or name.startswith("seg_outputs"):
+        if name.endswith("conv.weight") or name.startswith("up") or name.startswith("tu.") or name.startswith("seg_outputs"):
             # kaiming_normal_: fan_in = size(1) * receptive field
             fan_in = shp[1] * int(math.prod(shp[2:]))
             gain = math.sqrt(2.0 / (1 + 0.01 ** 2))
@@ -173,8 +206,31 @@ def _run_blocks(params, prefixes, x, first_stride=(1, 1, 1), shift_size=5):
     return x
 
 
+def forward_unet(spec: NetSpec, params, x, do_ds=True):
+    """unetpp_d_nodff.py:356-378: encoder with strided first convs, then per level transposed conv, cat((up, skip)), two conv
+    blocks and a 1x1x1 head; outputs [full res, 1/2, ..., lowest] = num_pool tensors."""
+    P = spec.num_pool
+    skips, cur = [], x
+    for st in range(P + 1):
+        stride = (1, 1, 1) if st == 0 else spec.pool_kernels[st - 1]
+        cur = _run_blocks(params, encoder_block_prefixes(spec, st), cur, stride, shift_size=spec.shift_size)
+        if st < P:
+            skips.append(cur)
+    segs = []
+    for u in range(P):
+        lvl = P - 1 - u
+        cur = F.conv_transpose3d(cur, params["tu.%d.weight" % u], stride=spec.pool_kernels[lvl])
+        cur = _run_blocks(params, unet_loc_prefixes(spec, u), torch.cat((cur, skips[lvl]), 1), shift_size=spec.shift_size)
+        segs.append(F.conv3d(cur, params["seg_outputs.%d.weight" % u]))
+    outs = [segs[-1]] + segs[:-1][::-1]
+    return outs if do_ds else outs[0]
+
+
 def forward(spec: NetSpec, params, x, do_ds=True, return_nodes=False):
     """unetpp_d.py:447-488.  Returns [full, 1/2, 1/4, 1/8] logits if do_ds else full only."""
+    if spec.graph == "unet":
+        assert not return_nodes
+        return forward_unet(spec, params, x, do_ds)
     P = spec.num_pool
     nodes = {}
     cur = x

@@ -500,3 +500,120 @@ def test_conv_variant_engine_fastpath_and_predict_vs_oracle(var):
                                                   mirror_axes=(0, 1, 2), use_gaussian=True)
     assert np.abs(probs - ref_probs).max() <= 2e-5
     assert (seg != ref_seg).mean() < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the 'shiftConvPP_nodff' ablation (reference unetpp_d_nodff.py): plain U-Net wiring of the shift-conv
+# blocks, shift size 3, five deep-supervision outputs; golden from the reference module
+def _nodff_net(seed=None):
+    from torch import nn
+    from e2enet_medical_amd.network_architecture import unetpp_d_nodff as mod
+    from tests.test_gpu_net import TINY
+    if seed is not None:
+        torch.manual_seed(seed)
+    return mod.Generic_UNetPlusPlus(TINY["patch"], TINY["cin"], TINY["base"], TINY["k"], 5, 2, 2, nn.Conv3d, nn.InstanceNorm3d,
+                                    {'eps': 1e-5, 'affine': True}, nn.Dropout3d, {'p': 0, 'inplace': True}, nn.LeakyReLU,
+                                    {'negative_slope': 1e-2, 'inplace': True}, True, False, lambda x: x,
+                                    mod.InitWeights_He(1e-2), [list(k) for k in TINY["pools"]], None, False, True, True,
+                                    max_num_features=TINY["max_feat"]).cuda()
+
+
+def test_nodff_init_and_masks_match_reference():
+    """state-dict names, He-init checksums under torch.manual_seed(1234) and the DSFF masks the reference's Masking draws on
+    this network (density 0.3, random.seed(0)): bit exact."""
+    from e2enet_medical_amd.training.network_training.sparselearning.core_channel import Masking, CosineDecay
+    g = golden("net_nodff.npz")
+    sd = _nodff_net(seed=1234).state_dict()
+    assert list(sd.keys()) == [str(s) for s in g["init_names"]]
+    np.testing.assert_array_equal(np.array([v.double().sum().item() for v in sd.values()]), g["init_sum"])
+    np.testing.assert_array_equal(np.array([v.double().abs().sum().item() for v in sd.values()]), g["init_abs"])
+    net = _nodff_net(seed=7)
+    opt = torch.optim.SGD(net.parameters(), 1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)
+
+    class A:
+        adv = False
+        fix = False
+        update_frequency = 1
+        final_density = 0.05
+    random.seed(0)
+    mask = Masking(opt, death_rate=0.5, death_mode='magnitude', death_rate_decay=CosineDecay(0.5, 10), growth_mode='random',
+                   redistribution_mode='none', args=A())
+    mask.add_module(net, sparse_init='uniform', density=0.3)
+    assert list(mask.masks.keys()) == [str(s) for s in g["masked_names"]]
+    assert [sha_of(pack_kernel_mask(m.cpu())) for m in mask.masks.values()] == [str(s) for s in g["mask_sha"]]
+
+
+def test_nodff_forward_backward_vs_reference_golden():
+    from e2enet_medical_amd.training.loss_functions.dice_loss import DC_and_CE_loss
+    from e2enet_medical_amd.training.loss_functions.deep_supervision import MultipleOutputLoss2
+    from tests.test_gpu_net import TINY
+    g = golden("net_nodff.npz")
+    net = _nodff_net()
+    shapes, params = load_closed_form(net)
+    assert list(shapes.keys()) == [str(s) for s in g["names"]]
+    x = seeded_input((2, TINY["cin"]) + TINY["patch"], seed=221).cuda()
+    outs = net(x)                                          # autograd path
+    assert [list(o.shape) for o in outs] == g["out_shapes"].tolist()
+    for i, o in enumerate(outs):
+        got = o.detach().cpu().numpy()
+        assert np.abs((got[..., ::2, ::2] if i == 0 else got) - g["logits%d" % i]).max() <= 1e-4, "logits%d" % i
+    targets = [seeded_labels((o.shape[0], 1) + tuple(o.shape[2:]), TINY["k"], seed=230 + i).cuda() for i, o in enumerate(outs)]
+    loss = MultipleOutputLoss2(DC_and_CE_loss({'batch_dice': False, 'smooth': 1e-5, 'do_bg': False}, {}), g["ds_weights"])(outs, targets)
+    assert abs(loss.item() - float(g["loss"])) < 2e-5
+    loss.backward()
+    names = [str(s) for s in g["names"]]
+    got_l2 = np.array([0.0 if net.get_parameter(n).grad is None else net.get_parameter(n).grad.double().norm().item() for n in names])
+    np.testing.assert_allclose(got_l2, g["grad_l2"], rtol=5e-3, atol=2e-6)
+    for key in g.files:
+        if key.startswith("grad::"):
+            ref = g[key]
+            got = net.get_parameter(key[6:]).grad.cpu().numpy()
+            assert np.abs(got - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max()), key
+
+
+def test_nodff_sparse_engine_fastpath_and_predict_vs_oracle():
+    """DSFF-masked nodff network (density 0.3) through the trainer's fast path (fused loss + backward) against the oracle's
+    autograd for every parameter, then sliding-window predict_3D with mirroring against the oracle's tiled prediction."""
+    from tests.test_gpu_net import TINY
+    net = _nodff_net()
+    shapes, params = load_closed_form(net)
+    spec = oracle.make_spec(TINY["cin"], TINY["base"], TINY["k"], TINY["pools"], 2, TINY["max_feat"], shift_size=3, graph="unet")
+    names = oracle.masked_names(spec)
+    random.seed(3)
+    masks = oracle.uniform_kernel_masks(shapes, names, 0.3)
+    with torch.no_grad():
+        for n in names:
+            params[n] = params[n] * masks[n]
+            net.get_parameter(n).copy_(params[n])
+    net.set_kernel_masks({n: (masks[n].reshape(masks[n].shape[0], masks[n].shape[1], -1).sum(-1) > 0).to(torch.uint8) for n in names})
+    x = seeded_input((2, TINY["cin"]) + TINY["patch"], seed=241)
+    eng = net.engine(x.cuda())
+    outs = eng.forward(x.cuda(), True)
+    assert len(outs) == 5
+    targets = [seeded_labels((o.shape[0], 1) + tuple(o.shape[2:]), TINY["k"], seed=250 + i) for i, o in enumerate(outs)]
+    w = golden("net_nodff.npz")["ds_weights"]
+    loss = eng.loss_backward([t.cuda() for t in targets], w, batch_dice=False)
+    leaves = {n: p.clone().requires_grad_(True) for n, p in params.items()}
+    ref = oracle.forward(spec, leaves, x)
+    ref_loss = oracle.deep_supervision_loss(ref, targets, w, False)
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < 2e-5
+    for o, r in zip(outs, ref):
+        assert (o.cpu() - r.detach()).abs().max() <= 1e-4
+    for n in shapes:
+        r = leaves[n].grad
+        if r is None:                                   # seg_outputs.0 (lowest head): loss weight 0
+            assert float(eng.grads[n].abs().max()) == 0.0
+            continue
+        assert (eng.grads[n].cpu() - r).abs().max().item() <= 2e-4 * max(1.0, r.abs().max().item()), n
+    vol = seeded_input((TINY["cin"], 24, 48, 40), seed=260).numpy()
+    net.eval()
+    net.inference_apply_nonlin = lambda t: F.softmax(t, 1)
+    seg, probs = net.predict_3D(vol, True, (0, 1, 2), True, 0.5, TINY["patch"], None, True, "constant", {'constant_values': 0},
+                                False, False)
+    with torch.no_grad():
+        fwd = lambda t: F.softmax(oracle.forward(spec, params, t, do_ds=False), 1)
+        ref_seg, ref_probs = oracle.predict_tiled(fwd, vol, TINY["k"], TINY["patch"], step_size=0.5, do_mirroring=True,
+                                                  mirror_axes=(0, 1, 2), use_gaussian=True)
+    assert np.abs(probs - ref_probs).max() <= 2e-5
+    assert (seg != ref_seg).mean() < 1e-3

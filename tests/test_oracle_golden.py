@@ -462,3 +462,35 @@ def test_conv_variants_vs_reference(var):
             n = key.split("::", 1)[1]
             ref = torch.from_numpy(g[key])
             assert (params[n].grad - ref).abs().max().item() <= 2e-4 * max(ref.abs().max().item(), 1e-3), n
+
+
+def test_nodff_unet_graph_vs_reference_golden():
+    """the 'shiftConvPP_nodff' ablation (reference unetpp_d_nodff.py:171-378): state-dict names and
+    shapes, the five logits, the deep-supervision loss, every gradient norm and the Masking selection of the oracle's 'unet'
+    graph against the golden produced by the reference module (tools/make_golden.py nodff)."""
+    import oracle
+    from tests.helpers import golden, closed_form_params, seeded_input, seeded_labels
+    g = golden("net_nodff.npz")
+    pools = [(2, 2, 2)] * 3 + [(1, 2, 2)] * 2
+    spec = oracle.make_spec(2, 8, 3, pools, 2, 32, shift_size=3, graph="unet")
+    shapes = oracle.param_shapes(spec)
+    assert list(shapes.keys()) == [str(s) for s in g["names"]]
+    assert [str(tuple(v)) for v in shapes.values()] == [str(s) for s in g["shapes"]]
+    assert oracle.masked_names(spec) == [str(s) for s in g["masked_names"]]
+    leaves = {n: p.clone().requires_grad_(True) for n, p in closed_form_params(shapes).items()}
+    x = seeded_input((2, 2, 16, 32, 32), seed=221)
+    outs = oracle.forward(spec, leaves, x)
+    assert [list(o.shape) for o in outs] == g["out_shapes"].tolist()
+    for i, o in enumerate(outs):
+        got = o.detach().numpy()
+        assert np.abs((got[..., ::2, ::2] if i == 0 else got) - g["logits%d" % i]).max() <= 1e-6
+        assert abs(o.detach().double().sum().item() - float(g["sum%d" % i])) <= 1e-4
+    targets = [seeded_labels((o.shape[0], 1) + tuple(o.shape[2:]), 3, seed=230 + i) for i, o in enumerate(outs)]
+    loss = oracle.deep_supervision_loss(outs, targets, g["ds_weights"], False)
+    assert abs(loss.item() - float(g["loss"])) < 1e-6
+    loss.backward()
+    l2 = np.array([0.0 if leaves[n].grad is None else leaves[n].grad.double().norm().item() for n in shapes])
+    np.testing.assert_allclose(l2, g["grad_l2"], rtol=1e-4, atol=1e-7)
+    for key in g.files:
+        if key.startswith("grad::"):
+            assert np.abs(leaves[key[6:]].grad.numpy() - g[key]).max() <= 1e-6 * max(1.0, np.abs(g[key]).max())

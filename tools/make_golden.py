@@ -520,6 +520,64 @@ def gen_net_variants():
     np.savez_compressed(os.path.join(OUT, "net_variants.npz"), **out)
 
 
+def gen_net_nodff():
+    """the 'shiftConvPP_nodff' ablation (unetpp_d_nodff.py:171-353, selected at
+    nnUNetTrainer_simple.py:326-335): a plain U-Net (no nested dense fusion) of the same shift-conv blocks with shift size 3;
+    five deep-supervision outputs.  TINY plan, B = 2, closed-form weights: forward + deep-supervision loss + backward, the
+    He-init checksums under torch.manual_seed(1234), and the tensors the reference's Masking selects."""
+    import importlib
+    mod = importlib.import_module("e2enet.network_architecture.unetpp_d_nodff")
+    T = TINY
+
+    def build(seed=None):
+        if seed is not None:
+            torch.manual_seed(seed)
+        return mod.Generic_UNetPlusPlus(T["patch"], T["cin"], T["base"], T["k"], len(T["pools"]), 2, 2, nn.Conv3d,
+                                        nn.InstanceNorm3d, {'eps': 1e-5, 'affine': True}, nn.Dropout3d,
+                                        {'p': 0, 'inplace': True}, nn.LeakyReLU, {'negative_slope': 1e-2, 'inplace': True},
+                                        True, False, lambda x: x, mod.InitWeights_He(1e-2), T["pools"], None, False, True,
+                                        True, max_num_features=T["max_feat"])
+    out = {}
+    net = build()
+    shapes = load_closed_form(net)
+    x = seeded_input((2, T["cin"]) + T["patch"], seed=221)
+    outs = net(x)
+    assert len(outs) == 5
+    targets = [seeded_labels((o.shape[0], 1) + tuple(o.shape[2:]), T["k"], seed=230 + i) for i, o in enumerate(outs)]
+    from e2enet.training.loss_functions.dice_loss import DC_and_CE_loss
+    from e2enet.training.loss_functions.deep_supervision import MultipleOutputLoss2
+    # the trainer's weights for net_numpool = 5 outputs (nnUNetTrainer_simple.py:207-213): last one masked to 0
+    w = np.array([1 / (2 ** i) for i in range(5)])
+    w[-1] = 0
+    w = w / w.sum()
+    loss = MultipleOutputLoss2(DC_and_CE_loss({'batch_dice': False, 'smooth': 1e-5, 'do_bg': False}, {}), w)(outs, targets)
+    loss.backward()
+    out["ds_weights"] = w
+    out["loss"] = np.float64(loss.item())
+    out["out_shapes"] = np.array([list(o.shape) for o in outs])
+    for i, o in enumerate(outs):
+        out["logits%d" % i] = o.detach().numpy()[..., ::2, ::2] if i == 0 else o.detach().numpy()
+        out["sum%d" % i] = np.float64(o.detach().double().sum().item())
+    names = list(shapes.keys())
+    out["names"] = np.array(names)
+    out["shapes"] = np.array([str(shapes[n]) for n in names])
+    out["grad_l2"] = np.array([0.0 if net.get_parameter(n).grad is None else net.get_parameter(n).grad.double().norm().item() for n in names])
+    for n in ("conv_blocks_context.0.blocks.0.conv.weight", "conv_blocks_localization.4.1.blocks.0.conv.weight", "tu.0.weight",
+              "tu.4.weight", "seg_outputs.4.weight", "seg_outputs.1.weight", "conv_blocks_localization.2.0.blocks.0.instnorm.weight",
+              "conv_blocks_context.5.1.blocks.0.conv.weight"):
+        out["grad::" + n] = net.get_parameter(n).grad.numpy()
+    sd = build(seed=1234).state_dict()
+    out["init_names"] = np.array(list(sd.keys()))
+    out["init_sum"] = np.array([v.double().sum().item() for v in sd.values()])
+    out["init_abs"] = np.array([v.double().abs().sum().item() for v in sd.values()])
+    # names the reference's Masking picks on this network, and its uniform masks at density 0.3 under random.seed(0)
+    net2 = build(seed=7)
+    mask, _ = make_masking(net2, 0.3)
+    out["masked_names"] = np.array(list(mask.masks.keys()))
+    out["mask_sha"] = np.array([sha_of(pack_kernel_mask(m)) for m in mask.masks.values()])
+    np.savez_compressed(os.path.join(OUT, "net_nodff.npz"), **out)
+
+
 def gen_export():
     """save_segmentation_nifti_from_softmax (segmentation_export.py:27-160) on volumes that need no resampling, with the
     SimpleITK writer, skimage and the batchgenerators file helpers stubbed (absent here): the uint8 array handed to the
@@ -579,7 +637,7 @@ def gen_export():
 
 ALL = dict(export=gen_export, shift=gen_shift, block=gen_block, net=gen_net_tiny, sparse=gen_net_sparse_tiny, net64=gen_net64,
            hippo=gen_net_hippo, amos=gen_net_amos,
-           variants=gen_net_variants, masks=gen_masks, loss=gen_loss, sliding=gen_sliding, dice=gen_dice, init=gen_init)
+           variants=gen_net_variants, nodff=gen_net_nodff, masks=gen_masks, loss=gen_loss, sliding=gen_sliding, dice=gen_dice, init=gen_init)
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
