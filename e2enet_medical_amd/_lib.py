@@ -81,6 +81,7 @@ SIGNATURES = {
     "e2e_sw_finalize_argmax": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
     "e2e_ensemble_accumulate": (I, [P, P, LL, I, I, P]),
     "e2e_export_argmax_u8": (I, [P, P, I, LL, I, I, I, LL, LL, LL, I, I, I, I, I, I, P, I, P]),
+    "e2e_resample_linear": (I, [P, P, I, LL, I, I, I, LL, LL, LL, I, I, I, I, P]),
 }
 
 _NO_STATUS = {"e2e_last_error", "e2e_abi_version", "e2e_last_kernel", "e2e_conv133_num_partials", "e2e_conv133_wgrad_ws_bytes", "e2e_conv133_fwd_ws_bytes", "e2e_conv133_dgrad_ws_bytes",
@@ -122,7 +123,7 @@ class _Lib:
 _lib = None
 
 
-ABI_VERSION = 9          # e2e_abi_version() of the library this binding was written against
+ABI_VERSION = 10          # e2e_abi_version() of the library this binding was written against
 
 
 def lib() -> _Lib:

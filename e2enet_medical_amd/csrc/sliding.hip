@@ -134,6 +134,77 @@ __global__ __launch_bounds__(256) void export_argmax_kernel(const float* __restr
   }
   seg[((long long)(a0 + a) * OB + (b0 + b)) * OC + (c0 + c)] = (unsigned char)lab;
 }
+// ---- N1: softmax volume resampled to the original (pre-resampling) grid on the device ---------------------------------
+// Reference: save_segmentation_nifti_from_softmax (segmentation_export.py:84-104) -> resample_data_or_seg(is_seg=False,
+// order=1, order_z=0) (preprocessing.py:113-202) -> skimage.transform.resize(order=1, mode='edge', anti_aliasing=False),
+// which (scikit-image 0.19.3) is scipy.ndimage.zoom(order=1, mode='nearest', grid_mode=True) on the float64 image; with a
+// separate low-resolution axis every slice is resized in the plane (cast back to float32) and the axis itself is then
+// picked by nearest neighbour (map_coordinates order 0, mode 'nearest', coordinates scale * (i + 0.5) - 0.5).
+// Arithmetic as scipy's NI_ZoomShift: coordinate = (o + 0.5) * (in / out) - 0.5 in double, clamped to [0, in - 1], floor and
+// fraction, weights (1 - t, t), the 2^n taps visited last axis fastest, coefficient multiplied by the axis weights in axis
+// order and added to a double sum (this file is built with -ffp-contract=off), result cast to float32.
+// lowres < 0: trilinear over all three axes; lowres = 0..2: nearest along that axis, bilinear in the plane.
+__device__ __forceinline__ void lin_coord(int o, int n_in, int n_out, int& i0, int& i1, double& t) {
+  double c = ((double)o + 0.5) * ((double)n_in / (double)n_out) - 0.5;
+  if (c < 0.0) c = 0.0;
+  if (c > (double)(n_in - 1)) c = (double)(n_in - 1);
+  const double f = floor(c);
+  i0 = (int)f;
+  t = c - f;
+  i1 = i0 + 1 < n_in ? i0 + 1 : n_in - 1;
+}
+__device__ __forceinline__ int near_coord(int o, int n_in, int n_out) {
+  double c = ((double)n_in / (double)n_out) * ((double)o + 0.5) - 0.5;
+  if (c < 0.0) c = 0.0;
+  if (c > (double)(n_in - 1)) c = (double)(n_in - 1);
+  return (int)floor(c + 0.5);
+}
+__global__ __launch_bounds__(256) void resample_linear_kernel(const float* __restrict__ src, float* __restrict__ dst, int K,
+                                                              long long kstride, int A, int B, int C, long long sa,
+                                                              long long sb, long long sc, int OA, int OB, int OC, int lowres) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long ovol = (long long)OA * OB * OC;
+  if (idx >= ovol) return;
+  const int oc = (int)(idx % OC);
+  const int ob = (int)((idx / OC) % OB);
+  const int oa = (int)(idx / ((long long)OC * OB));
+  const int n_in[3] = {A, B, C}, n_out[3] = {OA, OB, OC}, o[3] = {oa, ob, oc};
+  const long long st[3] = {sa, sb, sc};
+  int i0[3], i1[3];
+  double w0[3], w1[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    if (d == lowres || n_in[d] == n_out[d]) {
+      // nearest along the separate axis; an axis whose size does not change has coordinate o exactly (weight 1 on tap 0)
+      i0[d] = i1[d] = (d == lowres) ? near_coord(o[d], n_in[d], n_out[d]) : o[d];
+      w0[d] = 1.0; w1[d] = 0.0;
+    } else {
+      double t;
+      lin_coord(o[d], n_in[d], n_out[d], i0[d], i1[d], t);
+      w0[d] = 1.0 - t; w1[d] = t;
+    }
+  }
+  for (int k = 0; k < K; ++k) {
+    const float* sp = src + (long long)k * kstride;
+    double acc = 0.0;
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc) {
+          const double wa = ta ? w1[0] : w0[0], wb = tb ? w1[1] : w0[1], wc = tc ? w1[2] : w0[2];
+          if (wa == 0.0 || wb == 0.0 || wc == 0.0) continue;       // (taps scipy does not visit: nearest axis, unchanged axis)
+          double coeff = (double)sp[(ta ? i1[0] : i0[0]) * st[0] + (tb ? i1[1] : i0[1]) * st[1] + (tc ? i1[2] : i0[2]) * st[2]];
+          coeff *= wa;
+          coeff *= wb;
+          coeff *= wc;
+          acc += coeff;
+        }
+    dst[(long long)k * ovol + idx] = (float)acc;
+  }
+}
+
 }  // namespace
 
 extern "C" int e2e_ensemble_accumulate(float* dst, const float* src, long long n, int first, int n_folds, void* stream) {
@@ -184,4 +255,13 @@ extern "C" int e2e_sw_finalize_argmax(const float* agg, const float* cnt, float*
   dim3 grid((unsigned)e2e::cdivll((long long)CX * CY * CZ, 256));
   hipLaunchKernelGGL(sw_finalize_kernel, grid, dim3(256), 0, (hipStream_t)stream, agg, cnt, probs, seg, K, X, Y, Z, cx0, cy0, cz0, CX, CY, CZ);
   return e2e::check_launch("sw_finalize_kernel");
+}
+
+extern "C" int e2e_resample_linear(const float* src, float* dst, int K, long long kstride, int A, int B, int C, long long sa,
+                                   long long sb, long long sc, int OA, int OB, int OC, int lowres_axis, void* stream) {
+  E2E_REQUIRE(src && dst && src != dst && K > 0 && A > 0 && B > 0 && C > 0 && OA > 0 && OB > 0 && OC > 0, "resample_linear: bad arguments");
+  E2E_REQUIRE(lowres_axis >= -1 && lowres_axis <= 2, "resample_linear: lowres_axis must be -1 (none) or 0..2");
+  hipLaunchKernelGGL(resample_linear_kernel, dim3((unsigned)e2e::cdivll((long long)OA * OB * OC, 256)), dim3(256), 0,
+                     (hipStream_t)stream, src, dst, K, kstride, A, B, C, sa, sb, sc, OA, OB, OC, lowres_axis);
+  return e2e::check_launch("resample_linear_kernel");
 }

@@ -10,8 +10,12 @@ placement are two HIP kernels (``e2e_ensemble_accumulate``, ``e2e_export_argmax_
 uint8 label volume.  Arithmetic is bit-identical to the reference's numpy expressions (float32 adds in fold order,
 float32 division by the fold count, first maximum).
 
-Out of scope (explicit errors): resampling the softmax to another grid (third-party skimage ``resize`` semantics,
-segmentation_export.py:84-104) and the NIfTI writer (SimpleITK); ``predict_cases`` therefore takes a ``writer`` callback.
+Resampling to the grid the case had before preprocessing (segmentation_export.py:84-104: order 1, and order 0 along one
+separate low-resolution axis when the spacing is anisotropic beyond ``RESAMPLING_SEPARATE_Z_ANISO_THRESHOLD``) is a third
+kernel (``e2e_resample_linear``) with the arithmetic of ``scipy.ndimage.zoom(order=1, mode='nearest', grid_mode=True)`` --
+what scikit-image 0.19.3's ``resize(order=1, mode='edge', anti_aliasing=False)`` evaluates.  Parity for that step is against
+scipy (oracle/export.py; scikit-image is absent from the image: "parity unpinned").  The NIfTI writer (SimpleITK) is host
+tooling; ``predict_cases`` therefore takes a ``writer`` callback.
 """
 from typing import Callable, Iterable, Optional, Sequence, Tuple
 
@@ -50,10 +54,58 @@ def predict_case_ensemble(trainer, params: Sequence[dict], data: np.ndarray, do_
     return total
 
 
+RESAMPLING_SEPARATE_Z_ANISO_THRESHOLD = 3        # reference e2enet/configuration.py
+
+
+def get_do_separate_z(spacing, anisotropy_threshold=RESAMPLING_SEPARATE_Z_ANISO_THRESHOLD):
+    """reference preprocessing.py:28-30"""
+    return (np.max(spacing) / np.min(spacing)) > anisotropy_threshold
+
+
+def get_lowres_axis(new_spacing):
+    """reference preprocessing.py:33-35"""
+    return np.where(max(new_spacing) / np.array(new_spacing) == 1)[0]
+
+
+def resample_plan(properties_dict: dict, force_separate_z: Optional[bool] = None):
+    """(do_separate_z, lowres_axis or None): the decision of segmentation_export.py:85-106"""
+    if force_separate_z is None:
+        if get_do_separate_z(properties_dict.get('original_spacing')):
+            do_separate_z, lowres_axis = True, get_lowres_axis(properties_dict.get('original_spacing'))
+        elif get_do_separate_z(properties_dict.get('spacing_after_resampling')):
+            do_separate_z, lowres_axis = True, get_lowres_axis(properties_dict.get('spacing_after_resampling'))
+        else:
+            do_separate_z, lowres_axis = False, None
+    else:
+        do_separate_z = force_separate_z
+        lowres_axis = get_lowres_axis(properties_dict.get('original_spacing')) if do_separate_z else None
+    if lowres_axis is not None and len(lowres_axis) != 1:
+        do_separate_z = False          # spacings like (0.24, 1.25, 1.25): no separate out-of-plane axis (:102-105)
+    return do_separate_z, (int(lowres_axis[0]) if do_separate_z else None)
+
+
+def resample_softmax(softmax: torch.Tensor, new_shape: Sequence[int], transpose_backward: Optional[Sequence[int]] = None,
+                     lowres_axis: Optional[int] = None) -> torch.Tensor:
+    """Device softmax [K, X, Y, Z] -> contiguous [K] + new_shape in the transposed-backward frame, order 1 (order 0 along
+    ``lowres_axis``): resample_data_or_seg(..., is_seg=False, order=1, order_z=0), preprocessing.py:113-202."""
+    assert softmax.is_cuda and softmax.dtype == torch.float32 and softmax.dim() == 4
+    tb = [0, 1, 2] if transpose_backward is None else [int(i) for i in transpose_backward]
+    dims = [int(softmax.shape[1 + i]) for i in tb]
+    strides = [int(softmax.stride(1 + i)) for i in tb]
+    k = softmax.shape[0]
+    new_shape = [int(v) for v in new_shape]
+    out = torch.empty([k] + new_shape, dtype=torch.float32, device=softmax.device)
+    lib().resample_linear(softmax.data_ptr(), out.data_ptr(), k, int(softmax.stride(0)), dims[0], dims[1], dims[2], strides[0],
+                          strides[1], strides[2], new_shape[0], new_shape[1], new_shape[2],
+                          -1 if lowres_axis is None else int(lowres_axis), _stream())
+    return out
+
+
 def export_segmentation(softmax: torch.Tensor, properties_dict: dict, transpose_backward: Optional[Sequence[int]] = None,
-                        region_class_order: Optional[Sequence[int]] = None) -> np.ndarray:
+                        region_class_order: Optional[Sequence[int]] = None, force_separate_z: Optional[bool] = None,
+                        order: int = 1, interpolation_order_z: int = 0) -> np.ndarray:
     """uint8 label volume in the ORIGINAL (uncropped) geometry from a device softmax [K, X, Y, Z]
-    (reference predict.py:298-301 + segmentation_export.py:73-136 without the resampling branch)."""
+    (reference predict.py:298-301 + segmentation_export.py:73-136)."""
     assert softmax.is_cuda and softmax.dtype == torch.float32 and softmax.dim() == 4 and softmax.is_contiguous()
     k = softmax.shape[0]
     tb = [0, 1, 2] if transpose_backward is None else [int(i) for i in transpose_backward]
@@ -61,8 +113,14 @@ def export_segmentation(softmax: torch.Tensor, properties_dict: dict, transpose_
     strides = [int(softmax.stride(1 + i)) for i in tb]
     after_crop = properties_dict.get('size_after_cropping')
     if after_crop is not None and any(int(a) != int(b) for a, b in zip(dims, after_crop)):
-        raise NotImplementedError("the softmax grid %s differs from size_after_cropping %s: resampling to the original spacing "
-                                  "(skimage resize, segmentation_export.py:84-104) is outside the MI355X hot path" % (dims, tuple(after_crop)))
+        # the network ran on a resampled grid: back to the case's own grid before the argmax (segmentation_export.py:84-104)
+        if order != 1 or interpolation_order_z != 0:
+            raise NotImplementedError("device resampling implements the reference's defaults: order 1 in the plane, order 0 "
+                                      "along a separate low-resolution axis (predict.py:171-172)")
+        _, lowres = resample_plan(properties_dict, force_separate_z)
+        softmax = resample_softmax(softmax, after_crop, tb, lowres)
+        dims = [int(v) for v in after_crop]
+        strides = [int(softmax.stride(1 + i)) for i in range(3)]
     bbox = properties_dict.get('crop_bbox')
     if bbox is not None:
         out_shape = tuple(int(v) for v in properties_dict.get('original_size_of_raw_data'))

@@ -262,7 +262,7 @@ int e2e_sw_finalize_argmax(const float* agg, const float* cnt, float* probs, lon
  * Replaces: the per-fold softmax accumulation and average of predict_cases (e2enet/inference/predict.py:282-296; a
  * multi-GB device->host copy per fold in the reference) and transpose_backward + argmax / region thresholds + crop-box
  * placement into the uint8 volume of save_segmentation_nifti_from_softmax (e2enet/inference/segmentation_export.py:
- * 118-136, predict.py:298-301).  Resampling to another grid (skimage, :84-104) and the NIfTI writer stay on the host.
+ * 118-136, predict.py:298-301), and the resampling to the original grid (:84-104).  The NIfTI writer stays on the host.
  *   dst (+)= src over n floats (first != 0 overwrites); n_folds > 0 additionally divides by n_folds (float32 division) */
 int e2e_ensemble_accumulate(float* dst, const float* src, long long n, int first, int n_folds, void* stream);
 /*   probs [K, ...] with class stride kstride; output voxel (a,b,c) of the TRANSPOSED [A,B,C] frame reads source offset
@@ -271,6 +271,15 @@ int e2e_ensemble_accumulate(float* dst, const float* src, long long n, int first
 int e2e_export_argmax_u8(const float* probs, unsigned char* seg, int K, long long kstride, int A, int B, int C,
                          long long sa, long long sb, long long sc, int OA, int OB, int OC, int a0, int b0, int c0,
                          const int* regions, int n_regions, void* stream);
+/*   Softmax volume resampled to another grid (order 1; nearest along one optional low-resolution axis) -- replaces
+ *   resample_data_or_seg(is_seg=False, order=1, order_z=0) as called by save_segmentation_nifti_from_softmax
+ *   (e2enet/inference/segmentation_export.py:84-104, e2enet/preprocessing/preprocessing.py:113-202; skimage resize =
+ *   scipy.ndimage.zoom(order=1, mode='nearest', grid_mode=True) on float64, result cast to float32).
+ *   src: [K] volumes of the frame [A,B,C] read with strides (sa,sb,sc) (folds transpose_backward), class stride kstride;
+ *   dst: contiguous [K,OA,OB,OC]; lowres_axis: -1 = trilinear, 0..2 = nearest along that axis, bilinear in the plane.   */
+int e2e_resample_linear(const float* src, float* dst, int K, long long kstride, int A, int B, int C, long long sa,
+                        long long sb, long long sc, int OA, int OB, int OC, int lowres_axis, void* stream);
+
 
 #ifdef __cplusplus
 }

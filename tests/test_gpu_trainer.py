@@ -310,8 +310,41 @@ def test_export_kernels_match_reference_golden(tag):
     regions = tuple(int(v) for v in g[tag + "_regions"]) if tag + "_regions" in g.files else None
     seg = export_segmentation(total, props, tb, regions)
     assert seg.dtype == np.uint8 and np.array_equal(seg, g[tag + "_seg"])
+
+
+@pytest.mark.parametrize("tb,new_shape,spacing,expect_axis", [
+    ([0, 1, 2], (19, 40, 33), (1.0, 1.0, 1.0), None),          # isotropic: trilinear over all axes
+    ([2, 0, 1], (25, 17, 50), (1.2, 1.0, 0.9), None),          # with transpose_backward, up- and down-sampling mixed
+    ([0, 1, 2], (9, 44, 35), (5.0, 0.8, 0.8), 0),              # anisotropic: nearest along axis 0, bilinear in the plane
+    ([1, 0, 2], (30, 36, 7), (0.7, 0.7, 3.0), 2),
+    ([0, 1, 2], (12, 31, 28), (4.0, 1.0, 1.0), 0),             # the separate axis keeps its size: slices only
+])
+def test_export_resamples_softmax_to_original_grid(tb, new_shape, spacing, expect_axis):
+    """N1, segmentation_export.py:84-104: a softmax volume whose grid differs from size_after_cropping is resampled on the
+    device (order 1; order 0 along one separate low-resolution axis) before argmax and crop-box placement.  Checked against
+    the oracle's scipy restatement of resample_data_or_seg / skimage resize (parity unpinned: oracle/export.py)."""
+    from e2enet_medical_amd.inference.predict import export_segmentation, resample_softmax, resample_plan
+    rng = np.random.RandomState(5)
+    logits = rng.standard_normal((4, 12, 28, 31)).astype(np.float32) * 2
+    soft = np.exp(logits) / np.exp(logits).sum(0, keepdims=True)
+    soft = soft.astype(np.float32)
+    new_shape = tuple(new_shape)
+    props = {'size_after_cropping': np.array(new_shape), 'original_size_of_raw_data': np.array([new_shape[0] + 2, new_shape[1] + 1, new_shape[2]]),
+             'crop_bbox': [[1, 1 + new_shape[0]], [0, new_shape[1]], [0, new_shape[2]]],
+             'original_spacing': np.array(spacing), 'spacing_after_resampling': np.array([1.0, 1.0, 1.0])}
+    sep, axis = resample_plan(props)
+    assert axis == expect_axis and sep == (expect_axis is not None)
+    dev = torch.from_numpy(soft).cuda()
+    got = resample_softmax(dev, new_shape, tb, axis).cpu().numpy()
+    want = oracle.export.resample_softmax(soft.transpose([0] + [i + 1 for i in tb]), new_shape, axis)
+    assert got.shape == want.shape and got.dtype == np.float32
+    assert np.abs(got - want).max() <= 1e-6
+    assert (got != want).mean() <= 1e-3                     # same arithmetic, same order: bit-identical but for rare last-bit cases
+    seg = export_segmentation(dev, props, tb, None)
+    ref = oracle.export_segmentation(soft, props, tb, None, lowres_axis=axis)
+    assert seg.shape == ref.shape and (seg != ref).mean() <= 1e-5
     with pytest.raises(NotImplementedError):
-        export_segmentation(total, dict(props, size_after_cropping=np.array([s + 1 for s in size])), tb, regions)
+        export_segmentation(dev, props, tb, None, order=3)
 
 
 def test_predict_cases_fold_ensemble_on_device():

@@ -288,3 +288,25 @@ def test_ds_target_index_formula_is_scipy_zoom_order0():
     outs = oracle.downsample_seg_for_ds(seg, [[1, 1, 1], [0.5, 0.5, 0.5], [1, 0.5, 0.25]])
     assert outs[0] is seg and outs[1].shape == (2, 1, 3, 5, 6) and outs[2].shape == (2, 1, 6, 5, 3)
     assert np.array_equal(outs[1], seg[:, :, 1::2, 1::2, 1::2])
+
+
+def test_oracle_resample_softmax_properties():
+    """oracle.export.resample_softmax (scipy restatement of resample_data_or_seg, preprocessing.py:113-202; parity unpinned):
+    identity on an unchanged grid, exact on constants and on linear ramps away from the border, nearest pick along a separate
+    axis, and the separate-axis branch == slice-wise resize followed by the nearest pick."""
+    import numpy as np
+    from oracle.export import resample_softmax
+    rng = np.random.RandomState(0)
+    x = rng.rand(2, 6, 10, 12).astype(np.float32)
+    assert resample_softmax(x, (6, 10, 12)) is x
+    c = np.full((1, 5, 7, 9), 0.25, np.float32)
+    assert np.array_equal(resample_softmax(c, (8, 14, 5)), np.full((1, 8, 14, 5), 0.25, np.float32))
+    ramp = np.broadcast_to(np.arange(12, dtype=np.float32), (1, 6, 10, 12)).copy()
+    up = resample_softmax(ramp, (6, 10, 24))
+    want = np.clip((np.arange(24) + 0.5) * 0.5 - 0.5, 0, 11)
+    assert np.abs(up[0, 3, 4] - want).max() <= 1e-6
+    sep = resample_softmax(x, (3, 20, 18), lowres_axis=0)
+    assert sep.shape == (2, 3, 20, 18)
+    idx = np.floor(np.clip(6 / 3 * (np.arange(3) + 0.5) - 0.5, 0, 5) + 0.5).astype(int)
+    full = resample_softmax(x, (6, 20, 18), lowres_axis=0)
+    assert np.array_equal(sep, full[:, idx])
