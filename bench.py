@@ -210,31 +210,61 @@ def cpu_baseline(sample, patch_edge=128, budget_s=150.0):
     return base, parity
 
 
-def sliding_window_record(device):
+def sliding_window_record(device, rank=0, world=1):
     """BASELINE config 4 shape: AMOS-like volume [1,220,400,400], 16 classes, base 32, patch 128^3,
     step 0.5, 8 mirrors.  Wall time of predict_3D with the volume already on the host as float32 (the call uploads it
-    once, 141 MB; aggregation, softmax, flips, Gaussian weighting and argmax stay on the device)."""
+    once, 141 MB; aggregation, softmax, flips, Gaussian weighting and argmax stay on the device).
+    world > 1 (every rank calls this): the north_star's multi-GPU split -- tiles dealt round-robin over the ranks
+    (net.shard_tiles), per group of `world` tiles one asynchronous RCCL all-gather of the probability patches under the next
+    group's compute, every rank overlap-adds in the reference's order; time = max over ranks between two barriers."""
+    import torch.distributed as dist
     from e2enet_medical_amd.utilities.nd_softmax import softmax_helper
     net, _, mask, _ = build(device, PATCH, cin=1, k=16, seed=1)
     net.inference_apply_nonlin = softmax_helper
     net.eval()
     net.do_ds = False
+    if world > 1 or os.environ.get("E2E_FORCE_DIST") == "1":
+        net.shard_tiles(rank, world, None, force=world == 1)
     vol = torch.randn((1, 220, 400, 400), generator=torch.Generator().manual_seed(7)).numpy()
     kw = dict(do_mirroring=True, mirror_axes=(0, 1, 2), use_sliding_window=True, step_size=0.5, patch_size=PATCH,
               use_gaussian=True, verbose=False)
     steps = net._compute_steps_for_sliding_window(PATCH, vol.shape[1:], 0.5)
     tiles = len(steps[0]) * len(steps[1]) * len(steps[2])
-    net.predict_3D(vol[:, :128, :160, :160], **kw)          # warm-up: plan allocation for the 8-mirror batch
+    net.predict_3D(vol[:, :128, :160, :160], **kw)          # warm-up: plan allocation for the 8-mirror batch (and RCCL channels)
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     t0 = time.perf_counter()
     seg, probs = net.predict_3D(vol, **kw)
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
     vox = float(np.prod(vol.shape[1:]))
-    return {"workload": "predict_3D [1,220,400,400] N(0,1), K=16, base 32, density 0.2, patch 128^3, step 0.5, 8 mirrors "
-                        "(%d tiles x 8 forwards, mirrors of a tile as one batch-8 forward)" % tiles,
-            "seconds": dt, "volume_voxels_per_s": vox / dt, "patch_voxels_per_s": tiles * 8 * 128 ** 3 / dt,
-            "includes": "host->device upload of the volume, device->host copy of seg + probs (1.4 GB)"}
+    rec = {"workload": "predict_3D [1,220,400,400] N(0,1), K=16, base 32, density 0.2, patch 128^3, step 0.5, 8 mirrors "
+                       "(%d tiles x 8 forwards, mirrors of a tile as one batch-8 forward)" % tiles,
+           "seconds": dt, "volume_voxels_per_s": vox / dt, "patch_voxels_per_s": tiles * 8 * 128 ** 3 / dt,
+           "includes": "host->device upload of the volume, device->host copy of seg + probs (1.4 GB)", "n_gpus": world}
+    st = getattr(net, "last_shard_stats", None)
+    if st:
+        rec["sharding"] = dict(st)
+        if world > 1 or os.environ.get("E2E_FORCE_DIST") == "1":
+            # calibration: the same all-gather (one group: `world` patches of [16,128^3] fp32), blocking, 5 times
+            mine = torch.zeros((16,) + PATCH, dtype=torch.float32, device=device)
+            outb = torch.empty((world, 16) + PATCH, dtype=torch.float32, device=device)
+            dist.all_gather_into_tensor(outb.view(-1), mine.view(-1))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                dist.all_gather_into_tensor(outb.view(-1), mine.view(-1))
+            torch.cuda.synchronize()
+            rec["sharding"]["allgather_ms_per_group_blocking"] = (time.perf_counter() - t1) / 5 * 1e3
+            rec["sharding"]["allgather_bytes_per_group_per_rank_inbound"] = (world - 1) * mine.numel() * 4
+    return rec
 
 
 def main():
@@ -337,6 +367,11 @@ def main():
     for t in timers.values():
         t.enabled = False
 
+    sw_multi = None
+    if world > 1 and not args.no_extras and not args.forward_only:
+        # the north_star's multi-GPU path: tile-sharded sliding-window inference with RCCL all-gather (every rank takes part)
+        sw_multi = sliding_window_record(device, rank, world)
+
     if rank == 0:
         vox_per_step = world * args.batch * patch[0] * patch[1] * patch[2]
         value = vox_per_step * args.steps / dt
@@ -422,6 +457,8 @@ def main():
             net._engines.clear()
             torch.cuda.empty_cache()
             out["sliding_window"] = sliding_window_record(device)
+        if sw_multi is not None:
+            out["sliding_window"] = sw_multi
         if not args.no_cpu_baseline and world == 1:      # the CPU port is timed on rank 0 of the single-GPU run only
             if sample is None:
                 sample = parity_sample(net, device, patch, ds_w)

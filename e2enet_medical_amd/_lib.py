@@ -82,10 +82,17 @@ SIGNATURES = {
     "e2e_ensemble_accumulate": (I, [P, P, LL, I, I, P]),
     "e2e_export_argmax_u8": (I, [P, P, I, LL, I, I, I, LL, LL, LL, I, I, I, I, I, I, P, I, P]),
     "e2e_resample_linear": (I, [P, P, I, LL, I, I, I, LL, LL, LL, I, I, I, I, P]),
+    "e2e_aug_spatial": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, F, P]),
+    "e2e_aug_stats_ws_bytes": (LL, [I]),
+    "e2e_aug_stats": (I, [P, P, P, I, LL, P]),
+    "e2e_aug_pointwise": (I, [P, P, I, I, LL, C.c_ulonglong, P]),
+    "e2e_aug_blur_axis": (I, [P, P, P, I, I, I, I, I, P]),
+    "e2e_aug_lowres": (I, [P, P, P, I, I, I, I, P]),
+    "e2e_aug_finish": (I, [P, P, P, I, I, I, LL, P]),
 }
 
 _NO_STATUS = {"e2e_last_error", "e2e_abi_version", "e2e_last_kernel", "e2e_conv133_num_partials", "e2e_conv133_wgrad_ws_bytes", "e2e_conv133_fwd_ws_bytes", "e2e_conv133_dgrad_ws_bytes",
-              "e2e_convT_wgrad_ws_bytes", "e2e_head1x1_wgrad_ws_bytes", "e2e_loss_ws_bytes"}
+              "e2e_convT_wgrad_ws_bytes", "e2e_head1x1_wgrad_ws_bytes", "e2e_loss_ws_bytes", "e2e_aug_stats_ws_bytes"}
 
 
 class E2EError(RuntimeError):
@@ -123,7 +130,7 @@ class _Lib:
 _lib = None
 
 
-ABI_VERSION = 10          # e2e_abi_version() of the library this binding was written against
+ABI_VERSION = 11          # e2e_abi_version() of the library this binding was written against
 
 
 def lib() -> _Lib:

@@ -3,9 +3,11 @@
 // 24 CPU worker processes (batchgenerators 0.24, third party, not under /root/reference).  One 50 ms training step consumes
 // 40 batches/s of 2 x 4 x 128^3 voxels; these kernels turn a raw loaded patch into a network batch in a few ms.
 //
-//   e2e_aug_spatial     SpatialTransform (rotation + scaling as ONE affine gather, centre crop) + MirrorTransform folded into
-//                       the same coordinate map: data order 1 (cval 0), seg order 0 (cval border_val_seg).  [the reference
-//                       interpolates data with a cubic spline (order_data = 3); order 1 is what is built, see DESIGN.md]
+//   e2e_aug_spatial     SpatialTransform (rotation + scaling as ONE affine gather, centre crop): data order 1 (cval 0); seg
+//                       order 0 (cval border_val_seg) or order 1 (batchgenerators' interpolate_img(is_seg=True): per label a
+//                       linear interpolation of the binary mask, assigned where >= 0.5, labels in ascending order).  [the
+//                       reference interpolates data with a cubic spline (order_data = 3); order 1 is built, see DESIGN.md]
+//   (MirrorTransform: e2e_flip3d of sliding.hip, per sample, after the intensity transforms like in the reference)
 //   e2e_aug_stats       per-(sample, channel) min / max / mean / std (np.std, ddof 0): ContrastAugmentation, Gamma
 //   e2e_aug_pointwise   GaussianNoise (counter-based generator, Box-Muller), BrightnessMultiplicative, ContrastAugmentation,
 //                       Gamma (power step and retain_stats step), all parameterised per (sample, channel)
@@ -22,12 +24,12 @@
 namespace {
 
 // ---- spatial: out[b, c, o] = interp(in[b, c], A_b (o - c_out) + t_b) ---------------------------------------------------------
-// mat: per sample 12 floats (row-major 3 x 4: A | t) mapping zero-centred output coordinates (o - (size - 1) / 2, after the
-// mirror flips) to input voxel coordinates; computed on the host in double and passed as float (coordinates < 2^10).
+// mat: per sample 12 doubles (row-major 3 x 4: A | t) mapping zero-centred output coordinates o - (size - 1) / 2 to input
+// voxel coordinates; computed on the host.
 __global__ __launch_bounds__(256) void aug_spatial_kernel(const float* __restrict__ data, const float* __restrict__ seg,
                                                           float* __restrict__ odata, float* __restrict__ oseg,
                                                           const double* __restrict__ mat, int C, int CS, int Di, int Hi, int Wi,
-                                                          int Do, int Ho, int Wo, float cval_seg) {
+                                                          int Do, int Ho, int Wo, int order_seg, float cval_seg) {
   const long long ovol = (long long)Do * Ho * Wo;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   const int b = blockIdx.y;
@@ -66,17 +68,54 @@ __global__ __launch_bounds__(256) void aug_spatial_kernel(const float* __restric
       odata[((long long)b * C + c) * ovol + idx] = v;
     }
   }
-  // ---- seg: order 0 (nearest, round half up like scipy: floor(c + 0.5)), mode 'constant', cval ----
+  // ---- seg: mode 'constant' ----
   if (seg != nullptr) {
-    const int di = (int)floor(cd + 0.5), hi = (int)floor(ch + 0.5), wi = (int)floor(cw + 0.5);
     const bool inside = cd >= 0.0 && cd <= (double)(Di - 1) && ch >= 0.0 && ch <= (double)(Hi - 1) && cw >= 0.0 && cw <= (double)(Wi - 1);
-    for (int c = 0; c < CS; ++c) {
-      float v = cval_seg;
-      if (inside) {
-        const int dd = di < Di ? di : Di - 1, hh = hi < Hi ? hi : Hi - 1, ww = wi < Wi ? wi : Wi - 1;
-        v = seg[((long long)b * CS + c) * ivol + ((long long)dd * Hi + hh) * Wi + ww];
+    if (order_seg == 0) {       // nearest, round half up like scipy: floor(c + 0.5); outside: cval
+      const int di = (int)floor(cd + 0.5), hi = (int)floor(ch + 0.5), wi = (int)floor(cw + 0.5);
+      for (int c = 0; c < CS; ++c) {
+        float v = cval_seg;
+        if (inside) {
+          const int dd = di < Di ? di : Di - 1, hh = hi < Hi ? hi : Hi - 1, ww = wi < Wi ? wi : Wi - 1;
+          v = seg[((long long)b * CS + c) * ivol + ((long long)dd * Hi + hh) * Wi + ww];
+        }
+        oseg[((long long)b * CS + c) * ovol + idx] = v;
       }
-      oseg[((long long)b * CS + c) * ovol + idx] = v;
+    } else {
+      // batchgenerators interpolate_img(is_seg=True, order=1): result = 0; for every label c of the image in ascending order:
+      // result[map_coordinates(img == c, coords, order=1, cval) >= 0.5] = c.  Outside the volume every mask interpolates to
+      // cval (-1 < 0.5): the voxel keeps 0.
+      const double fd = floor(cd), fh = floor(ch), fw = floor(cw);
+      const int d0 = (int)fd, h0 = (int)fh, w0 = (int)fw;
+      const double td = cd - fd, th = ch - fh, tw = cw - fw;
+      for (int c = 0; c < CS; ++c) {
+        float res = 0.f;
+        if (inside) {
+          const float* p = seg + ((long long)b * CS + c) * ivol;
+          float lab[8];
+          double wgt[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int a = k >> 2, bb = (k >> 1) & 1, e = k & 1;
+            const int di = d0 + a < Di ? d0 + a : Di - 1, hi = h0 + bb < Hi ? h0 + bb : Hi - 1, wi = w0 + e < Wi ? w0 + e : Wi - 1;
+            lab[k] = p[((long long)di * Hi + hi) * Wi + wi];
+            wgt[k] = (a ? td : 1.0 - td) * (bb ? th : 1.0 - th) * (e ? tw : 1.0 - tw);
+          }
+          // ascending label order: the largest label whose mask reaches 0.5 wins
+          float best = -INFINITY;
+          bool any = false;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            double sum = 0.0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (lab[j] == lab[k]) sum += wgt[j];
+            if (sum >= 0.5 && (!any || lab[k] > best)) { best = lab[k]; any = true; }
+          }
+          if (any) res = best;
+        }
+        oseg[((long long)b * CS + c) * ovol + idx] = res;
+      }
     }
   }
 }
@@ -268,12 +307,14 @@ __global__ __launch_bounds__(256) void aug_finish_kernel(float* __restrict__ dat
 }  // namespace
 
 extern "C" int e2e_aug_spatial(const float* data, const float* seg, float* out_data, float* out_seg, const double* mat, int B,
-                               int C, int CS, int Di, int Hi, int Wi, int Do, int Ho, int Wo, float cval_seg, void* stream) {
+                               int C, int CS, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int order_seg, float cval_seg,
+                               void* stream) {
   E2E_REQUIRE(data && out_data && mat && B > 0 && C > 0 && Di > 0 && Hi > 0 && Wi > 0 && Do > 0 && Ho > 0 && Wo > 0, "aug_spatial: bad arguments");
   E2E_REQUIRE((seg == nullptr) == (out_seg == nullptr) && (seg == nullptr || CS > 0), "aug_spatial: seg / out_seg must come together");
+  E2E_REQUIRE(order_seg == 0 || order_seg == 1, "aug_spatial: order_seg must be 0 or 1");
   dim3 grid((unsigned)e2e::cdivll((long long)Do * Ho * Wo, 256), B);
   hipLaunchKernelGGL(aug_spatial_kernel, grid, dim3(256), 0, (hipStream_t)stream, data, seg, out_data, out_seg, mat, C, CS, Di, Hi,
-                     Wi, Do, Ho, Wo, cval_seg);
+                     Wi, Do, Ho, Wo, order_seg, cval_seg);
   return e2e::check_launch("aug_spatial_kernel");
 }
 

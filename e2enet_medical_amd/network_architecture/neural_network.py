@@ -12,6 +12,8 @@ bar needs fp32).
 """
 from typing import List, Optional, Tuple, Union
 
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -271,7 +273,9 @@ class SegmentationNetwork(NeuralNetwork):
                 accumulate(ti, predict_tile(ti))
         else:
             from ..parallel import run_tiles_sharded
-            run_tiles_sharded(num_tiles, rank, world, self.tile_group, predict_tile, accumulate, (K, px, py, pz), dev)
+            self.last_shard_stats = {}
+            run_tiles_sharded(num_tiles, rank, world, self.tile_group, predict_tile, accumulate, (K, px, py, pz), dev,
+                              pipelined=os.environ.get("E2E_SW_BLOCKING") != "1", stats=self.last_shard_stats)
 
         crop = [(s.start, s.stop) for s in slicer[1:]]
         (cx0, cx1), (cy0, cy1), (cz0, cz1) = crop

@@ -1,10 +1,11 @@
 """Multi-GPU sharding of the hot path: one process per GPU, torch.distributed over RCCL (backend "nccl" on ROCm).
 
 * Sliding-window inference (BASELINE config 4): the x->y->z tile list is dealt round-robin over the ranks; weights
-  are replicated; one all-gather moves every rank's Gaussian-weighted probability patches to all ranks, which then
-  overlap-add them in the reference's tile order (neural_network.py:373-393), so fp32 summation order -- and the
-  result -- is identical to the single-GPU run.  xGMI is point-to-point: an all-gather lets every peer push its
-  shard over its own link instead of funnelling partial volumes through a ring all-reduce.
+  are replicated; per group of `world` consecutive tiles one asynchronous all-gather moves the ranks' mirror-averaged
+  probability patches to all ranks while the next group's tiles are computed; every rank overlap-adds the groups in
+  the reference's tile order (neural_network.py:373-393), so fp32 summation order -- and the result -- is identical
+  to the single-GPU run.  xGMI is point-to-point: an all-gather lets every peer push its shard over its own link
+  instead of funnelling partial volumes through a ring all-reduce.
 * Data-parallel training (config 5): replicas with identical weights; gradients are averaged with one flat
   all-reduce before the fused clip+SGD step (the clip norm must see the reduced gradients); after every prune/grow
   ``Masking.sync_kernel_maps`` broadcasts rank 0's kernel maps (host mirror, device maps, element masks and liveness
@@ -42,22 +43,79 @@ def gather_patches(mine: torch.Tensor, world: int, group=None) -> torch.Tensor:
     return out
 
 
+def _all_gather_async(out: torch.Tensor, mine: torch.Tensor, world: int, group=None):
+    """out [world, ...] <- every rank's `mine`; returns the work handle (the collective runs on the process group's stream)"""
+    if mine.is_cuda:
+        return dist.all_gather_into_tensor(out.view(-1), mine.view(-1), group=group, async_op=True)
+    return dist.all_gather([out[r] for r in range(world)], mine, group=group, async_op=True)      # gloo (CPU tests)
+
+
 def run_tiles_sharded(num_tiles: int, rank: int, world: int, group, predict_tile, accumulate, patch_shape, device,
-                      dtype=torch.float32):
-    """The sharded tile loop of sliding-window inference (BASELINE config 4), shared by ``predict_3D`` and the tests:
-    this rank evaluates tiles ``rank::world`` (``predict_tile(ti) -> [K, px, py, pz]`` mirror-averaged probabilities),
-    ONE all-gather moves every rank's patches to every rank, and all tiles are then handed to ``accumulate(ti, patch)``
-    in the reference's x -> y -> z order (neural_network.py:373-393), so the fp32 overlap-add -- and the result -- is
-    bit-identical to the single-process loop.  Returns the gathered buffer [world, slots, K, px, py, pz]."""
-    per = slots_per_rank(num_tiles, world)
-    mine = torch.zeros((per,) + tuple(patch_shape), dtype=dtype, device=device)
-    for slot, ti in enumerate(partition_tiles(num_tiles, rank, world)):
-        mine[slot].copy_(predict_tile(ti))
-    gathered = gather_patches(mine, world, group)
-    for ti in range(num_tiles):
-        owner, slot = tile_slot(ti, world)
-        accumulate(ti, gathered[owner, slot])
-    return gathered
+                      dtype=torch.float32, pipelined: bool = True, stats: dict = None):
+    """The sharded tile loop of sliding-window inference (BASELINE config 4), shared by ``predict_3D`` and the tests.
+
+    The x -> y -> z tile list is cut into groups of ``world`` consecutive tiles; in group g this rank evaluates tile
+    ``g * world + rank`` (``predict_tile(ti) -> [K, px, py, pz]`` mirror-averaged probabilities).  Pipelined form: the group's
+    patches are exchanged by ONE asynchronous all-gather on the process group's stream while the next group's tile is being
+    computed; when a group has landed its ``world`` tiles are handed to ``accumulate(ti, patch)`` in tile order.  Groups are
+    drained in order, so every rank overlap-adds all tiles in the reference's x -> y -> z order (neural_network.py:373-393): the
+    fp32 sums -- and the result -- are bit-identical to the single-process loop.  Two group buffers are live (2 x world
+    patches: 2.1 GB at K = 16, 128^3, 8 ranks) instead of every tile of the volume (14.5 GB for the AMOS-shaped benchmark volume).
+    ``pipelined=False``: the former blocking form (all local tiles, one all-gather of everything, then the overlap-add);
+    kept for A/B timing.  ``stats`` (dict) receives tile counts and, for CUDA tensors, the time the compute stream spent
+    waiting for collectives."""
+    if stats is None:
+        stats = {}
+    mine_tiles = partition_tiles(num_tiles, rank, world)
+    stats.update(tiles_total=num_tiles, tiles_local=len(mine_tiles), world=world, pipelined=bool(pipelined))
+    if not pipelined:
+        per = slots_per_rank(num_tiles, world)
+        mine = torch.zeros((per,) + tuple(patch_shape), dtype=dtype, device=device)
+        for slot, ti in enumerate(mine_tiles):
+            mine[slot].copy_(predict_tile(ti))
+        gathered = gather_patches(mine, world, group)
+        for ti in range(num_tiles):
+            owner, slot = tile_slot(ti, world)
+            accumulate(ti, gathered[owner, slot])
+        return gathered
+    ngroups = slots_per_rank(num_tiles, world)
+    send = [torch.zeros(tuple(patch_shape), dtype=dtype, device=device) for _ in range(2)]
+    recv = [torch.empty((world,) + tuple(patch_shape), dtype=dtype, device=device) for _ in range(2)]
+    cuda = torch.device(device).type == "cuda"
+    waits = []
+
+    def drain(g, handle):
+        if cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            handle.wait()                       # the compute stream waits for the collective; the host does not
+            e1.record()
+            waits.append((e0, e1))
+        else:
+            handle.wait()
+        for r in range(world):
+            ti = g * world + r
+            if ti < num_tiles:
+                accumulate(ti, recv[g & 1][r])
+    pending = None
+    for g in range(ngroups):
+        ti = g * world + rank
+        if ti < num_tiles:
+            send[g & 1].copy_(predict_tile(ti))
+        # (buffer g & 1 was last used by group g - 2, drained one iteration ago: its accumulate kernels are ahead of this
+        #  collective on the compute stream, and its own collective has been waited for)
+        handle = _all_gather_async(recv[g & 1], send[g & 1], world, group)
+        if pending is not None:
+            drain(*pending)
+        pending = (g, handle)
+    if pending is not None:
+        drain(*pending)
+    if cuda and waits:
+        torch.cuda.synchronize()
+        stats["collective_wait_ms"] = sum(a.elapsed_time(b) for a, b in waits)
+    stats["groups"] = ngroups
+    stats["exchange_buffer_bytes"] = 2 * (world + 1) * int(torch.tensor(patch_shape).prod()) * 4
+    return recv
 
 
 def allreduce_mean_gradients(grads: Dict[str, torch.Tensor], names: List[str], group=None, flat: torch.Tensor = None,

@@ -281,6 +281,29 @@ int e2e_resample_linear(const float* src, float* dst, int K, long long kstride, 
                         long long sb, long long sc, int OA, int OB, int OC, int lowres_axis, void* stream);
 
 
+/* ---- N3: training input feed on the device ------------------------------------------------------------------------
+ * Replaces the spatial and intensity transforms of get_moreDA_augmentation
+ * (e2enet/training/data_augmentation/data_augmentation_moreDA.py:66-111; batchgenerators 0.24 transforms executed by 24 CPU
+ * worker processes in the reference).  All tensors float32 [B, C, D, H, W] contiguous; parameters are drawn on the host.
+ *   e2e_aug_spatial: SpatialTransform (:66-79) as one affine gather: source coordinate = A (o - (size_out - 1) / 2) + t per
+ *     sample (mat: B x 12 doubles, row-major 3 x 4); data order 1 / cval 0; seg (may be NULL) order `order_seg` (0: nearest;
+ *     1: batchgenerators' per-label linear interpolation thresholded at 0.5), outside the volume cval_seg (order 0) / 0 (order 1)
+ *   e2e_aug_stats: per (sample, channel) min, max, mean, std (ddof 0) as 4 doubles; ws of e2e_aug_stats_ws_bytes(nbc) bytes
+ *   e2e_aug_pointwise: op 1 GaussianNoise (:85), 2 BrightnessMultiplicative (:88), 3 ContrastAugmentation (:96), 4 / 5 the
+ *     power and retain_stats steps of GammaTransform (:102-109); prm: nbc x 8 doubles, prm[0] == 0 leaves the channel untouched
+ *   e2e_aug_blur_axis: one axis of GaussianBlurTransform (:86-87) = scipy gaussian_filter1d (truncate 4, 'reflect');
+ *     wts: nbc x 16 floats (radius, w[0..radius])
+ *   e2e_aug_lowres: SimulateLowResolutionTransform (:97-100): nearest down to lo_shape (nbc x 3 ints, 0 = untouched), linear up
+ *   e2e_aug_finish: MaskTransform (:117-119; use_mask: C ints or NULL) and RemoveLabelTransform(-1, 0) (:121)               */
+int e2e_aug_spatial(const float* data, const float* seg, float* out_data, float* out_seg, const double* mat, int B, int C,
+                    int CS, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int order_seg, float cval_seg, void* stream);
+long long e2e_aug_stats_ws_bytes(int nbc);
+int e2e_aug_stats(const float* x, double* stats, double* ws, int nbc, long long vol, void* stream);
+int e2e_aug_pointwise(float* x, const double* prm, int op, int nbc, long long vol, unsigned long long seed, void* stream);
+int e2e_aug_blur_axis(const float* src, float* dst, const float* wts, int nbc, int D, int H, int W, int axis, void* stream);
+int e2e_aug_lowres(const float* src, float* dst, const int* lo_shape, int nbc, int D, int H, int W, void* stream);
+int e2e_aug_finish(float* data, float* seg, const int* use_mask, int B, int C, int CS, long long vol, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

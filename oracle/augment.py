@@ -1,0 +1,110 @@
+"""Training-time augmentation transforms, given their drawn parameters (oracle; test infrastructure only).
+
+numpy / scipy restatement of the batchgenerators 0.24 transforms that reference
+e2enet/training/data_augmentation/data_augmentation_moreDA.py:66-121 composes (third party, absent from the image and from
+/root/reference: PARITY UNPINNED -- no golden could be generated; each function states the batchgenerators routine it follows).
+Where the device path deviates from the reference on purpose (linear instead of cubic interpolation of the data, linear
+up-sampling in the low-resolution simulation) this file restates the DEVICE's choice, so that the kernels are checked against an
+independent implementation of the same arithmetic.
+"""
+import numpy as np
+from scipy import ndimage
+
+
+def coordinate_mesh(patch_size, mat):
+    """augment_spatial: create_zero_centered_coordinate_mesh, rotate_coords_3d / scale_coords (folded into A), + centre (t)."""
+    grids = np.meshgrid(*[np.arange(s, dtype=np.float64) - (s - 1) / 2. for s in patch_size], indexing="ij")
+    c = np.stack([g.reshape(-1) for g in grids])
+    m = np.asarray(mat, dtype=np.float64).reshape(3, 4)
+    return (m[:, :3] @ c + m[:, 3:4]).reshape((3,) + tuple(patch_size))
+
+
+def spatial(data, seg, mats, patch_size, order_seg=1, cval_seg=-1.0):
+    """SpatialTransform per sample: data map_coordinates(order=1, mode='constant', cval=0) [reference: order 3]; seg either
+    order 0 with cval, or interpolate_img(is_seg=True, order=1): per label (ascending) a linear interpolation of the binary mask
+    with the same cval, assigned where >= 0.5."""
+    B = data.shape[0]
+    out = np.zeros((B, data.shape[1]) + tuple(patch_size), np.float32)
+    oseg = None if seg is None else np.zeros((B, seg.shape[1]) + tuple(patch_size), np.float32)
+    for b in range(B):
+        coords = coordinate_mesh(patch_size, mats[b])
+        for c in range(data.shape[1]):
+            out[b, c] = ndimage.map_coordinates(data[b, c].astype(float), coords, order=1, mode='constant', cval=0.0).astype(np.float32)
+        if seg is not None:
+            for c in range(seg.shape[1]):
+                img = seg[b, c]
+                if order_seg == 0:
+                    oseg[b, c] = ndimage.map_coordinates(img.astype(float), coords, order=0, mode='constant', cval=cval_seg).astype(np.float32)
+                else:
+                    res = np.zeros(tuple(patch_size), np.float32)
+                    for lab in np.unique(img):
+                        m = ndimage.map_coordinates((img == lab).astype(float), coords, order=1, mode='constant', cval=cval_seg)
+                        res[m >= 0.5] = lab
+                    oseg[b, c] = res
+    return out, oseg
+
+
+def gaussian_blur(x, sigma):
+    """augment_gaussian_blur: scipy.ndimage.gaussian_filter(channel, sigma, order=0)"""
+    return ndimage.gaussian_filter(x.astype(np.float64), sigma, order=0).astype(np.float32)
+
+
+def contrast(x, factor):
+    """augment_contrast(preserve_range=True): (x - mean) * factor + mean, clipped to the channel's former [min, max]"""
+    x = x.astype(np.float64)
+    mn, lo, hi = x.mean(), x.min(), x.max()
+    return np.clip((x - mn) * factor + mn, lo, hi).astype(np.float32)
+
+
+def gamma(x, g, invert, retain_stats=True, eps=1e-7):
+    """augment_gamma(per_channel=True) on one channel"""
+    x = x.astype(np.float64)
+    if invert:
+        x = -x
+    mn, sd = x.mean(), x.std()
+    lo = x.min()
+    rng = x.max() - lo
+    x = np.power((x - lo) / float(rng + eps), g) * rng + lo
+    if retain_stats:
+        x = x - x.mean()
+        x = x / (x.std() + 1e-8) * sd
+        x = x + mn
+    if invert:
+        x = -x
+    return x.astype(np.float32)
+
+
+def _resize(img, shape, order):
+    """skimage.transform.resize(order, mode='edge', anti_aliasing=False) of scikit-image 0.19.3 = scipy zoom, grid_mode"""
+    return ndimage.zoom(img, np.array(shape, dtype=float) / np.array(img.shape), order=order, mode='nearest', grid_mode=True)
+
+
+def low_resolution(x, zoom):
+    """augment_linear_downsampling_scipy on one channel: nearest down to round(shape * zoom), then up-sampling back [order 1
+    here like the device; the reference passes order_upsample=3]"""
+    shp = np.array(x.shape)
+    target = np.round(shp * zoom).astype(int)
+    down = _resize(x.astype(float), target, 0)
+    return _resize(down, shp, 1).astype(np.float32)
+
+
+def mirror(data, seg, axes_flags):
+    """augment_mirroring on one sample: axes_flags[i] flips spatial axis i"""
+    for ax in range(3):
+        if axes_flags[ax]:
+            data = np.flip(data, 1 + ax)
+            seg = None if seg is None else np.flip(seg, 1 + ax)
+    return np.ascontiguousarray(data), None if seg is None else np.ascontiguousarray(seg)
+
+
+def finish(data, seg, use_mask):
+    """MaskTransform(mask_idx_in_seg=0, set_outside_to=0) + RemoveLabelTransform(-1, 0)"""
+    data, seg = data.copy(), seg.copy()
+    if use_mask is not None:
+        for b in range(data.shape[0]):
+            m = seg[b, 0] < 0
+            for c in range(data.shape[1]):
+                if use_mask[c]:
+                    data[b, c][m] = 0
+    seg[seg == -1] = 0
+    return data, seg

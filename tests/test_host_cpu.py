@@ -159,13 +159,19 @@ def accumulate(ti, patch_t):               # stands in for e2e_sw_accumulate
     agg[:, sx:sx + 16, sy:sy + 32, sz:sz + 32] += patch_t.numpy() * g
     cnt[:, sx:sx + 16, sy:sy + 32, sz:sz + 32] += g
 
-# the product's sharded tile loop (the function predict_3D itself runs when tile_world > 1)
-parallel.run_tiles_sharded(len(tiles), rank, world, None, predict_tile, accumulate, (3,) + patch, torch.device("cpu"))
-assert evaluated == list(range(rank, len(tiles), world))
+# the product's sharded tile loop (the function predict_3D itself runs when tile_world > 1): pipelined (groups of `world`
+# tiles, asynchronous all-gather under the next group's compute) and the blocking form it replaced
 sl = tuple([slice(0, 3)] + slicer[1:])
-probs = agg[sl] / cnt[sl]
-assert np.array_equal(probs, probs_ref), "sharded overlap-add must be bit identical to the single-process order"
-assert np.array_equal(probs.argmax(0), seg_ref)
+for pipelined in (True, False):
+    agg[:] = 0; cnt[:] = 0; del evaluated[:]
+    st = {}
+    parallel.run_tiles_sharded(len(tiles), rank, world, None, predict_tile, accumulate, (3,) + patch, torch.device("cpu"),
+                               pipelined=pipelined, stats=st)
+    assert evaluated == list(range(rank, len(tiles), world))
+    assert st["tiles_total"] == len(tiles) and st["tiles_local"] == len(evaluated) and st["pipelined"] == pipelined
+    probs = agg[sl] / cnt[sl]
+    assert np.array_equal(probs, probs_ref), "sharded overlap-add must be bit identical to the single-process order"
+    assert np.array_equal(probs.argmax(0), seg_ref)
 
 # data-parallel gradient averaging + DSFF mask broadcast
 grads = {"a": torch.full((5, 3), float(rank + 1)), "b": torch.arange(4, dtype=torch.float32) * (rank + 1)}
