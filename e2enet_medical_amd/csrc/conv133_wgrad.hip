@@ -1128,7 +1128,7 @@ inline int plan_v3(WgParams& p, int pairs) {
 }
 
 // bf3 (conv133_wgrad_bf3.hip: bf16 matrix pipe, fp32-exact three-piece operands): the shapes v3 serves; E2E_WG_BF3=0 keeps
-// the fp32-MFMA kernels (A/B runs).  32 x 32 channel blocks, chunks planned like v3's.
+// the fp32-MFMA kernels, 1 selects the first bf3 form (A/B runs).  32 x 32 channel blocks, chunks planned like v3's.
 inline bool use_bf3(int Cin, int Hi, int Wi, int sh, int sw) {
   static const int on = getenv("E2E_WG_BF3") ? atoi(getenv("E2E_WG_BF3")) : 1;
   return on && Cin > 4 && use_v3(Cin, Hi, Wi, sh, sw);

@@ -468,13 +468,15 @@ def test_conv133_persistent_run_loop_forced():
     assert "passed" in r.stdout
 
 
-def test_conv133_wgrad_fp32_mfma_path_forced():
+@pytest.mark.parametrize("variant", ["0", "1"])
+def test_conv133_wgrad_alternative_paths_forced(variant):
     """The dense weight gradient of large stride-1 planes runs on the bf16 matrix pipe with three-piece fp32 operands
-    (conv133_wgrad_bf3_kernel); E2E_WG_BF3=0 selects the fp32-MFMA kernels (v3) it replaced, which stay in the library for
-    A/B runs.  The knob is read once per process: run the operator cases again in a child process."""
+    (conv133_wgrad_bf3v2_kernel: 32x32x16 MFMA, twelve waves).  E2E_WG_BF3=1 selects its first form (16x16x32 MFMA, eight
+    waves), E2E_WG_BF3=0 the fp32-MFMA kernels (v3) both replaced; they stay in the library for A/B runs.  The knob is read
+    once per process: run the operator cases again in a child process."""
     import subprocess
     import sys
-    env = dict(os.environ, E2E_WG_BF3="0")
+    env = dict(os.environ, E2E_WG_BF3=variant)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
                         "test_conv133_fwd_bwd", "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, timeout=900,
