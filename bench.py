@@ -353,7 +353,9 @@ def main():
         dt = float(tt.item())
 
     # ---- instrumented steps (outside the timed region): HIP events around the conv entry points --------------------
-    names = ["conv133_fwd", "conv133_fwd_splitk", "conv133_dgrad", "conv133_dgrad_splitk", "conv133_wgrad"]    # (_splitk: the deep levels' forward, same kernel + a sum kernel)
+    # (_splitk: the deep levels' forward / data gradient, same kernel + a sum kernel; _dense: the unmasked layers on the matrix cores)
+    names = ["conv133_fwd", "conv133_fwd_splitk", "conv133_fwd_dense", "conv133_dgrad", "conv133_dgrad_splitk", "conv133_dgrad_dense",
+             "conv133_wgrad"]
     if args.op_profile:
         names += ["in_stats_finalize", "in_lrelu_bwd", "convT_fwd", "convT_dgrad", "convT_wgrad", "maxpool_fwd", "maxpool_bwd",
                   "head1x1_fwd", "head1x1_dgrad", "head1x1_wgrad", "dc_ce_reduce", "dc_ce_grad", "grad_sqnorm", "sgd_clip_mask_step"]
@@ -393,16 +395,19 @@ def main():
         if args.forward_only:
             out["metric"] = "voxels/sec (inference forward only), 128^3 patch 32ch density=0.2"
         work = conv_work(eng, mask)
-        ev = [(e0.elapsed_time(e1), work[a[0]]) for e0, e1, a in timers["conv133_fwd"].events + timers["conv133_fwd_splitk"].events]
+        ev = [(e0.elapsed_time(e1), work[a[0]]) for e0, e1, a in timers["conv133_fwd"].events + timers["conv133_fwd_splitk"].events +
+              timers["conv133_fwd_dense"].events]
         ev += [(e0.elapsed_time(e1), work[a[3]]) for e0, e1, a in timers["conv133_dgrad"].events + timers["conv133_dgrad_splitk"].events]
+        ev += [(e0.elapsed_time(e1), work[a[2]]) for e0, e1, a in timers["conv133_dgrad_dense"].events]
         if ev:
             ms = sum(t for t, _ in ev)
             byt = sum(w["bytes"] for _, w in ev)
             fl = sum(w["flops_live"] for _, w in ev)
             gbs = byt / (ms * 1e-3) / 1e9
             out["roofline"] = {
-                "bound": "hbm", "kernel": "conv133_kernel: every launch of e2e_conv133_fwd and e2e_conv133_dgrad "
-                                          "(depth shift + concat + 1x3x3 conv, forward and data gradient)",
+                "bound": "hbm", "kernel": "conv133_kernel + conv133_dense_kernel: every launch of e2e_conv133_fwd* and e2e_conv133_dgrad* "
+                                          "(depth shift + concat + 1x3x3 conv, forward and data gradient; DSFF-masked layers on the "
+                                          "sparse VALU walk, unmasked layers on the bf16 matrix pipe with fp32-exact operands)",
                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                 "traffic": pmc_traffic("conv133_kernel"),
                 "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" % TRAFFIC_FILE,

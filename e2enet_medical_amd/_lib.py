@@ -46,6 +46,9 @@ SIGNATURES = {
     "e2e_conv133_dgrad": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "e2e_conv133_dgrad_ws_bytes": (LL, [I, I, I, I, I, I, I, I, I]),
     "e2e_conv133_dgrad_splitk": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, P, LL, P]),
+    "e2e_conv133_dense_ws_bytes": (LL, [I, I, I, I, I, I, I, I, I]),
+    "e2e_conv133_fwd_dense": (I, [P, I, P, P, P, P, I, I, I, I, I, P, LL, P]),
+    "e2e_conv133_dgrad_dense": (I, [P, P, P, I, I, I, I, I, I, P, LL, P]),
     "e2e_conv133_wgrad_ws_bytes": (LL, [I, I, I, I, I, I, I, I, I]),
     "e2e_conv133_wgrad": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "e2e_in_stats_finalize": (I, [P, I, P, P, F, P, P, P, P, I, I, P]),
@@ -91,7 +94,7 @@ SIGNATURES = {
     "e2e_aug_finish": (I, [P, P, P, I, I, I, LL, P]),
 }
 
-_NO_STATUS = {"e2e_last_error", "e2e_abi_version", "e2e_last_kernel", "e2e_conv133_num_partials", "e2e_conv133_wgrad_ws_bytes", "e2e_conv133_fwd_ws_bytes", "e2e_conv133_dgrad_ws_bytes",
+_NO_STATUS = {"e2e_last_error", "e2e_abi_version", "e2e_last_kernel", "e2e_conv133_num_partials", "e2e_conv133_wgrad_ws_bytes", "e2e_conv133_dense_ws_bytes", "e2e_conv133_fwd_ws_bytes", "e2e_conv133_dgrad_ws_bytes",
               "e2e_convT_wgrad_ws_bytes", "e2e_head1x1_wgrad_ws_bytes", "e2e_loss_ws_bytes", "e2e_aug_stats_ws_bytes"}
 
 
@@ -130,7 +133,7 @@ class _Lib:
 _lib = None
 
 
-ABI_VERSION = 11          # e2e_abi_version() of the library this binding was written against
+ABI_VERSION = 12          # e2e_abi_version() of the library this binding was written against
 
 
 def lib() -> _Lib:

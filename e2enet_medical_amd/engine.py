@@ -13,6 +13,7 @@ Design notes:
 """
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -21,6 +22,8 @@ from ._lib import lib, InChan, OutChan, ParamEntry
 
 LRELU_SLOPE = 0.01
 IN_EPS = 1e-5
+DENSE_MIN_DENSITY = float(os.environ.get("E2E_DENSE_MIN_DENSITY", "0.5"))
+DENSE_ENABLED = True          # tests switch the matrix-core conv path off to compare the sparse walk with itself
 
 
 def shift_amounts(num_channels: int, shift_size: int = 5):
@@ -100,6 +103,7 @@ class ConvOp:
         self.w_name = prefix + ".conv.weight"
         self.live = None        # quad words [ceil(Cout/4), ceil(Cin/8)] int32 (e2e_dsff_expand_quads)
         self.live_t = None      # quad words [ceil(Cin/4), ceil(Cout/8)] int32
+        self.density = 1.0      # live (out, in) kernels / all, set with the kernel maps (dispatch between the two conv kernels)
         # per input channel plane table
         shifts = shift_amounts(self.cin, getattr(getattr(eng, 'cfg', None), 'shift_size', 5))
         structs = []
@@ -137,6 +141,14 @@ class ConvOp:
                 c += 1
         self.outs = _upload_structs(structs, self.eng.device)
 
+    def use_dense(self):
+        """Dense layers (no DSFF map, or a map too dense for the kernel-granular sparse walk to pay) run on the bf16 matrix
+        pipe (conv133_dense.hip: fp32-exact three-piece operands) where the shape is served; E2E_DENSE_MIN_DENSITY moves the
+        switch-over (measured on 64 -> 32 @128^3: at d = 0.5 the dense kernel 1.16 ms, the sparse walk 1.27 ms; at d = 0.2 the walk 0.69 ms)."""
+        if not DENSE_ENABLED or self.dense_ws_bytes <= 0 or getattr(self.eng, "fwd_ws", None) is None:
+            return False
+        return self.live is None or self.density >= DENSE_MIN_DENSITY
+
     def forward(self):
         e = self.eng
         p = e.params
@@ -145,7 +157,11 @@ class ConvOp:
         sd, sh, sw = self.stride
         L = lib()
         ws = getattr(e, "fwd_ws", None)
-        if ws is not None and self.fwd_ws_bytes > 0:      # deep levels: input-plane chunks split over several workgroups
+        if self.use_dense():
+            L.conv133_fwd_dense(self.chans.data_ptr(), self.cin, p[self.w_name].data_ptr(), p[self.prefix + ".conv.bias"].data_ptr(),
+                                self.out.data.data_ptr(), self.part.data_ptr(), b, self.cout, di, hi, wi, ws.data_ptr(),
+                                ws.numel() * 4, _stream())
+        elif ws is not None and self.fwd_ws_bytes > 0:      # deep levels: input-plane chunks split over several workgroups
             L.conv133_fwd_splitk(self.chans.data_ptr(), self.cin, p[self.w_name].data_ptr(),
                                  p[self.prefix + ".conv.bias"].data_ptr(), _ptr(self.live), self.out.data.data_ptr(),
                                  self.part.data_ptr(), b, self.cout, di, hi, wi, sd, sh, sw, ws.data_ptr(), ws.numel() * 4,
@@ -177,7 +193,10 @@ class ConvOp:
                         b, self.cin, self.cout, di, hi, wi, sd, sh, sw, _stream())
         if self.do_dgrad:
             ws = getattr(e, "fwd_ws", None)
-            if ws is not None and self.dgrad_ws_bytes > 0:        # deep levels: split-K (the workspace is idle during backward)
+            if self.use_dense():
+                L.conv133_dgrad_dense(o.grad.data_ptr(), p[self.w_name].data_ptr(), self.outs.data_ptr(), b, self.cin, self.cout,
+                                      di, hi, wi, ws.data_ptr(), ws.numel() * 4, _stream())
+            elif ws is not None and self.dgrad_ws_bytes > 0:        # deep levels: split-K (the workspace is idle during backward)
                 L.conv133_dgrad_splitk(o.grad.data_ptr(), p[self.w_name].data_ptr(), _ptr(self.live_t), self.outs.data_ptr(),
                                        b, self.cin, self.cout, di, hi, wi, sd, sh, sw, ws.data_ptr(), ws.numel() * 4, _stream())
             else:
@@ -187,6 +206,13 @@ class ConvOp:
     def wgrad_ws_bytes(self):
         di, hi, wi = self.in_dims
         return lib().conv133_wgrad_ws_bytes(self.out.shape[0], self.cin, self.cout, di, hi, wi, *self.stride)
+
+    @property
+    def dense_ws_bytes(self):
+        if not hasattr(self, "_dense_ws_bytes"):
+            di, hi, wi = self.in_dims
+            self._dense_ws_bytes = int(lib().conv133_dense_ws_bytes(self.out.shape[0], self.cin, self.cout, di, hi, wi, *self.stride))
+        return self._dense_ws_bytes
 
     @property
     def dgrad_ws_bytes(self):
@@ -377,7 +403,7 @@ class Engine:
         self.loss_ws = None
         self.loss_val = None
         self.generation = 0                # bumped by every forward(): activations are reused in place
-        fws = max([max(op.fwd_ws_bytes, op.dgrad_ws_bytes if op.do_dgrad else 0) for op in self.conv_ops.values()] + [0])
+        fws = max([max(op.fwd_ws_bytes, op.dgrad_ws_bytes if op.do_dgrad else 0, op.dense_ws_bytes) for op in self.conv_ops.values()] + [0])
         self.fwd_ws = torch.empty(fws // 4, dtype=torch.float32, device=self.device) if fws > 0 else None   # split-K partial sums (deep levels)
         self.pre_forward_hook = None       # callable(): set by the owning network, brings masks / parameters up to date
         self._eval_counts = None
@@ -462,8 +488,10 @@ class Engine:
             km = kmasks.get(name)
             if km is None:
                 op.live = op.live_t = None
+                op.density = 1.0
                 continue
             r, cc = km.shape
+            op.density = float(km.float().mean().item())
             km = km.to(device=self.device, dtype=torch.uint8).contiguous()
             if isinstance(op, ConvOp):         # weight [Cout, Cin, ...]: quad words (4 output x 8 input planes)
                 rows = torch.empty(((r + 3) // 4) * ((cc + 7) // 8), dtype=torch.int32, device=self.device)

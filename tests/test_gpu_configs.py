@@ -274,7 +274,7 @@ FULL_CONV = [
     ("loc L0 64->32 @128^3 B=2 d=0.2", (2, [(32, True), (32, False)], 32, (128, 128, 128), (1, 1, 1), 0.2),
      "tile=16x32", "conv133_wgrad_bf3 chunks=128 pairs=2", "mode=1"),
     ("c0.b1 32->32 @128^3 dense", (2, [(32, True)], 32, (128, 128, 128), (1, 1, 1), 1.0),
-     "tile=16x32", "conv133_wgrad_bf3", "mode=1"),
+     "conv133_dense_bf3<mode=0>", "conv133_wgrad_bf3", "conv133_dense_bf3<mode=1>"),
     ("loc L1 160->64 @64^3 d=0.2", (2, [(64, True), (64, False), (32, False)], 64, (64, 64, 64), (1, 1, 1), 0.2),
      "tile=16x32", "conv133_wgrad_bf3", "mode=1"),
     ("c1.b0 32->64 s2 @128^3", (1, [(32, True)], 64, (128, 128, 128), (2, 2, 2), 1.0),
@@ -284,11 +284,13 @@ FULL_CONV = [
 
 @pytest.mark.parametrize("name,case,k_fwd,k_wgrad,k_dgrad", FULL_CONV, ids=[c[0] for c in FULL_CONV])
 def test_conv133_at_benchmarked_shapes(name, case, k_fwd, k_wgrad, k_dgrad):
-    with KernelLog(["conv133_fwd", "conv133_wgrad", "conv133_dgrad"]) as kl:
+    with KernelLog(["conv133_fwd", "conv133_fwd_dense", "conv133_wgrad", "conv133_dgrad", "conv133_dgrad_dense"]) as kl:
         ops.test_conv133_fwd_bwd(case)
-    assert all(k_fwd in k for k in kl.of("conv133_fwd")) and kl.of("conv133_fwd"), kl.log
+    fwd = kl.of("conv133_fwd") + kl.of("conv133_fwd_dense")
+    dgr = kl.of("conv133_dgrad") + kl.of("conv133_dgrad_dense")
+    assert all(k_fwd in k for k in fwd) and fwd, kl.log
     assert all(k_wgrad in k for k in kl.of("conv133_wgrad")) and kl.of("conv133_wgrad"), kl.log
-    assert all(k_dgrad in k for k in kl.of("conv133_dgrad")) and kl.of("conv133_dgrad"), kl.log
+    assert all(k_dgrad in k for k in dgr) and dgr, kl.log
 
 
 @pytest.mark.parametrize("B,cin,cout,dims,density,k_dgrad,k_wgrad", [

@@ -74,6 +74,10 @@ CONV_CASES = [
     (1, [(4, True)], 32, (2, 16, 64), (1, 1, 1), 1.0),
     (2, [(20, True)], 24, (2, 20, 36), (1, 1, 1), 1.0),                      # one 32 x 32 block: row-split double-buffered wgrad
     (2, [(33, True)], 40, (5, 4, 12), (1, 1, 1), 0.5),                       # 4-row planes with wide rows (found by tools/scratch/fuzz_ops.py)
+    # dense matrix-core path (conv133_dense.hip: stride 1, W % 32 == 0, H % 16 == 0, >= 16 channels, dense or density >= 0.5)
+    (1, [(32, True)], 32, (6, 32, 64), (1, 1, 1), 1.0),
+    (2, [(20, True), (28, False)], 40, (3, 32, 32), (1, 1, 1), 1.0),         # ragged channel blocks (48 -> 40), two sources, shift
+    (1, [(16, True), (16, False), (8, False)], 64, (7, 48, 96), (1, 1, 1), 0.6),   # DSFF map dense enough for the dense kernel
 ]
 
 
@@ -139,12 +143,18 @@ def test_conv133_fwd_bwd(case):
     e = _eng_stub(params)
     e.batch = B
     op = ConvOp(e, "blk", srcs, cout, stride)
+    if op.dense_ws_bytes > 0:
+        e.fwd_ws = torch.empty(op.dense_ws_bytes // 4, dtype=torch.float32, device=e.device)
     if km is not None:
         rows = torch.empty(((cout + 3) // 4) * ((cin + 7) // 8), dtype=torch.int32, device=e.device)
         cols = torch.empty(((cin + 3) // 4) * ((cout + 7) // 8), dtype=torch.int32, device=e.device)
         kmd = km.to(e.device)
         lib().dsff_expand_quads(kmd.data_ptr(), rows.data_ptr(), cols.data_ptr(), cout, cin, 0)
         op.live, op.live_t = rows, cols
+        op.density = float(km.float().mean())
+    if dims[2] % 32 == 0 and dims[1] % 16 == 0 and dims[1] > 16 and stride == (1, 1, 1) and cin >= 16 and cout >= 16 and density >= 0.5 \
+            and os.environ.get("E2E_CONV_DENSE", "1") != "0":
+        assert op.use_dense(), "this case is meant to reach conv133_dense_kernel"
     op.forward()
     torch.cuda.synchronize()
     # ---- forward: pre-norm output and the normalise-on-load coefficients

@@ -71,6 +71,20 @@ def conv_case(B, srcs, cout, dims, stride, density, tag):
     di, hi, wi = dims
     p = e.params
 
+    if op.dense_ws_bytes > 0:
+        e.fwd_ws = torch.empty(op.dense_ws_bytes // 4, dtype=torch.float32, device=dev)
+    if density < 1.0:
+        op.density = float(km.float().mean())
+    dense_path = op.use_dense() and os.environ.get("KB_NO_DENSE") is None
+
+    def fwd_dense():
+        L.conv133_fwd_dense(op.chans.data_ptr(), cin, w.data_ptr(), p["b.conv.bias"].data_ptr(), op.out.data.data_ptr(), op.part.data_ptr(),
+                            B, cout, di, hi, wi, e.fwd_ws.data_ptr(), e.fwd_ws.numel() * 4, 0)
+
+    def dgrad_dense():
+        L.conv133_dgrad_dense(op.out.grad.data_ptr(), w.data_ptr(), op.outs.data_ptr(), B, cin, cout, di, hi, wi, e.fwd_ws.data_ptr(),
+                              e.fwd_ws.numel() * 4, 0)
+
     def fwd():
         L.conv133_fwd(op.chans.data_ptr(), cin, w.data_ptr(), p["b.conv.bias"].data_ptr(), op.live.data_ptr() if op.live is not None else None,
                       op.out.data.data_ptr(), op.part.data_ptr(), B, cout, di, hi, wi, *stride, 0)
@@ -84,6 +98,9 @@ def conv_case(B, srcs, cout, dims, stride, density, tag):
                         B, cin, cout, di, hi, wi, *stride, 0)
     dense = 2.0 * 9 * cin * cout * (vout / cout)
     res = {}
+    if dense_path:
+        fwd, dgrad = fwd_dense, dgrad_dense
+        tag = tag + "[dense]"
     for name, fn, flops in (("fwd", fwd, dense * density), ("dgrad", dgrad, dense * density), ("wgrad", wgrad, dense)):
         ms = time_ms(fn)
         gbs = (vin + vout) * 4 / ms / 1e6
@@ -93,6 +110,8 @@ def conv_case(B, srcs, cout, dims, stride, density, tag):
 
 
 CASES = {
+    "L0_64x32_d05": (2, [(32, True), (32, False)], 32, (128, 128, 128), (1, 1, 1), 0.5),
+    "L1_64x64d": (2, [(64, True)], 64, (64, 64, 64), (1, 1, 1), 1.0),
     "L0_64x32": (2, [(32, True), (32, False)], 32, (128, 128, 128), (1, 1, 1), 0.2),
     "L0_32x32d": (2, [(32, True)], 32, (128, 128, 128), (1, 1, 1), 1.0),
     "L0_4x32d": (2, [(4, False)], 32, (128, 128, 128), (1, 1, 1), 1.0),
