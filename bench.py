@@ -43,9 +43,10 @@ BASE, CIN, K, DENSITY, BATCH = 32, 4, 4, 0.2, 2
 POOLS = [(2, 2, 2)] * 5
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 FP32_PEAK_TF = 157.3           # fp32 vector FMA peak = fp32-input MFMA peak (MI355X_MICROARCH.md)
+BF16_PEAK_TF = 2500.0          # dense bf16 MFMA peak (MI355X_MICROARCH.md; the 5 PF headline figure includes 2:1 sparsity)
 FWD_BYTES_PER_VOXEL = 5393.0   # BASELINE.md section 3 / SURVEY section 8(d): algorithmic fwd bytes per voxel at 32 ch
 TRAIN_BYTES_PER_VOXEL = 3 * FWD_BYTES_PER_VOXEL
-TRAFFIC_FILE = "r02_pmc_traffic.json"
+TRAFFIC_FILE = "r03_pmc_traffic.json"
 
 
 def build(device, patch=PATCH, cin=CIN, k=K, seed=0, density=DENSITY):
@@ -104,17 +105,18 @@ class KernelTimer:
         return sum(e0.elapsed_time(e1) for e0, e1, _ in self.events)
 
 
-def pmc_traffic(prefix):
-    """HBM bytes per launch of the kernels whose name starts with `prefix`, from the committed PMC summary
+def pmc_traffic(*prefixes):
+    """HBM bytes per launch of the kernels whose name starts with one of `prefixes`, from the committed PMC summary
     (measured by rocprofv3 outside this process, separate --pmc passes: tools/prof_bench.sh)."""
     path = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
     if not os.path.exists(path):
         return None
     d = json.load(open(path))
-    n = sum(v["launches"] for k, v in d.items() if k.startswith(prefix))
+    sel = {k: v for k, v in d.items() if any(k.startswith(pf) for pf in prefixes)}
+    n = sum(v["launches"] for v in sel.values())
     if not n:
         return None
-    return sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in d.items() if k.startswith(prefix)) / n
+    return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel.values()) / n
 
 
 def conv_work(eng, mask):
@@ -409,7 +411,7 @@ def main():
                                           "(depth shift + concat + 1x3x3 conv, forward and data gradient; DSFF-masked layers on the "
                                           "sparse VALU walk, unmasked layers on the bf16 matrix pipe with fp32-exact operands)",
                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                "traffic": pmc_traffic("conv133_kernel"),
+                "traffic": pmc_traffic("conv133_kernel", "conv133_dense_kernel"),
                 "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" % TRAFFIC_FILE,
                 "algorithmic_bytes_per_launch": byt / len(ev), "launches_per_step": len(ev) // isteps,
                 "avg_ms": ms / len(ev), "ms_per_step": ms / isteps, "share_of_step": (ms / isteps) / ms_step,
@@ -422,8 +424,12 @@ def main():
             fl = sum(work[a[0]]["flops_dense"] for _, _, a in wt.events)
             tf = fl / (ms * 1e-3) / 1e12
             out["roofline_secondary"] = {
-                "bound": "mfma", "kernel": "conv133_wgrad_v3/v2/s2_kernel (+ slab reduce): every launch of e2e_conv133_wgrad (dense)",
-                "achieved": tf, "peak": FP32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP32_PEAK_TF,
+                "bound": "mfma", "kernel": "conv133_wgrad_bf3v2 (bf16 MFMA, six bf16 products per fp32 product) / v2 / s2 / smallc (fp32 MFMA) "
+                                           "+ slab reduce: every launch of e2e_conv133_wgrad (dense weight gradient)",
+                "achieved": tf, "peak": BF16_PEAK_TF / 6.0, "unit": "TFLOP/s", "frac": tf / (BF16_PEAK_TF / 6.0),
+                "note": "fp32-equivalent dense FLOPs / time; peak = the dense bf16 MFMA peak (2500 TFLOP/s) / 6, the rate an fp32 "
+                        "product rebuilt from six bf16 products can reach; against the fp32 MFMA / vector peak (157.3) the fraction "
+                        "is %.3f" % (tf / FP32_PEAK_TF),
                 "traffic": pmc_traffic("conv133_wgrad"), "launches_per_step": len(wt.events) // isteps,
                 "avg_ms": ms / len(wt.events), "ms_per_step": ms / isteps, "share_of_step": (ms / isteps) / ms_step}
         if args.op_profile:

@@ -407,6 +407,12 @@ class Engine:
         self.fwd_ws = torch.empty(fws // 4, dtype=torch.float32, device=self.device) if fws > 0 else None   # split-K partial sums (deep levels)
         self.pre_forward_hook = None       # callable(): set by the owning network, brings masks / parameters up to date
         self._eval_counts = None
+        # HIP-graph replay of the op lists for small plans (the host issues ~300-600 launches per pass: a Hippocampus-sized
+        # patch is launch bound, 128^3 is not).  E2E_GRAPHS=0 / 1 / auto (default: plans of at most E2E_GRAPH_MAX_VOXELS voxels)
+        self._graphs = {}                  # key -> torch.cuda.CUDAGraph
+        self._graph_seen = set()           # keys that ran eagerly once (lazy allocations done)
+        self.maps_generation = 0           # bumped when the liveness tables are replaced (their pointers are baked into a graph)
+        self._tgt_static = None
 
     def _build_unetpp(self, cfg):
         """reference Generic_UNetPlusPlus.forward (unetpp_d.py:447-488) and create_nest (:491-550)"""
@@ -484,6 +490,9 @@ class Engine:
         """kmasks: weight name -> uint8 [dim0, dim1] kernel map (1 = alive).  Builds the liveness bit tables the
         kernels walk.  Names absent from the dict are treated as dense."""
         L = lib()
+        self.maps_generation += 1
+        self._graphs.clear()
+        self._graph_seen.clear()
         for name, op in list(self.conv_ops.items()) + list(self.up_ops.items()):
             km = kmasks.get(name)
             if km is None:
@@ -530,14 +539,49 @@ class Engine:
             self.pre_forward_hook()
         self.input.data.copy_(x)
         self.generation += 1
-        for op in self.ops:
-            if isinstance(op, HeadOp):
-                op.active = deep_supervision or op is self.heads[0]
-                if not op.active:
-                    continue
-            op.forward()
+        for h in self.heads:               # (set here, not inside the op list: a graph replay does not run Python)
+            h.active = bool(deep_supervision) or h is self.heads[0]
+        self._run(("fwd", bool(deep_supervision)), self._forward_ops)
         outs = [h.out.data for h in self.heads]
         return outs if deep_supervision else outs[0]
+
+    def _forward_ops(self):
+        for op in self.ops:
+            if isinstance(op, HeadOp) and not op.active:
+                continue
+            op.forward()
+
+    # ------------------------------------------------------------------------------------------ graph replay
+    def _graph_ok(self):
+        mode = os.environ.get("E2E_GRAPHS", "auto")
+        if mode == "0" or self.grad_bucket_hook is not None or self.batch_dice_hook is not None:
+            return False                     # (collectives inside the pass: issued eagerly)
+        if torch.cuda.is_current_stream_capturing():
+            return False                     # a caller is capturing the whole pass itself
+        if mode == "1":
+            return True
+        vox = self.batch * self.patch[0] * self.patch[1] * self.patch[2]
+        return vox <= int(os.environ.get("E2E_GRAPH_MAX_VOXELS", str(1 << 20)))
+
+    def _run(self, key, fn):
+        """fn() issues a fixed list of kernel launches over this plan's buffers.  Small plans replay it as a HIP graph: first
+        call eager (lazy allocations), second call captured, later calls replayed; a new set of liveness tables drops the
+        graphs (set_kernel_masks).  Weights, masks and inputs are read through stable pointers, so replays see their
+        current contents."""
+        if not self._graph_ok():
+            return fn()
+        key = key + (self.maps_generation,)
+        g = self._graphs.get(key)
+        if g is None:
+            if key not in self._graph_seen:
+                self._graph_seen.add(key)
+                return fn()
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g):
+                fn()
+            self._graphs[key] = g
+        g.replay()
 
     # ------------------------------------------------------------------------------------------ backward
     def prepare_backward(self):
@@ -645,8 +689,24 @@ class Engine:
         """Deep-supervision Dice+CE loss (reference MultipleOutputLoss2(DC_and_CE_loss), deep_supervision.py:31-43)
         and the full backward pass.  targets[i]: [B,1,...] float labels at scale i.  Returns the device loss scalar."""
         self.prepare_backward()
-        self._loss(targets, weights, batch_dice, smooth, True)
-        self.backward(None)
+        if not self._graph_ok():
+            self._loss(targets, weights, batch_dice, smooth, True)
+            self.backward(None)
+            return self.loss_val
+        # graph replay: the targets are staged into buffers of this plan (their pointers are part of the graph)
+        if self._tgt_static is None:
+            self._tgt_static = [torch.empty((self.batch, 1) + tuple(h.out.shape[2:]), dtype=torch.float32, device=self.device)
+                                for h in self.heads]
+        n = min(len(targets), len(self.heads))
+        for i in range(n):
+            self._tgt_static[i].copy_(targets[i].reshape(self._tgt_static[i].shape))
+        wkey = tuple(float(weights[i]) if i < len(weights) else 0.0 for i in range(len(self.heads)))
+        active = tuple(h.active for h in self.heads)
+
+        def body():
+            self._loss(self._tgt_static, weights, batch_dice, smooth, True)
+            self.backward(None)
+        self._run(("lossbwd", wkey, bool(batch_dice), float(smooth), active), body)
         return self.loss_val
 
     def loss_value(self, targets: Sequence[torch.Tensor], weights: Sequence[float], batch_dice=False, smooth=1e-5):

@@ -799,3 +799,48 @@ def test_engine_forward_and_backward_are_graph_capturable(mode):
                 assert torch.equal(eng.grads[n], g_ref[n]), n
             else:
                 assert (eng.grads[n] - g_ref[n]).abs().max().item() <= 1e-6 * max(1.0, g_ref[n].abs().max().item()), (tag, n)
+
+
+def test_small_plan_graph_replay_matches_eager(monkeypatch):
+    """Engine._run: a small plan replays its forward and its loss + backward op lists as HIP graphs from the third call on.
+    Replays must be bit-identical to eager execution, follow weight updates (stable parameter pointers), switch correctly
+    between deep-supervision modes, and be dropped when new liveness tables arrive (prune / grow)."""
+    net, shapes, params = tiny_net()
+    w = oracle.ds_weights(5)
+
+    def run(mode, steps):
+        monkeypatch.setenv("E2E_GRAPHS", mode)
+        net._engines.clear()
+        with torch.no_grad():
+            for n, p in net.named_parameters():
+                p.copy_(params[n])
+        net.set_kernel_masks(None)
+        res = []
+        for it in range(steps):
+            x = seeded_input((2, TINY["cin"]) + TINY["patch"], seed=500 + it).cuda()
+            eng = net.engine(x)
+            outs = [o.clone() for o in eng.forward(x, True)]
+            targets = [seeded_labels((2, 1) + tuple(o.shape[2:]), TINY["k"], seed=600 + it + i).cuda() for i, o in enumerate(outs)]
+            loss = eng.loss_backward(targets, w, batch_dice=False).clone()
+            grads = {n: g.clone() for n, g in eng.grads.items()}
+            with torch.no_grad():                         # a weight update between iterations (plain SGD: pointers stay)
+                for n, p in net.named_parameters():
+                    p.add_(grads[n], alpha=-0.05)
+            if it == 3:                                    # new liveness tables: graphs must be rebuilt
+                names = oracle.masked_names(oracle.make_spec(TINY["cin"], TINY["base"], TINY["k"], TINY["pools"], 2, TINY["max_feat"]))
+                random.seed(9)
+                masks = oracle.uniform_kernel_masks(shapes, names, 0.5)
+                with torch.no_grad():
+                    for n in names:
+                        net.get_parameter(n).mul_(masks[n].cuda())
+                net.set_kernel_masks({n: (masks[n].reshape(masks[n].shape[0], masks[n].shape[1], -1).sum(-1) > 0).to(torch.uint8) for n in names})
+            full = eng.forward(x, False).clone() if it % 2 == 0 else None        # inference pass without deep supervision in between
+            res.append((outs, loss, grads, full))
+        return res, net.engine(x)
+    eager, _ = run("0", 8)
+    graphed, eng = run("1", 8)
+    assert len(eng._graphs) >= 2, "the graphs were not built"
+    for (o1, l1, g1, f1), (o2, l2, g2, f2) in zip(eager, graphed):
+        assert all(torch.equal(a, b) for a, b in zip(o1, o2)) and torch.equal(l1, l2)
+        assert all(torch.equal(g1[n], g2[n]) for n in g1)
+        assert (f1 is None) == (f2 is None) and (f1 is None or torch.equal(f1, f2))
