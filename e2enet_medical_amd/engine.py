@@ -11,6 +11,7 @@ Design notes:
   * backward is the reverse op list; gradients w.r.t. a tensor are accumulated in one buffer whose first writer
     (in backward order) overwrites and later writers add -- decided statically when the plan is built.
 """
+import contextlib
 import ctypes as C
 import math
 import os
@@ -23,6 +24,8 @@ from ._lib import lib, InChan, OutChan, ParamEntry
 LRELU_SLOPE = 0.01
 IN_EPS = 1e-5
 DENSE_MIN_DENSITY = float(os.environ.get("E2E_DENSE_MIN_DENSITY", "0.5"))
+WGRAD_STREAM = os.environ.get("E2E_WGRAD_STREAM", "1") != "0"      # weight gradients on a second HIP stream
+WGRAD_STREAM_MAX_ELEMS = int(os.environ.get("E2E_WGRAD_STREAM_MAX_ELEMS", "40000000"))   # level 0 of 128^3 stays in line
 DENSE_ENABLED = True          # tests switch the matrix-core conv path off to compare the sparse walk with itself
 
 
@@ -36,6 +39,18 @@ def shift_amounts(num_channels: int, shift_size: int = 5):
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+@contextlib.contextmanager
+def _wgrad_stream(eng, elems):
+    """Run the enclosed launches on the plan's weight-gradient stream (Engine.backward sets it up and joins it)."""
+    side = getattr(eng, "_wg_active", None)
+    if side is None or elems > WGRAD_STREAM_MAX_ELEMS:
+        yield eng.wgrad_ws
+        return
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        yield eng.wgrad_ws_side              # its own workspace: in-line weight gradients may run at the same time
 
 
 def _ptr(t: Optional[torch.Tensor]) -> int:
@@ -189,8 +204,9 @@ class ConvOp:
                        LRELU_SLOPE, g[self.prefix + ".instnorm.weight"].data_ptr(),
                        g[self.prefix + ".instnorm.bias"].data_ptr(), g[self.prefix + ".conv.bias"].data_ptr(),
                        e.in_sums.data_ptr(), b, self.cout, o.spatial, _stream())
-        L.conv133_wgrad(self.chans.data_ptr(), o.grad.data_ptr(), g[self.w_name].data_ptr(), e.wgrad_ws.data_ptr(),
-                        b, self.cin, self.cout, di, hi, wi, sd, sh, sw, _stream())
+        with _wgrad_stream(e, o.data.numel()) as ws:
+            L.conv133_wgrad(self.chans.data_ptr(), o.grad.data_ptr(), g[self.w_name].data_ptr(), ws.data_ptr(),
+                            b, self.cin, self.cout, di, hi, wi, sd, sh, sw, _stream())
         if self.do_dgrad:
             ws = getattr(e, "fwd_ws", None)
             if self.use_dense():
@@ -256,9 +272,10 @@ class UpOp:
         s, e = self.src, self.eng
         b, cin, d, h, w = s.shape
         L = lib()
-        L.convT_wgrad(s.data.data_ptr(), _ptr(s.scale), _ptr(s.shift), LRELU_SLOPE, self.out.grad.data_ptr(),
-                      e.grads[self.w_name].data_ptr(), e.wgrad_ws.data_ptr(), b, cin, self.cout, d, h, w, *self.kernel,
-                      _stream())
+        with _wgrad_stream(e, self.out.data.numel()) as ws:
+            L.convT_wgrad(s.data.data_ptr(), _ptr(s.scale), _ptr(s.shift), LRELU_SLOPE, self.out.grad.data_ptr(),
+                          e.grads[self.w_name].data_ptr(), ws.data_ptr(), b, cin, self.cout, d, h, w, *self.kernel,
+                          _stream())
         L.convT_dgrad(self.out.grad.data_ptr(), e.params[self.w_name].data_ptr(), _ptr(self.live_t), s.grad.data_ptr(),
                       self.acc, b, cin, self.cout, d, h, w, *self.kernel, _stream())
 
@@ -319,8 +336,9 @@ class HeadOp:
         s, e = self.src, self.eng
         b, c = s.shape[:2]
         L = lib()
-        L.head1x1_wgrad(s.data.data_ptr(), _ptr(s.scale), _ptr(s.shift), LRELU_SLOPE, self.out.grad.data_ptr(),
-                        e.grads[self.w_name].data_ptr(), e.wgrad_ws.data_ptr(), b, c, self.k, s.spatial, _stream())
+        with _wgrad_stream(e, s.data.numel()) as ws:
+            L.head1x1_wgrad(s.data.data_ptr(), _ptr(s.scale), _ptr(s.shift), LRELU_SLOPE, self.out.grad.data_ptr(),
+                            e.grads[self.w_name].data_ptr(), ws.data_ptr(), b, c, self.k, s.spatial, _stream())
         L.head1x1_dgrad(self.out.grad.data_ptr(), e.params[self.w_name].data_ptr(), s.grad.data_ptr(), self.acc, b, c,
                         self.k, s.spatial, _stream())
 
@@ -409,6 +427,7 @@ class Engine:
         self._eval_counts = None
         # HIP-graph replay of the op lists for small plans (the host issues ~300-600 launches per pass: a Hippocampus-sized
         # patch is launch bound, 128^3 is not).  E2E_GRAPHS=0 / 1 / auto (default: plans of at most E2E_GRAPH_MAX_VOXELS voxels)
+        self._wg_side, self._wg_active = None, None
         self._graphs = {}                  # key -> torch.cuda.CUDAGraph
         self._graph_seen = set()           # keys that ran eagerly once (lazy allocations done)
         self.maps_generation = 0           # bumped when the liveness tables are replaced (their pointers are baked into a graph)
@@ -641,6 +660,24 @@ class Engine:
                 else:
                     h.out.grad.copy_(g)
         hook = self.grad_bucket_hook
+        main = torch.cuda.current_stream()
+        if WGRAD_STREAM and hook is None and not self._graph_ok() and not torch.cuda.is_current_stream_capturing():
+            # weight gradients have no consumer inside the backward pass: they run on a second stream beside the data
+            # gradient of the same layer (they share wgrad_ws, so they stay ordered among themselves).  Plans replayed as
+            # HIP graphs stay single-stream: replaying a two-stream capture faults on ROCm 7.2.
+            if self._wg_side is None:
+                self._wg_side = torch.cuda.Stream(device=self.device)
+                self.wgrad_ws_side = torch.empty_like(self.wgrad_ws)
+            self._wg_active = self._wg_side
+        try:
+            self._backward_ops(hook)
+        finally:
+            if self._wg_active is not None:
+                main.wait_stream(self._wg_active)
+                self._wg_active = None
+        return self.grads
+
+    def _backward_ops(self, hook):
         for op in reversed(self.ops):
             if isinstance(op, HeadOp) and not op.active:
                 # inactive head (no deep supervision): its source still needs a defined gradient
@@ -653,7 +690,6 @@ class Engine:
                 hook(*self._bucket_after_op[id(op)])           # gradients in flat[lo:hi] are final
         if hook is not None and self._bucket_tail[1] > self._bucket_tail[0]:
             hook(*self._bucket_tail)
-        return self.grads
 
     def _loss_buffers(self):
         if self.loss_ws is None:
