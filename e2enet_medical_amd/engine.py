@@ -26,6 +26,8 @@ IN_EPS = 1e-5
 DENSE_MIN_DENSITY = float(os.environ.get("E2E_DENSE_MIN_DENSITY", "0.5"))
 WGRAD_STREAM = os.environ.get("E2E_WGRAD_STREAM", "1") != "0"      # weight gradients on a second HIP stream
 WGRAD_STREAM_MAX_ELEMS = int(os.environ.get("E2E_WGRAD_STREAM_MAX_ELEMS", "40000000"))   # level 0 of 128^3 stays in line
+LANES = os.environ.get("E2E_LANES", "1") != "0"                    # deep levels on their own HIP stream (Engine._exec)
+LANE_LIGHT_DIV = int(os.environ.get("E2E_LANE_LIGHT_DIV", "64"))   # an op is 'light' when its output has <= 1/64 of the patch voxels
 DENSE_ENABLED = True          # tests switch the matrix-core conv path off to compare the sparse walk with itself
 
 
@@ -422,7 +424,11 @@ class Engine:
         self.loss_val = None
         self.generation = 0                # bumped by every forward(): activations are reused in place
         fws = max([max(op.fwd_ws_bytes, op.dgrad_ws_bytes if op.do_dgrad else 0, op.dense_ws_bytes) for op in self.conv_ops.values()] + [0])
-        self.fwd_ws = torch.empty(fws // 4, dtype=torch.float32, device=self.device) if fws > 0 else None   # split-K partial sums (deep levels)
+        # split-K partial sums (deep levels) / packed weights of the matrix-core conv; one per lane (see _exec)
+        self._fwd_ws = [torch.empty(fws // 4, dtype=torch.float32, device=self.device) if fws > 0 else None for _ in range(2)]
+        self._in_sums, self._wgrad_ws = [None, None], [None, None]
+        self._lane = 0
+        self._plan_lanes()
         self.pre_forward_hook = None       # callable(): set by the owning network, brings masks / parameters up to date
         self._eval_counts = None
         # HIP-graph replay of the op lists for small plans (the host issues ~300-600 launches per pass: a Hippocampus-sized
@@ -565,10 +571,93 @@ class Engine:
         return outs if deep_supervision else outs[0]
 
     def _forward_ops(self):
-        for op in self.ops:
-            if isinstance(op, HeadOp) and not op.active:
-                continue
-            op.forward()
+        def act(op):
+            if not (isinstance(op, HeadOp) and not op.active):
+                op.forward()
+        self._exec(range(len(self.ops)), self._deps_fwd, self._ev_fwd, act)
+
+    # ------------------------------------------------------------------------------------------ two lanes
+    # The UNet++ nest is a wavefront: the deep end of diagonal d+1 only needs the encoder, not the full-resolution end of
+    # diagonal d.  Ops of the deep levels (tiny grids, latency bound) are issued on a second HIP stream ('light' lane) so
+    # they run beside the full-resolution kernels instead of between them.  The op ORDER is unchanged (every wait points
+    # at an op issued earlier), gradient buffers are written in the planned order (overwrite first, then accumulate), so
+    # results are bit-identical to the single-stream pass.  Scratch buffers exist once per lane.
+    fwd_ws = property(lambda self: self._fwd_ws[self._lane])
+    in_sums = property(lambda self: self._in_sums[self._lane])
+    wgrad_ws = property(lambda self: self._wgrad_ws[self._lane])
+
+    @staticmethod
+    def _reads(op):
+        return list(op.sources) if isinstance(op, ConvOp) else [op.src]
+
+    def _plan_lanes(self):
+        vox = self.patch[0] * self.patch[1] * self.patch[2]
+        self._lane_of = [1 if op.out.spatial * LANE_LIGHT_DIV <= vox else 0 for op in self.ops]
+        writer = {}
+        self._deps_fwd = []
+        for i, op in enumerate(self.ops):
+            self._deps_fwd.append(sorted({writer[id(a)] for a in self._reads(op)
+                                          if id(a) in writer and self._lane_of[writer[id(a)]] != self._lane_of[i]}))
+            writer[id(op.out)] = i
+        self._ev_fwd = self._events_for(self._deps_fwd)
+        self._deps_bwd, self._ev_bwd = None, None
+        self._lane_stream = None
+
+    def _plan_lanes_backward(self):
+        last = {}                              # gradient buffer -> op that touched it last (in backward order)
+        self._deps_bwd = [None] * len(self.ops)
+        for i in reversed(range(len(self.ops))):
+            op = self.ops[i]
+            touched = [op.out] + [a for a in self._reads(op) if a.grad is not None]
+            self._deps_bwd[i] = sorted({last[id(a)] for a in touched
+                                        if id(a) in last and self._lane_of[last[id(a)]] != self._lane_of[i]})
+            for a in touched:
+                last[id(a)] = i
+        self._ev_bwd = self._events_for(self._deps_bwd)
+
+    @staticmethod
+    def _events_for(deps):
+        return {j: None for d in deps for j in d}
+
+    def _lanes_on(self):
+        return LANES and any(self._lane_of) and not self._graph_ok() and not torch.cuda.is_current_stream_capturing()
+
+    def _exec(self, order, deps, events, action, checkpoint=None):
+        """Issue action(op) for the ops in `order`; `checkpoint(op)` (data-parallel bucket hook) runs on the caller's stream
+        after both lanes have been joined."""
+        if not self._lanes_on():
+            for i in order:
+                action(self.ops[i])
+                if checkpoint is not None:
+                    checkpoint(self.ops[i], lambda: None)
+            return
+        main = torch.cuda.current_stream()
+        if self._lane_stream is None:
+            self._lane_stream = torch.cuda.Stream(device=self.device)
+        light = self._lane_stream
+        streams = (main, light)
+        light.wait_stream(main)
+        try:
+            for i in order:
+                ln = self._lane_of[i]
+                for j in deps[i]:
+                    streams[ln].wait_event(events[j])
+                self._lane = ln
+                if ln:
+                    with torch.cuda.stream(light):
+                        action(self.ops[i])
+                else:
+                    action(self.ops[i])
+                self._lane = 0
+                if i in events:
+                    if events[i] is None:
+                        events[i] = torch.cuda.Event()
+                    events[i].record(streams[ln])
+                if checkpoint is not None:
+                    checkpoint(self.ops[i], lambda: main.wait_stream(light))
+        finally:
+            self._lane = 0
+            main.wait_stream(light)
 
     # ------------------------------------------------------------------------------------------ graph replay
     def _graph_ok(self):
@@ -643,9 +732,10 @@ class Engine:
         self._bucket_tail = (lo, total)
         ws = max([op.wgrad_ws_bytes() for op in self.ops if hasattr(op, "wgrad_ws_bytes")] +
                  [lib().head1x1_wgrad_ws_bytes(self.batch, h.src.shape[1], h.k, h.src.spatial) for h in self.heads])
-        self.wgrad_ws = torch.empty((ws + 3) // 4, dtype=torch.float32, device=self.device)
+        self._wgrad_ws = [torch.empty((ws + 3) // 4, dtype=torch.float32, device=self.device) for _ in range(2)]
         cmax = max(op.cout for op in self.conv_ops.values())
-        self.in_sums = torch.empty(self.batch * cmax * 3, dtype=torch.float64, device=self.device)
+        self._in_sums = [torch.empty(self.batch * cmax * 3, dtype=torch.float64, device=self.device) for _ in range(2)]
+        self._plan_lanes_backward()
         self._loss_buffers()
         self._backward_ready = True
 
@@ -661,24 +751,17 @@ class Engine:
                     h.out.grad.copy_(g)
         hook = self.grad_bucket_hook
         main = torch.cuda.current_stream()
-        if WGRAD_STREAM and hook is None and not self._graph_ok() and not torch.cuda.is_current_stream_capturing():
+        if WGRAD_STREAM and not self._graph_ok() and not torch.cuda.is_current_stream_capturing():
             # weight gradients have no consumer inside the backward pass: they run on a second stream beside the data
-            # gradient of the same layer (they share wgrad_ws, so they stay ordered among themselves).  Plans replayed as
+            # gradient of the same layer (with their own workspace, in issue order among themselves).  Plans replayed as
             # HIP graphs stay single-stream: replaying a two-stream capture faults on ROCm 7.2.
             if self._wg_side is None:
                 self._wg_side = torch.cuda.Stream(device=self.device)
-                self.wgrad_ws_side = torch.empty_like(self.wgrad_ws)
+                self.wgrad_ws_side = torch.empty_like(self._wgrad_ws[0])
             self._wg_active = self._wg_side
-        try:
-            self._backward_ops(hook)
-        finally:
-            if self._wg_active is not None:
-                main.wait_stream(self._wg_active)
-                self._wg_active = None
-        return self.grads
+        side = self._wg_active
 
-    def _backward_ops(self, hook):
-        for op in reversed(self.ops):
+        def act(op):
             if isinstance(op, HeadOp) and not op.active:
                 # inactive head (no deep supervision): its source still needs a defined gradient
                 if op.acc == 0:
@@ -686,10 +769,22 @@ class Engine:
                 self.grads[op.w_name].zero_()
             else:
                 op.backward()
+
+        def checkpoint(op, join_lanes):
             if hook is not None and id(op) in self._bucket_after_op:
+                join_lanes()
+                if side is not None:
+                    main.wait_stream(side)
                 hook(*self._bucket_after_op[id(op)])           # gradients in flat[lo:hi] are final
+        try:
+            self._exec(reversed(range(len(self.ops))), self._deps_bwd, self._ev_bwd, act, checkpoint)
+        finally:
+            if side is not None:
+                main.wait_stream(side)
+                self._wg_active = None
         if hook is not None and self._bucket_tail[1] > self._bucket_tail[0]:
             hook(*self._bucket_tail)
+        return self.grads
 
     def _loss_buffers(self):
         if self.loss_ws is None:

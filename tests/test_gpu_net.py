@@ -844,3 +844,46 @@ def test_small_plan_graph_replay_matches_eager(monkeypatch):
         assert all(torch.equal(a, b) for a, b in zip(o1, o2)) and torch.equal(l1, l2)
         assert all(torch.equal(g1[n], g2[n]) for n in g1)
         assert (f1 is None) == (f2 is None) and (f1 is None or torch.equal(f1, f2))
+
+
+@pytest.mark.gpu
+def test_two_lane_issue_matches_single_stream(monkeypatch):
+    """Engine._exec: the deep levels on the 'light' HIP stream and the weight gradients on a third one must give bit-identical
+    logits, loss and gradients to the single-stream pass (same op order, same accumulation order into shared gradient
+    buffers), over several iterations (stream joins between passes) and with the data-parallel bucket hook installed."""
+    from e2enet_medical_amd import engine as E
+    monkeypatch.setenv("E2E_GRAPHS", "0")
+    patch = (32, 64, 64)
+    net, shapes, params = tiny_net(patch)
+    w = oracle.ds_weights(5)
+
+    def run(lanes, wg, hook):
+        monkeypatch.setattr(E, "LANES", lanes)
+        monkeypatch.setattr(E, "WGRAD_STREAM", wg)
+        monkeypatch.setattr(E, "LANE_LIGHT_DIV", 8)           # levels >= 1 of this small patch on the light lane
+        monkeypatch.setattr(E, "WGRAD_STREAM_MAX_ELEMS", 1 << 22)
+        net._engines.clear()
+        res = []
+        for it in range(3):
+            x = seeded_input((2, TINY["cin"]) + patch, seed=700 + it).cuda()
+            eng = net.engine(x)
+            seen = []
+            eng.grad_bucket_hook = (lambda lo, hi: seen.append((lo, hi, eng.grad_flat[lo:hi].clone()))) if hook else None
+            outs = [o.clone() for o in eng.forward(x, True)]
+            targets = [seeded_labels((2, 1) + tuple(o.shape[2:]), TINY["k"], seed=800 + it + i).cuda() for i, o in enumerate(outs)]
+            loss = eng.loss_backward(targets, w, batch_dice=False).clone()
+            grads = {n: g.clone() for n, g in eng.grads.items()}
+            for lo, hi, snap in seen:                             # a bucket handed to the hook is final
+                assert torch.equal(snap, eng.grad_flat[lo:hi]), "bucket [%d,%d) changed after its hook" % (lo, hi)
+            res.append((outs, loss, grads))
+        if lanes:
+            assert any(eng._lane_of) and not all(eng._lane_of) and eng._lane_stream is not None
+            assert any(eng._deps_fwd) and any(eng._deps_bwd)
+        return res
+    base = run(False, False, False)
+    for cfg in ((True, True, False), (True, False, False), (False, True, False), (True, True, True)):
+        other = run(*cfg)
+        for (o1, l1, g1), (o2, l2, g2) in zip(base, other):
+            assert all(torch.equal(a, b) for a, b in zip(o1, o2)) and torch.equal(l1, l2), cfg
+            bad = [n for n in g1 if not torch.equal(g1[n], g2[n])]
+            assert not bad, (cfg, bad[:4])
