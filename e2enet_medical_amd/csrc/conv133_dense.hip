@@ -22,10 +22,19 @@
 // forward: bias, coalesced stores, (count, mean, M2) per wave and half, combined in fp64 to the tile's partial record;
 // data gradient: the scatter epilogue of conv133_kernel (un-shift on store, zero-fill, accumulate).
 //
-// Shapes: stride (1,1,1), W % 32 == 0, H % 16 == 0, H > 16 (the patch sizes of the BASELINE configs at the levels this kernel is
+// Staging loads are aligned float4s over columns w0 - 4 .. w0 + 35 (one lane = one (row, 4-column group) x 8 channels); the plane
+// pointers and normalise-on-load coefficients come from a per-workgroup LDS table built once (round 3: read through the
+// descriptor table with dependent scalar loads in every staging step, each matrix phase started ~4000 cycles late;
+// s_memtime stamps of a DENSE_DIAG=4 build: a chunk's matrix phase alone 4300 cycles, the staging commit 3000-3500).
+//
+// Shapes: stride (1,1,1), Cin <= 128 (the LDS table), W % 32 == 0, H % 16 == 0, H > 16 (the patch sizes of the BASELINE configs at the levels this kernel is
 // dispatched for); everything else stays on conv133_kernel.
 #include "e2e_common.h"
 #include <cstdlib>
+
+#ifndef DENSE_DIAG
+#define DENSE_DIAG 0     // diagnostic builds only (make DEFS=-DDENSE_DIAG=n): 1 no matrix phase, 2 no input loads, 3 no split, 4 s_memtime stamps per phase (printf)
+#endif
 
 namespace {
 
@@ -34,17 +43,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef const u32x4_t __attribute__((address_space(1)))* gu4_p;
+typedef const f32x4_t __attribute__((address_space(1)))* gf4_p;
 
 constexpr int SUBH = 8, TW = 32, XR = SUBH + 2, XC = TW + 2;
 constexpr int PXB = 48;                          // bytes per staged pixel and piece: 16 channels bf16 + 16 (odd multiple of 16)
 constexpr int SPL = XR * XC * PXB;               // 16 320 B per piece
 constexpr int XBYTES = 3 * SPL;                  // 48 960 B
-constexpr int NPIX = XR * XC;                    // 340 halo'd pixels per half
-constexpr int PPW = NPIX / 2;                    // 170 pixels per staging wave pair member
-constexpr int NRND = (PPW + 63) / 64;            // 3 rounds of 64 lanes
+constexpr int XG = 10;                           // 16-byte column groups per halo'd row: columns w0 - 4 .. w0 + 35 (aligned float4 loads)
+constexpr int NITEM = XR * XG;                   // 100 (row, group) items per channel half: one lane each, two waves per half
 constexpr int WBYTES = 27 * 1024;                // one chunk of packed weights: 9 taps x 3 pieces x 32 out channels x 16 ch bf16
 constexpr int WRND = (WBYTES / 16 + 255) / 256;  // 16-byte units per thread and chunk
-static_assert(2 * (XBYTES + WBYTES + 8 * 32 * 2 * 4) <= 163840, "two workgroups per CU");
+constexpr int CTAB_MAX = 128;                    // forward: input planes with an entry in the LDS channel table
+constexpr int CTAB_ENT = 24;                     // bytes per entry: plane pointer of (n, d - s) 8, scale 4, shift 4, slope 4, valid 4
+static_assert(2 * (XBYTES + WBYTES + 8 * 32 * 2 * 4 + CTAB_MAX * CTAB_ENT) <= 163840, "two workgroups per CU");
 constexpr int SPITCH = 36;                       // floats per (row, out channel) of the epilogue staging: 32 pixels + 4
 static_assert(SUBH * 32 * SPITCH * 4 <= XBYTES, "the epilogue staging (8 rows x 32 channels x 32 pixels fp32) fits the input image");
 
@@ -103,7 +114,18 @@ __global__ __launch_bounds__(256, 2) void conv133_dense_kernel(DenseParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[XBYTES];
   __shared__ __attribute__((aligned(16))) unsigned char wlds[WBYTES];      // the chunk's weight fragments [tap][piece][32 q][16 ch]
   __shared__ float red[8][32][2];                          // (mean, M2) of 64 values per (half, wave) and out channel
+  // forward: per input plane the resolved plane pointer (batch item, shifted depth) and the normalise-on-load coefficients,
+  // built once per workgroup.  (Read through the descriptor table with scalar loads in every staging step, the compiler
+  // serialised sixteen dependent scalar round trips in front of each matrix phase: ~4000 of a chunk's ~8000 cycles.)
+  __shared__ __attribute__((aligned(8))) unsigned char ctab[MODE == 0 ? CTAB_MAX * CTAB_ENT : 8];
 
+#if DENSE_DIAG == 4
+  unsigned long long stamp[24];
+  int ns = 0;
+#define STAMP() do { if (ns < 24) stamp[ns++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP() do {} while (0)
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int item = e2e::xcd_remap(blockIdx.x, p.padded_total);
@@ -115,84 +137,77 @@ __global__ __launch_bounds__(256, 2) void conv133_dense_kernel(DenseParams p) {
   const int h0 = ty * 16, w0 = tx * TW;
   const long long plane = (long long)p.H * p.W;
 
-  // ---- staging geometry: wave -> (channel half, pixel range); lane -> up to NRND halo'd pixels ----
-  const int shalf = wave & 1, sbase = (wave >> 1) * PPW;
-  int s_off[NRND];                                        // element offset inside a plane, -1 = outside the image
-  int s_pix[NRND];
+  // ---- staging geometry: wave -> (channel half, item range); lane -> one (halo row, 4-column group) item.  Staging loads are
+  // aligned float4s (w0 - 4 + 4 g): the vector-memory address path takes a wave instruction at a fixed cost whatever its
+  // width (measured: a chunk's 24 dword loads per lane held the issuing wave ~2500 cycles inside the matrix phase), so the
+  // same bytes go in a third of the instructions; the three columns loaded beyond either halo edge are dropped. ----
+  const int shalf = wave & 1;
+  const int sitem = (wave >> 1) * 64 + lane;
+  const bool s_act = sitem < NITEM;
+  const int s_row = (s_act ? sitem : 0) / XG, s_g = (s_act ? sitem : 0) - s_row * XG;
+  const int s_pix0 = s_row * XC + 4 * s_g - 3;           // halo'd pixel index of the group's first column (may be < row start)
+  int s_off = -1;                                        // element offset inside a plane, -1 = outside the image / inactive lane
   auto set_geometry = [&](int sub) {
-    const int hs = h0 + sub * SUBH;
-#pragma unroll
-    for (int r = 0; r < NRND; ++r) {
-      int pi = r * 64 + lane;
-      const bool act = pi < PPW;
-      pi = sbase + (act ? pi : PPW - 1);
-      const int row = pi / XC, col = pi - row * XC;
-      const int hi = hs - 1 + row, wi = w0 - 1 + col;
-      const bool ok = act && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-      s_off[r] = ok ? hi * p.W + wi : -1;
-      s_pix[r] = act ? pi : -1;
-    }
+    const int hi = h0 + sub * SUBH - 1 + s_row, wi = w0 - 4 + 4 * s_g;
+    const bool ok = s_act && (unsigned)hi < (unsigned)p.H && wi >= 0 && wi < p.W;
+    s_off = ok ? hi * p.W + wi : -1;
   };
-  float xv[NRND][8];
-  // normalise-on-load coefficients and validity of the eight channels in flight (wave-uniform: scalar registers), fetched with
-  // the staging loads and used when they are committed: the scalar loads of all eight descriptors are issued back to back
-  // (one round trip each for the descriptors and for the coefficients, not sixteen dependent ones)
-  float pa[8], pb[8], psl[8];
-  bool pvalid[8];
+  f32x4_t xv[8];
+  unsigned pvalid = 0;                                    // bit j: channel j of the half in flight is a real plane at a valid depth
   auto prefetch_x = [&](int c) {
     gfloat_p base[8];
+    pvalid = 0;
     if (MODE == 0) {
-      e2e_in_chan_t cd[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int ch = c * 16 + shalf * 8 + j;
-        cd[j] = load_uniform(p.chans + (ch < p.P ? ch : 0));
+        const unsigned char* e = ctab + (c * 16 + shalf * 8 + j) * CTAB_ENT;
+        base[j] = (gfloat_p)(*reinterpret_cast<const unsigned long long*>(e));
+        pvalid |= (*reinterpret_cast<const unsigned*>(e + 20) & 1u) << j;
       }
+      } else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int ch = c * 16 + shalf * 8 + j;
-        const int din = d - cd[j].dshift;
-        pvalid[j] = ch < p.P && (unsigned)din < (unsigned)p.D;
-        base[j] = (gfloat_p)(cd[j].ptr + (long long)n * cd[j].nstride + (long long)(pvalid[j] ? din : 0) * plane);
-        pa[j] = 1.f; pb[j] = 0.f; psl[j] = 1.f;
+        const bool v = ch < p.P;
+        pvalid |= (v ? 1u : 0u) << j;
+        base[j] = (gfloat_p)(p.xin + (((long long)n * p.P + (v ? ch : 0)) * p.D + d) * plane);
       }
+    }
+    const int off = s_off >= 0 ? s_off : 0;
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (cd[j].scale != nullptr) {
-          pa[j] = load_uniform(cd[j].scale + (long long)n * cd[j].ab_nstride);
-          pb[j] = load_uniform(cd[j].shift + (long long)n * cd[j].ab_nstride);
-          psl[j] = cd[j].slope;
-        }
-    } else {
+    for (int j = 0; j < 8; ++j)
+      xv[j] = DENSE_DIAG == 2 ? f32x4_t{1.f, 1.f, 1.f, 1.f} : *(gf4_p)(unsigned long long)(base[j] + off);
+  };
+  auto commit_x = [&](int c) {
+    if (!s_act) return;
+    const bool inside = s_off >= 0;
+    float pa[8], pb[8], psl[8];
+    if (MODE == 0) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int ch = c * 16 + shalf * 8 + j;
-        pvalid[j] = ch < p.P;
-        base[j] = (gfloat_p)(p.xin + (((long long)n * p.P + (pvalid[j] ? ch : 0)) * p.D + d) * plane);
+        const unsigned char* e = ctab + (c * 16 + shalf * 8 + j) * CTAB_ENT;
+        const float2 ab = *reinterpret_cast<const float2*>(e + 8);
+        pa[j] = ab.x; pb[j] = ab.y;
+        psl[j] = *reinterpret_cast<const float*>(e + 16);
       }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-#pragma unroll
-      for (int r = 0; r < NRND; ++r) xv[r][j] = base[j][(pvalid[j] && s_off[r] >= 0) ? s_off[r] : 0];
-  };
-  auto commit_x = [&](int c) {
-    (void)c;
-#pragma unroll
-    for (int r = 0; r < NRND; ++r) {
-      if (s_pix[r] < 0) continue;
+    for (int k = 0; k < 4; ++k) {
+      const int hc = 4 * s_g - 3 + k;                     // halo column of this pixel
+      if (hc < 0 || hc >= XC) continue;
       unsigned hh[8], mm[8], ll[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        float v = xv[r][j];
+        float v = xv[j][k];
         if (MODE == 0) {
           const float u = fmaf(v, pa[j], pb[j]);
           v = fmaxf(u, u * psl[j]);                      // LeakyReLU, 0 <= slope <= 1 (the engine's contract); slope 1 = identity
         }
-        v = (pvalid[j] && s_off[r] >= 0) ? v : 0.f;
-        split1(v, hh[j], mm[j], ll[j]);
+        v = (((pvalid >> j) & 1u) && inside) ? v : 0.f;
+        if (DENSE_DIAG == 3) { hh[j] = mm[j] = ll[j] = __builtin_bit_cast(unsigned, v); }
+        else split1(v, hh[j], mm[j], ll[j]);
       }
-      unsigned char* dst = lds + s_pix[r] * PXB + shalf * 16;
+      unsigned char* dst = lds + (s_pix0 + k) * PXB + shalf * 16;
       // v_perm_b32 0x07060302: (S1 >> 16) | (S0 & 0xffff0000): two bf16 pieces per word, element 0 in the low half
       *reinterpret_cast<u32x4_t*>(dst) = u32x4_t{__builtin_amdgcn_perm(hh[1], hh[0], 0x07060302u), __builtin_amdgcn_perm(hh[3], hh[2], 0x07060302u),
                                                  __builtin_amdgcn_perm(hh[5], hh[4], 0x07060302u), __builtin_amdgcn_perm(hh[7], hh[6], 0x07060302u)};
@@ -226,8 +241,28 @@ __global__ __launch_bounds__(256, 2) void conv133_dense_kernel(DenseParams p) {
   };
   const float bq = (MODE == 0 && p.bias != nullptr && qb * 32 + fq < p.Q) ? p.bias[qb * 32 + fq] : 0.f;
 
+  STAMP();
   set_geometry(0);
   prefetch_w(0);
+  if (MODE == 0) {
+    for (int ch = tid; ch < p.nchunks * 16; ch += 256) {
+      const e2e_in_chan_t cd = p.chans[ch < p.P ? ch : 0];
+      const int din = d - cd.dshift;
+      const bool valid = ch < p.P && (unsigned)din < (unsigned)p.D;
+      float a = 1.f, b = 0.f, sl = 1.f;
+      if (cd.scale != nullptr) {
+        a = cd.scale[(long long)n * cd.ab_nstride];
+        b = cd.shift[(long long)n * cd.ab_nstride];
+        sl = cd.slope;
+      }
+      unsigned char* e = ctab + ch * CTAB_ENT;
+      *reinterpret_cast<unsigned long long*>(e) = (unsigned long long)(cd.ptr + (long long)n * cd.nstride + (long long)(valid ? din : 0) * plane);
+      *reinterpret_cast<float2*>(e + 8) = float2{a, b};
+      *reinterpret_cast<float*>(e + 16) = sl;
+      *reinterpret_cast<unsigned*>(e + 20) = valid ? 1u : 0u;
+    }
+    __syncthreads();
+  }
   prefetch_x(0);
   for (int sub = 0; sub < 2; ++sub) {
     f32x16 acc[2];
@@ -236,9 +271,12 @@ __global__ __launch_bounds__(256, 2) void conv133_dense_kernel(DenseParams p) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[r][i] = 0.f;
     for (int c = 0; c < p.nchunks; ++c) {
+      STAMP();
       commit_w();
       commit_x(c);
+      STAMP();
       __syncthreads();
+      STAMP();
       bf16x8 wb[2][3];                                    // ring over taps: [tap & 1][piece]
 #pragma unroll
       for (int s = 0; s < 3; ++s) wb[0][s] = wfrag(0, s);
@@ -250,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void conv133_dense_kernel(DenseParams p) {
 #pragma unroll
       for (int s = 0; s < 3; ++s) af[0][s] = *reinterpret_cast<const bf16x8*>(abase + s * SPL);
 #pragma unroll
-      for (int step = 0; step < 18; ++step) {
+      for (int step = 0; step < (DENSE_DIAG == 1 ? 1 : 18); ++step) {
         const int tap = step >> 1, r = step & 1;
         if (r == 0 && tap + 1 < 9) {
 #pragma unroll
@@ -277,7 +315,9 @@ __global__ __launch_bounds__(256, 2) void conv133_dense_kernel(DenseParams p) {
         a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[step & 1][0], wb[tap & 1][0], a, 0, 0, 0);
         acc[r] = a;
       }
+      STAMP();
       __syncthreads();
+      STAMP();
     }
 
     // ---- epilogue of this half.  D layout of v_mfma_f32_32x32x16: column (out channel) = lane & 31, row (pixel of the tile
@@ -346,8 +386,16 @@ __global__ __launch_bounds__(256, 2) void conv133_dense_kernel(DenseParams p) {
         *dst = o;
       }
     }
+    STAMP();
     __syncthreads();                                       // the staging area is the next half's input image
   }
+#if DENSE_DIAG == 4
+  if (MODE == 0 && tid == 64 && (blockIdx.x == 4001 || blockIdx.x == 4002 || blockIdx.x == 7000)) {
+#define DD(i) (unsigned)(stamp[i] - stamp[i - 1])
+    printf("WG %d | pre %u | c0: commit %u bar %u mma %u bar %u | c1: %u %u %u %u | epi %u | c0: %u %u %u %u %u | c1: %u %u %u %u | epi %u\n", blockIdx.x,
+           DD(1), DD(2), DD(3), DD(4), DD(5), DD(7), DD(8), DD(9), DD(10), DD(11), DD(12), DD(13), DD(14), DD(15), DD(16), DD(18), DD(19), DD(20), DD(21), DD(22));
+  }
+#endif
 
   if (MODE == 0 && p.part != nullptr && tid < 32 && qb * 32 + tid < p.Q) {
     // Chan combination of the eight (count 64, mean, M2) records of this tile, fp64
@@ -378,6 +426,7 @@ extern "C" long long e2e_conv133_dense_ws_bytes(int B, int Cin, int Cout, int Di
   if (sd != 1 || sh != 1 || sw != 1) return 0;
   if (Wi % 32 != 0 || Hi % 16 != 0 || Hi <= 16 || Di < 1) return 0;   // (planes of conv133_kernel's 16 x 32 tile class: the partial records line up)
   if (Cin < 16 || Cout < 16) return 0;                    // thin layers (the 4-modal input): padding would dominate
+  if (Cin > CTAB_MAX) return 0;                           // the forward kernel's LDS channel table
   const long long cmax = Cin > Cout ? Cin : Cout;
   const long long blocks = e2e::cdiv((int)cmax, 32) * (long long)e2e::cdiv((int)cmax, 16);
   return blocks * 9 * 3 * 512 * 2;                        // packed weights of either direction
