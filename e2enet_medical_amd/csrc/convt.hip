@@ -427,6 +427,212 @@ __global__ __launch_bounds__(256 * NCB) void convT_wgrad_v2_kernel(const float* 
     }
 }
 
+// ---- v3 of the weight gradient (kw == 2, even W): the v2 pipeline on the bf16 matrix pipe with fp32-exact operands -------
+// v2 is bound by its fp32 MFMAs (128 x 32 cycles per 64-voxel tile and wave, two waves per SIMD: 0.125 ms of a 0.25 ms
+// launch at 64 -> 32 @64^3).  Both operands are split into three bf16 pieces when they are staged ([piece][row][64 voxels]
+// bf16, row stride 144 B); the reduction dimension (voxels) is contiguous in both images, so an A / B fragment is one
+// ds_read_b128; 96 v_mfma_f32_16x16x32_bf16 x 16 cycles per tile and wave.  The split3 / pack_hi16 helpers and the data
+// gradient of the same scheme follow below (convT_dgrad_bf3_kernel); they are declared here.
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3(float v, unsigned& h, unsigned& m, unsigned& l) {
+  h = __builtin_bit_cast(unsigned, v);
+  const float r1 = v - __builtin_bit_cast(float, h & 0xffff0000u);            // exact
+  m = __builtin_bit_cast(unsigned, r1);
+  const float r2 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);           // exact, <= 8 significant bits
+  l = __builtin_bit_cast(unsigned, r2);
+}
+// (S1 >> 16) | (S0 & 0xffff0000): the bf16 (truncated) pieces of two values in one word, `lo` in the low half
+__device__ __forceinline__ unsigned pack_hi16(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
+
+template <int KDH, int NCB>     // KDH = kd * kh (output rows per input voxel row), KT = 2 * KDH
+__global__ __launch_bounds__(256 * NCB) void convT_wgrad_bf3_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift, float slope,
+                                                                   const float* __restrict__ dy, float* __restrict__ slab,
+                                                                   int B, int Cin, int Cout, int D, int H, int W, int kd, int kh,
+                                                                   int tiles_per_chunk, int cgroups) {
+  constexpr int KT = 2 * KDH;
+  constexpr int RS = WG_TPX * 2 + 16;                  // bytes per staged row (64 voxels bf16 + 16: odd multiple of 16, conflict-free b128)
+  constexpr int ZP = NCB * 32 * RS, YP = KT * 32 * RS;  // bytes per piece
+  constexpr int YCW = 32 / (4 * NCB);                  // dy channels staged per wave
+  constexpr int YIT = KDH * 32 / 64;                   // wave iterations per dy channel (KDH rows x 32 voxel pairs)
+  static_assert(KDH == 2 || KDH == 4, "kd*kh in {2,4}");
+  __shared__ __attribute__((aligned(16))) unsigned char zs[3 * ZP];     // [piece][channel][voxel] bf16
+  __shared__ __attribute__((aligned(16))) unsigned char ds[3 * YP];     // [piece][tap][out channel][voxel] bf16
+
+  const int chunk = blockIdx.x;
+  const int cg = blockIdx.y % cgroups, ob = blockIdx.y / cgroups;
+  const long long spatial = (long long)D * H * W;
+  const long long tiles_per_n = e2e::cdivll(spatial, WG_TPX);
+  const long long total_tiles = tiles_per_n * B;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cbl = wave >> 2, ch = wave & 1, oh = (wave >> 1) & 1;
+  const int Ho = H * kh, Wo = W * 2;
+  const long long ospatial = spatial * KT;
+  const int cbase = cg * NCB * 32;
+
+  f32x4 acc[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const long long tile_lo = (long long)chunk * tiles_per_chunk;
+  long long tile_hi = tile_lo + tiles_per_chunk;
+  if (tile_hi > total_tiles) tile_hi = total_tiles;
+
+  // z: each wave stages 8 channels x 64 voxels = 128 float4 -> 2 iterations; lane -> (channel k = g / 16, group g % 16)
+  f32x4_t vz[2], vy[YCW][YIT];
+  float za[2], zb[2];
+  const bool row_tiles = (W % WG_TPX) == 0;            // => spatial % 64 == 0 as well: no ragged last tile
+  long long yoff[YIT];
+#pragma unroll
+  for (int it = 0; it < YIT; ++it) {
+    const int g = lane + 64 * it;
+    const int rr = g >> 5, vp = g & 31;
+    const int i = rr / kh, j = rr - i * kh;
+    yoff[it] = ((long long)i * Ho + j) * Wo + 4 * vp;
+  }
+  auto prefetch = [&](long long tile) {
+    const int n = (int)((unsigned)tile / (unsigned)tiles_per_n);
+    const long long vbase = (tile - (long long)n * tiles_per_n) * WG_TPX;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int g = lane + 64 * it;
+      const int c = cbase + wave * 8 + (g >> 4);
+      const long long vi = vbase + (g & 15) * 4;
+      const bool ok = c < Cin && vi + 3 < spatial;
+      const long long off = ok ? ((long long)n * Cin + c) * spatial + vi : 0;
+      vz[it] = *reinterpret_cast<gf4_p>((gfloat_p)x + off);
+      za[it] = 1.f; zb[it] = 0.f;
+      if (scale != nullptr && c < Cin) { za[it] = scale[(long long)n * Cin + c]; zb[it] = shift[(long long)n * Cin + c]; }
+    }
+    if (row_tiles) {      // the 64-voxel tile lies inside one input row: wave-uniform base + per-thread constant offsets
+      int dv, hv, w0;
+      decode_dhw(vbase, W, H, dv, hv, w0);
+      const long long tbase = ((long long)n * Cout + ob * 32 + wave * YCW) * ospatial +
+                              ((long long)dv * kd * Ho + (long long)hv * kh) * Wo + 2 * w0;
+#pragma unroll
+      for (int k = 0; k < YCW; ++k)
+#pragma unroll
+        for (int it = 0; it < YIT; ++it) {
+          const bool ok = ob * 32 + wave * YCW + k < Cout;
+          vy[k][it] = *reinterpret_cast<gf4_p>((gfloat_p)dy + (ok ? tbase + k * ospatial + yoff[it] : 0));
+        }
+      return;
+    }
+#pragma unroll
+    for (int k = 0; k < YCW; ++k) {
+      const int o = ob * 32 + wave * YCW + k;
+#pragma unroll
+      for (int it = 0; it < YIT; ++it) {
+        const int g = lane + 64 * it;                 // (row rr = g / 32, voxel pair vp = g % 32)
+        const int rr = g >> 5, vp = g & 31;
+        const long long vi = vbase + 2 * vp;
+        const bool ok = o < Cout && vi + 1 < spatial;
+        long long off = 0;
+        if (ok) {
+          int dv, hv, wv;
+          decode_dhw(vi, W, H, dv, hv, wv);
+          const int i = rr / kh, j = rr - i * kh;
+          off = ((long long)n * Cout + o) * ospatial + ((long long)(dv * kd + i) * Ho + (hv * kh + j)) * Wo + 2 * wv;
+        }
+        vy[k][it] = *reinterpret_cast<gf4_p>((gfloat_p)dy + off);
+      }
+    }
+  };
+  auto commit = [&](long long tile) {
+    const int n = (int)((unsigned)tile / (unsigned)tiles_per_n);
+    const long long vbase = (tile - (long long)n * tiles_per_n) * WG_TPX;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int g = lane + 64 * it;
+      const int cl = wave * 8 + (g >> 4);
+      const long long vi = vbase + (g & 15) * 4;
+      const bool ok = cbase + cl < Cin && vi + 3 < spatial;
+      unsigned char* dst = zs + cl * RS + (g & 15) * 8;
+      unsigned h[4], m[4], l[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float t = vz[it][j];
+        if (scale != nullptr) t = e2e::in_act(t, za[it], zb[it], slope);
+        split3(ok ? t : 0.f, h[j], m[j], l[j]);
+      }
+      *reinterpret_cast<uint2*>(dst) = make_uint2(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]));
+      *reinterpret_cast<uint2*>(dst + ZP) = make_uint2(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]));
+      *reinterpret_cast<uint2*>(dst + 2 * ZP) = make_uint2(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]));
+    }
+#pragma unroll
+    for (int k = 0; k < YCW; ++k) {
+      const int ol = wave * YCW + k;
+#pragma unroll
+      for (int it = 0; it < YIT; ++it) {
+        const int g = lane + 64 * it;
+        const int rr = g >> 5, vp = g & 31;
+        const bool ok = ob * 32 + ol < Cout && vbase + 2 * vp + 1 < spatial;
+        const f32x4_t q = vy[k][it];                  // (k=0,v) (k=1,v) (k=0,v+1) (k=1,v+1)
+        unsigned h[4], m[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split3(ok ? q[j] : 0.f, h[j], m[j], l[j]);
+        unsigned char* d0 = ds + ((rr * 2 + 0) * 32 + ol) * RS + 4 * vp;      // tap (rr, 0): voxels 2 vp, 2 vp + 1
+        unsigned char* d1 = ds + ((rr * 2 + 1) * 32 + ol) * RS + 4 * vp;
+        *reinterpret_cast<unsigned*>(d0) = pack_hi16(h[0], h[2]);
+        *reinterpret_cast<unsigned*>(d1) = pack_hi16(h[1], h[3]);
+        *reinterpret_cast<unsigned*>(d0 + YP) = pack_hi16(m[0], m[2]);
+        *reinterpret_cast<unsigned*>(d1 + YP) = pack_hi16(m[1], m[3]);
+        *reinterpret_cast<unsigned*>(d0 + 2 * YP) = pack_hi16(l[0], l[2]);
+        *reinterpret_cast<unsigned*>(d1 + 2 * YP) = pack_hi16(l[1], l[3]);
+      }
+    }
+  };
+
+  if (tile_lo < tile_hi) {
+    prefetch(tile_lo);
+    for (long long tile = tile_lo; tile < tile_hi; ++tile) {
+      commit(tile);
+      __syncthreads();
+      if (tile + 1 < tile_hi) prefetch(tile + 1);
+      const int li = lane & 15, lk = lane >> 4;
+      // A: channel row, 8 consecutive voxels 32 kb + 8 lk ..; B: out channel row of tap t, the same voxels
+      const unsigned char* ap = zs + (cbl * 32 + ch * 16 + li) * RS + lk * 16;
+      const unsigned char* bp = ds + (oh * 16 + li) * RS + lk * 16;
+#pragma unroll
+      for (int kb = 0; kb < WG_TPX / 32; ++kb) {
+        bf16x8_t af[3];
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) af[sp] = *reinterpret_cast<const bf16x8_t*>(ap + sp * ZP + kb * 64);
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+          bf16x8_t bf[3];
+#pragma unroll
+          for (int sp = 0; sp < 3; ++sp) bf[sp] = *reinterpret_cast<const bf16x8_t*>(bp + sp * YP + t * 32 * RS + kb * 64);
+          f32x4 a = acc[t];
+          // small terms first: lo*hi, mid*mid, hi*lo, then mid*hi, hi*mid, then hi*hi
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bf[0], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[1], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[2], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[0], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[1], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[0], a, 0, 0, 0);
+          acc[t] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // D[i = c][j = o]: col = lane & 15 -> o, row = (lane >> 4) * 4 + reg -> c
+  float* sp = slab + (long long)chunk * Cin * Cout * KT;
+  const int o = ob * 32 + oh * 16 + (lane & 15);
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = cbase + cbl * 32 + ch * 16 + (lane >> 4) * 4 + r;
+      if (c < Cin && o < Cout) sp[((long long)c * Cout + o) * KT + t] = acc[t][r];
+    }
+}
+
+
 // ---- data gradient v2 (kw == 2, even W): dy tile staged once in LDS ---------------------------------------------------
 // dx[c, v] = sum_o sum_t W[c, o, t] * dy[o, out(v, t)].  A tile = 64 consecutive input voxels (lane = voxel); the dy
 // values of 32 output channels x KT taps are loaded as aligned float4 and scattered to an LDS image [tap][o][voxel];
@@ -679,6 +885,166 @@ __global__ __launch_bounds__(256) void convT_dgrad_v3_kernel(const float* __rest
   }
 }
 
+// ---- data gradient v4 (kw == 2, W % 32 == 0): the v3 GEMM on the bf16 matrix pipe with fp32-exact operands ----------------
+// v3 is bound by its fp32 MFMAs (128 x 32 cycles per 32-voxel tile and wave: ~0.15 ms of a 0.31 ms launch at 64 -> 32 @64^3,
+// the staging and the HBM stream not overlapped with them).  Every fp32 value is split without error into three bf16
+// pieces (hi, mid, lo) and a product is rebuilt from the six leading cross terms, as in conv133_wgrad_bf3.hip / conv133_dense.hip
+// (error class of an fp32 FMA chain): 96 v_mfma_f32_16x16x32_bf16 x 16 cycles per tile and wave.
+//   * K order k = o * KT + t (the memory order of W[c][o][t]): a lane's A fragment (8 consecutive k of row c) is 32
+//     contiguous bytes of W; a wave keeps the split fragments of its 16 x K slice in registers (K/32 x 3 x 4 VGPRs);
+//   * the dy tile is staged voxel-major, [piece][32 voxels][K bf16 + 16 B] (row stride an odd multiple of 16 B:
+//     conflict-free ds_read_b128 B fragments); a float4 of dy (two voxels x taps (2 rr, 2 rr + 1) of one output channel)
+//     becomes one packed word per voxel and piece; the loads of the next tile are in flight during the matrix phase.
+template <int KDH>
+__global__ __launch_bounds__(256, 2) void convT_dgrad_bf3_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                                 float* __restrict__ dx, int accumulate, int B, int Cin, int Cout,
+                                                                 int D, int H, int W, int kd, int kh, int tiles_per_wg) {
+  constexpr int KT = 2 * KDH;
+  constexpr int OC = 32, TV = 32;
+  constexpr int K = OC * KT, NKB = K / 32;             // 16x16x32 k-blocks per chunk
+  constexpr int S = K * 2 + 16;                        // bytes per staged voxel and piece (528 / 272: odd multiples of 16)
+  constexpr int PSZ = TV * S;
+  constexpr int NUY = OC * KDH * (TV / 2) / 256;       // float4 loads per thread per tile
+  __shared__ __attribute__((aligned(16))) unsigned char ds[3 * PSZ];
+
+  const long long spatial = (long long)D * H * W;
+  const long long tiles_per_n = spatial / TV;          // (W % 32 == 0: a tile is 32 consecutive voxels of one row)
+  const long long total_tiles = tiles_per_n * B;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  const int Ho = H * kh, Wo = W * 2;
+  const long long ospatial = spatial * KT;
+  const int cbase = blockIdx.y * 64 + wave * 16;
+  const long long tile_lo = (long long)blockIdx.x * tiles_per_wg;
+  long long tile_hi = tile_lo + tiles_per_wg;
+  if (tile_hi > total_tiles) tile_hi = total_tiles;
+  if (tile_lo >= tile_hi) return;
+
+  f32x4_t v[NUY];
+  long long uoff[NUY];
+  int ulds[NUY];
+#pragma unroll
+  for (int i = 0; i < NUY; ++i) {
+    const int u = tid + i * 256;                        // unit = (o, output row rr, voxel pair vp), vp fastest (coalesced float4s)
+    const int ol = u / (KDH * (TV / 2));
+    const int rem = u - ol * (KDH * (TV / 2));
+    const int rr = rem / (TV / 2), vp = rem - rr * (TV / 2);
+    const int ii = rr / kh, jj = rr - ii * kh;
+    uoff[i] = (long long)ol * ospatial + ((long long)ii * Ho + jj) * Wo + 4 * vp;
+    ulds[i] = (2 * vp) * S + (ol * KT + 2 * rr) * 2;
+  }
+  auto prefetch = [&](long long tile, int o0) {
+    const int n = (int)((unsigned)tile / (unsigned)tiles_per_n);
+    const long long vbase = (tile - (long long)n * tiles_per_n) * TV;
+    int dv, hv, w0;
+    decode_dhw(vbase, W, H, dv, hv, w0);
+    const long long tbase = ((long long)n * Cout + o0) * ospatial + ((long long)dv * kd * Ho + (long long)hv * kh) * Wo + 2 * w0;
+#pragma unroll
+    for (int i = 0; i < NUY; ++i) {
+      const int ol = (tid + i * 256) / (KDH * (TV / 2));
+      v[i] = *reinterpret_cast<gf4_p>((gfloat_p)dy + (o0 + ol < Cout ? tbase + uoff[i] : 0));
+    }
+  };
+  auto commit = [&](int o0) {
+#pragma unroll
+    for (int i = 0; i < NUY; ++i) {
+      const int ol = (tid + i * 256) / (KDH * (TV / 2));
+      const bool ok = o0 + ol < Cout;
+      unsigned h[4], m[4], l[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) split3(ok ? v[i][e] : 0.f, h[e], m[e], l[e]);
+      unsigned char* d0 = ds + ulds[i];
+      *reinterpret_cast<unsigned*>(d0) = pack_hi16(h[0], h[1]);
+      *reinterpret_cast<unsigned*>(d0 + S) = pack_hi16(h[2], h[3]);
+      *reinterpret_cast<unsigned*>(d0 + PSZ) = pack_hi16(m[0], m[1]);
+      *reinterpret_cast<unsigned*>(d0 + PSZ + S) = pack_hi16(m[2], m[3]);
+      *reinterpret_cast<unsigned*>(d0 + 2 * PSZ) = pack_hi16(l[0], l[1]);
+      *reinterpret_cast<unsigned*>(d0 + 2 * PSZ + S) = pack_hi16(l[2], l[3]);
+    }
+  };
+
+  for (int o0 = 0; o0 < Cout; o0 += OC) {
+    // A fragments of this wave: row c = cbase + li, k-block kb, k = 32 kb + 8 lk + j  <->  W[c][o0 + k / KT][k % KT]
+    bf16x8_t af[NKB][3];
+    {
+      const int c = cbase + li;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        const int k0 = kb * 32 + lk * 8;
+        float wv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int o = o0 + (k0 + j) / KT;
+          wv[j] = (c < Cin && o < Cout) ? w[((long long)c * Cout + o0) * KT + k0 + j] : 0.f;
+        }
+        unsigned h[8], m[8], l[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) split3(wv[j], h[j], m[j], l[j]);
+        af[kb][0] = __builtin_bit_cast(bf16x8_t, u32x4_t{pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]), pack_hi16(h[4], h[5]), pack_hi16(h[6], h[7])});
+        af[kb][1] = __builtin_bit_cast(bf16x8_t, u32x4_t{pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]), pack_hi16(m[4], m[5]), pack_hi16(m[6], m[7])});
+        af[kb][2] = __builtin_bit_cast(bf16x8_t, u32x4_t{pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]), pack_hi16(l[4], l[5]), pack_hi16(l[6], l[7])});
+      }
+    }
+    prefetch(tile_lo, o0);
+    for (long long tile = tile_lo; tile < tile_hi; ++tile) {
+      commit(o0);
+      __syncthreads();
+      if (tile + 1 < tile_hi) prefetch(tile + 1, o0);    // in flight during the matrix phase
+      f32x4 acc[TV / 16];
+#pragma unroll
+      for (int b = 0; b < TV / 16; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // B fragment: voxel 16 b + li, k = 32 kb + 8 lk .. + 7
+      const unsigned char* bp = ds + li * S + lk * 16;
+      bf16x8_t bf[2][TV / 16][3];
+#pragma unroll
+      for (int b = 0; b < TV / 16; ++b)
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) bf[0][b][sp] = *reinterpret_cast<const bf16x8_t*>(bp + sp * PSZ + b * 16 * S);
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        if (kb + 1 < NKB) {
+#pragma unroll
+          for (int b = 0; b < TV / 16; ++b)
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp)
+              bf[(kb + 1) & 1][b][sp] = *reinterpret_cast<const bf16x8_t*>(bp + sp * PSZ + b * 16 * S + (kb + 1) * 64);
+        }
+#pragma unroll
+        for (int b = 0; b < TV / 16; ++b) {
+          f32x4 a = acc[b];
+          // small terms first: lo*hi, mid*mid, hi*lo, then mid*hi, hi*mid, then hi*hi
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kb][2], bf[kb & 1][b][0], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kb][1], bf[kb & 1][b][1], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kb][0], bf[kb & 1][b][2], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kb][1], bf[kb & 1][b][0], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kb][0], bf[kb & 1][b][1], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kb][0], bf[kb & 1][b][0], a, 0, 0, 0);
+          acc[b] = a;
+        }
+      }
+      // D[i = c][j = v]: col = lane & 15 -> v, row = (lane >> 4) * 4 + reg -> c
+      const int n = (int)((unsigned)tile / (unsigned)tiles_per_n);
+      const long long vbase = (tile - (long long)n * tiles_per_n) * TV;
+#pragma unroll
+      for (int b = 0; b < TV / 16; ++b) {
+        const long long vi = vbase + b * 16 + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = cbase + lk * 4 + r;
+          if (c < Cin) {
+            float* dst = dx + ((long long)n * Cin + c) * spatial + vi;
+            if (accumulate || o0 > 0) *dst += acc[b][r];
+            else *dst = acc[b][r];
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
                                                           long long numel, int nchunks) {
   // out[e] = sum_k slab[k][e]: 4 waves x 4 independent running sums per element, combined in a fixed order
@@ -767,8 +1133,9 @@ extern "C" int e2e_convT_dgrad(const float* dy, const float* w, const unsigned* 
   E2E_REQUIRE((long long)D * H * W * kd * kh * kw < (1ll << 31), "convT_dgrad: a sample must have fewer than 2^31 output voxels");
   hipStream_t st = (hipStream_t)stream;
   const long long spatial = (long long)D * H * W;
-  // v3 (dense GEMM on the matrix cores) for the large planes
+  // v3 / v4 (dense GEMM on the matrix cores) for the large planes; E2E_CT_BF3=0 keeps the fp32 matrix instructions (v3)
   static const int no_v3 = getenv("E2E_CT_NOV3") ? atoi(getenv("E2E_CT_NOV3")) : 0;
+  static const int use_bf3 = getenv("E2E_CT_BF3") ? atoi(getenv("E2E_CT_BF3")) : 1;
   if (!no_v3 && kw == 2 && (kd * kh == 2 || kd * kh == 4) && (W % 2) == 0 && spatial % 4 == 0 && e2e::cdivll(spatial, 32) * B >= dg_min_tiles()) {
     const long long total_tiles = e2e::cdivll(spatial, 32) * B;
     const int cgroups = e2e::cdiv(Cin, 64);
@@ -778,6 +1145,14 @@ extern "C" int e2e_convT_dgrad(const float* dy, const float* w, const unsigned* 
     int tpw = (int)e2e::cdivll(total_tiles, wgs);
     if (tpw < 4) tpw = 4;
     dim3 grid((unsigned)e2e::cdivll(total_tiles, tpw), cgroups);
+    if (use_bf3 && W % 32 == 0) {
+      e2e::note_kernel("convT_dgrad_bf3<%d> wgs=%u cgroups=%d tiles_per_wg=%d", kd * kh, grid.x, cgroups, tpw);
+      if (kd * kh == 4)
+        hipLaunchKernelGGL((convT_dgrad_bf3_kernel<4>), grid, dim3(256), 0, st, dy, w, dx, accumulate, B, Cin, Cout, D, H, W, kd, kh, tpw);
+      else
+        hipLaunchKernelGGL((convT_dgrad_bf3_kernel<2>), grid, dim3(256), 0, st, dy, w, dx, accumulate, B, Cin, Cout, D, H, W, kd, kh, tpw);
+      return e2e::check_launch("convT_dgrad_bf3_kernel");
+    }
     e2e::note_kernel("convT_dgrad_v3<%d> wgs=%u cgroups=%d tiles_per_wg=%d", kd * kh, grid.x, cgroups, tpw);
     if (kd * kh == 4)
       hipLaunchKernelGGL((convT_dgrad_v3_kernel<4>), grid, dim3(256), 0, st, dy, w, dx, accumulate, B, Cin, Cout, D, H, W, kd, kh, tpw);
@@ -835,6 +1210,17 @@ extern "C" int e2e_convT_wgrad(const float* x, const float* scale, const float* 
     const int nch = wgrad_chunks(total_tiles, pairs2, &tpc);
     dim3 grid2(nch, pairs2);
     const int kdh = kd * kh;
+    static const int use_bf3 = getenv("E2E_CT_BF3") ? atoi(getenv("E2E_CT_BF3")) : 1;
+    if (use_bf3) {
+      e2e::note_kernel("convT_wgrad_bf3<%d,%d> chunks=%d pairs=%d", kdh, ncb, nch, pairs2);
+#define LAUNCH_B3(KDH, NCB) hipLaunchKernelGGL((convT_wgrad_bf3_kernel<KDH, NCB>), grid2, dim3(256 * NCB), 0, st, x, scale, shift, \
+                                               slope, dy, slab, B, Cin, Cout, D, H, W, kd, kh, tpc, cgroups)
+      if (kdh == 4) { if (ncb == 2) LAUNCH_B3(4, 2); else LAUNCH_B3(4, 1); }
+      else { if (ncb == 2) LAUNCH_B3(2, 2); else LAUNCH_B3(2, 1); }
+#undef LAUNCH_B3
+      hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)e2e::cdivll(numel_all, 64)), dim3(256), 0, st, slab, dw, numel_all, nch);
+      return e2e::check_launch("convT_wgrad_bf3");
+    }
     e2e::note_kernel("convT_wgrad_v2<%d,%d> chunks=%d pairs=%d", kdh, ncb, nch, pairs2);
 #define LAUNCH_V2(KDH, NCB) hipLaunchKernelGGL((convT_wgrad_v2_kernel<KDH, NCB>), grid2, dim3(256 * NCB), 0, st, x, scale, shift, \
                                                slope, dy, slab, B, Cin, Cout, D, H, W, kd, kh, tpc, cgroups)

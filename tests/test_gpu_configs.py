@@ -294,9 +294,9 @@ def test_conv133_at_benchmarked_shapes(name, case, k_fwd, k_wgrad, k_dgrad):
 
 
 @pytest.mark.parametrize("B,cin,cout,dims,density,k_dgrad,k_wgrad", [
-    (2, 64, 32, (64, 64, 64), 0.2, "convT_dgrad_v3<4>", "convT_wgrad_v2<4,2>"),        # up*.{L0}: 64^3 -> 128^3
-    (2, 128, 64, (32, 32, 32), 0.2, "convT_dgrad_v3<4>", "convT_wgrad_v2<4,2>"),
-    (2, 320, 256, (8, 8, 8), 0.2, "convT_dgrad_gather", "convT_wgrad_v2<4,2>"),
+    (2, 64, 32, (64, 64, 64), 0.2, "convT_dgrad_bf3<4>", "convT_wgrad_bf3<4,2>"),        # up*.{L0}: 64^3 -> 128^3
+    (2, 128, 64, (32, 32, 32), 0.2, "convT_dgrad_bf3<4>", "convT_wgrad_bf3<4,2>"),
+    (2, 320, 256, (8, 8, 8), 0.2, "convT_dgrad_gather", "convT_wgrad_bf3<4,2>"),
 ])
 def test_convT_at_benchmarked_shapes(B, cin, cout, dims, density, k_dgrad, k_wgrad):
     with KernelLog(["convT_fwd", "convT_wgrad", "convT_dgrad"]) as kl:

@@ -214,7 +214,8 @@ def test_conv133_fwd_bwd(case):
     (1, 70, 64, (1, 4, 4), (1, 1, 1), 0.5, False),
     (1, 64, 32, (16, 16, 16), (2, 2, 2), 0.2, True),
     (1, 72, 40, (16, 64, 64), (2, 2, 2), 0.2, True),       # >= 2048 tiles of 32 voxels: matrix-core data gradient, ragged blocks
-    (2, 20, 70, (32, 32, 34), (1, 2, 2), 0.5, False),      # same path, [1,2,2] kernel, three output-channel chunks
+    (2, 20, 70, (32, 32, 34), (1, 2, 2), 0.5, False),      # same path (fp32 matrix instructions: W % 32 != 0), [1,2,2] kernel, three output-channel chunks
+    (2, 20, 70, (8, 32, 32), (1, 2, 2), 0.5, False),       # bf16 three-piece data gradient, [1,2,2] kernel, three output-channel chunks
 ])
 def test_convT_fwd_bwd(B, cin, cout, dims, kernel, density, normed):
     from e2enet_medical_amd.engine import UpOp

@@ -147,7 +147,17 @@ def convt_case(B, cin, cout, dims, kernel, density, tag):
     vin, vout = src.data.numel(), op.out.data.numel()
     kt = kernel[0] * kernel[1] * kernel[2]
     dense = 2.0 * cin * cout * kt * (vin / cin)
-    for name, fn, fl in (("fwd", op.forward, dense * density), ("bwd(w+d)", op.backward, dense * (1 + density))):
+    L = lib()
+    b_, _, d_, h_, w_ = src.shape
+
+    def wgrad():
+        L.convT_wgrad(src.data.data_ptr(), src.scale.data_ptr(), src.shift.data_ptr(), 0.01, op.out.grad.data_ptr(),
+                      e.grads["up.weight"].data_ptr(), e.wgrad_ws.data_ptr(), b_, cin, cout, d_, h_, w_, *kernel, 0)
+
+    def dgrad():
+        L.convT_dgrad(op.out.grad.data_ptr(), e.params["up.weight"].data_ptr(), op.live_t.data_ptr() if op.live_t is not None else None,
+                      src.grad.data_ptr(), 0, b_, cin, cout, d_, h_, w_, *kernel, 0)
+    for name, fn, fl in (("fwd", op.forward, dense * density), ("wgrad", wgrad, dense), ("dgrad", dgrad, dense * density)):
         ms = time_ms(fn)
         print("%-26s %-8s %8.3f ms  %7.1f GB/s(alg)  %6.1f TFLOP/s" % (tag, name, ms, (vin + vout) * 4 / ms / 1e6, fl / ms / 1e9))
 
