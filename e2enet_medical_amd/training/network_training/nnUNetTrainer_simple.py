@@ -148,6 +148,7 @@ class nnUNetTrainer_simple(object):
         self.base_num_features_override = None      # reference hard-codes 48 for shiftConvPP (:296)
         self.prefetch_batches = True                # fetch + upload batch i+1 under the GPU work of batch i (see run_iteration)
         self._prefetched, self._copy_stream = {}, None
+        self._prefetch_error = {}                   # id(generator) -> (generator, exception raised by its one-ahead fetch)
         self.process_group = None                   # torch.distributed group of the data-parallel replicas (None = world)
         self._fused = None
         self._dp = {}                               # id(engine) -> OverlappedGradAllReduce
@@ -322,6 +323,11 @@ class nnUNetTrainer_simple(object):
             eng.prepare_backward()
             dp = parallel.OverlappedGradAllReduce(eng, group=group, force=os.environ.get("E2E_FORCE_DIST") == "1")
             eng.batch_dice_hook = parallel.batch_dice_allreduce(group)
+            for old in self._dp.values():                        # a plan evicted from the network's cache: drop its hooks
+                old_eng = getattr(old, "engine", None)
+                if old_eng is not None and old_eng is not eng:
+                    old_eng.grad_bucket_hook = None
+                    old_eng.batch_dice_hook = None
             self._dp = {id(eng): dp}
         return dp
 
@@ -332,6 +338,9 @@ class nnUNetTrainer_simple(object):
         if dev.type != "cuda":
             raise RuntimeError("nnUNetTrainer_simple (MI355X) needs the network on a GPU: there is no CPU fallback")
         # the batch: uploaded under the previous iteration when it was fetched one call ahead (prefetch_batches), else now
+        err = self._prefetch_error.pop(id(data_generator), None)
+        if err is not None:
+            raise err[1]        # the generator failed while the previous step (already applied, loss returned) fetched one ahead
         slot = self._prefetched.pop(id(data_generator), None) if self.prefetch_batches else None
         if slot is None:
             data, target = self._upload(next(data_generator), dev)
@@ -377,6 +386,9 @@ class nnUNetTrainer_simple(object):
                 nxt = next(data_generator)
             except StopIteration:
                 nxt = None
+            except Exception as e:                               # this step is applied: report on the next call for this generator
+                self._prefetch_error[id(data_generator)] = (data_generator, e)
+                nxt = None
             if nxt is not None:
                 if self._copy_stream is None:
                     self._copy_stream = torch.cuda.Stream(device=dev)
@@ -387,10 +399,23 @@ class nnUNetTrainer_simple(object):
                     ev.record(self._copy_stream)
                 for t in [d2] + list(t2):
                     t.record_stream(main)
+                if self._has_pinned(nxt):
+                    ev.synchronize()                             # a generator may refill its pinned buffers in place on the next fetch
                 while len(self._prefetched) >= 4:               # generators that were dropped by the caller: forget their batch
                     self._prefetched.pop(next(iter(self._prefetched)))
                 self._prefetched[id(data_generator)] = (data_generator, d2, t2, ev)
         return loss.detach().cpu().numpy().reshape(())
+
+    def drain_prefetched(self):
+        """Forget the batches fetched one call ahead (run_iteration consumes a generator one batch ahead of the step it
+        returns; call this when a generator is replaced and its pending batch must not be used)."""
+        self._prefetched.clear()
+        self._prefetch_error.clear()
+
+    @staticmethod
+    def _has_pinned(data_dict):
+        vals = [data_dict['data']] + (list(data_dict['target']) if isinstance(data_dict['target'], (list, tuple)) else [data_dict['target']])
+        return any(isinstance(v, torch.Tensor) and v.is_pinned() for v in vals)
 
     @staticmethod
     def _upload(data_dict, dev):
@@ -406,10 +431,24 @@ class nnUNetTrainer_simple(object):
         """reference :371-405: hard tp/fp/fn per foreground class of the full-resolution prediction, summed over the
         batch (HIP kernel e2e_online_eval_counts; under data parallelism summed over the ranks as
         nnUNetTrainerV2_DDP.py:303-305 does)."""
-        eng = _engine if _engine is not None else self.network.engine(output[0])
-        if _engine is None:                                      # called with foreign logits: evaluate those
-            eng.heads[0].out.data.copy_(output[0])
-        counts = eng.online_eval_counts(target[0])
+        if _engine is not None:
+            counts = _engine.online_eval_counts(target[0])
+        else:
+            # the reference's public signature (foreign logits [B, K, ...] + labels): counted straight from those tensors,
+            # no activation plan is built for them
+            from ..._lib import lib
+            logits, tgt = output[0], target[0]
+            if getattr(self.network, "conv_variant", "133") != "133":
+                logits, tgt = self.network.to_engine_layout(logits), self.network.to_engine_layout(tgt)
+            logits, tgt = logits.float().contiguous(), tgt.float().contiguous()
+            if not logits.is_cuda:
+                raise RuntimeError("run_online_evaluation (MI355X) needs GPU tensors: there is no CPU fallback")
+            b, k = logits.shape[:2]
+            spatial = logits[0, 0].numel()
+            assert tgt.numel() == b * spatial, "target must hold one label per voxel of the logits"
+            counts = torch.zeros((k, 3), dtype=torch.int64, device=logits.device)
+            lib().online_eval_counts(logits.data_ptr(), tgt.data_ptr(), counts.data_ptr(), b, k, spatial,
+                                     torch.cuda.current_stream().cuda_stream)
         dp_on, group = self._data_parallel()
         if dp_on:
             import torch.distributed as dist

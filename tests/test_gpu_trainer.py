@@ -132,6 +132,38 @@ def test_online_evaluation_counts_match_torch():
     assert abs(tr.all_val_eval_metrics[-1] - want) < 1e-6          # the reference keeps the counts in float32
 
 
+def test_online_evaluation_public_signature_and_deferred_prefetch_error():
+    """(a) run_online_evaluation(output, target) with foreign logits (the reference's public signature, K != input channels)
+    counts straight from those tensors and builds no activation plan for them; (b) an exception raised by the generator
+    while run_iteration fetches one batch ahead surfaces on the NEXT call, after the applied step's loss was returned."""
+    tr, net, opt = _trainer()
+    plans_before = len(net._engines)
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn((2, 7, 6, 10, 12), generator=g).cuda()
+    target = torch.randint(0, 7, (2, 1, 6, 10, 12), generator=g).float().cuda()
+    tr.run_online_evaluation([logits], [target])
+    assert len(net._engines) == plans_before
+    seg = logits.argmax(1)
+    tgt = target[:, 0]
+    tp = np.array([((seg == c) & (tgt == c)).sum().item() for c in range(1, 7)], dtype=np.float32)
+    fn = np.array([((seg != c) & (tgt == c)).sum().item() for c in range(1, 7)], dtype=np.float32)
+    assert np.array_equal(np.array(tr.online_eval_tp[-1]), tp) and np.array_equal(np.array(tr.online_eval_fn[-1]), fn)
+
+    batch = next(tr.tr_gen)
+
+    def gen():
+        yield batch
+        raise ValueError("augmenter failed")
+    it = gen()
+    tr.prefetch_batches = True
+    loss = tr.run_iteration(it, True)                    # step applied, the one-ahead fetch fails quietly
+    assert np.isfinite(loss)
+    with pytest.raises(ValueError, match="augmenter failed"):
+        tr.run_iteration(it, True)
+    tr.drain_prefetched()
+    assert not tr._prefetched and not tr._prefetch_error
+
+
 def test_validation_loss_value_matches_training_loss():
     tr, net, opt = _trainer(batch_dice=True)
     batch = next(tr.tr_gen)
