@@ -493,9 +493,51 @@ __global__ __launch_bounds__(256 * NCB) void convT_wgrad_bf3_kernel(const float*
     const int i = rr / kh, j = rr - i * kh;
     yoff[it] = ((long long)i * Ho + j) * Wo + 4 * vp;
   }
+  // row tiles (W % 64 == 0): a tile's addresses are a wave-uniform base (scalar arithmetic) plus per-lane byte offsets that
+  // never change; the normalise-on-load coefficients change only with the batch item.  (s_memtime stamps: issuing the ten
+  // float4 loads of a tile with per-lane 64-bit index arithmetic, two integer divisions and four coefficient loads took
+  // ~2500 cycles, as long as the tile's matrix phase.)
+  unsigned zoffb[2], yoffb[YCW][YIT];
+  bool zcok[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int g = lane + 64 * it;
+    zcok[it] = cbase + wave * 8 + (g >> 4) < Cin;
+    zoffb[it] = zcok[it] ? (unsigned)(((long long)(wave * 8 + (g >> 4)) * spatial + (g & 15) * 4) * 4) : 0u;
+  }
+#pragma unroll
+  for (int k = 0; k < YCW; ++k)
+#pragma unroll
+    for (int it = 0; it < YIT; ++it)
+      yoffb[k][it] = (ob * 32 + wave * YCW + k < Cout) ? (unsigned)(((long long)k * ospatial + yoff[it]) * 4) : 0u;
+  int cur_n = -1;
   auto prefetch = [&](long long tile) {
     const int n = (int)((unsigned)tile / (unsigned)tiles_per_n);
     const long long vbase = (tile - (long long)n * tiles_per_n) * WG_TPX;
+    if (row_tiles) {
+      if (n != cur_n) {
+        cur_n = n;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int c = cbase + wave * 8 + ((lane + 64 * it) >> 4);
+          za[it] = 1.f; zb[it] = 0.f;
+          if (scale != nullptr && c < Cin) { za[it] = scale[(long long)n * Cin + c]; zb[it] = shift[(long long)n * Cin + c]; }
+        }
+      }
+      int dv, hv, w0;
+      decode_dhw(vbase, W, H, dv, hv, w0);
+      const char* zb8 = reinterpret_cast<const char*>(x + ((long long)n * Cin + cbase) * spatial + vbase);
+      const int ych = ob * 32 + wave * YCW < Cout ? ob * 32 + wave * YCW : 0;      // (waves past the last channel read channel 0 and drop it)
+      const char* yb8 = reinterpret_cast<const char*>(dy + ((long long)n * Cout + ych) * ospatial +
+                                                      ((long long)dv * kd * Ho + (long long)hv * kh) * Wo + 2 * w0);
+#pragma unroll
+      for (int it = 0; it < 2; ++it) vz[it] = *reinterpret_cast<gf4_p>((gfloat_p)(zb8 + zoffb[it]));
+#pragma unroll
+      for (int k = 0; k < YCW; ++k)
+#pragma unroll
+        for (int it = 0; it < YIT; ++it) vy[k][it] = *reinterpret_cast<gf4_p>((gfloat_p)(yb8 + yoffb[k][it]));
+      return;
+    }
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int g = lane + 64 * it;
@@ -506,20 +548,6 @@ __global__ __launch_bounds__(256 * NCB) void convT_wgrad_bf3_kernel(const float*
       vz[it] = *reinterpret_cast<gf4_p>((gfloat_p)x + off);
       za[it] = 1.f; zb[it] = 0.f;
       if (scale != nullptr && c < Cin) { za[it] = scale[(long long)n * Cin + c]; zb[it] = shift[(long long)n * Cin + c]; }
-    }
-    if (row_tiles) {      // the 64-voxel tile lies inside one input row: wave-uniform base + per-thread constant offsets
-      int dv, hv, w0;
-      decode_dhw(vbase, W, H, dv, hv, w0);
-      const long long tbase = ((long long)n * Cout + ob * 32 + wave * YCW) * ospatial +
-                              ((long long)dv * kd * Ho + (long long)hv * kh) * Wo + 2 * w0;
-#pragma unroll
-      for (int k = 0; k < YCW; ++k)
-#pragma unroll
-        for (int it = 0; it < YIT; ++it) {
-          const bool ok = ob * 32 + wave * YCW + k < Cout;
-          vy[k][it] = *reinterpret_cast<gf4_p>((gfloat_p)dy + (ok ? tbase + k * ospatial + yoff[it] : 0));
-        }
-      return;
     }
 #pragma unroll
     for (int k = 0; k < YCW; ++k) {
@@ -586,12 +614,23 @@ __global__ __launch_bounds__(256 * NCB) void convT_wgrad_bf3_kernel(const float*
     }
   };
 
+#ifdef CT_DIAG
+  unsigned long long stamp[16]; int ns = 0;
+#define CSTAMP() do { if (ns < 16) stamp[ns++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CSTAMP() do {} while (0)
+#endif
   if (tile_lo < tile_hi) {
+    CSTAMP();
     prefetch(tile_lo);
     for (long long tile = tile_lo; tile < tile_hi; ++tile) {
+      CSTAMP();
       commit(tile);
+      CSTAMP();
       __syncthreads();
+      CSTAMP();
       if (tile + 1 < tile_hi) prefetch(tile + 1);
+      CSTAMP();
       const int li = lane & 15, lk = lane >> 4;
       // A: channel row, 8 consecutive voxels 32 kb + 8 lk ..; B: out channel row of tap t, the same voxels
       const unsigned char* ap = zs + (cbl * 32 + ch * 16 + li) * RS + lk * 16;
@@ -617,9 +656,17 @@ __global__ __launch_bounds__(256 * NCB) void convT_wgrad_bf3_kernel(const float*
           acc[t] = a;
         }
       }
+      CSTAMP();
       __syncthreads();
     }
   }
+#ifdef CT_DIAG
+  if (tid == 64 && blockIdx.y == 0 && (blockIdx.x == 100 || blockIdx.x == 101))
+    printf("WG %d tiles %d | pre %u | t0: wait+commit %u bar %u pf %u mma %u | t1: bar %u commit %u bar %u pf %u mma %u | t2: bar %u commit %u bar %u\n", blockIdx.x, (int)(tile_hi - tile_lo),
+           (unsigned)(stamp[1]-stamp[0]), (unsigned)(stamp[2]-stamp[1]), (unsigned)(stamp[3]-stamp[2]), (unsigned)(stamp[4]-stamp[3]), (unsigned)(stamp[5]-stamp[4]),
+           (unsigned)(stamp[6]-stamp[5]), (unsigned)(stamp[7]-stamp[6]), (unsigned)(stamp[8]-stamp[7]), (unsigned)(stamp[9]-stamp[8]), (unsigned)(stamp[10]-stamp[9]),
+           (unsigned)(stamp[11]-stamp[10]), (unsigned)(stamp[12]-stamp[11]), (unsigned)(stamp[13]-stamp[12]));
+#endif
   // D[i = c][j = o]: col = lane & 15 -> o, row = (lane >> 4) * 4 + reg -> c
   float* sp = slab + (long long)chunk * Cin * Cout * KT;
   const int o = ob * 32 + oh * 16 + (lane & 15);
@@ -885,6 +932,170 @@ __global__ __launch_bounds__(256) void convT_dgrad_v3_kernel(const float* __rest
   }
 }
 
+// ---- forward v2 (kw == 2, W % 32 == 0, Cin <= 256): dense GEMM on the bf16 matrix pipe with fp32-exact operands ------------
+// y[v, (o, t)] = sum_c z[v, c] W[c, (o, t)]:  M = 32 consecutive input voxels of a row per tile, K = Cin (NKB blocks of 32),
+// N = Cout x KT output columns.  The gather kernel above re-reads the input once per output channel (through L2) and is
+// bound by scalar weight loads and the per-voxel FMA chains (2.9 TB/s at 64 -> 32 @64^3); here
+//   * a wave keeps the three-piece B fragments of its 8 / NKB column tiles (16 columns = 16 / KT output channels x KT taps)
+//     in registers for its whole run of tiles (96 VGPRs);
+//   * the z tile (normalise-on-load applied) is split and staged voxel-major, [piece][32 voxels][K bf16 + 16 B], once per
+//     tile for all columns of the workgroup (4 waves x 8 / NKB x 16 columns); the next tile's loads fly during the matrix phase;
+//   * D[voxel][column]: a lane holds 4 consecutive voxels of one (o, i, j, k) column; the k = 0 / 1 columns are neighbouring
+//     lanes, so one DPP pair swap turns them into two aligned float4 stores of the interleaved output row.
+template <int KDH, int NKB>
+__global__ __launch_bounds__(256, 2) void convT_fwd_bf3_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, float slope,
+                                                               const float* __restrict__ w, float* __restrict__ y, int B, int Cin,
+                                                               int Cout, int D, int H, int W, int kd, int kh, int tiles_per_wg) {
+  constexpr int KT = 2 * KDH;
+  constexpr int TV = 32;
+  constexpr int K = NKB * 32;
+  constexpr int NTW = 8 / NKB;                          // 16-column tiles per wave
+  constexpr int RS = K * 2 + 16;                        // bytes per staged voxel and piece (odd multiple of 16)
+  constexpr int PSZ = TV * RS;
+  constexpr int NRD = K / 64;                           // staging rounds: 256 threads x (2 channels x 4 voxels)
+  __shared__ __attribute__((aligned(16))) unsigned char zs[3 * PSZ];
+
+  const long long spatial = (long long)D * H * W;
+  const long long tiles_per_n = spatial / TV;
+  const long long total_tiles = tiles_per_n * B;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  const int Ho = H * kh, Wo = W * 2;
+  const long long ospatial = spatial * KT;
+  const int ncols = Cout * KT;
+  const int col0 = (blockIdx.y * 4 + wave) * NTW * 16;   // first column of this wave
+  const long long tile_lo = (long long)blockIdx.x * tiles_per_wg;
+  long long tile_hi = tile_lo + tiles_per_wg;
+  if (tile_hi > total_tiles) tile_hi = total_tiles;
+  if (tile_lo >= tile_hi) return;
+
+  // B fragments: column n = col0 + 16 nt + li = (o, t), k = 32 kb + 8 lk + j = input channel
+  bf16x8_t bfr[NTW][NKB][3];
+  long long coff[NTW];                                   // offset of the column's output row origin inside a sample
+  bool cok[NTW];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) {
+    const int col = col0 + nt * 16 + li;
+    cok[nt] = col < ncols;
+    const int o = cok[nt] ? col / KT : 0, t = cok[nt] ? col - o * KT : 0;
+    const int rr = t >> 1, kk = t & 1;
+    const int ii = rr / kh, jj = rr - ii * kh;
+    coff[nt] = (long long)o * ospatial + ((long long)ii * Ho + jj) * Wo + 4 * kk;   // + 4 kk: the second float4 of the pair
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      unsigned h[8], m[8], l[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = kb * 32 + lk * 8 + j;
+        const float wv = (cok[nt] && c < Cin) ? w[((long long)c * Cout + o) * KT + t] : 0.f;
+        split3(wv, h[j], m[j], l[j]);
+      }
+      bfr[nt][kb][0] = __builtin_bit_cast(bf16x8_t, u32x4_t{pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]), pack_hi16(h[4], h[5]), pack_hi16(h[6], h[7])});
+      bfr[nt][kb][1] = __builtin_bit_cast(bf16x8_t, u32x4_t{pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]), pack_hi16(m[4], m[5]), pack_hi16(m[6], m[7])});
+      bfr[nt][kb][2] = __builtin_bit_cast(bf16x8_t, u32x4_t{pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]), pack_hi16(l[4], l[5]), pack_hi16(l[6], l[7])});
+    }
+  }
+
+  // staging: thread -> channel pair cp = tid / 8 (+ 32 per round), voxel group vq = tid % 8 (4 voxels)
+  const int cp = tid >> 3, vq = tid & 7;
+  f32x4_t vx[NRD][2];
+  float za[NRD][2], zb[NRD][2];
+  auto prefetch = [&](long long tile) {
+    const int n = (int)((unsigned)tile / (unsigned)tiles_per_n);
+    const long long vbase = (tile - (long long)n * tiles_per_n) * TV;
+#pragma unroll
+    for (int r = 0; r < NRD; ++r)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int c = r * 64 + cp * 2 + e;
+        const bool ok = c < Cin;
+        vx[r][e] = *reinterpret_cast<gf4_p>((gfloat_p)x + (((long long)n * Cin + (ok ? c : 0)) * spatial + vbase + vq * 4));
+        za[r][e] = 1.f; zb[r][e] = 0.f;
+        if (scale != nullptr && ok) { za[r][e] = scale[(long long)n * Cin + c]; zb[r][e] = shift[(long long)n * Cin + c]; }
+      }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int r = 0; r < NRD; ++r) {
+      unsigned h[2][4], m[2][4], l[2][4];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const bool ok = r * 64 + cp * 2 + e < Cin;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float t = vx[r][e][q];
+          if (scale != nullptr) t = e2e::in_act(t, za[r][e], zb[r][e], slope);
+          split3(ok ? t : 0.f, h[e][q], m[e][q], l[e][q]);
+        }
+      }
+      unsigned char* dst = zs + (vq * 4) * RS + (r * 64 + cp * 2) * 2;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        *reinterpret_cast<unsigned*>(dst + q * RS) = pack_hi16(h[0][q], h[1][q]);
+        *reinterpret_cast<unsigned*>(dst + q * RS + PSZ) = pack_hi16(m[0][q], m[1][q]);
+        *reinterpret_cast<unsigned*>(dst + q * RS + 2 * PSZ) = pack_hi16(l[0][q], l[1][q]);
+      }
+    }
+  };
+
+  prefetch(tile_lo);
+  for (long long tile = tile_lo; tile < tile_hi; ++tile) {
+    commit();
+    __syncthreads();
+    if (tile + 1 < tile_hi) prefetch(tile + 1);          // in flight during the matrix phase
+    f32x4 acc[2][NTW];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // A fragment: voxel 16 mt + li, channels 32 kb + 8 lk .. + 7
+    const unsigned char* ap = zs + li * RS + lk * 16;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        bf16x8_t af[3];
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) af[sp] = *reinterpret_cast<const bf16x8_t*>(ap + sp * PSZ + mt * 16 * RS + kb * 64);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+          f32x4 a = acc[mt][nt];
+          // small terms first: lo*hi, mid*mid, hi*lo, then mid*hi, hi*mid, then hi*hi
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bfr[nt][kb][0], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bfr[nt][kb][1], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bfr[nt][kb][2], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bfr[nt][kb][0], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bfr[nt][kb][1], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bfr[nt][kb][0], a, 0, 0, 0);
+          acc[mt][nt] = a;
+        }
+      }
+    // D: row (voxel) = 16 mt + 4 lk + i, column = lane & 15.  Lanes 2p, 2p + 1 hold taps k = 0, 1 of one (o, i, j): after the
+    // pair swap lane k = 0 owns output floats [2 v .. 2 v + 3] and lane k = 1 the next four of the interleaved row.
+    const int n = (int)((unsigned)tile / (unsigned)tiles_per_n);
+    const long long vbase = (tile - (long long)n * tiles_per_n) * TV;
+    int dv, hv, w0;
+    decode_dhw(vbase, W, H, dv, hv, w0);
+    float* yb = y + (long long)n * Cout * ospatial + ((long long)dv * kd * Ho + (long long)hv * kh) * Wo + 2 * w0;
+    const bool odd = (lane & 1) != 0;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        const f32x4 a = acc[mt][nt];
+        const float s0 = odd ? a[0] : a[2], s1 = odd ? a[1] : a[3];
+        // quad_perm [1, 0, 3, 2]: swap with the neighbouring lane
+        const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s0), 0xb1, 0xf, 0xf, true));
+        const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s1), 0xb1, 0xf, 0xf, true));
+        const f32x4_t o4 = odd ? f32x4_t{r0, a[2], r1, a[3]} : f32x4_t{a[0], r0, a[1], r1};
+        if (cok[nt]) *reinterpret_cast<f32x4_t*>(yb + coff[nt] + 2 * (mt * 16 + lk * 4)) = o4;
+      }
+    __syncthreads();
+  }
+}
+
 // ---- data gradient v4 (kw == 2, W % 32 == 0): the v3 GEMM on the bf16 matrix pipe with fp32-exact operands ----------------
 // v3 is bound by its fp32 MFMAs (128 x 32 cycles per 32-voxel tile and wave: ~0.15 ms of a 0.31 ms launch at 64 -> 32 @64^3,
 // the staging and the HBM stream not overlapped with them).  Every fp32 value is split without error into three bf16
@@ -1104,6 +1315,26 @@ extern "C" int e2e_convT_fwd(const float* x, const float* scale, const float* sh
   hipStream_t st = (hipStream_t)stream;
   const long long spatial = (long long)D * H * W;
   const int kt = kd * kh * kw;
+  static const int use_bf3 = getenv("E2E_CT_BF3") ? atoi(getenv("E2E_CT_BF3")) : 1;
+  const int kdh = kd * kh;
+  if (use_bf3 && kw == 2 && (kdh == 2 || kdh == 4) && W % 32 == 0 && Cin <= 256 && (spatial / 32) * B >= 256) {
+    const int nkb = Cin <= 64 ? 2 : (Cin <= 128 ? 4 : 8);
+    const int cols_per_wg = 4 * (8 / nkb) * 16;
+    const int cgroups = e2e::cdiv(Cout * kt, cols_per_wg);
+    const long long total_tiles = (spatial / 32) * B;
+    long long wgs = 512 / cgroups;                         // two 4-wave workgroups per CU: one round
+    if (wgs < 1) wgs = 1;
+    int tpw = (int)e2e::cdivll(total_tiles, wgs);
+    if (tpw < 4) tpw = 4;
+    dim3 grid((unsigned)e2e::cdivll(total_tiles, tpw), cgroups);
+    e2e::note_kernel("convT_fwd_bf3<%d,%d> wgs=%u cgroups=%d tiles_per_wg=%d", kdh, nkb, grid.x, cgroups, tpw);
+#define LAUNCH_F3(KDH, NKB) hipLaunchKernelGGL((convT_fwd_bf3_kernel<KDH, NKB>), grid, dim3(256), 0, st, x, scale, shift, slope, w, y, \
+                                               B, Cin, Cout, D, H, W, kd, kh, tpw)
+    if (kdh == 4) { if (nkb == 2) LAUNCH_F3(4, 2); else if (nkb == 4) LAUNCH_F3(4, 4); else LAUNCH_F3(4, 8); }
+    else { if (nkb == 2) LAUNCH_F3(2, 2); else if (nkb == 4) LAUNCH_F3(2, 4); else LAUNCH_F3(2, 8); }
+#undef LAUNCH_F3
+    return e2e::check_launch("convT_fwd_bf3_kernel");
+  }
   e2e::note_kernel("convT_fwd_gather<%d,%d>", kt, spatial >= 4096 ? (kt <= 4 ? 4 : 2) : 1);
   if (spatial >= 4096 && kt <= 4) {
     dim3 grid((unsigned)e2e::cdivll(spatial, 256 * 4), Cout, B);

@@ -26,6 +26,7 @@ IN_EPS = 1e-5
 DENSE_MIN_DENSITY = float(os.environ.get("E2E_DENSE_MIN_DENSITY", "0.5"))
 WGRAD_STREAM = os.environ.get("E2E_WGRAD_STREAM", "1") != "0"      # weight gradients on a second HIP stream
 WGRAD_STREAM_MAX_ELEMS = int(os.environ.get("E2E_WGRAD_STREAM_MAX_ELEMS", "40000000"))   # level 0 of 128^3 stays in line
+WGRAD_LATE = os.environ.get("E2E_WGRAD_LATE", "1") != "0"            # level-0 weight gradients behind their data gradient, on the side stream
 LANES = os.environ.get("E2E_LANES", "1") != "0"                    # deep levels on their own HIP stream (Engine._exec)
 LANE_LIGHT_DIV = int(os.environ.get("E2E_LANE_LIGHT_DIV", "64"))   # an op is 'light' when its output has <= 1/64 of the patch voxels
 DENSE_ENABLED = True          # tests switch the matrix-core conv path off to compare the sparse walk with itself
@@ -206,9 +207,9 @@ class ConvOp:
                        LRELU_SLOPE, g[self.prefix + ".instnorm.weight"].data_ptr(),
                        g[self.prefix + ".instnorm.bias"].data_ptr(), g[self.prefix + ".conv.bias"].data_ptr(),
                        e.in_sums.data_ptr(), b, self.cout, o.spatial, _stream())
-        with _wgrad_stream(e, o.data.numel()) as ws:
-            L.conv133_wgrad(self.chans.data_ptr(), o.grad.data_ptr(), g[self.w_name].data_ptr(), ws.data_ptr(),
-                            b, self.cin, self.cout, di, hi, wi, sd, sh, sw, _stream())
+        late = WGRAD_LATE and getattr(e, "_wg_active", None) is not None and o.data.numel() > WGRAD_STREAM_MAX_ELEMS
+        if not late:
+            self._wgrad(e, L, g, o, b, di, hi, wi, sd, sh, sw, o.data.numel())
         if self.do_dgrad:
             ws = getattr(e, "fwd_ws", None)
             if self.use_dense():
@@ -220,6 +221,16 @@ class ConvOp:
             else:
                 L.conv133_dgrad(o.grad.data_ptr(), p[self.w_name].data_ptr(), _ptr(self.live_t), self.outs.data_ptr(),
                                 b, self.cin, self.cout, di, hi, wi, sd, sh, sw, _stream())
+        if late:
+            # full-resolution layers: the matrix-pipe weight gradient is issued BEHIND the layer's data gradient on the
+            # weight-gradient stream, so that it runs beside the next layer's HBM-bound in_lrelu_bwd passes (no LDS, few
+            # registers: they share CUs with it) instead of beside the LDS/VALU-bound data gradient
+            self._wgrad(e, L, g, o, b, di, hi, wi, sd, sh, sw, 0)
+
+    def _wgrad(self, e, L, g, o, b, di, hi, wi, sd, sh, sw, elems):
+        with _wgrad_stream(e, elems) as ws:
+            L.conv133_wgrad(self.chans.data_ptr(), o.grad.data_ptr(), g[self.w_name].data_ptr(), ws.data_ptr(),
+                            b, self.cin, self.cout, di, hi, wi, sd, sh, sw, _stream())
 
     def wgrad_ws_bytes(self):
         di, hi, wi = self.in_dims
