@@ -156,7 +156,7 @@ def convt_case(B, cin, cout, dims, kernel, density, tag):
 
     def dgrad():
         L.convT_dgrad(op.out.grad.data_ptr(), e.params["up.weight"].data_ptr(), op.live_t.data_ptr() if op.live_t is not None else None,
-                      src.grad.data_ptr(), 0, b_, cin, cout, d_, h_, w_, *kernel, 0)
+                      src.grad.data_ptr(), int(os.environ.get("KB_ACC", "0")), b_, cin, cout, d_, h_, w_, *kernel, 0)
     for name, fn, fl in (("fwd", op.forward, dense * density), ("wgrad", wgrad, dense), ("dgrad", dgrad, dense * density)):
         ms = time_ms(fn)
         print("%-26s %-8s %8.3f ms  %7.1f GB/s(alg)  %6.1f TFLOP/s" % (tag, name, ms, (vin + vout) * 4 / ms / 1e6, fl / ms / 1e9))
