@@ -28,7 +28,9 @@ WGRAD_STREAM = os.environ.get("E2E_WGRAD_STREAM", "1") != "0"      # weight grad
 WGRAD_STREAM_MAX_ELEMS = int(os.environ.get("E2E_WGRAD_STREAM_MAX_ELEMS", "40000000"))   # level 0 of 128^3 stays in line
 WGRAD_LATE = os.environ.get("E2E_WGRAD_LATE", "1") != "0"            # level-0 weight gradients behind their data gradient, on the side stream
 LANES = os.environ.get("E2E_LANES", "1") != "0"                    # deep levels on their own HIP stream (Engine._exec)
-LANE_LIGHT_DIV = int(os.environ.get("E2E_LANE_LIGHT_DIV", "64"))   # an op is 'light' when its output has <= 1/64 of the patch voxels
+# lane of an op = how many of these it passes: output voxels * div <= patch voxels (lane 0 = the caller's stream).  "64" puts
+# levels >= 2 on a second stream; "64,4096" gives levels >= 4 a third one
+LANE_DIVS = tuple(int(v) for v in os.environ.get("E2E_LANE_DIVS", "64").split(",") if v.strip())
 DENSE_ENABLED = True          # tests switch the matrix-core conv path off to compare the sparse walk with itself
 
 
@@ -436,8 +438,9 @@ class Engine:
         self.generation = 0                # bumped by every forward(): activations are reused in place
         fws = max([max(op.fwd_ws_bytes, op.dgrad_ws_bytes if op.do_dgrad else 0, op.dense_ws_bytes) for op in self.conv_ops.values()] + [0])
         # split-K partial sums (deep levels) / packed weights of the matrix-core conv; one per lane (see _exec)
-        self._fwd_ws = [torch.empty(fws // 4, dtype=torch.float32, device=self.device) if fws > 0 else None for _ in range(2)]
-        self._in_sums, self._wgrad_ws = [None, None], [None, None]
+        nl = len(LANE_DIVS) + 1
+        self._fwd_ws = [torch.empty(fws // 4, dtype=torch.float32, device=self.device) if fws > 0 else None for _ in range(nl)]
+        self._in_sums, self._wgrad_ws = [None] * nl, [None] * nl
         self._lane = 0
         self._plan_lanes()
         self.pre_forward_hook = None       # callable(): set by the owning network, brings masks / parameters up to date
@@ -603,7 +606,7 @@ class Engine:
 
     def _plan_lanes(self):
         vox = self.patch[0] * self.patch[1] * self.patch[2]
-        self._lane_of = [1 if op.out.spatial * LANE_LIGHT_DIV <= vox else 0 for op in self.ops]
+        self._lane_of = [sum(1 for dv in LANE_DIVS if op.out.spatial * dv <= vox) for op in self.ops]
         writer = {}
         self._deps_fwd = []
         for i, op in enumerate(self.ops):
@@ -612,7 +615,7 @@ class Engine:
             writer[id(op.out)] = i
         self._ev_fwd = self._events_for(self._deps_fwd)
         self._deps_bwd, self._ev_bwd = None, None
-        self._lane_stream = None
+        self._lane_streams = None
 
     def _plan_lanes_backward(self):
         last = {}                              # gradient buffer -> op that touched it last (in backward order)
@@ -643,11 +646,16 @@ class Engine:
                     checkpoint(self.ops[i], lambda: None)
             return
         main = torch.cuda.current_stream()
-        if self._lane_stream is None:
-            self._lane_stream = torch.cuda.Stream(device=self.device)
-        light = self._lane_stream
-        streams = (main, light)
-        light.wait_stream(main)
+        if self._lane_streams is None:
+            self._lane_streams = [torch.cuda.Stream(device=self.device) for _ in LANE_DIVS]
+        side = self._lane_streams
+        streams = [main] + side
+
+        def join():
+            for st in side:
+                main.wait_stream(st)
+        for st in side:
+            st.wait_stream(main)
         try:
             for i in order:
                 ln = self._lane_of[i]
@@ -655,7 +663,7 @@ class Engine:
                     streams[ln].wait_event(events[j])
                 self._lane = ln
                 if ln:
-                    with torch.cuda.stream(light):
+                    with torch.cuda.stream(streams[ln]):
                         action(self.ops[i])
                 else:
                     action(self.ops[i])
@@ -665,10 +673,10 @@ class Engine:
                         events[i] = torch.cuda.Event()
                     events[i].record(streams[ln])
                 if checkpoint is not None:
-                    checkpoint(self.ops[i], lambda: main.wait_stream(light))
+                    checkpoint(self.ops[i], join)
         finally:
             self._lane = 0
-            main.wait_stream(light)
+            join()
 
     # ------------------------------------------------------------------------------------------ graph replay
     def _graph_ok(self):
@@ -679,6 +687,11 @@ class Engine:
             return False                     # a caller is capturing the whole pass itself
         if mode == "1":
             return True
+        if LANES and LANE_DIVS:
+            # measured (tools/scratch/small_bench.py): issued eagerly on two lanes + the weight-gradient stream a small plan
+            # is shorter on the GPU than its single-stream graph replay (64^3 x 2 fwd+loss+bwd 11.4 vs 14.5 ms, Hippocampus
+            # patch 9.1 vs 10.8) and the host still issues a step in less than half of that; graphs are for E2E_LANES=0
+            return False
         vox = self.batch * self.patch[0] * self.patch[1] * self.patch[2]
         return vox <= int(os.environ.get("E2E_GRAPH_MAX_VOXELS", str(1 << 20)))
 
@@ -743,9 +756,9 @@ class Engine:
         self._bucket_tail = (lo, total)
         ws = max([op.wgrad_ws_bytes() for op in self.ops if hasattr(op, "wgrad_ws_bytes")] +
                  [lib().head1x1_wgrad_ws_bytes(self.batch, h.src.shape[1], h.k, h.src.spatial) for h in self.heads])
-        self._wgrad_ws = [torch.empty((ws + 3) // 4, dtype=torch.float32, device=self.device) for _ in range(2)]
+        self._wgrad_ws = [torch.empty((ws + 3) // 4, dtype=torch.float32, device=self.device) for _ in range(len(LANE_DIVS) + 1)]
         cmax = max(op.cout for op in self.conv_ops.values())
-        self._in_sums = [torch.empty(self.batch * cmax * 3, dtype=torch.float64, device=self.device) for _ in range(2)]
+        self._in_sums = [torch.empty(self.batch * cmax * 3, dtype=torch.float64, device=self.device) for _ in range(len(LANE_DIVS) + 1)]
         self._plan_lanes_backward()
         self._loss_buffers()
         self._backward_ready = True

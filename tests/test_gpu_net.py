@@ -860,7 +860,7 @@ def test_two_lane_issue_matches_single_stream(monkeypatch):
     def run(lanes, wg, hook):
         monkeypatch.setattr(E, "LANES", lanes)
         monkeypatch.setattr(E, "WGRAD_STREAM", wg)
-        monkeypatch.setattr(E, "LANE_LIGHT_DIV", 8)           # levels >= 1 of this small patch on the light lane
+        monkeypatch.setattr(E, "LANE_DIVS", (8, 512))         # three lanes: level 0 | levels 1-2 | levels >= 3 of this small patch
         monkeypatch.setattr(E, "WGRAD_STREAM_MAX_ELEMS", 1 << 22)
         net._engines.clear()
         res = []
@@ -877,7 +877,7 @@ def test_two_lane_issue_matches_single_stream(monkeypatch):
                 assert torch.equal(snap, eng.grad_flat[lo:hi]), "bucket [%d,%d) changed after its hook" % (lo, hi)
             res.append((outs, loss, grads))
         if lanes:
-            assert any(eng._lane_of) and not all(eng._lane_of) and eng._lane_stream is not None
+            assert set(eng._lane_of) == {0, 1, 2} and eng._lane_streams is not None
             assert any(eng._deps_fwd) and any(eng._deps_bwd)
         return res
     base = run(False, False, False)
