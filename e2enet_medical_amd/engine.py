@@ -30,7 +30,16 @@ WGRAD_LATE = os.environ.get("E2E_WGRAD_LATE", "1") != "0"            # level-0 w
 LANES = os.environ.get("E2E_LANES", "1") != "0"                    # deep levels on their own HIP stream (Engine._exec)
 # lane of an op = how many of these it passes: output voxels * div <= patch voxels (lane 0 = the caller's stream).  "64" puts
 # levels >= 2 on a second stream; "64,4096" gives levels >= 4 a third one
-LANE_DIVS = tuple(int(v) for v in os.environ.get("E2E_LANE_DIVS", "64").split(",") if v.strip())
+# "auto": plans of at most 2^20 voxels (everything latency bound) use three lanes split at 1/8 and 1/512 of the patch
+# (Hippocampus patch fwd+loss+bwd 9.1 -> 7.3 ms), larger plans two lanes split at 1/64 (128^3: a third lane changed nothing)
+LANE_DIVS_ENV = os.environ.get("E2E_LANE_DIVS", "auto")
+LANE_DIVS = None if LANE_DIVS_ENV == "auto" else tuple(int(v) for v in LANE_DIVS_ENV.split(",") if v.strip())
+
+
+def _lane_divs(voxels):
+    if LANE_DIVS is not None:
+        return LANE_DIVS
+    return (8, 512) if voxels <= (1 << 20) else (64,)
 DENSE_ENABLED = True          # tests switch the matrix-core conv path off to compare the sparse walk with itself
 
 
@@ -438,7 +447,8 @@ class Engine:
         self.generation = 0                # bumped by every forward(): activations are reused in place
         fws = max([max(op.fwd_ws_bytes, op.dgrad_ws_bytes if op.do_dgrad else 0, op.dense_ws_bytes) for op in self.conv_ops.values()] + [0])
         # split-K partial sums (deep levels) / packed weights of the matrix-core conv; one per lane (see _exec)
-        nl = len(LANE_DIVS) + 1
+        self.lane_divs = _lane_divs(batch * self.patch[0] * self.patch[1] * self.patch[2])
+        nl = len(self.lane_divs) + 1
         self._fwd_ws = [torch.empty(fws // 4, dtype=torch.float32, device=self.device) if fws > 0 else None for _ in range(nl)]
         self._in_sums, self._wgrad_ws = [None] * nl, [None] * nl
         self._lane = 0
@@ -606,7 +616,7 @@ class Engine:
 
     def _plan_lanes(self):
         vox = self.patch[0] * self.patch[1] * self.patch[2]
-        self._lane_of = [sum(1 for dv in LANE_DIVS if op.out.spatial * dv <= vox) for op in self.ops]
+        self._lane_of = [sum(1 for dv in self.lane_divs if op.out.spatial * dv <= vox) for op in self.ops]
         writer = {}
         self._deps_fwd = []
         for i, op in enumerate(self.ops):
@@ -647,7 +657,7 @@ class Engine:
             return
         main = torch.cuda.current_stream()
         if self._lane_streams is None:
-            self._lane_streams = [torch.cuda.Stream(device=self.device) for _ in LANE_DIVS]
+            self._lane_streams = [torch.cuda.Stream(device=self.device) for _ in self.lane_divs]
         side = self._lane_streams
         streams = [main] + side
 
@@ -687,7 +697,7 @@ class Engine:
             return False                     # a caller is capturing the whole pass itself
         if mode == "1":
             return True
-        if LANES and LANE_DIVS:
+        if LANES and self.lane_divs:
             # measured (tools/scratch/small_bench.py): issued eagerly on two lanes + the weight-gradient stream a small plan
             # is shorter on the GPU than its single-stream graph replay (64^3 x 2 fwd+loss+bwd 11.4 vs 14.5 ms, Hippocampus
             # patch 9.1 vs 10.8) and the host still issues a step in less than half of that; graphs are for E2E_LANES=0
@@ -756,9 +766,9 @@ class Engine:
         self._bucket_tail = (lo, total)
         ws = max([op.wgrad_ws_bytes() for op in self.ops if hasattr(op, "wgrad_ws_bytes")] +
                  [lib().head1x1_wgrad_ws_bytes(self.batch, h.src.shape[1], h.k, h.src.spatial) for h in self.heads])
-        self._wgrad_ws = [torch.empty((ws + 3) // 4, dtype=torch.float32, device=self.device) for _ in range(len(LANE_DIVS) + 1)]
+        self._wgrad_ws = [torch.empty((ws + 3) // 4, dtype=torch.float32, device=self.device) for _ in range(len(self.lane_divs) + 1)]
         cmax = max(op.cout for op in self.conv_ops.values())
-        self._in_sums = [torch.empty(self.batch * cmax * 3, dtype=torch.float64, device=self.device) for _ in range(len(LANE_DIVS) + 1)]
+        self._in_sums = [torch.empty(self.batch * cmax * 3, dtype=torch.float64, device=self.device) for _ in range(len(self.lane_divs) + 1)]
         self._plan_lanes_backward()
         self._loss_buffers()
         self._backward_ready = True
