@@ -657,7 +657,8 @@ class Engine:
             return
         main = torch.cuda.current_stream()
         if self._lane_streams is None:
-            self._lane_streams = [torch.cuda.Stream(device=self.device) for _ in self.lane_divs]
+            prio = int(os.environ.get("E2E_LANE_PRIORITY", "0"))
+            self._lane_streams = [torch.cuda.Stream(device=self.device, priority=prio) for _ in self.lane_divs]
         side = self._lane_streams
         streams = [main] + side
 
@@ -790,7 +791,7 @@ class Engine:
             # gradient of the same layer (with their own workspace, in issue order among themselves).  Plans replayed as
             # HIP graphs stay single-stream: replaying a two-stream capture faults on ROCm 7.2.
             if self._wg_side is None:
-                self._wg_side = torch.cuda.Stream(device=self.device)
+                self._wg_side = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("E2E_WGRAD_PRIORITY", "0")))
                 self.wgrad_ws_side = torch.empty_like(self._wgrad_ws[0])
             self._wg_active = self._wg_side
         side = self._wg_active
