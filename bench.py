@@ -168,7 +168,7 @@ def parity_sample(net, device, patch, ds_w):
             "params": {n: p.detach().cpu().clone() for n, p in net.named_parameters()}}
 
 
-def cpu_baseline(sample, patch_edge=128, budget_s=150.0):
+def cpu_baseline(sample, patch_edge=128, budget_s=45.0):
     """The oracle (CPU restatement, kind "port") on the host cores: fwd + loss + bwd of ONE patch of the benchmarked
     network (B = 1, 4 x 128^3, 32 ch, density 0.2; dense masked weights like the reference) with the GPU network's own
     weights, masks, input and targets (`sample`), 1 warm-up + up to 3 timed steps; the loop stops
