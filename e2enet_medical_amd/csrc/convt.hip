@@ -484,7 +484,8 @@ __global__ __launch_bounds__(256 * NCB) void convT_wgrad_bf3_kernel(const float*
   // z: each wave stages 8 channels x 64 voxels = 128 float4 -> 2 iterations; lane -> (channel k = g / 16, group g % 16)
   f32x4_t vz[2], vy[YCW][YIT];
   float za[2], zb[2];
-  const bool row_tiles = (W % WG_TPX) == 0;            // => spatial % 64 == 0 as well: no ragged last tile
+  // (=> spatial % 64 == 0 as well: no ragged last tile; the fast path keeps per-lane byte offsets in 32 bits: 96 spatial x 4 B)
+  const bool row_tiles = (W % WG_TPX) == 0 && spatial < (1ll << 24);
   long long yoff[YIT];
 #pragma unroll
   for (int it = 0; it < YIT; ++it) {
