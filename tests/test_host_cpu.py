@@ -316,3 +316,53 @@ def test_oracle_resample_softmax_properties():
     idx = np.floor(np.clip(6 / 3 * (np.arange(3) + 0.5) - 0.5, 0, 5) + 0.5).astype(int)
     full = resample_softmax(x, (6, 20, 18), lowres_axis=0)
     assert np.array_equal(sep, full[:, idx])
+
+
+@pytest.mark.parametrize("graph,divs", [("unetpp", (64,)), ("unetpp", (8, 512)), ("unet", (8, 64))])
+def test_lane_plan_orders_every_cross_lane_dependency(graph, divs, monkeypatch):
+    """Engine._plan_lanes / _plan_lanes_backward (plan only, no kernel is launched: the plan builds on the CPU device): replay the
+    issue order with vector clocks — a lane knows what was issued on it earlier and whatever an awaited event's op knew.
+    Forward: every source tensor's producer must be known when its consumer is issued.  Backward: every earlier toucher of a
+    gradient buffer an op touches must be known (first writer overwrites, later writers accumulate in the planned order,
+    the producer's in-place dz -> dy pass comes last).  Events are only awaited after they were recorded."""
+    import oracle
+    from e2enet_medical_amd import engine as E
+    monkeypatch.setattr(E, "LANE_DIVS", divs)
+    pools = [(2, 2, 2)] * 5
+    cfg = E.NetConfig(4, 8, 3, pools, 2, 64, graph=graph)
+    spec = oracle.make_spec(4, 8, 3, pools, 2, 64, graph=graph) if graph != "unetpp" else oracle.make_spec(4, 8, 3, pools, 2, 64)
+    eng = E.Engine(cfg, oracle.init_params(spec, 0), 2, (64, 64, 64), torch.device("cpu"))
+    eng.prepare_backward()
+    lanes = eng._lane_of
+    assert set(lanes) == set(range(len(divs) + 1)), "every lane is used at this shape"
+
+    def replay(order, deps, touched_of):
+        known = [set() for _ in range(len(divs) + 1)]        # per lane: ops known to be complete when the lane reaches this point
+        snapshot, recorded, last_toucher = {}, set(), {}
+        for i in order:
+            ln = lanes[i]
+            for j in deps[i]:
+                assert j in recorded, "op %d waits for the event of op %d before it is recorded" % (i, j)
+                known[ln] |= snapshot[j] | {j}
+            for res, prev in touched_of(i, last_toucher):
+                for j in prev:
+                    assert j in known[ln], "op %d (lane %d) is not ordered behind op %d (lane %d) on %s" % (i, ln, j, lanes[j], res)
+            known[ln].add(i)                                 # in-order stream: later ops of the lane see this one complete
+            snapshot[i] = set(known[ln])
+            recorded.add(i)
+
+    producer = {id(op.out): i for i, op in enumerate(eng.ops)}
+
+    def fwd_touch(i, _last):
+        return [(a.name, [producer[id(a)]] if id(a) in producer else []) for a in E.Engine._reads(eng.ops[i])]
+    replay(range(len(eng.ops)), eng._deps_fwd, fwd_touch)
+
+    def bwd_touch(i, last):
+        op = eng.ops[i]
+        out = []
+        for a in [op.out] + [s for s in E.Engine._reads(op) if s.grad is not None]:
+            out.append((a.name, list(last.get(id(a), []))))
+            last.setdefault(id(a), []).append(i)
+        return out
+    replay(list(reversed(range(len(eng.ops)))), eng._deps_bwd, bwd_touch)
+    assert any(eng._deps_fwd) and any(eng._deps_bwd)
