@@ -216,6 +216,7 @@ def test_conv133_fwd_bwd(case):
     (1, 72, 40, (16, 64, 64), (2, 2, 2), 0.2, True),       # >= 2048 tiles of 32 voxels: matrix-core data gradient, ragged blocks
     (2, 20, 70, (32, 32, 34), (1, 2, 2), 0.5, False),      # same path (fp32 matrix instructions: W % 32 != 0), [1,2,2] kernel, three output-channel chunks
     (2, 20, 70, (8, 32, 32), (1, 2, 2), 0.5, False),       # bf16 three-piece data gradient, [1,2,2] kernel, three output-channel chunks
+    (1, 136, 24, (8, 32, 32), (2, 2, 2), 0.3, True),       # forward GEMM with eight 32-channel k-blocks (one column tile per wave), ragged Cin
 ])
 def test_convT_fwd_bwd(B, cin, cout, dims, kernel, density, normed):
     from e2enet_medical_amd.engine import UpOp
