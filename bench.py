@@ -3,6 +3,8 @@
 clip_grad_norm_, SGD-Nesterov, DSFF mask step) of the shiftConvPP network on synthetic BraTS-shaped patches.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus N --steps K --warmup W        (no WORLD_SIZE in the environment: this process touches no GPU,
+                                                          starts N children -- one rank per GPU -- and relays rank 0's line)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -138,18 +140,25 @@ def conv_work(eng, mask):
     return by_ptr
 
 
-def host_threads():
+def host_cpu_info():
+    """(threads to use, logical CPUs visible, cgroup CPU quota in cores or None)."""
     try:
-        avail = len(os.sched_getaffinity(0))
+        visible = len(os.sched_getaffinity(0))
     except AttributeError:
-        avail = os.cpu_count() or 1
+        visible = os.cpu_count() or 1
+    quota_cores = None
     try:                                       # cgroup v2 CPU quota (the GPU box: 256 logical CPUs visible, 16 granted)
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
         if quota != "max":
-            avail = min(avail, max(1, int(quota) // int(period)))
+            quota_cores = int(quota) / int(period)
     except (OSError, ValueError):
         pass
-    return max(1, min(avail, int(os.environ.get("E2E_CPU_THREADS", "16"))))
+    avail = visible if quota_cores is None else min(visible, max(1, int(quota_cores)))
+    return max(1, min(avail, int(os.environ.get("E2E_CPU_THREADS", "16")))), visible, quota_cores
+
+
+def host_threads():
+    return host_cpu_info()[0]
 
 
 def parity_sample(net, device, patch, ds_w):
@@ -168,14 +177,14 @@ def parity_sample(net, device, patch, ds_w):
             "params": {n: p.detach().cpu().clone() for n, p in net.named_parameters()}}
 
 
-def cpu_baseline(sample, patch_edge=128, budget_s=45.0):
+def cpu_baseline(sample, patch_edge=128, budget_s=150.0):
     """The oracle (CPU restatement, kind "port") on the host cores: fwd + loss + bwd of ONE patch of the benchmarked
     network (B = 1, 4 x 128^3, 32 ch, density 0.2; dense masked weights like the reference) with the GPU network's own
-    weights, masks, input and targets (`sample`), 1 warm-up + up to 3 timed steps; the loop stops
-    early when the projected time leaves the budget.  The warm-up step's logits and loss are compared with the engine's
-    on the identical patch: returns (cpu_baseline record, parity record)."""
+    weights, masks, input and targets (`sample`), 1 warm-up + 3 timed steps (the loop stops early only
+    when the projected time leaves the budget), then a forward-only leg (no_grad, 1 warm-up + 3 timed).  The warm-up step's
+    logits and loss are compared with the engine's on the identical patch: returns (cpu_baseline record, parity record)."""
     import oracle
-    threads = host_threads()
+    threads, visible, quota = host_cpu_info()
     torch.set_num_threads(threads)
     spec = oracle.make_spec(CIN, BASE, K, POOLS)
     params, x, targets = sample["params"], sample["x"], sample["targets"]
@@ -190,6 +199,10 @@ def cpu_baseline(sample, patch_edge=128, budget_s=45.0):
         if not keep:
             keep["logits"], keep["loss"] = [o.detach() for o in outs], float(loss.detach())
         return float(loss.detach())
+
+    def fwd():
+        with torch.no_grad():
+            oracle.forward(spec, params, x, do_ds=False)
     t0 = time.time()
     step()                                     # warm-up
     first = time.time() - t0
@@ -198,9 +211,22 @@ def cpu_baseline(sample, patch_edge=128, budget_s=45.0):
         step()
         n += 1
     dt = time.time() - t1
+    fwd()
+    nf, t2 = 0, time.time()
+    while nf < 3 and (nf == 0 or time.time() - t0 < budget_s):
+        fwd()
+        nf += 1
+    fdt = time.time() - t2
     base = {"value": n * patch_edge ** 3 / dt, "unit": "voxels/s", "cores": threads, "kind": "port",
             "sample": "%d timed fwd+loss+bwd steps (+1 warm-up of %.1f s) of one 4 x %d^3 patch (B=1, 32 ch, density 0.2, dense "
-                      "masked weights: the GPU network's own), torch-CPU oracle, %d threads, %.1f s" % (n, first, patch_edge, threads, dt)}
+                      "masked weights: the GPU network's own), torch-CPU oracle, %d threads, %.1f s" % (n, first, patch_edge, threads, dt),
+            "seconds_per_step": dt / n,
+            "forward_only": {"value": nf * patch_edge ** 3 / fdt, "unit": "voxels/s", "seconds_per_patch": fdt / nf,
+                             "sample": "%d timed inference forwards (+1 warm-up) of the same patch, no_grad" % nf},
+            "host_cores_total": visible, "cgroup_cpu_quota_cores": quota, "torch_threads": threads,
+            "reference_in_container": "the reference itself (imported in the build container, 8 threads, 64^3 patch, same net): "
+                                      "2.43 s fwd+bwd against 2.08 s for this oracle there (DESIGN.md section 6); it cannot "
+                                      "travel to the GPU box"}
     # ---- Dice(GPU argmax, CPU argmax) and max |dlogit| on the identical patch (metrics.py:106-121)
     dl = [float((a - b).abs().max()) for a, b in zip(sample["logits"], keep["logits"])]
     seg_g, seg_c = sample["logits"][0].argmax(1).numpy(), keep["logits"][0].argmax(1).numpy()
@@ -269,13 +295,73 @@ def sliding_window_record(device, rank=0, world=1):
     return rec
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: this parent has made no GPU call (importing torch initialises nothing);
+    it starts N fresh children of this same script, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as
+    torch.distributed.run would), relays rank 0's single JSON line on stdout (the other ranks' stdout goes to stderr), and
+    returns the first non-zero exit code, stopping the remaining ranks (by their exact PIDs) as soon as one has failed."""
+    import socket
+    import subprocess
+    import threading
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL between processes on this image)
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                sys.stderr.write("bench.py: rank %d exited with code %d, stopping the other ranks\n" % (r, code))
+                for o in alive:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    if chunks and chunks[0]:
+        sys.stdout.write(chunks[0].decode())
+        sys.stdout.flush()
+    return rc
+
+
+def dry_rank(args, rank, world, json_fd):
+    """E2E_BENCH_DRY=1 (CPU test of the launcher, tests/test_host_cpu.py): no GPU, gloo instead of RCCL; every rank joins the
+    group, checks the all-reduce and rank 0 prints a line with the same `rccl` / per-rank fields as the real run."""
+    import torch.distributed as dist
+    if os.environ.get("E2E_BENCH_DRY_FAIL_RANK") == str(rank):      # launcher test: one rank dies before the rendezvous
+        sys.exit(3)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ones = torch.ones(1, dtype=torch.float64)
+    dist.all_reduce(ones)
+    per_rank = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(per_rank, torch.tensor([float(rank + 1)], dtype=torch.float64))
+    if rank == 0:
+        rec = {"metric": "dry run of the launcher (no GPU work)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "rccl": {"backend": "gloo", "world": dist.get_world_size(), "allreduce_of_ones": float(ones.item())},
+               "ms_per_step_per_rank": [float(t.item()) for t in per_rank]}
+        os.write(json_fd, (json.dumps(rec) + "\n").encode())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     # stdout carries exactly ONE line, the result JSON of rank 0.  Libraries write there too (RCCL prints a version
     # banner through C stdio at init, flushed at exit): from here on file descriptor 1 is stderr, and the JSON line goes
     # to the saved descriptor.
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -288,10 +374,21 @@ def main():
     ap.add_argument("--op-profile", action="store_true", help="print per-entry-point GPU time (diagnostic)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))           # before anything touches a GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "--gpus must equal WORLD_SIZE (launch N>1 with torch.distributed.run)"
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (start it as `python bench.py --gpus N` or under torch.distributed.run "
+                 "with --nproc-per-node N)" % (args.gpus, world))
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    if os.environ.get("E2E_BENCH_DRY") == "1":
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        return dry_rank(args, rank, world, json_fd)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     import torch.distributed as dist
@@ -349,10 +446,17 @@ def main():
     for _ in range(args.warmup):
         step()
     dt = timed(step, args.steps)
+    rccl = per_rank_ms = None
     if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        mine = torch.tensor([dt], dtype=torch.float64, device=device)
+        every = torch.zeros(world, dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(every, mine)
+        per_rank_ms = [float(v) / args.steps * 1e3 for v in every.tolist()]
+        dt = max(float(v) for v in every.tolist())               # MAX over ranks
+        ones = torch.ones(1, dtype=torch.float32, device=device)
+        dist.all_reduce(ones)
+        rccl = {"backend": dist.get_backend(), "world": dist.get_world_size(), "allreduce_of_ones": float(ones.item()),
+                "devices": torch.cuda.device_count()}
 
     # ---- instrumented steps (outside the timed region): HIP events around the conv entry points --------------------
     # (_splitk: the deep levels' forward / data gradient, same kernel + a sum kernel; _dense: the unmasked layers on the matrix cores)
@@ -398,6 +502,7 @@ def main():
                                                              "fwd+loss+bwd+clip+SGD+mask step, dense (parity) wgrad"),
                        "parallelism": "dp%d" % world},
             "per_gpu_voxels_per_s": value / world,
+            "rccl": rccl, "ms_per_step_per_rank": per_rank_ms,
             "hbm_roofline_frac_whole_step": (value / world) * (FWD_BYTES_PER_VOXEL if args.forward_only else TRAIN_BYTES_PER_VOXEL)
             / (HBM_PEAK_GBS * 1e9),
         }

@@ -754,7 +754,7 @@ def test_engine_forward_and_backward_are_graph_capturable(mode):
     launches.  "loss": forward + fused loss kernels + backward -- logits bit-identical, loss and gradients at 1e-6 (the
     Dice sums are fp64 atomics whose order is not fixed, eager or not).  This test is why the library zeroes its small
     accumulators with a kernel (e2e::zero_async) and not with hipMemsetAsync: with memset nodes in the graph the second
-    replay returned NaN gradients whenever eager work ran between two replays (tools/scratch/graph_dbg3.py)."""
+    replay returned NaN gradients whenever eager work ran between two replays."""
     net, shapes, _ = tiny_net()
     xa = seeded_input((2, TINY["cin"]) + TINY["patch"], seed=61).cuda()
     xb = seeded_input((2, TINY["cin"]) + TINY["patch"], seed=62).cuda()

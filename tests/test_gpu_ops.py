@@ -175,7 +175,7 @@ def test_conv133_fwd_bwd(case):
     dz = seeded_input(tuple(z.shape), seed=8)
     # an element sitting on the LeakyReLU kink (|u| of the order of the fp32 noise of u) legitimately takes either branch,
     # which moves its dy by ~|dz| and, through the InstanceNorm-backward sums, everything downstream; with millions of
-    # elements some always do (tools/scratch/inbwd_dbg.py).  No gradient is sent into those elements.
+    # elements some always do.  No gradient is sent into those elements.
     dz[u.detach().abs() < 2e-5] = 0.0
     z.backward(dz)
     for s in srcs:

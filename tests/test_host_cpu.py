@@ -366,3 +366,31 @@ def test_lane_plan_orders_every_cross_lane_dependency(graph, divs, monkeypatch):
         return out
     replay(list(reversed(range(len(eng.ops)))), eng._deps_bwd, bwd_touch)
     assert any(eng._deps_fwd) and any(eng._deps_bwd)
+
+
+def _bench(extra_env, *argv):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), env=env, capture_output=True,
+                          text=True, timeout=300)
+
+
+def test_bench_self_launches_n_ranks_without_torchrun():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the form the driver uses): the parent starts two
+    children, one rank each, and relays exactly one JSON line from rank 0 (dry mode: gloo, no GPU work)."""
+    import json
+    r = _bench({"E2E_BENCH_DRY": "1"}, "--gpus", "2", "--steps", "4", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 4 and rec["warmup"] == 1
+    assert rec["rccl"]["world"] == 2 and rec["rccl"]["allreduce_of_ones"] == 2.0
+    assert rec["ms_per_step_per_rank"] == [1.0, 2.0]                  # rank r contributed r + 1: both ranks were in the group
+
+
+def test_bench_launcher_propagates_a_failed_rank_and_refuses_a_mismatched_world():
+    r = _bench({"E2E_BENCH_DRY": "1", "E2E_BENCH_DRY_FAIL_RANK": "1"}, "--gpus", "2")
+    assert r.returncode == 3 and "rank 1 exited with code 3" in r.stderr and not r.stdout.strip()
+    r = _bench({"E2E_BENCH_DRY": "1", "WORLD_SIZE": "1"}, "--gpus", "2")       # torchrun form with the wrong --gpus
+    assert r.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in r.stderr
