@@ -512,7 +512,7 @@ def main():
         ev = [(e0.elapsed_time(e1), work[a[0]]) for e0, e1, a in timers["conv133_fwd"].events + timers["conv133_fwd_splitk"].events +
               timers["conv133_fwd_dense"].events]
         ev += [(e0.elapsed_time(e1), work[a[3]]) for e0, e1, a in timers["conv133_dgrad"].events + timers["conv133_dgrad_splitk"].events]
-        ev += [(e0.elapsed_time(e1), work[a[2]]) for e0, e1, a in timers["conv133_dgrad_dense"].events]
+        ev += [(e0.elapsed_time(e1), work[a[3]]) for e0, e1, a in timers["conv133_dgrad_dense"].events]
         if ev:
             ms = sum(t for t, _ in ev)
             byt = sum(w["bytes"] for _, w in ev)

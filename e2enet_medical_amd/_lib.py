@@ -47,8 +47,8 @@ SIGNATURES = {
     "e2e_conv133_dgrad_ws_bytes": (LL, [I, I, I, I, I, I, I, I, I]),
     "e2e_conv133_dgrad_splitk": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, P, LL, P]),
     "e2e_conv133_dense_ws_bytes": (LL, [I, I, I, I, I, I, I, I, I]),
-    "e2e_conv133_fwd_dense": (I, [P, I, P, P, P, P, I, I, I, I, I, P, LL, P]),
-    "e2e_conv133_dgrad_dense": (I, [P, P, P, I, I, I, I, I, I, P, LL, P]),
+    "e2e_conv133_fwd_dense": (I, [P, I, P, P, P, P, P, I, I, I, I, I, P, LL, P]),
+    "e2e_conv133_dgrad_dense": (I, [P, P, P, P, I, I, I, I, I, I, P, LL, P]),
     "e2e_conv133_wgrad_ws_bytes": (LL, [I, I, I, I, I, I, I, I, I]),
     "e2e_conv133_wgrad": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "e2e_in_stats_finalize": (I, [P, I, P, P, F, P, P, P, P, I, I, P]),
@@ -133,7 +133,7 @@ class _Lib:
 _lib = None
 
 
-ABI_VERSION = 12          # e2e_abi_version() of the library this binding was written against
+ABI_VERSION = 13          # e2e_abi_version() of the library this binding was written against
 
 
 def lib() -> _Lib:

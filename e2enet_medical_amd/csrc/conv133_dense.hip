@@ -89,7 +89,11 @@ __device__ __forceinline__ void split1(float v, unsigned& h, unsigned& m, unsign
 }
 
 // ---- weights: fp32 [Q][P][9] (strides wq, wp; reversed taps for the data gradient) -> packed three-piece bf16 -------------------
-__global__ __launch_bounds__(256) void pack_weights_bf3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wpk, int P, int Q,
+// `quads` (null = dense layer): the DSFF liveness quad words of this direction, word [q / 4][p / 8], bit (p % 8) * 4 + q % 4
+// (e2e_dsff_expand_quads).  A pruned (q, p) kernel is packed as zeros: the matrix-pipe kernel multiplies whole tiles, and its
+// result must not depend on pruned weights being exact zeros in `w`.
+__global__ __launch_bounds__(256) void pack_weights_bf3_kernel(const float* __restrict__ w, const unsigned* __restrict__ quads,
+                                                               unsigned short* __restrict__ wpk, int P, int Q,
                                                                int wq_stride, int wp_stride, int reverse, int nchunks, int qblocks) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long n = (long long)qblocks * nchunks * 9 * 32 * 16;
@@ -98,7 +102,10 @@ __global__ __launch_bounds__(256) void pack_weights_bf3_kernel(const float* __re
   const int ch = (int)((idx / (512 * 9)) % nchunks), qb = (int)(idx / ((long long)512 * 9 * nchunks));
   const int q = qb * 32 + ql, pp = ch * 16 + k;
   float v = 0.f;
-  if (q < Q && pp < P) v = w[(long long)q * wq_stride + (long long)pp * wp_stride + (reverse ? 8 - tap : tap)];
+  if (q < Q && pp < P) {
+    const bool alive = quads == nullptr || ((quads[(long long)(q >> 2) * ((P + 7) >> 3) + (pp >> 3)] >> (((pp & 7) << 2) + (q & 3))) & 1u);
+    if (alive) v = w[(long long)q * wq_stride + (long long)pp * wp_stride + (reverse ? 8 - tap : tap)];
+  }
   unsigned h, m, l;
   split1(v, h, m, l);
   // the two 8-channel halves of rows 16..31 are swapped: with lane -> (row fq = lane & 31, half lane >> 5) fixed by the MFMA
@@ -432,7 +439,7 @@ extern "C" long long e2e_conv133_dense_ws_bytes(int B, int Cin, int Cout, int Di
   return blocks * 9 * 3 * 512 * 2;                        // packed weights of either direction
 }
 
-static int dense_launch(int mode, const e2e_in_chan_t* chans, const float* xin, const float* w, const float* bias, float* y, double* part,
+static int dense_launch(int mode, const e2e_in_chan_t* chans, const float* xin, const float* w, const unsigned* quads, const float* bias, float* y, double* part,
                         const e2e_out_chan_t* outs, int B, int P, int Q, int D, int H, int W, int wq_stride, int wp_stride,
                         void* ws, long long ws_bytes, hipStream_t st) {
   DenseParams p{};
@@ -448,7 +455,7 @@ static int dense_launch(int mode, const e2e_in_chan_t* chans, const float* xin, 
   p.total = B * p.tiles_per_n * p.qblocks;
   p.padded_total = (p.total + 7) & ~7;
   const long long nel = (long long)p.qblocks * p.nchunks * 9 * 512;
-  hipLaunchKernelGGL(pack_weights_bf3_kernel, dim3((unsigned)e2e::cdivll(nel, 256)), dim3(256), 0, st, w, reinterpret_cast<unsigned short*>(ws),
+  hipLaunchKernelGGL(pack_weights_bf3_kernel, dim3((unsigned)e2e::cdivll(nel, 256)), dim3(256), 0, st, w, quads, reinterpret_cast<unsigned short*>(ws),
                      P, Q, wq_stride, wp_stride, mode == 1 ? 1 : 0, p.nchunks, p.qblocks);
   e2e::note_kernel("conv133_dense_bf3<mode=%d> wgs=%d chunks=%d", mode, p.padded_total, p.nchunks);
   if (mode == 0) hipLaunchKernelGGL((conv133_dense_kernel<0>), dim3(p.padded_total), dim3(256), 0, st, p);
@@ -456,18 +463,18 @@ static int dense_launch(int mode, const e2e_in_chan_t* chans, const float* xin, 
   return e2e::check_launch("conv133_dense_kernel");
 }
 
-extern "C" int e2e_conv133_fwd_dense(const e2e_in_chan_t* chans, int Cin, const float* w, const float* bias, float* y, double* part,
+extern "C" int e2e_conv133_fwd_dense(const e2e_in_chan_t* chans, int Cin, const float* w, const float* bias, const unsigned* live, float* y, double* part,
                                      int B, int Cout, int Di, int Hi, int Wi, void* ws, long long ws_bytes, void* stream) {
   E2E_REQUIRE(chans && w && y, "conv133_fwd_dense: null pointer");
   E2E_REQUIRE(e2e_conv133_dense_ws_bytes(B, Cin, Cout, Di, Hi, Wi, 1, 1, 1) > 0, "conv133_fwd_dense: shape not served (stride 1, W %% 32 == 0, H %% 16 == 0, >= 16 channels)");
-  return dense_launch(0, chans, nullptr, w, bias, y, part, nullptr, B, Cin, Cout, Di, Hi, Wi, Cin * 9, 9, ws, ws_bytes, (hipStream_t)stream);
+  return dense_launch(0, chans, nullptr, w, live, bias, y, part, nullptr, B, Cin, Cout, Di, Hi, Wi, Cin * 9, 9, ws, ws_bytes, (hipStream_t)stream);
 }
 
-extern "C" int e2e_conv133_dgrad_dense(const float* dy, const float* w, const e2e_out_chan_t* outs, int B, int Cin, int Cout, int Di,
+extern "C" int e2e_conv133_dgrad_dense(const float* dy, const float* w, const unsigned* live_t, const e2e_out_chan_t* outs, int B, int Cin, int Cout, int Di,
                                        int Hi, int Wi, void* ws, long long ws_bytes, void* stream) {
   E2E_REQUIRE(dy && w && outs, "conv133_dgrad_dense: null pointer");
   E2E_REQUIRE(e2e_conv133_dense_ws_bytes(B, Cin, Cout, Di, Hi, Wi, 1, 1, 1) > 0, "conv133_dgrad_dense: shape not served");
   // the forward kernel with transposed, tap-reversed weights: its "input planes" are dy's Cout channels, its output planes the
   // Cin virtual-concat channels (weight element [q = c][p = o][tap] = w[o][c][8 - tap])
-  return dense_launch(1, nullptr, dy, w, nullptr, nullptr, nullptr, outs, B, Cout, Cin, Di, Hi, Wi, 9, Cin * 9, ws, ws_bytes, (hipStream_t)stream);
+  return dense_launch(1, nullptr, dy, w, live_t, nullptr, nullptr, nullptr, outs, B, Cout, Cin, Di, Hi, Wi, 9, Cin * 9, ws, ws_bytes, (hipStream_t)stream);
 }

@@ -768,17 +768,28 @@ __global__ __launch_bounds__(256) void convT_dgrad_v2_kernel(const float* __rest
   }
 }
 
+// DSFF liveness of the (in channel c, out channel o) kernel from the bit tables of e2e_dsff_expand (null = all alive).  The
+// GEMM kernels below multiply whole tiles, so a pruned kernel is dropped where the weight enters a fragment -- the result
+// does not depend on pruned weights being exact zeros in memory.
+__device__ __forceinline__ bool ct_alive_rows(const unsigned* live_t, int Cout, int c, int o) {   // live_t: [Cin][ceil(Cout/32)]
+  return live_t == nullptr || ((live_t[(long long)c * ((Cout + 31) >> 5) + (o >> 5)] >> (o & 31)) & 1u);
+}
+__device__ __forceinline__ bool ct_alive_cols(const unsigned* live, int Cin, int c, int o) {      // live: [Cout][ceil(Cin/32)]
+  return live == nullptr || ((live[(long long)o * ((Cin + 31) >> 5) + (c >> 5)] >> (c & 31)) & 1u);
+}
+
 // ---- data gradient v3 (kw == 2): dense GEMM on the fp32 matrix cores ----------------------------------------------------
 // dx[c, v] = sum_{(t, o)} W[c, o, t] * dy[o, out(v, t)]:  M = 64 input channels per workgroup (16 per wave), N = 32
 // consecutive input voxels per tile, K = 32 output channels x KT taps per chunk.  At DSFF density 0.2 the dense GEMM does
 // 5x the useful FLOPs, but the sparse walk of v2 issues one scalar weight load and KT dependent LDS reads per live (c, o)
 // pair with two waves per SIMD -- latency bound at ~4x the HBM time of this op -- while the matrix pipe runs the dense
-// product in less time than that (dead kernels are exact zeros in W, so the result is the same sum).
+// product in less time than that (dead kernels enter the fragments as zeros, so the result is the same sum).
 //   * a wave keeps its 16 x K slice of W in registers (K/4 A fragments) for the whole run of tiles;
 //   * the dy tile [K][32 voxels] is staged through LDS (row stride 48: the two k-rows of a 32-lane read group land on
 //     disjoint banks), software pipelined: the float4 loads of the next tile are issued before the MFMA phase.
 template <int KDH>
 __global__ __launch_bounds__(256) void convT_dgrad_v3_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                             const unsigned* __restrict__ live_t,
                                                              float* __restrict__ dx, int accumulate, int B, int Cin, int Cout,
                                                              int D, int H, int W, int kd, int kh, int tiles_per_wg) {
   constexpr int KT = 2 * KDH;
@@ -877,7 +888,7 @@ __global__ __launch_bounds__(256) void convT_dgrad_v3_kernel(const float* __rest
       const int k = 4 * s + lk;
       const int t = k / OC, ol = k - t * OC;
       const int c = cbase + li, o = o0 + ol;
-      afrag[s] = (c < Cin && o < Cout) ? w[((long long)c * Cout + o) * KT + t] : 0.f;
+      afrag[s] = (c < Cin && o < Cout && ct_alive_rows(live_t, Cout, c, o)) ? w[((long long)c * Cout + o) * KT + t] : 0.f;
     }
     prefetch(tile_lo, o0);
     for (long long tile = tile_lo; tile < tile_hi; ++tile) {
@@ -946,7 +957,8 @@ __global__ __launch_bounds__(256) void convT_dgrad_v3_kernel(const float* __rest
 template <int KDH, int NKB>
 __global__ __launch_bounds__(256, 2) void convT_fwd_bf3_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, float slope,
-                                                               const float* __restrict__ w, float* __restrict__ y, int B, int Cin,
+                                                               const float* __restrict__ w, const unsigned* __restrict__ live,
+                                                               float* __restrict__ y, int B, int Cin,
                                                                int Cout, int D, int H, int W, int kd, int kh, int tiles_per_wg) {
   constexpr int KT = 2 * KDH;
   constexpr int TV = 32;
@@ -990,7 +1002,7 @@ __global__ __launch_bounds__(256, 2) void convT_fwd_bf3_kernel(const float* __re
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int c = kb * 32 + lk * 8 + j;
-        const float wv = (cok[nt] && c < Cin) ? w[((long long)c * Cout + o) * KT + t] : 0.f;
+        const float wv = (cok[nt] && c < Cin && ct_alive_cols(live, Cin, c, o)) ? w[((long long)c * Cout + o) * KT + t] : 0.f;
         split3(wv, h[j], m[j], l[j]);
       }
       bfr[nt][kb][0] = __builtin_bit_cast(bf16x8_t, u32x4_t{pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]), pack_hi16(h[4], h[5]), pack_hi16(h[6], h[7])});
@@ -1109,7 +1121,7 @@ __global__ __launch_bounds__(256, 2) void convT_fwd_bf3_kernel(const float* __re
 //     becomes one packed word per voxel and piece; the loads of the next tile are in flight during the matrix phase.
 template <int KDH>
 __global__ __launch_bounds__(256, 2) void convT_dgrad_bf3_kernel(const float* __restrict__ dy, const float* __restrict__ w,
-                                                                 float* __restrict__ dx, int accumulate, int B, int Cin, int Cout,
+                                                                 const unsigned* __restrict__ live_t, float* __restrict__ dx, int accumulate, int B, int Cin, int Cout,
                                                                  int D, int H, int W, int kd, int kh, int tiles_per_wg) {
   constexpr int KT = 2 * KDH;
   constexpr int OC = 32, TV = 32;
@@ -1188,7 +1200,7 @@ __global__ __launch_bounds__(256, 2) void convT_dgrad_bf3_kernel(const float* __
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int o = o0 + (k0 + j) / KT;
-          wv[j] = (c < Cin && o < Cout) ? w[((long long)c * Cout + o0) * KT + k0 + j] : 0.f;
+          wv[j] = (c < Cin && o < Cout && ct_alive_rows(live_t, Cout, c, o)) ? w[((long long)c * Cout + o0) * KT + k0 + j] : 0.f;
         }
         unsigned h[8], m[8], l[8];
 #pragma unroll
@@ -1334,7 +1346,7 @@ extern "C" int e2e_convT_fwd(const float* x, const float* scale, const float* sh
     if (tpw < 4) tpw = 4;
     dim3 grid((unsigned)e2e::cdivll(total_tiles, tpw), cgroups);
     e2e::note_kernel("convT_fwd_bf3<%d,%d> wgs=%u cgroups=%d tiles_per_wg=%d", kdh, nkb, grid.x, cgroups, tpw);
-#define LAUNCH_F3(KDH, NKB) hipLaunchKernelGGL((convT_fwd_bf3_kernel<KDH, NKB>), grid, dim3(256), 0, st, x, scale, shift, slope, w, y, \
+#define LAUNCH_F3(KDH, NKB) hipLaunchKernelGGL((convT_fwd_bf3_kernel<KDH, NKB>), grid, dim3(256), 0, st, x, scale, shift, slope, w, live, y, \
                                                B, Cin, Cout, D, H, W, kd, kh, tpw)
     if (kdh == 4) { if (nkb == 2) LAUNCH_F3(4, 2); else if (nkb == 4) LAUNCH_F3(4, 4); else LAUNCH_F3(4, 8); }
     else { if (nkb == 2) LAUNCH_F3(2, 2); else if (nkb == 4) LAUNCH_F3(2, 4); else LAUNCH_F3(2, 8); }
@@ -1385,16 +1397,16 @@ extern "C" int e2e_convT_dgrad(const float* dy, const float* w, const unsigned* 
     if (use_bf3 && W % 32 == 0) {
       e2e::note_kernel("convT_dgrad_bf3<%d> wgs=%u cgroups=%d tiles_per_wg=%d", kd * kh, grid.x, cgroups, tpw);
       if (kd * kh == 4)
-        hipLaunchKernelGGL((convT_dgrad_bf3_kernel<4>), grid, dim3(256), 0, st, dy, w, dx, accumulate, B, Cin, Cout, D, H, W, kd, kh, tpw);
+        hipLaunchKernelGGL((convT_dgrad_bf3_kernel<4>), grid, dim3(256), 0, st, dy, w, live_t, dx, accumulate, B, Cin, Cout, D, H, W, kd, kh, tpw);
       else
-        hipLaunchKernelGGL((convT_dgrad_bf3_kernel<2>), grid, dim3(256), 0, st, dy, w, dx, accumulate, B, Cin, Cout, D, H, W, kd, kh, tpw);
+        hipLaunchKernelGGL((convT_dgrad_bf3_kernel<2>), grid, dim3(256), 0, st, dy, w, live_t, dx, accumulate, B, Cin, Cout, D, H, W, kd, kh, tpw);
       return e2e::check_launch("convT_dgrad_bf3_kernel");
     }
     e2e::note_kernel("convT_dgrad_v3<%d> wgs=%u cgroups=%d tiles_per_wg=%d", kd * kh, grid.x, cgroups, tpw);
     if (kd * kh == 4)
-      hipLaunchKernelGGL((convT_dgrad_v3_kernel<4>), grid, dim3(256), 0, st, dy, w, dx, accumulate, B, Cin, Cout, D, H, W, kd, kh, tpw);
+      hipLaunchKernelGGL((convT_dgrad_v3_kernel<4>), grid, dim3(256), 0, st, dy, w, live_t, dx, accumulate, B, Cin, Cout, D, H, W, kd, kh, tpw);
     else
-      hipLaunchKernelGGL((convT_dgrad_v3_kernel<2>), grid, dim3(256), 0, st, dy, w, dx, accumulate, B, Cin, Cout, D, H, W, kd, kh, tpw);
+      hipLaunchKernelGGL((convT_dgrad_v3_kernel<2>), grid, dim3(256), 0, st, dy, w, live_t, dx, accumulate, B, Cin, Cout, D, H, W, kd, kh, tpw);
     return e2e::check_launch("convT_dgrad_v3_kernel");
   }
   // v2 needs enough 64-voxel tiles to fill the chip (one workgroup per tile); small planes keep the gather kernel

@@ -188,7 +188,7 @@ class ConvOp:
         ws = getattr(e, "fwd_ws", None)
         if self.use_dense():
             L.conv133_fwd_dense(self.chans.data_ptr(), self.cin, p[self.w_name].data_ptr(), p[self.prefix + ".conv.bias"].data_ptr(),
-                                self.out.data.data_ptr(), self.part.data_ptr(), b, self.cout, di, hi, wi, ws.data_ptr(),
+                                _ptr(self.live), self.out.data.data_ptr(), self.part.data_ptr(), b, self.cout, di, hi, wi, ws.data_ptr(),
                                 ws.numel() * 4, _stream())
         elif ws is not None and self.fwd_ws_bytes > 0:      # deep levels: input-plane chunks split over several workgroups
             L.conv133_fwd_splitk(self.chans.data_ptr(), self.cin, p[self.w_name].data_ptr(),
@@ -224,7 +224,7 @@ class ConvOp:
         if self.do_dgrad:
             ws = getattr(e, "fwd_ws", None)
             if self.use_dense():
-                L.conv133_dgrad_dense(o.grad.data_ptr(), p[self.w_name].data_ptr(), self.outs.data_ptr(), b, self.cin, self.cout,
+                L.conv133_dgrad_dense(o.grad.data_ptr(), p[self.w_name].data_ptr(), _ptr(self.live_t), self.outs.data_ptr(), b, self.cin, self.cout,
                                       di, hi, wi, ws.data_ptr(), ws.numel() * 4, _stream())
             elif ws is not None and self.dgrad_ws_bytes > 0:        # deep levels: split-K (the workspace is idle during backward)
                 L.conv133_dgrad_splitk(o.grad.data_ptr(), p[self.w_name].data_ptr(), _ptr(self.live_t), self.outs.data_ptr(),

@@ -608,19 +608,38 @@ class nnUNetTrainer_simple(object):
             print(*args)
 
     # ------------------------------------------------------------------------------------------ checkpoints
-    def save_checkpoint(self, fname, save_optimizer=True, mask=None):
+    def save_checkpoint(self, fname, save_optimizer=True, mask=None, collective=True):
         """reference :1140-1176 (same dict keys and the side-car .pkl).  With ``mask`` (a Masking) the checkpoint also
         carries 'dsff_state' (packed kernel maps, death-rate schedule position, growth RNG state); reference loaders
-        ignore the extra key."""
+        ignore the extra key.
+
+        Under data parallelism this call is COLLECTIVE by default: every rank must make it; rank 0 writes, the others wait,
+        and the outcome is broadcast so that a failed write (disk full, permissions) raises on every rank rather than leaving
+        the others in a barrier.  ``collective=False`` is the escape for callers that guard the call with ``if rank == 0``:
+        the calling rank writes and no other rank is involved."""
         mask = mask if mask is not None else self._mask
         rank, world, group = self._rank()
-        if world > 1:
-            # replicas hold identical weights, optimizer state and masks: rank 0 writes, the others wait until the file is
-            # complete (every rank writing the same path at once can leave a torn .model / .pkl)
+        if world > 1 and collective:
+            # replicas hold identical weights, optimizer state and masks: rank 0 writes (every rank writing the same path at
+            # once can leave a torn .model / .pkl), then one broadcast carries success / failure to everybody
             import torch.distributed as dist
-            if rank != 0:
-                dist.barrier(group=group)
-                return
+            err = None
+            if rank == 0:
+                try:
+                    self._write_checkpoint(fname, save_optimizer, mask)
+                except Exception as e:          # noqa: BLE001 -- reported on every rank below, re-raised on rank 0
+                    err = e
+            dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+            ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=dev)
+            dist.broadcast(ok, src=0, group=group)
+            if err is not None:
+                raise err
+            if int(ok.item()) != 1:
+                raise RuntimeError("save_checkpoint(%s): rank 0 failed to write the checkpoint" % fname)
+            return
+        self._write_checkpoint(fname, save_optimizer, mask)
+
+    def _write_checkpoint(self, fname, save_optimizer, mask):
         state_dict = OrderedDict((k, v.cpu()) for k, v in self.network.state_dict().items())
         save_this = {'epoch': self.epoch + 1, 'state_dict': state_dict,
                      'optimizer_state_dict': self.optimizer.state_dict() if save_optimizer else None,
@@ -636,8 +655,6 @@ class nnUNetTrainer_simple(object):
         info['class'] = str(self.__class__)
         with open(fname + ".pkl", 'wb') as f:
             pickle.dump(info, f)
-        if world > 1:
-            dist.barrier(group=group)
 
     def load_best_checkpoint(self, train=True, mask=None):
         """reference :1178-1186"""

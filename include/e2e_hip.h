@@ -283,15 +283,16 @@ int e2e_resample_linear(const float* src, float* dst, int K, long long kstride, 
 
 /* ---- K1d: dense 1x3x3 convolution on the bf16 matrix pipe (fp32-exact three-piece operands) --------------------------
  * Same operator as e2e_conv133_fwd / e2e_conv133_dgrad (unetpp_d.py:45-59, :453-478, :93/:108 and their autograd) for layers
- * without DSFF sparsity to exploit (the encoder; masked layers at high density -- dead kernels are exact zeros in `w`):
+ * without DSFF sparsity to exploit (the encoder; masked layers at high density -- `live` / `live_t` are the quad words of
+ * e2e_conv133_fwd / e2e_conv133_dgrad, null for a dense layer: pruned kernels are packed as zeros whatever `w` holds):
  * stride (1,1,1), Wi % 32 == 0, Hi % 16 == 0, >= 16 channels on both sides.  e2e_conv133_dense_ws_bytes returns the
  * workspace (packed weights) these calls need, 0 when the shape is not served (use the e2e_conv133_* entry points then).
  * `part` as e2e_conv133_fwd (the partial records are those of its 16 x 32 tiles).                                        */
 long long e2e_conv133_dense_ws_bytes(int B, int Cin, int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw);
-int e2e_conv133_fwd_dense(const e2e_in_chan_t* chans, int Cin, const float* w, const float* bias, float* y, double* part, int B,
-                          int Cout, int Di, int Hi, int Wi, void* ws, long long ws_bytes, void* stream);
-int e2e_conv133_dgrad_dense(const float* dy, const float* w, const e2e_out_chan_t* outs, int B, int Cin, int Cout, int Di,
-                            int Hi, int Wi, void* ws, long long ws_bytes, void* stream);
+int e2e_conv133_fwd_dense(const e2e_in_chan_t* chans, int Cin, const float* w, const float* bias, const unsigned* live, float* y,
+                          double* part, int B, int Cout, int Di, int Hi, int Wi, void* ws, long long ws_bytes, void* stream);
+int e2e_conv133_dgrad_dense(const float* dy, const float* w, const unsigned* live_t, const e2e_out_chan_t* outs, int B, int Cin,
+                            int Cout, int Di, int Hi, int Wi, void* ws, long long ws_bytes, void* stream);
 
 /* ---- N3: training input feed on the device ------------------------------------------------------------------------
  * Replaces the spatial and intensity transforms of get_moreDA_augmentation

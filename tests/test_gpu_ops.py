@@ -633,3 +633,81 @@ def test_conv133_data_gradient_split_k_matches_unsplit(B, src_desc, cout, dims, 
             assert torch.isfinite(g).all()
             assert (g - r).abs().max().item() <= 2e-5 * max(1.0, r.abs().max().item())
             assert torch.equal(g, a)
+
+
+@pytest.mark.parametrize("density", [0.6, 0.2])
+def test_conv133_masks_are_structural_on_every_path(density):
+    """A DSFF map is enforced by the kernels, not by pruned weights happening to be zero: with garbage left in the dead
+    kernels the dense matrix-pipe path (density >= 0.5) and the sparse walk must both return the masked convolution
+    (forward and data gradient).  (Advisor, round 3: the dense pack ignored the liveness words.)"""
+    from e2enet_medical_amd.engine import ConvOp
+    from e2enet_medical_amd._lib import lib
+    B, cin, cout, dims = 1, 40, 48, (3, 32, 64)
+    srcs = [_make_act((B, cin) + dims, True, 61)]
+    w_raw = seeded_input((cout, cin, 1, 3, 3), seed=62) * (1.0 / math.sqrt(cin * 9))
+    km = _kmask(cout, cin, density, 63)
+    w_masked = w_raw * km.view(cout, cin, 1, 1, 1)
+    w_dirty = torch.where(km.view(cout, cin, 1, 1, 1) > 0, w_raw, torch.full_like(w_raw, 3.0))     # dead kernels hold 3.0
+    params = {"blk.conv.weight": w_dirty, "blk.conv.bias": torch.zeros(cout), "blk.instnorm.weight": torch.ones(cout),
+              "blk.instnorm.bias": torch.zeros(cout)}
+    e = _eng_stub(params)
+    op = ConvOp(e, "blk", srcs, cout, (1, 1, 1))
+    e.fwd_ws = torch.empty(op.dense_ws_bytes // 4, dtype=torch.float32, device=e.device)
+    rows = torch.empty(((cout + 3) // 4) * ((cin + 7) // 8), dtype=torch.int32, device=e.device)
+    cols = torch.empty(((cin + 3) // 4) * ((cout + 7) // 8), dtype=torch.int32, device=e.device)
+    lib().dsff_expand_quads(km.to(e.device).data_ptr(), rows.data_ptr(), cols.data_ptr(), cout, cin, 0)
+    op.live, op.live_t, op.density = rows, cols, float(km.float().mean())
+    assert op.use_dense() == (density >= 0.5)
+    op.forward()
+    x = _act_value(srcs[0]).requires_grad_(True)
+    y = F.conv3d(oracle.depth_shift(x), w_masked, None, padding=(0, 1, 1))
+    assert (op.out.data.cpu() - y.detach()).abs().max() < 2e-5, "forward used a pruned kernel"
+    dy = seeded_input(tuple(y.shape), seed=64)
+    y.backward(dy)
+    op.out.alloc_grad()
+    op.plan_backward()
+    # data gradient alone (dy handed over as the pre-norm gradient)
+    op.out.grad.copy_(dy)
+    L = lib()
+    if op.use_dense():
+        L.conv133_dgrad_dense(op.out.grad.data_ptr(), e.params["blk.conv.weight"].data_ptr(), op.live_t.data_ptr(), op.outs.data_ptr(),
+                              B, cin, cout, *dims, e.fwd_ws.data_ptr(), e.fwd_ws.numel() * 4, 0)
+    else:
+        L.conv133_dgrad(op.out.grad.data_ptr(), e.params["blk.conv.weight"].data_ptr(), op.live_t.data_ptr(), op.outs.data_ptr(),
+                        B, cin, cout, *dims, 1, 1, 1, 0)
+    torch.cuda.synchronize()
+    # srcs[0] is a normalised tensor: its grad buffer holds d/d(post-activation value), which is what x.grad is
+    assert (srcs[0].grad.cpu() - x.grad).abs().max() < 2e-4 * max(1.0, float(x.grad.abs().max())), "data gradient used a pruned kernel"
+
+
+@pytest.mark.parametrize("dims,kernel", [((8, 32, 32), (2, 2, 2)), ((16, 16, 32), (1, 2, 2)), ((8, 32, 34), (2, 2, 2))])
+def test_convT_masks_are_structural_on_the_gemm_paths(dims, kernel):
+    """Same for the transposed convolution: the bf16x3 forward / data-gradient GEMMs (W % 32 == 0) and the fp32-MFMA data
+    gradient (other widths) drop pruned kernels where the weight enters a fragment."""
+    from e2enet_medical_amd.engine import UpOp
+    from e2enet_medical_amd._lib import lib
+    B, cin, cout = 2, 40, 24
+    src = _make_act((B, cin) + dims, True, 71)
+    w_raw = seeded_input((cin, cout) + kernel, seed=72) * (1.0 / math.sqrt(cin))
+    km = _kmask(cin, cout, 0.3, 73)
+    w_masked = w_raw * km.view(cin, cout, 1, 1, 1)
+    w_dirty = torch.where(km.view(cin, cout, 1, 1, 1) > 0, w_raw, torch.full_like(w_raw, -2.0))
+    e = _eng_stub({"up.weight": w_dirty})
+    op = UpOp(e, "up.weight", src, cout, kernel)
+    rows = torch.empty(cin * ((cout + 31) // 32), dtype=torch.int32, device=e.device)
+    cols = torch.empty(cout * ((cin + 31) // 32), dtype=torch.int32, device=e.device)
+    lib().dsff_expand(km.to(e.device).data_ptr(), None, rows.data_ptr(), cols.data_ptr(), cin, cout, 1, 0)
+    op.live, op.live_t = cols, rows
+    op.forward()
+    fwd_kernel = lib().last_kernel()
+    xl = _act_value(src).requires_grad_(True)
+    y = F.conv_transpose3d(xl, w_masked, stride=kernel)
+    assert (op.out.data.cpu() - y.detach()).abs().max() < 2e-5, "forward used a pruned kernel (%s)" % fwd_kernel
+    dy = seeded_input(tuple(y.shape), seed=74)
+    y.backward(dy)
+    op.out.alloc_grad()
+    op.plan_backward()
+    op.out.grad.copy_(dy)
+    op.backward()
+    torch.cuda.synchronize()
+    assert (src.grad.cpu() - xl.grad).abs().max() < 2e-4 * max(1.0, float(xl.grad.abs().max())), "data gradient used a pruned kernel"

@@ -205,7 +205,26 @@ assert np.array_equal(got["b"], (np.arange(10).reshape(2, 5) %% 3 == 0).astype(n
 t = torch.arange(9, dtype=torch.float64) * (rank + 1)
 parallel.batch_dice_allreduce(None)(t)
 assert torch.equal(t, torch.arange(9, dtype=torch.float64) * sum(range(1, world + 1)))
+# collective save_checkpoint: rank 0 writes, a failed write raises on EVERY rank instead of leaving the others in a barrier
+from e2enet_medical_amd.training.network_training.nnUNetTrainer_simple import nnUNetTrainer_simple
+tr = nnUNetTrainer_simple.__new__(nnUNetTrainer_simple)
+tr.network = torch.nn.Linear(3, 2); tr.optimizer = torch.optim.SGD(tr.network.parameters(), 0.1)
+tr.epoch = 4; tr.process_group = None; tr._mask = None; tr.init_args = (); tr.plans = {"k": 1}
+tr.all_tr_losses = tr.all_val_losses = tr.all_val_losses_tr_mode = tr.all_val_eval_metrics = []
+tr.best_epoch_based_on_MA_tr_loss = tr.best_MA_tr_loss_for_patience = tr.best_val_eval_criterion_MA = None
+ck = os.path.join(%(tmp)r, "ck.model")
+tr.save_checkpoint(ck)
+assert os.path.isfile(ck) and os.path.isfile(ck + ".pkl")          # complete on every rank when the call returns
+assert torch.load(ck, weights_only=False)["epoch"] == 5
+try:
+    tr.save_checkpoint(os.path.join(%(tmp)r, "no_such_dir", "ck.model"))
+    raise SystemExit("a failed checkpoint write must raise on rank %%d" %% rank)
+except (RuntimeError, OSError):
+    pass
+if rank == 1:                                                       # the `if rank == r: save` idiom: no other rank involved
+    tr.save_checkpoint(os.path.join(%(tmp)r, "solo.model"), collective=False)
 dist.barrier()
+assert os.path.isfile(os.path.join(%(tmp)r, "solo.model"))
 if rank == 0:
     print("WORKER_OK")
 dist.destroy_process_group()
@@ -214,7 +233,7 @@ dist.destroy_process_group()
 
 def test_world_size_2_tile_sharding_and_dp_exchange_gloo(tmp_path):
     script = tmp_path / "worker.py"
-    script.write_text(_WORKER % {"root": ROOT})
+    script.write_text(_WORKER % {"root": ROOT, "tmp": str(tmp_path)})
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29553", WORLD_SIZE="2", OMP_NUM_THREADS="2")
     procs = []
     for r in range(2):

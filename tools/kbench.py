@@ -78,11 +78,12 @@ def conv_case(B, srcs, cout, dims, stride, density, tag):
     dense_path = op.use_dense() and os.environ.get("KB_NO_DENSE") is None
 
     def fwd_dense():
-        L.conv133_fwd_dense(op.chans.data_ptr(), cin, w.data_ptr(), p["b.conv.bias"].data_ptr(), op.out.data.data_ptr(), op.part.data_ptr(),
+        L.conv133_fwd_dense(op.chans.data_ptr(), cin, w.data_ptr(), p["b.conv.bias"].data_ptr(),
+                            op.live.data_ptr() if op.live is not None else None, op.out.data.data_ptr(), op.part.data_ptr(),
                             B, cout, di, hi, wi, e.fwd_ws.data_ptr(), e.fwd_ws.numel() * 4, 0)
 
     def dgrad_dense():
-        L.conv133_dgrad_dense(op.out.grad.data_ptr(), w.data_ptr(), op.outs.data_ptr(), B, cin, cout, di, hi, wi, e.fwd_ws.data_ptr(),
+        L.conv133_dgrad_dense(op.out.grad.data_ptr(), w.data_ptr(), op.live_t.data_ptr() if op.live_t is not None else None, op.outs.data_ptr(), B, cin, cout, di, hi, wi, e.fwd_ws.data_ptr(),
                               e.fwd_ws.numel() * 4, 0)
 
     def fwd():
