@@ -21,6 +21,8 @@ bucketed RCCL all-reduce of the gradients overlapped with the backward pass.  Pr
   sliding_window         BASELINE config 4 shape: predict_3D of a [1,220,400,400] volume, 16 classes, patch 128^3,
                          step 0.5, 8 mirrors, everything device resident
   dsff_update            BASELINE config 3: one Masking.truncate_weights() (prune + grow of all 35 masked tensors)
+  config3                BASELINE config 3 at its own shape ([2,1,48,192,192], anisotropic pools, 14 classes): ms per training step
+                         and the cost of one DSFF update measured inside the running loop
   cpu_baseline           the CPU oracle on the same 128^3 patch (B = 1: fwd + loss + bwd), 1 warm-up + up to 3 timed
   parity                 the metric's "Dice vs CPU ref" half: engine vs that oracle on the IDENTICAL patch (the GPU network's
                          weights and masks): Dice of the argmax maps, max |dlogit| per head, loss difference
@@ -51,7 +53,7 @@ TRAIN_BYTES_PER_VOXEL = 3 * FWD_BYTES_PER_VOXEL
 TRAFFIC_FILE = "r03_pmc_traffic.json"
 
 
-def build(device, patch=PATCH, cin=CIN, k=K, seed=0, density=DENSITY):
+def build(device, patch=PATCH, cin=CIN, k=K, seed=0, density=DENSITY, pools=None, update_frequency=1200):
     from torch import nn
     from e2enet_medical_amd.network_architecture.unetpp_d import Generic_UNetPlusPlus
     from e2enet_medical_amd.network_architecture.initialization import InitWeights_He
@@ -61,14 +63,14 @@ def build(device, patch=PATCH, cin=CIN, k=K, seed=0, density=DENSITY):
     net = Generic_UNetPlusPlus(patch, cin, BASE, k, 5, 2, 2, nn.Conv3d, nn.InstanceNorm3d, {'eps': 1e-5, 'affine': True},
                                nn.Dropout3d, {'p': 0, 'inplace': True}, nn.LeakyReLU,
                                {'negative_slope': 1e-2, 'inplace': True}, True, False, lambda x: x, InitWeights_He(1e-2),
-                               POOLS, None, False, True, True).to(device)
+                               pools or POOLS, None, False, True, True).to(device)
     opt = torch.optim.SGD(net.parameters(), 1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)
 
     class A:
         adv = False
         fix = False
-        update_frequency = 1200          # BASELINE configs[2]
         final_density = 0.05
+    A.update_frequency = update_frequency          # 1200: BASELINE configs[2]
     random.seed(seed)
     mask = Masking(opt, death_rate=0.5, death_mode='magnitude', death_rate_decay=CosineDecay(0.5, 250 * 1000),
                    growth_mode='random', redistribution_mode='none', args=A())
@@ -293,6 +295,43 @@ def sliding_window_record(device, rank=0, world=1):
             rec["sharding"]["allgather_ms_per_group_blocking"] = (time.perf_counter() - t1) / 5 * 1e3
             rec["sharding"]["allgather_bytes_per_group_per_rank_inbound"] = (world - 1) * mine.numel() * 4
     return rec
+
+
+def config3_record(device):
+    """BASELINE config 3 at its SURVEY section 8d shape: BTCV-like [2, 1, 48, 192, 192], pools [[1,2,2],[2,2,2]x3,[1,2,2]], 14 classes, base
+    32, DSFF density 0.2: ms per training step, and the measured cost of one DSFF update (Masking.truncate_weights inside
+    mask.step, reference core_channel.py:290-317 / :556-611) INSIDE the running loop: the update fires every 6th step here
+    (update_frequency 1200 in the reference; the step that carries it is timed against the median of the others)."""
+    pools = [(1, 2, 2), (2, 2, 2), (2, 2, 2), (2, 2, 2), (1, 2, 2)]
+    patch, k, b = (48, 192, 192), 14, 2
+    net, opt, mask, fused = build(device, patch, cin=1, k=k, seed=3, pools=pools, update_frequency=6)
+    g = torch.Generator().manual_seed(33)
+    x = torch.randn((b, 1) + patch, generator=g).to(device)
+    eng = net.engine(x)
+    outs = eng.forward(x, True)
+    targets = [torch.randint(0, k, (b, 1) + tuple(o.shape[2:]), generator=g).float().to(device) for o in outs]
+    ds_w = np.array([8, 4, 2, 1, 0], dtype=np.float64) / 15.0
+    times, updated = [], []
+    for it in range(6 + 18):                       # 6 warm-up steps (they end with the first update: allocations), 18 timed
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.forward(x, True)
+        eng.loss_backward(targets, ds_w, batch_dice=False)
+        fused.step(eng.grads, mask.masks)
+        up = mask.step(masks_already_applied=True)
+        torch.cuda.synchronize()
+        if it >= 6:
+            times.append((time.perf_counter() - t0) * 1e3)
+            updated.append(bool(up))
+    plain = sorted(t for t, u in zip(times, updated) if not u)
+    with_up = [t for t, u in zip(times, updated) if u]
+    med = plain[len(plain) // 2]
+    vox = b * patch[0] * patch[1] * patch[2]
+    return {"workload": "BTCV-shaped [2,1,48,192,192], pools [[1,2,2],[2,2,2]x3,[1,2,2]], K=14, base 32, density 0.2, full training step",
+            "ms_per_step": med, "voxels_per_s": vox / (med * 1e-3), "steps_timed": len(times), "updates_timed": len(with_up),
+            "ms_step_with_dsff_update": sum(with_up) / max(1, len(with_up)),
+            "dsff_update_ms_inside_loop": sum(with_up) / max(1, len(with_up)) - med,
+            "amortised_ms_per_step_at_update_frequency_1200": (sum(with_up) / max(1, len(with_up)) - med) / 1200.0}
 
 
 def launch_ranks(n, argv):
@@ -583,6 +622,7 @@ def main():
             net._engines.clear()
             torch.cuda.empty_cache()
             out["sliding_window"] = sliding_window_record(device)
+            out["config3"] = config3_record(device)
         if sw_multi is not None:
             out["sliding_window"] = sw_multi
         if not args.no_cpu_baseline and world == 1:      # the CPU port is timed on rank 0 of the single-GPU run only

@@ -30,7 +30,14 @@ class ParamEntry(C.Structure):
                 ("numel", C.c_longlong)]
 
 
-assert C.sizeof(InChan) == 48 and C.sizeof(OutChan) == 24 and C.sizeof(ParamEntry) == 40
+class SparsePackJob(C.Structure):
+    """e2e_sparse_pack_job_t"""
+    _fields_ = [("w", C.c_void_p), ("wpk", C.c_void_p), ("qslot", C.c_void_p), ("pslot", C.c_void_p), ("quads", C.c_void_p),
+                ("groups", C.c_int), ("nchunks", C.c_int), ("wq_stride", C.c_int), ("wp_stride", C.c_int),
+                ("reverse", C.c_int), ("reserved", C.c_int)]
+
+
+assert C.sizeof(InChan) == 48 and C.sizeof(OutChan) == 24 and C.sizeof(ParamEntry) == 40 and C.sizeof(SparsePackJob) == 64
 
 P, I, F, LL = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 
@@ -47,6 +54,12 @@ SIGNATURES = {
     "e2e_conv133_dgrad_ws_bytes": (LL, [I, I, I, I, I, I, I, I, I]),
     "e2e_conv133_dgrad_splitk": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, P, LL, P]),
     "e2e_conv133_dense_ws_bytes": (LL, [I, I, I, I, I, I, I, I, I]),
+    "e2e_conv133_sparse_eligible": (I, [I, I, I, I, I, I, I, I]),
+    "e2e_conv133_sparse_wpk_floats": (LL, [I, I]),
+    "e2e_conv133_sparse_plan": (I, [P, I, I, I, P, P, P, P]),
+    "e2e_conv133_sparse_pack": (I, [P, I, LL, P]),
+    "e2e_conv133_fwd_sparse": (I, [P, I, P, P, P, P, I, P, P, I, I, I, I, I, P]),
+    "e2e_conv133_dgrad_sparse": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "e2e_conv133_fwd_dense": (I, [P, I, P, P, P, P, P, I, I, I, I, I, P, LL, P]),
     "e2e_conv133_dgrad_dense": (I, [P, P, P, P, I, I, I, I, I, I, P, LL, P]),
     "e2e_conv133_wgrad_ws_bytes": (LL, [I, I, I, I, I, I, I, I, I]),
@@ -85,16 +98,19 @@ SIGNATURES = {
     "e2e_ensemble_accumulate": (I, [P, P, LL, I, I, P]),
     "e2e_export_argmax_u8": (I, [P, P, I, LL, I, I, I, LL, LL, LL, I, I, I, I, I, I, P, I, P]),
     "e2e_resample_linear": (I, [P, P, I, LL, I, I, I, LL, LL, LL, I, I, I, I, P]),
-    "e2e_aug_spatial": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, F, P]),
+    "e2e_aug_spatial": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, F, P]),
+    "e2e_aug_bspline_prefilter_axis": (I, [P, P, I, I, I, I, I, P]),
     "e2e_aug_stats_ws_bytes": (LL, [I]),
     "e2e_aug_stats": (I, [P, P, P, I, LL, P]),
     "e2e_aug_pointwise": (I, [P, P, I, I, LL, C.c_ulonglong, P]),
     "e2e_aug_blur_axis": (I, [P, P, P, I, I, I, I, I, P]),
     "e2e_aug_lowres": (I, [P, P, P, I, I, I, I, P]),
+    "e2e_aug_lowres_down": (I, [P, P, I, I, I, I, I, I, I, P]),
+    "e2e_aug_lowres_up3": (I, [P, P, P, I, I, I, I, I, I, I, P]),
     "e2e_aug_finish": (I, [P, P, P, I, I, I, LL, P]),
 }
 
-_NO_STATUS = {"e2e_last_error", "e2e_abi_version", "e2e_last_kernel", "e2e_conv133_num_partials", "e2e_conv133_wgrad_ws_bytes", "e2e_conv133_dense_ws_bytes", "e2e_conv133_fwd_ws_bytes", "e2e_conv133_dgrad_ws_bytes",
+_NO_STATUS = {"e2e_last_error", "e2e_abi_version", "e2e_last_kernel", "e2e_conv133_num_partials", "e2e_conv133_wgrad_ws_bytes", "e2e_conv133_dense_ws_bytes", "e2e_conv133_sparse_eligible", "e2e_conv133_sparse_wpk_floats", "e2e_conv133_fwd_ws_bytes", "e2e_conv133_dgrad_ws_bytes",
               "e2e_convT_wgrad_ws_bytes", "e2e_head1x1_wgrad_ws_bytes", "e2e_loss_ws_bytes", "e2e_aug_stats_ws_bytes"}
 
 

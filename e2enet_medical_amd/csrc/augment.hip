@@ -3,18 +3,24 @@
 // 24 CPU worker processes (batchgenerators 0.24, third party, not under /root/reference).  One 50 ms training step consumes
 // 40 batches/s of 2 x 4 x 128^3 voxels; these kernels turn a raw loaded patch into a network batch in a few ms.
 //
-//   e2e_aug_spatial     SpatialTransform (rotation + scaling as ONE affine gather, centre crop): data order 1 (cval 0); seg
-//                       order 0 (cval border_val_seg) or order 1 (batchgenerators' interpolate_img(is_seg=True): per label a
-//                       linear interpolation of the binary mask, assigned where >= 0.5, labels in ascending order).  [the
-//                       reference interpolates data with a cubic spline (order_data = 3); order 1 is built, see DESIGN.md]
+//   e2e_aug_spatial     SpatialTransform (rotation + scaling as ONE affine gather, centre crop): data order 3 (the reference's
+//                       order_data: cubic B-spline = scipy map_coordinates(order=3, mode='constant', cval 0) over the coefficient
+//                       image of e2e_aug_bspline_prefilter_axis) or order 1; seg order 0 (cval border_val_seg) or order 1
+//                       (batchgenerators' interpolate_img(is_seg=True): per label a linear interpolation of the binary mask,
+//                       assigned where >= 0.5, labels in ascending order)
+//   e2e_aug_bspline_prefilter_axis   scipy.ndimage.spline_filter1d(order=3, mode='mirror') along one axis (the recursive
+//                       prefilter scipy applies in front of every order-3 interpolation; 'constant' and the pre-padded 'nearest'
+//                       mode use the mirror boundary too)
 //   (MirrorTransform: e2e_flip3d of sliding.hip, per sample, after the intensity transforms like in the reference)
 //   e2e_aug_stats       per-(sample, channel) min / max / mean / std (np.std, ddof 0): ContrastAugmentation, Gamma
 //   e2e_aug_pointwise   GaussianNoise (counter-based generator, Box-Muller), BrightnessMultiplicative, ContrastAugmentation,
 //                       Gamma (power step and retain_stats step), all parameterised per (sample, channel)
 //   e2e_aug_blur_axis   GaussianBlurTransform: one axis of scipy.ndimage.gaussian_filter (truncate 4, mode 'reflect')
-//   e2e_aug_lowres      SimulateLowResolutionTransform: nearest down-sampling to round(shape * zoom) followed by the
-//                       up-sampling back, evaluated as one composite gather (no low-resolution volume is materialised)
-//                       [up-sampling order 1 here, order 3 in the reference]
+//   e2e_aug_lowres      SimulateLowResolutionTransform with order_upsample 1: nearest down-sampling to round(shape * zoom)
+//                       followed by the linear up-sampling back, evaluated as one composite gather
+//   e2e_aug_lowres_down / e2e_aug_lowres_up3   the same transform with the reference's order_upsample = 3: the low-resolution
+//                       volume is materialised edge-padded by 12 (scipy's pre-padding for mode 'nearest'), prefiltered, and
+//                       up-sampled with the cubic B-spline, clipped to the low-resolution volume's range (skimage resize clip=True)
 //   e2e_aug_finish      MaskTransform (data = 0 where seg < 0, for the channels normalised inside the mask) and
 //                       RemoveLabelTransform(-1, 0)
 // All of them are HBM streaming kernels.  Parity: unpinned by construction (batchgenerators is absent from the image); every
@@ -23,10 +29,145 @@
 
 namespace {
 
+// ---- cubic B-spline (scipy.ndimage, order 3) --------------------------------------------------------------------------------
+// weights of the four taps floor(x) - 1 .. floor(x) + 2 at offset t = x - floor(x)
+__device__ __forceinline__ void bspline3_weights(double t, double (&w)[4]) {
+  const double u = 1.0 - t;
+  w[0] = u * u * u / 6.0;
+  w[1] = (3.0 * t * t * t - 6.0 * t * t + 4.0) / 6.0;
+  w[2] = (-3.0 * t * t * t + 3.0 * t * t + 3.0 * t + 1.0) / 6.0;
+  w[3] = t * t * t / 6.0;
+}
+// tap index outside [0, n): the coefficient image continues by mirror (d c b | a b c d | c b a), period 2 n - 2
+__device__ __forceinline__ int mirror_index(int i, int n) {
+  if (n <= 1) return 0;
+  const int s2 = 2 * n - 2;
+  if (i < 0) {
+    i = s2 * (-i / s2) + i;
+    return i <= 1 - n ? i + s2 : -i;
+  }
+  if (i >= n) {
+    i -= s2 * (i / s2);
+    if (i >= n) i = s2 - i;
+  }
+  return i;
+}
+// value of the spline with coefficient image c [D, H, W] at (cd, ch, cw); the caller has checked the coordinate range
+__device__ __forceinline__ double bspline3_at(const float* __restrict__ c, int D, int H, int W, double cd, double ch, double cw) {
+  const double fd = floor(cd), fh = floor(ch), fw = floor(cw);
+  double wd[4], wh[4], ww[4];
+  bspline3_weights(cd - fd, wd);
+  bspline3_weights(ch - fh, wh);
+  bspline3_weights(cw - fw, ww);
+  int id[4], ih[4], iw[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    id[k] = mirror_index((int)fd - 1 + k, D);
+    ih[k] = mirror_index((int)fh - 1 + k, H);
+    iw[k] = mirror_index((int)fw - 1 + k, W);
+  }
+  double acc = 0.0;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    double sa = 0.0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const float* row = c + ((long long)id[a] * H + ih[b]) * W;
+      double sb = 0.0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sb += ww[e] * (double)row[iw[e]];
+      sa += wh[b] * sb;
+    }
+    acc += wd[a] * sa;
+  }
+  return acc;
+}
+
+// The recursive prefilter of a line (scipy ni_splines.c: gain 6, pole z = sqrt(3) - 2, causal initialisation
+// _init_causal_mirror, anticausal _init_anticausal_mirror): fp64 arithmetic, fp32 storage (the causal results included).
+#define BSPLINE_POLE (-0.26794919243112270647)
+
+// strided axis (D or H): one thread per line, neighbouring threads on neighbouring inner positions (coalesced)
+__global__ __launch_bounds__(256) void bspline_prefilter_strided_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                                        long long n_outer, int len, long long inner) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_outer * inner) return;
+  const long long o = t / inner, i = t - o * inner;
+  const float* s = src + o * len * inner + i;
+  float* d = dst + o * len * inner + i;
+  // pass 1 reads src (initial sum + causal recursion), pass 2 reads the causal results in dst
+  const double z = BSPLINE_POLE;
+  if (len < 2) { if (len == 1) d[0] = s[0]; return; }
+  const double zn1 = pow(z, (double)(len - 1));
+  double c0 = 6.0 * ((double)s[0] + zn1 * (double)s[(long long)(len - 1) * inner]);
+  double zi = z;
+  const int hz = len - 1 < 40 ? len - 1 : 40;
+  for (int k = 1; k < hz; ++k) {
+    c0 += zi * 6.0 * ((double)s[(long long)k * inner] + zn1 * (double)s[(long long)(len - 1 - k) * inner]);
+    zi *= z;
+  }
+  c0 /= 1.0 - zn1 * zn1;
+  double prev = c0;
+  float last2 = 0.f, last1 = (float)prev;
+  d[0] = (float)prev;
+  for (int k = 1; k < len; ++k) {
+    prev = 6.0 * (double)s[(long long)k * inner] + z * (double)last1;      // (scipy recurses on the stored value: float here)
+    last2 = last1; last1 = (float)prev;
+    d[(long long)k * inner] = last1;
+  }
+  double nxt = (z * (double)last2 + (double)last1) * z / (z * z - 1.0);
+  float nf = (float)nxt;
+  d[(long long)(len - 1) * inner] = nf;
+  for (int k = len - 2; k >= 0; --k) {
+    nxt = z * ((double)nf - (double)d[(long long)k * inner]);
+    nf = (float)nxt;
+    d[(long long)k * inner] = nf;
+  }
+}
+
+// contiguous axis (W): a block stages LPB lines in LDS (coalesced loads), one thread filters one line there, coalesced stores
+template <int LPB>
+__global__ __launch_bounds__(256) void bspline_prefilter_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                                     long long n_lines, int len) {
+  extern __shared__ float rows[];                       // [LPB][pitch], pitch odd: the LPB serial walkers hit distinct banks
+  const int pitch = len | 1;
+  const long long line0 = (long long)blockIdx.x * LPB;
+  const int nl = n_lines - line0 < LPB ? (int)(n_lines - line0) : LPB;
+  for (int e = threadIdx.x; e < nl * len; e += 256) {
+    const int l = e / len, k = e - l * len;
+    rows[l * pitch + k] = src[(line0 + l) * len + k];
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < nl) {
+    float* r = rows + threadIdx.x * pitch;
+    const double z = BSPLINE_POLE;
+    if (len >= 2) {
+      const double zn1 = pow(z, (double)(len - 1));
+      double c0 = 6.0 * ((double)r[0] + zn1 * (double)r[len - 1]);
+      double zi = z;
+      const int hz = len - 1 < 40 ? len - 1 : 40;
+      for (int k = 1; k < hz; ++k) { c0 += zi * 6.0 * ((double)r[k] + zn1 * (double)r[len - 1 - k]); zi *= z; }
+      c0 /= 1.0 - zn1 * zn1;
+      float last = (float)c0;
+      r[0] = last;
+      for (int k = 1; k < len; ++k) { last = (float)(6.0 * (double)r[k] + z * (double)last); r[k] = last; }
+      float nf = (float)((z * (double)r[len - 2] + (double)r[len - 1]) * z / (z * z - 1.0));
+      r[len - 1] = nf;
+      for (int k = len - 2; k >= 0; --k) { nf = (float)(z * ((double)nf - (double)r[k])); r[k] = nf; }
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < nl * len; e += 256) {
+    const int l = e / len, k = e - l * len;
+    dst[(line0 + l) * len + k] = rows[l * pitch + k];
+  }
+}
+
 // ---- spatial: out[b, c, o] = interp(in[b, c], A_b (o - c_out) + t_b) ---------------------------------------------------------
 // mat: per sample 12 doubles (row-major 3 x 4: A | t) mapping zero-centred output coordinates o - (size - 1) / 2 to input
 // voxel coordinates; computed on the host.
-__global__ __launch_bounds__(256) void aug_spatial_kernel(const float* __restrict__ data, const float* __restrict__ seg,
+__global__ __launch_bounds__(256) void aug_spatial_kernel(const float* __restrict__ data, const float* __restrict__ coef,
+                                                          const int* __restrict__ cubic, const float* __restrict__ seg,
                                                           float* __restrict__ odata, float* __restrict__ oseg,
                                                           const double* __restrict__ mat, int C, int CS, int Di, int Hi, int Wi,
                                                           int Do, int Ho, int Wo, int order_seg, float cval_seg) {
@@ -41,6 +182,14 @@ __global__ __launch_bounds__(256) void aug_spatial_kernel(const float* __restric
   const double ch = m[4] * z + m[5] * y + m[6] * x + m[7];
   const double cw = m[8] * z + m[9] * y + m[10] * x + m[11];
   const long long ivol = (long long)Di * Hi * Wi;
+  // ---- data: order 3 on the coefficient image (samples flagged in `cubic`), mode 'constant', cval 0: a coordinate outside
+  //      [0, n - 1] returns cval, taps of an inside coordinate that fall outside read the mirrored coefficients ----
+  if (coef != nullptr && (cubic == nullptr || cubic[b] != 0)) {
+    const bool inside = cd >= 0.0 && cd <= (double)(Di - 1) && ch >= 0.0 && ch <= (double)(Hi - 1) && cw >= 0.0 && cw <= (double)(Wi - 1);
+    for (int c = 0; c < C; ++c)
+      odata[((long long)b * C + c) * ovol + idx] =
+          inside ? (float)bspline3_at(coef + ((long long)b * C + c) * ivol, Di, Hi, Wi, cd, ch, cw) : 0.f;
+  } else
   // ---- data: order 1, mode 'constant', cval 0 (scipy map_coordinates: a tap outside the volume contributes cval) ----
   {
     const double fd = floor(cd), fh = floor(ch), fw = floor(cw);
@@ -288,6 +437,36 @@ __global__ __launch_bounds__(256) void aug_lowres_kernel(const float* __restrict
   dst[(long long)bc * vol + idx] = (float)acc;
 }
 
+// ---- low-resolution simulation with cubic up-sampling (order_upsample = 3) ---------------------------------------------------
+// down: dst [(ld + 2 pad), (lh + 2 pad), (lw + 2 pad)] = the nearest-down-sampled volume, edge padded (scipy zoom pre-pads by 12 for
+// mode 'nearest' before the spline prefilter)
+__global__ __launch_bounds__(256) void aug_lowres_down_kernel(const float* __restrict__ src, float* __restrict__ dst, int D, int H,
+                                                              int W, int ld, int lh, int lw, int pad) {
+  const int pd = ld + 2 * pad, ph = lh + 2 * pad, pw = lw + 2 * pad;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)pd * ph * pw) return;
+  int k = (int)(idx % pw) - pad, j = (int)((idx / pw) % ph) - pad, i = (int)(idx / ((long long)pw * ph)) - pad;
+  i = i < 0 ? 0 : (i >= ld ? ld - 1 : i);
+  j = j < 0 ? 0 : (j >= lh ? lh - 1 : j);
+  k = k < 0 ? 0 : (k >= lw ? lw - 1 : k);
+  dst[idx] = src[((long long)lr_near(i, D, ld) * H + lr_near(j, H, lh)) * W + lr_near(k, W, lw)];
+}
+// up: dst [D, H, W] = clip(spline(coef)(grid-mode coordinate + pad), min, max of the low-resolution volume)
+__global__ __launch_bounds__(256) void aug_lowres_up3_kernel(const float* __restrict__ coef, float* __restrict__ dst,
+                                                             const double* __restrict__ minmax, int D, int H, int W, int ld, int lh,
+                                                             int lw, int pad) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)D * H * W) return;
+  const int ow = (int)(idx % W), oh = (int)((idx / W) % H), od = (int)(idx / ((long long)W * H));
+  const double cd = ((double)od + 0.5) * ((double)ld / (double)D) - 0.5 + pad;
+  const double ch = ((double)oh + 0.5) * ((double)lh / (double)H) - 0.5 + pad;
+  const double cw = ((double)ow + 0.5) * ((double)lw / (double)W) - 0.5 + pad;
+  double v = bspline3_at(coef, ld + 2 * pad, lh + 2 * pad, lw + 2 * pad, cd, ch, cw);
+  float f = (float)v;
+  const float mn = (float)minmax[0], mx = (float)minmax[1];
+  dst[idx] = f < mn ? mn : (f > mx ? mx : f);
+}
+
 // ---- finish: MaskTransform (set_outside_to 0 where seg channel 0 < 0) and RemoveLabelTransform(-1, 0) -----------------------
 __global__ __launch_bounds__(256) void aug_finish_kernel(float* __restrict__ data, float* __restrict__ seg,
                                                          const int* __restrict__ use_mask, int C, int CS, long long vol) {
@@ -306,16 +485,40 @@ __global__ __launch_bounds__(256) void aug_finish_kernel(float* __restrict__ dat
 
 }  // namespace
 
-extern "C" int e2e_aug_spatial(const float* data, const float* seg, float* out_data, float* out_seg, const double* mat, int B,
-                               int C, int CS, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int order_seg, float cval_seg,
-                               void* stream) {
+extern "C" int e2e_aug_spatial(const float* data, const float* coef, const int* cubic, const float* seg, float* out_data,
+                               float* out_seg, const double* mat, int B, int C, int CS, int Di, int Hi, int Wi, int Do, int Ho,
+                               int Wo, int order_seg, float cval_seg, void* stream) {
   E2E_REQUIRE(data && out_data && mat && B > 0 && C > 0 && Di > 0 && Hi > 0 && Wi > 0 && Do > 0 && Ho > 0 && Wo > 0, "aug_spatial: bad arguments");
   E2E_REQUIRE((seg == nullptr) == (out_seg == nullptr) && (seg == nullptr || CS > 0), "aug_spatial: seg / out_seg must come together");
   E2E_REQUIRE(order_seg == 0 || order_seg == 1, "aug_spatial: order_seg must be 0 or 1");
   dim3 grid((unsigned)e2e::cdivll((long long)Do * Ho * Wo, 256), B);
-  hipLaunchKernelGGL(aug_spatial_kernel, grid, dim3(256), 0, (hipStream_t)stream, data, seg, out_data, out_seg, mat, C, CS, Di, Hi,
-                     Wi, Do, Ho, Wo, order_seg, cval_seg);
+  hipLaunchKernelGGL(aug_spatial_kernel, grid, dim3(256), 0, (hipStream_t)stream, data, coef, cubic, seg, out_data, out_seg, mat, C,
+                     CS, Di, Hi, Wi, Do, Ho, Wo, order_seg, cval_seg);
   return e2e::check_launch("aug_spatial_kernel");
+}
+
+extern "C" int e2e_aug_bspline_prefilter_axis(const float* src, float* dst, int nvol, int D, int H, int W, int axis, void* stream) {
+  E2E_REQUIRE(src && dst && nvol > 0 && D > 0 && H > 0 && W > 0 && axis >= 0 && axis <= 2, "aug_bspline_prefilter_axis: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (axis == 2) {
+    const long long lines = (long long)nvol * D * H;
+    const int pitch = W | 1;
+    E2E_REQUIRE((long long)16 * pitch * 4 <= 160 * 1024, "aug_bspline_prefilter_axis: rows longer than 2559 voxels are not served");
+    if ((long long)64 * pitch * 4 <= 64 * 1024)
+      hipLaunchKernelGGL((bspline_prefilter_rows_kernel<64>), dim3((unsigned)e2e::cdivll(lines, 64)), dim3(256), (size_t)64 * pitch * 4, st, src, dst, lines, W);
+    else {
+      static bool attr = false;
+      if (!attr) { (void)hipFuncSetAttribute((const void*)bspline_prefilter_rows_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+      hipLaunchKernelGGL((bspline_prefilter_rows_kernel<16>), dim3((unsigned)e2e::cdivll(lines, 16)), dim3(256), (size_t)16 * pitch * 4, st, src, dst, lines, W);
+    }
+    return e2e::check_launch("bspline_prefilter_rows_kernel");
+  }
+  const long long n_outer = axis == 0 ? nvol : (long long)nvol * D;
+  const int len = axis == 0 ? D : H;
+  const long long inner = axis == 0 ? (long long)H * W : W;
+  hipLaunchKernelGGL(bspline_prefilter_strided_kernel, dim3((unsigned)e2e::cdivll(n_outer * inner, 256)), dim3(256), 0, st, src, dst,
+                     n_outer, len, inner);
+  return e2e::check_launch("bspline_prefilter_strided_kernel");
 }
 
 extern "C" long long e2e_aug_stats_ws_bytes(int nbc) { return (long long)nbc * 64 * 4 * (long long)sizeof(double); }
@@ -348,6 +551,22 @@ extern "C" int e2e_aug_lowres(const float* src, float* dst, const int* lo_shape,
   dim3 grid((unsigned)e2e::cdivll((long long)D * H * W, 256), nbc);
   hipLaunchKernelGGL(aug_lowres_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, lo_shape, D, H, W);
   return e2e::check_launch("aug_lowres_kernel");
+}
+
+extern "C" int e2e_aug_lowres_down(const float* src, float* dst, int D, int H, int W, int ld, int lh, int lw, int pad, void* stream) {
+  E2E_REQUIRE(src && dst && src != dst && D > 0 && H > 0 && W > 0 && ld > 0 && lh > 0 && lw > 0 && pad >= 0, "aug_lowres_down: bad arguments");
+  const long long n = (long long)(ld + 2 * pad) * (lh + 2 * pad) * (lw + 2 * pad);
+  hipLaunchKernelGGL(aug_lowres_down_kernel, dim3((unsigned)e2e::cdivll(n, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, D, H, W,
+                     ld, lh, lw, pad);
+  return e2e::check_launch("aug_lowres_down_kernel");
+}
+
+extern "C" int e2e_aug_lowres_up3(const float* coef, float* dst, const double* minmax, int D, int H, int W, int ld, int lh, int lw,
+                                  int pad, void* stream) {
+  E2E_REQUIRE(coef && dst && minmax && D > 0 && H > 0 && W > 0 && ld > 0 && lh > 0 && lw > 0 && pad >= 2, "aug_lowres_up3: bad arguments");
+  hipLaunchKernelGGL(aug_lowres_up3_kernel, dim3((unsigned)e2e::cdivll((long long)D * H * W, 256)), dim3(256), 0, (hipStream_t)stream,
+                     coef, dst, minmax, D, H, W, ld, lh, lw, pad);
+  return e2e::check_launch("aug_lowres_up3_kernel");
 }
 
 extern "C" int e2e_aug_finish(float* data, float* seg, const int* use_mask, int B, int C, int CS, long long vol, void* stream) {

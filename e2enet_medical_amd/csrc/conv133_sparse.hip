@@ -1,0 +1,605 @@
+// K1s: the DSFF-masked 1x3x3 convolution (forward and stride-1 data gradient) on a LOAD-BALANCED execution plan.
+//
+// Reference semantics: unetpp_d.py:45-59 (depth shift), :453-478 (concat), :93/:108 (Conv3d k(1,3,3) of a DSFF-masked weight,
+// core_channel.py:427-434) and autograd of the same for the data gradient -- the operator of conv133.hip, for the layers that
+// dominate the step (planes wider than 16 voxels, W % 4 == 0, stride 1, more than one 8-plane chunk, a DSFF kernel map).
+//
+// Why a second kernel.  In conv133_kernel a wave owns 4 output planes and the eight waves of a workgroup walk the live kernels
+// of one 8-plane chunk between two barriers.  With a random kernel map at density 0.2 a wave has Binomial(32, 0.2) live kernels
+// per chunk (6.4 +- 2.3) and every barrier waits for the slowest of eight: s_memtime stamps of the shipping kernel
+// (profiles/r04_k1_phases.txt) put 18 % of a wave's life into that barrier and 47 % into the walk itself.  The ORDER in which
+// input planes are chunked and the assignment of output planes to waves are free, so the host picks them per 32-plane group
+// such that every (chunk, wave) cell carries nearly the same work (e2e_conv133_sparse_plan: longest-processing-time assignment
+// + pair swaps; sum over chunks of the slowest wave drops from 1.48x to 1.15x of the mean).  What follows from the plan:
+//   * weights are read from a PACKED copy in plan order, [group][chunk][32 output slots][8 plane slots][12] floats with pruned
+//     kernels and padding as zeros (e2e_conv133_sparse_pack: one launch for all layers of a network, after every optimizer step):
+//     a chunk's weights are one contiguous 12 KB block that goes global -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPRs,
+//     no ds_write), double buffered;
+//   * the plane table, the destination table and the liveness words arrive in plan order (built by the caller);
+//   * a neighbourhood row is read as ds_read_b128 + ds_read_b64 (the compiler merged the halo halves of two rows into one
+//     ds_read2_b64, whose accesses are banked mod 32 and collide 2-way: SQ_LDS_BANK_CONFLICT was 39 % of the LDS cycles);
+//   * the two-level summation flushes after `flush_every` chunks (= a chain of ~72 products, what a dense chunk has) instead of
+//     after every chunk;
+//   * an accumulating data gradient loads the old dx values in its PROLOGUE into the outer accumulators (they are free until the
+//     first flush): no read-modify-write round trip in the epilogue.
+// Everything else (16 x 32 tile, 8 waves x 4 output planes, 2 x 4 micro-tile per lane, register-prefetched float4 plane staging
+// with normalise-on-load, quad-nibble walk unrolled over the eight plane slots, fp64 statistics records) is conv133_kernel's.
+#include "e2e_common.h"
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+
+namespace {
+
+constexpr int TH = 16, TW = 32, LX = 8, PH = 2, PW = 4, OPW = 4, NW = 8, CK = 8, OCG = 32;
+constexpr int IH = TH + 2, IW = TW + 2;
+constexpr int NQ = (IW + 3 + 3) / 4;             // float4 groups per staged row (the one 4 columns left of the tile covers the halo)
+constexpr int PITCH = 48;                         // (2 * PITCH) % 64 == 32: the lane groups of a ds_read_b128 fall on disjoint bank quarters
+constexpr int CHS = IH * PITCH;
+constexpr int UPP = IH * NQ, NUP = (UPP + 63) / 64;
+constexpr int WSLOT = 12;                         // 9 taps padded to 3 x 16 bytes
+constexpr int WCHUNK = OCG * CK * WSLOT;          // floats of one chunk's weight block (12 KB)
+constexpr int NR = PH + 2, NCL = 6;
+
+struct SparseParams {
+  const e2e_in_chan_t* chans;   // MODE 0: [groups][ppad] plane descriptors in plan order (ptr == null: empty slot)
+  const float* xin;             // MODE 1: dy [B, P, D, H, W]
+  const int* pslot;             // MODE 1: [groups][ppad] dy channel of each chunk slot (-1: empty)
+  const float* wpk;             // [groups][nchunks][32][8][12]
+  const unsigned* quads;        // [groups][8 waves][nchunks]: bit cl * 4 + a
+  const int* qslot;             // MODE 0: [groups][32] output plane of slot wave * 4 + a (-1: empty)
+  const e2e_out_chan_t* outs;   // MODE 1: [groups][32] destinations in plan order (ptr == null: nothing to store)
+  const float* bias;
+  float* y;
+  double* part;
+  int P, Q, B, D, H, W;
+  int nchunks, ppad, groups, flush_every;
+  int tiles_x, tiles_y, tiles_per_n, total, padded_total;
+};
+
+struct PlaneDesc {
+  gfloat_p base;
+  float a, b, slope;
+  int valid;
+};
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef const f32x4_t __attribute__((address_space(1)))* gfloat4_p;
+typedef const volatile f32x2_t __attribute__((address_space(3)))* lds_v2_p;      // (volatile: not merged into ds_read2_b64)
+
+template <class T>
+__device__ __forceinline__ T load_uniform(const T* ptr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return *reinterpret_cast<const T __attribute__((address_space(4)))*>((unsigned long long)ptr);      // scalar cache
+#else
+  return *ptr;
+#endif
+}
+
+template <int MODE>
+__global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams p) {
+  __shared__ __attribute__((aligned(16))) float lds_raw[CK * CHS + 4];
+  __shared__ __attribute__((aligned(16))) float wl[2 * WCHUNK];
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+  PlaneDesc* tab = reinterpret_cast<PlaneDesc*>(dyn_lds);
+  float* const lds = lds_raw + 4;
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int lx = lane % LX, ly = lane / LX;
+  const long long plane = (long long)p.H * p.W;
+  const float* lane_tp = lds + (ly * PH) * PITCH + lx * PW;
+
+  int item = e2e::xcd_remap(blockIdx.x, p.padded_total);
+  if (item >= p.total) return;
+  const int g = item % p.groups;
+  item /= p.groups;
+  const int n = item / p.tiles_per_n, tile_in_n = item - n * p.tiles_per_n;
+  const int tx = tile_in_n % p.tiles_x, ty = (tile_in_n / p.tiles_x) % p.tiles_y, d = tile_in_n / (p.tiles_x * p.tiles_y);
+  const int h0 = ty * TH, w0 = tx * TW;
+
+  // ---- plane table of this (group, batch item, depth slice) ------------------------------------------------------------------
+  for (int pl = tid; pl < p.ppad; pl += NW * 64) {
+    PlaneDesc ds;
+    ds.a = 1.f; ds.b = 0.f; ds.slope = 1.f; ds.valid = 0;
+    ds.base = (gfloat_p)p.wpk;                                    // always dereferenceable
+    if (MODE == 0) {
+      const e2e_in_chan_t ch = p.chans[(long long)g * p.ppad + pl];
+      const int din = d - ch.dshift;
+      if (ch.ptr != nullptr && (unsigned)din < (unsigned)p.D) {
+        ds.valid = 1;
+        ds.base = (gfloat_p)(ch.ptr + (long long)n * ch.nstride + (long long)din * plane);
+        if (ch.scale != nullptr) {
+          ds.a = ch.scale[(long long)n * ch.ab_nstride];
+          ds.b = ch.shift[(long long)n * ch.ab_nstride];
+          ds.slope = ch.slope;
+        }
+      }
+    } else {
+      const int c = p.pslot[(long long)g * p.ppad + pl];
+      if (c >= 0) {
+        ds.valid = 1;
+        ds.base = (gfloat_p)(p.xin + (((long long)n * p.P + c) * p.D + d) * plane);
+      }
+    }
+    tab[pl] = ds;
+  }
+
+  // ---- staging geometry: a wave stages one whole plane of each chunk, a lane NUP float4 groups of it --------------------------
+  int su_lds[NUP], su_goff[NUP];
+  bool su_ok[NUP];
+#pragma unroll
+  for (int i = 0; i < NUP; ++i) {
+    int u = lane + 64 * i;
+    if (u >= UPP) u = UPP - 1;
+    const int r = u / NQ, q = u - r * NQ;
+    const int hi = h0 - 1 + r, gc = w0 - 4 + 4 * q;
+    const bool ok = (unsigned)hi < (unsigned)p.H && gc >= 0 && gc + 3 < p.W;
+    su_lds[i] = r * PITCH + 4 * q - 3;
+    su_goff[i] = ok ? (hi * p.W + gc) * 4 : 0;
+    su_ok[i] = ok;
+  }
+
+  // ---- epilogue operands, requested up front --------------------------------------------------------------------------------
+  const int slot0 = g * OCG + wave * OPW;
+  int qphys[MODE == 0 ? OPW : 1];
+  float bqs[MODE == 0 ? OPW : 1];
+  e2e_out_chan_t ocs[MODE != 0 ? OPW : 1];
+#pragma unroll
+  for (int a = 0; a < OPW; ++a) {
+    if (MODE == 0) {
+      qphys[a] = load_uniform(p.qslot + slot0 + a);
+      bqs[a] = (p.bias != nullptr && qphys[a] >= 0) ? load_uniform(p.bias + qphys[a]) : 0.f;
+    } else {
+      ocs[a] = load_uniform(p.outs + slot0 + a);
+    }
+  }
+
+  // ---- accumulators; an accumulating data gradient starts its outer accumulators from the old dx values -----------------------
+  float acc[OPW][PH][PW], acc2[OPW][PH][PW];
+  const int oh0 = h0 + ly * PH, ow0 = w0 + lx * PW;
+#pragma unroll
+  for (int a = 0; a < OPW; ++a)
+#pragma unroll
+    for (int i = 0; i < PH; ++i)
+#pragma unroll
+      for (int j = 0; j < PW; ++j) { acc[a][i][j] = 0.f; acc2[a][i][j] = 0.f; }
+  // data gradient: gradient of virtual-concat channel q at (shifted) depth d goes to depth d - s(q) of its source; the slices that
+  // receive nothing are zero-filled by the workgroups of the slices that fall outside (conv133_kernel's rule).  Wave-uniform.
+  // mode: 0 store, 1 accumulate (the old values are the initial outer accumulators), 2 zero fill, 3 nothing to do
+  auto destination = [&](const e2e_out_chan_t& oc, int& mode) -> float* {
+    mode = 3;
+    if (oc.ptr == nullptr) return nullptr;
+    int dd = d - oc.dshift;
+    bool zero_fill = false;
+    if (dd < 0) {
+      const int lo = p.D - oc.dshift > 0 ? p.D - oc.dshift : 0;
+      dd = lo + d;
+      zero_fill = true;
+    } else if (dd >= p.D) {
+      const int lo = p.D + oc.dshift > 0 ? p.D + oc.dshift : 0;
+      dd = d - lo;
+      zero_fill = true;
+    }
+    if (zero_fill && oc.accumulate) return nullptr;
+    mode = zero_fill ? 2 : (oc.accumulate ? 1 : 0);
+    return oc.ptr + (long long)n * oc.nstride + (long long)dd * plane;
+  };
+  if (MODE != 0) {
+#pragma unroll
+    for (int a = 0; a < OPW; ++a) {
+      int mode;
+      const float* xp = destination(ocs[a], mode);
+      if (mode != 1) continue;
+#pragma unroll
+      for (int i = 0; i < PH; ++i) {
+        const int oh = oh0 + i;
+        if (oh < p.H && ow0 < p.W) {
+          const float4 o = *reinterpret_cast<const float4*>(xp + (long long)oh * p.W + ow0);
+          acc2[a][i][0] = o.x; acc2[a][i][1] = o.y; acc2[a][i][2] = o.z; acc2[a][i][3] = o.w;
+        }
+      }
+    }
+  }
+
+  __syncthreads();                                      // the plane table is complete
+
+  // ---- staging: planes through registers (prefetched one chunk ahead), weights by LDS-DMA into the other weight buffer ---------
+  f32x4_t v4[NUP];
+  float pd_a = 1.f, pd_b = 0.f, pd_slope = 1.f;
+  bool pd_ok = false;
+  unsigned pf_blo = 0, pf_bhi = 0;
+  const float* wblock = p.wpk + (long long)g * p.nchunks * WCHUNK;
+  auto request_begin = [&](int c) {
+    const PlaneDesc ds = tab[c * CK + wave];
+    const unsigned long long bb = (unsigned long long)ds.base;
+    pf_blo = __builtin_amdgcn_readfirstlane((unsigned)bb);
+    pf_bhi = __builtin_amdgcn_readfirstlane((unsigned)(bb >> 32));
+    pd_a = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ds.a)));
+    pd_b = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ds.b)));
+    pd_slope = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ds.slope)));
+    pd_ok = __builtin_amdgcn_readfirstlane(ds.valid) != 0;
+  };
+  auto request_plane = [&](int k, bool live) {           // k: compile-time
+    const char __attribute__((address_space(1)))* base =
+        (const char __attribute__((address_space(1)))*)(((unsigned long long)pf_bhi << 32) | pf_blo);
+    const unsigned off = live && pd_ok ? (unsigned)su_goff[k] : 0u;
+    v4[k] = *reinterpret_cast<gfloat4_p>(base + off);
+  };
+  // a chunk's weight block = 768 float4 units; wave w moves units [96 w, 96 w + 96): one full and one half LDS-DMA instruction
+  // (LDS destination = wave-uniform base + 16 * lane)
+  auto request_weights = [&](int c, int half, bool live) {
+    if (!live) return;                                    // (wave-uniform)
+    const float* src = wblock + (long long)c * WCHUNK + (wave * 96 + half * 64 + lane) * 4;
+    float* dst = wl + (c & 1) * WCHUNK + (wave * 96 + half * 64) * 4;
+    if (half == 0 || lane < 32)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+  auto commit = [&]() {
+    float* pl = lds + wave * CHS;
+#pragma unroll
+    for (int i = 0; i < NUP; ++i) {
+      if ((i + 1) * 64 > UPP && lane + 64 * i >= UPP) continue;
+      float* dst = pl + su_lds[i];
+      if (!pd_ok) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[e] = 0.f;
+      } else if (MODE == 0) {
+        const float ae = su_ok[i] ? pd_a : 0.f, be = su_ok[i] ? pd_b : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[e] = e2e::in_act(v4[i][e], ae, be, pd_slope);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[e] = su_ok[i] ? v4[i][e] : 0.f;
+      }
+    }
+  };
+
+  const unsigned* qrow = p.quads + ((long long)g * NW + wave) * p.nchunks;
+  request_begin(0);
+#pragma unroll
+  for (int k = 0; k < NUP; ++k) request_plane(k, true);
+  request_weights(0, 0, true);
+  request_weights(0, 1, true);
+  unsigned m_cur = load_uniform(qrow);
+
+  int until_flush = p.flush_every;
+  for (int c = 0; c < p.nchunks; ++c) {
+    const bool more = c + 1 < p.nchunks;
+    const unsigned m_next = more ? load_uniform(qrow + c + 1) : 0u;
+    commit();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's LDS-DMA share of the chunk's weights has landed
+    __syncthreads();
+    request_begin(more ? c + 1 : c);
+    const float* wbuf = wl + (c & 1) * WCHUNK + (wave * OPW) * CK * WSLOT;
+#pragma unroll
+    for (int cl = 0; cl < CK; ++cl) {
+      if (cl < NUP) request_plane(cl, more);
+      else if (cl < NUP + 2) request_weights(c + 1, cl - NUP, more);
+      const unsigned nib = (m_cur >> (cl * 4)) & 15u;
+      if (nib) {
+        float nb[NR][NCL];
+        const float* tp = lane_tp + cl * CHS;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          // (the halo pair as its own ds_read_b64: merged with the next row's into a ds_read2_b64 -- what the compiler does with
+          //  plain loads -- the two accesses are banked mod 32 and collide 2-way on top of twice the base cost)
+          const float4 lo = *reinterpret_cast<const float4*>(tp + r * PITCH);
+          const f32x2_t hi = *(lds_v2_p)(tp + r * PITCH + 4);
+          nb[r][0] = lo.x; nb[r][1] = lo.y; nb[r][2] = lo.z; nb[r][3] = lo.w;
+          nb[r][4] = hi[0]; nb[r][5] = hi[1];
+        }
+#pragma unroll
+        for (int a = 0; a < OPW; ++a) {
+          if (nib & (1u << a)) {
+            const float* wp = wbuf + (a * CK + cl) * WSLOT;
+            const float4 w0v = *reinterpret_cast<const float4*>(wp);
+            const float4 w1v = *reinterpret_cast<const float4*>(wp + 4);
+            const float wk[9] = {w0v.x, w0v.y, w0v.z, w0v.w, w1v.x, w1v.y, w1v.z, w1v.w, wp[8]};
+#pragma unroll
+            for (int i = 0; i < PH; ++i)
+#pragma unroll
+              for (int j = 0; j < PW; ++j)
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                  for (int kw = 0; kw < 3; ++kw) acc[a][i][j] = fmaf(wk[kh * 3 + kw], nb[i + kh][j + kw], acc[a][i][j]);
+          }
+        }
+      }
+    }
+    m_cur = m_next;
+    if (--until_flush == 0 || !more) {
+      until_flush = p.flush_every;
+#pragma unroll
+      for (int a = 0; a < OPW; ++a)
+#pragma unroll
+        for (int i = 0; i < PH; ++i)
+#pragma unroll
+          for (int j = 0; j < PW; ++j) { acc2[a][i][j] += acc[a][i][j]; acc[a][i][j] = 0.f; }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue --------------------------------------------------------------------------------------------------------------
+  if (MODE == 0) {
+    float psum[OPW];
+    const long long out_n = (long long)p.Q * p.D * plane;
+#pragma unroll
+    for (int a = 0; a < OPW; ++a) {
+      psum[a] = 0.f;
+      if (qphys[a] < 0) continue;
+      float* yp = p.y + (long long)n * out_n + ((long long)qphys[a] * p.D + d) * plane;
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < PH; ++i) {
+        const int oh = oh0 + i;
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+          acc2[a][i][j] += bqs[a];
+          if (oh < p.H && ow0 + j < p.W) s += acc2[a][i][j];
+        }
+        if (oh < p.H && ow0 < p.W)
+          *reinterpret_cast<float4*>(yp + (long long)oh * p.W + ow0) = make_float4(acc2[a][i][0], acc2[a][i][1], acc2[a][i][2], acc2[a][i][3]);
+      }
+      psum[a] = s;
+    }
+    if (p.part != nullptr) {
+      const int vr = p.H - h0 < TH ? p.H - h0 : TH, vc = p.W - w0 < TW ? p.W - w0 : TW;
+      const float tcnt = (float)(vr * vc);
+      float mean[OPW], m2[OPW];
+#pragma unroll
+      for (int a = 0; a < OPW; ++a) mean[a] = e2e::wave_sum_dpp(psum[a]) / tcnt;
+#pragma unroll
+      for (int a = 0; a < OPW; ++a) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < PH; ++i)
+#pragma unroll
+          for (int j = 0; j < PW; ++j)
+            if (oh0 + i < p.H && ow0 + j < p.W) {
+              const float dlt = acc2[a][i][j] - mean[a];
+              t = fmaf(dlt, dlt, t);
+            }
+        m2[a] = t;
+      }
+#pragma unroll
+      for (int a = 0; a < OPW; ++a) m2[a] = e2e::wave_sum_dpp(m2[a]);
+      if (lane < OPW) {
+        float mm = mean[0], vv = m2[0];
+        int qq = qphys[0];
+#pragma unroll
+        for (int a = 1; a < OPW; ++a)
+          if (lane == a) { mm = mean[a]; vv = m2[a]; qq = qphys[a]; }
+        if (qq >= 0) {
+          double* pp = p.part + (((long long)n * p.Q + qq) * p.tiles_per_n + tile_in_n) * 3;
+          pp[0] = (double)tcnt;
+          pp[1] = (double)mm;
+          pp[2] = (double)vv;
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int a = 0; a < OPW; ++a) {
+      int mode;
+      float* xp = destination(ocs[a], mode);
+      if (mode == 3) continue;
+#pragma unroll
+      for (int i = 0; i < PH; ++i) {
+        const int oh = oh0 + i;
+        if (oh >= p.H || ow0 >= p.W) continue;
+        float4 val = make_float4(acc2[a][i][0], acc2[a][i][1], acc2[a][i][2], acc2[a][i][3]);
+        if (mode == 2) val = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(xp + (long long)oh * p.W + ow0) = val;
+      }
+    }
+  }
+}
+
+// ---- weight packing: one launch for a table of (layer, direction) jobs --------------------------------------------------------
+__global__ __launch_bounds__(256) void sparse_pack_kernel(const e2e_sparse_pack_job_t* __restrict__ jobs) {
+  const e2e_sparse_pack_job_t jb = jobs[blockIdx.y];
+  const long long total = (long long)jb.groups * jb.nchunks * WCHUNK;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int t = (int)(idx % WSLOT), cl = (int)((idx / WSLOT) % CK), ql = (int)((idx / (WSLOT * CK)) % OCG);
+    const long long gc = idx / WCHUNK;
+    const int c = (int)(gc % jb.nchunks), g = (int)(gc / jb.nchunks);
+    float v = 0.f;
+    if (t < 9) {
+      const int q = jb.qslot[g * OCG + ql];
+      const int pp = jb.pslot[((long long)g * jb.nchunks + c) * CK + cl];
+      const unsigned word = jb.quads[((long long)g * NW + (ql >> 2)) * jb.nchunks + c];
+      if (q >= 0 && pp >= 0 && ((word >> (cl * 4 + (ql & 3))) & 1u))
+        v = jb.w[(long long)q * jb.wq_stride + (long long)pp * jb.wp_stride + (jb.reverse ? 8 - t : t)];
+    }
+    jb.wpk[idx] = v;
+  }
+}
+
+inline bool sparse_knob() {
+  static const int v = getenv("E2E_CONV_SPARSE2") ? atoi(getenv("E2E_CONV_SPARSE2")) : 1;
+  return v != 0;
+}
+
+int sparse_launch(int mode, SparseParams p, hipStream_t st) {
+  p.tiles_x = e2e::cdiv(p.W, TW);
+  p.tiles_y = e2e::cdiv(p.H, TH);
+  p.tiles_per_n = p.D * p.tiles_y * p.tiles_x;
+  p.groups = e2e::cdiv(p.Q, OCG);
+  p.nchunks = e2e::cdiv(p.P, CK);
+  p.ppad = p.nchunks * CK;
+  p.total = p.B * p.tiles_per_n * p.groups;
+  p.padded_total = (p.total + 7) & ~7;
+  if (p.flush_every < 1) p.flush_every = 1;
+  const size_t dyn = (size_t)p.ppad * sizeof(PlaneDesc);
+  e2e::note_kernel("conv133_sparse_kernel<mode=%d> wgs=%d groups=%d chunks=%d flush=%d", mode, p.padded_total, p.groups, p.nchunks, p.flush_every);
+  if (mode == 0) hipLaunchKernelGGL((conv133_sparse_kernel<0>), dim3(p.padded_total), dim3(NW * 64), dyn, st, p);
+  else hipLaunchKernelGGL((conv133_sparse_kernel<1>), dim3(p.padded_total), dim3(NW * 64), dyn, st, p);
+  return e2e::check_launch("conv133_sparse_kernel");
+}
+
+// ---- host: the load-balanced plan ---------------------------------------------------------------------------------------------
+// cost of a (chunk, wave) cell: live kernels + 0.35 per visited plane (neighbourhood rows are read once per visited plane)
+struct Balancer {
+  int P, nchunks;
+  const unsigned char* live;      // [32 slots][P]: kernel (slot, plane) alive
+  std::vector<int> chunk_of;      // plane -> chunk
+  std::vector<int> fill;          // planes per chunk
+  std::vector<float> load;        // [nchunks][8]
+  float cell(int wave, int plane) const {
+    int k = 0;
+    for (int a = 0; a < OPW; ++a) k += live[(wave * OPW + a) * P + plane];
+    return k ? (float)k + 0.35f : 0.f;
+  }
+  float chunk_max(int c) const {
+    float m = 0.f;
+    for (int w = 0; w < NW; ++w) m = std::max(m, load[c * NW + w]);
+    return m;
+  }
+  void add(int c, int plane, float sign) {
+    for (int w = 0; w < NW; ++w) load[c * NW + w] += sign * cell(w, plane);
+  }
+};
+
+}  // namespace
+
+extern "C" int e2e_conv133_sparse_eligible(int Cin, int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw) {
+  if (!sparse_knob()) return 0;
+  if (sd != 1 || sh != 1 || sw != 1) return 0;
+  if (Wi % 4 != 0 || Hi <= 16 || Wi <= 16 || Di < 1) return 0;      // the 16 x 32 tile class of conv133_kernel, float4 staging
+  if (Cin <= CK || Cout <= CK) return 0;                             // both directions need more than one chunk
+  if ((long long)e2e::cdiv(Cin > Cout ? Cin : Cout, CK) * CK * (long long)sizeof(PlaneDesc) > 40 * 1024) return 0;
+  return 1;
+}
+
+extern "C" long long e2e_conv133_sparse_wpk_floats(int P, int Q) {
+  return (long long)e2e::cdiv(Q, OCG) * e2e::cdiv(P, CK) * WCHUNK;
+}
+
+extern "C" int e2e_conv133_sparse_plan(const unsigned char* kmask, int R, int Cc, int transpose, int* qslot, int* pslot,
+                                       unsigned* quads, int* flush_every) {
+  E2E_REQUIRE(kmask && qslot && pslot && quads && R > 0 && Cc > 0, "conv133_sparse_plan: bad arguments");
+  const int Q = transpose ? Cc : R, P = transpose ? R : Cc;
+  const int groups = e2e::cdiv(Q, OCG), nchunks = e2e::cdiv(P, CK);
+  auto alive = [&](int q, int pp) -> unsigned char { return transpose ? kmask[(long long)pp * Cc + q] : kmask[(long long)q * Cc + pp]; };
+  long long nlive = 0;
+  for (int g = 0; g < groups; ++g) {
+    const int q0 = g * OCG, nq = std::min(OCG, Q - q0);
+    // -- output planes to waves: longest-processing-time first on the planes' live counts
+    std::vector<int> cnt(nq, 0), order(nq);
+    for (int i = 0; i < nq; ++i) {
+      for (int pp = 0; pp < P; ++pp) cnt[i] += alive(q0 + i, pp);
+      order[i] = i;
+      nlive += cnt[i];
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cnt[a] > cnt[b]; });
+    int wload[NW] = {0}, wfill[NW] = {0};
+    int* qs = qslot + g * OCG;
+    for (int s = 0; s < OCG; ++s) qs[s] = -1;
+    for (int i : order) {
+      int best = -1;
+      for (int w = 0; w < NW; ++w)
+        if (wfill[w] < OPW && (best < 0 || wload[w] < wload[best])) best = w;
+      qs[best * OPW + wfill[best]++] = q0 + i;
+      wload[best] += cnt[i];
+    }
+    // -- input planes to chunks
+    std::vector<unsigned char> live((size_t)OCG * P, 0);
+    for (int s = 0; s < OCG; ++s)
+      if (qs[s] >= 0)
+        for (int pp = 0; pp < P; ++pp) live[(size_t)s * P + pp] = alive(qs[s], pp);
+    Balancer b;
+    b.P = P; b.nchunks = nchunks; b.live = live.data();
+    b.chunk_of.assign(P, -1); b.fill.assign(nchunks, 0); b.load.assign((size_t)nchunks * NW, 0.f);
+    std::vector<int> porder(P), pcnt(P, 0);
+    for (int pp = 0; pp < P; ++pp) {
+      for (int s = 0; s < OCG; ++s) pcnt[pp] += live[(size_t)s * P + pp];
+      porder[pp] = pp;
+    }
+    std::stable_sort(porder.begin(), porder.end(), [&](int a, int bb) { return pcnt[a] > pcnt[bb]; });
+    for (int pp : porder) {                              // greedy: the chunk whose slowest wave grows least (ties: the lighter chunk)
+      int best = -1;
+      float bmax = 0.f, bsum = 0.f;
+      for (int c = 0; c < nchunks; ++c) {
+        if (b.fill[c] >= CK) continue;
+        float mx = 0.f, sm = 0.f;
+        for (int w = 0; w < NW; ++w) { const float v = b.load[c * NW + w] + b.cell(w, pp); mx = std::max(mx, v); sm += v; }
+        if (best < 0 || mx < bmax || (mx == bmax && sm < bsum)) { best = c; bmax = mx; bsum = sm; }
+      }
+      b.chunk_of[pp] = best;
+      b.fill[best]++;
+      b.add(best, pp, 1.f);
+    }
+    // pair swaps between chunks (fixed pseudo-random sequence: the plan is a pure function of the kernel map)
+    unsigned long long rng = 0x9e3779b97f4a7c15ull ^ ((unsigned long long)P * 1315423911ull + (unsigned long long)g);
+    auto next = [&]() { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return (unsigned)(rng >> 33); };
+    const int tries = nchunks > 1 ? 400 * nchunks : 0;
+    for (int t = 0; t < tries; ++t) {
+      const int p1 = (int)(next() % (unsigned)P), p2 = (int)(next() % (unsigned)P);
+      const int c1 = b.chunk_of[p1], c2 = b.chunk_of[p2];
+      if (c1 == c2) continue;
+      const float before = b.chunk_max(c1) + b.chunk_max(c2);
+      b.add(c1, p1, -1.f); b.add(c2, p2, -1.f); b.add(c1, p2, 1.f); b.add(c2, p1, 1.f);
+      const float after = b.chunk_max(c1) + b.chunk_max(c2);
+      if (after < before) { b.chunk_of[p1] = c2; b.chunk_of[p2] = c1; }
+      else { b.add(c1, p2, -1.f); b.add(c2, p1, -1.f); b.add(c1, p1, 1.f); b.add(c2, p2, 1.f); }
+    }
+    // -- emit: planes of a chunk in ascending order (deterministic), liveness words
+    int* ps = pslot + (long long)g * nchunks * CK;
+    for (int i = 0; i < nchunks * CK; ++i) ps[i] = -1;
+    std::vector<int> at(nchunks, 0);
+    for (int pp = 0; pp < P; ++pp) { const int c = b.chunk_of[pp]; ps[c * CK + at[c]++] = pp; }
+    for (int w = 0; w < NW; ++w)
+      for (int c = 0; c < nchunks; ++c) {
+        unsigned word = 0u;
+        for (int cl = 0; cl < CK; ++cl) {
+          const int pp = ps[c * CK + cl];
+          if (pp < 0) continue;
+          for (int a = 0; a < OPW; ++a)
+            if (qs[w * OPW + a] >= 0 && live[(size_t)(w * OPW + a) * P + pp]) word |= 1u << (cl * 4 + a);
+        }
+        quads[((long long)g * NW + w) * nchunks + c] = word;
+      }
+  }
+  if (flush_every != nullptr) {
+    // flush the chunk accumulators into the outer ones once a chain holds about as many products as a dense chunk (72)
+    const double per_plane_chunk = Q > 0 ? (double)nlive / ((double)Q * nchunks) : (double)CK;   // live kernels per output plane and chunk
+    int f = per_plane_chunk > 0.0 ? (int)((double)CK / per_plane_chunk) : nchunks;
+    *flush_every = f < 1 ? 1 : (f > nchunks ? nchunks : f);
+  }
+  return E2E_OK;
+}
+
+extern "C" int e2e_conv133_sparse_pack(const e2e_sparse_pack_job_t* jobs, int njobs, long long max_floats, void* stream) {
+  E2E_REQUIRE(jobs && njobs > 0 && max_floats > 0, "conv133_sparse_pack: bad arguments");
+  long long blocks = e2e::cdivll(max_floats, 256 * 4);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(sparse_pack_kernel, dim3((unsigned)blocks, njobs), dim3(256), 0, (hipStream_t)stream, jobs);
+  return e2e::check_launch("sparse_pack_kernel");
+}
+
+extern "C" int e2e_conv133_fwd_sparse(const e2e_in_chan_t* chans_plan, int Cin, const float* wpk, const float* bias, const unsigned* quads,
+                                      const int* qslot, int flush_every, float* y, double* part, int B, int Cout, int Di, int Hi,
+                                      int Wi, void* stream) {
+  E2E_REQUIRE(chans_plan && wpk && quads && qslot && y, "conv133_fwd_sparse: null pointer");
+  E2E_REQUIRE(e2e_conv133_sparse_eligible(Cin, Cout, Di, Hi, Wi, 1, 1, 1), "conv133_fwd_sparse: shape not served");
+  SparseParams p{};
+  p.chans = chans_plan; p.wpk = wpk; p.bias = bias; p.quads = quads; p.qslot = qslot; p.y = y; p.part = part;
+  p.P = Cin; p.Q = Cout; p.B = B; p.D = Di; p.H = Hi; p.W = Wi; p.flush_every = flush_every;
+  return sparse_launch(0, p, (hipStream_t)stream);
+}
+
+extern "C" int e2e_conv133_dgrad_sparse(const float* dy, const float* wpk_t, const unsigned* quads_t, const int* pslot_t,
+                                        const e2e_out_chan_t* outs_plan, int flush_every, int B, int Cin, int Cout, int Di, int Hi,
+                                        int Wi, void* stream) {
+  E2E_REQUIRE(dy && wpk_t && quads_t && pslot_t && outs_plan, "conv133_dgrad_sparse: null pointer");
+  E2E_REQUIRE(e2e_conv133_sparse_eligible(Cin, Cout, Di, Hi, Wi, 1, 1, 1), "conv133_dgrad_sparse: shape not served");
+  SparseParams p{};
+  p.xin = dy; p.wpk = wpk_t; p.quads = quads_t; p.pslot = pslot_t; p.outs = outs_plan;
+  p.P = Cout; p.Q = Cin; p.B = B; p.D = Di; p.H = Hi; p.W = Wi; p.flush_every = flush_every;
+  return sparse_launch(1, p, (hipStream_t)stream);
+}

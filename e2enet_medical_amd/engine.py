@@ -19,7 +19,9 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
-from ._lib import lib, InChan, OutChan, ParamEntry
+import numpy as np
+
+from ._lib import lib, InChan, OutChan, ParamEntry, SparsePackJob
 
 LRELU_SLOPE = 0.01
 IN_EPS = 1e-5
@@ -40,6 +42,7 @@ def _lane_divs(voxels):
     if LANE_DIVS is not None:
         return LANE_DIVS
     return (8, 512) if voxels <= (1 << 20) else (64,)
+SPARSE2 = os.environ.get("E2E_CONV_SPARSE2", "1") != "0"         # load-balanced kernel for the DSFF-masked full-resolution layers
 DENSE_ENABLED = True          # tests switch the matrix-core conv path off to compare the sparse walk with itself
 
 
@@ -112,6 +115,46 @@ class Act:
         return acc
 
 
+class SparsePlan:
+    """One direction of a DSFF-masked conv on the load-balanced kernel (csrc/conv133_sparse.hip): the host plan
+    (e2e_conv133_sparse_plan: which output planes a wave owns, which input planes form a chunk -- chosen from the kernel map
+    so that the eight waves of a workgroup carry the same work in every chunk), its device copies and the packed weights."""
+
+    def __init__(self, km_host, transpose, device):
+        L = lib()
+        r, cc = km_host.shape
+        self.Q, self.P = (cc, r) if transpose else (r, cc)
+        self.groups, self.nchunks = (self.Q + 31) // 32, (self.P + 7) // 8
+        qslot = np.empty(self.groups * 32, dtype=np.int32)
+        pslot = np.empty(self.groups * self.nchunks * 8, dtype=np.int32)
+        quads = np.empty(self.groups * 8 * self.nchunks, dtype=np.uint32)
+        flush = C.c_int(1)
+        km_host = np.ascontiguousarray(km_host, dtype=np.uint8)
+        L.conv133_sparse_plan(km_host.ctypes.data, r, cc, 1 if transpose else 0, qslot.ctypes.data, pslot.ctypes.data,
+                              quads.ctypes.data, C.addressof(flush))
+        self.flush_every = int(flush.value)
+        self.qslot_host, self.pslot_host = qslot, pslot
+        self.qslot = torch.from_numpy(qslot).to(device)
+        self.pslot = torch.from_numpy(pslot).to(device)
+        self.quads = torch.from_numpy(quads.view(np.int32)).to(device)
+        self.wpk = torch.zeros(int(L.conv133_sparse_wpk_floats(self.P, self.Q)), dtype=torch.float32, device=device)
+        self.table = None           # forward: plane descriptors in plan order; data gradient: destinations in plan order
+
+    def job(self, w, cin, reverse):
+        wq, wp = (9, cin * 9) if reverse else (cin * 9, 9)
+        return SparsePackJob(w.data_ptr(), self.wpk.data_ptr(), self.qslot.data_ptr(), self.pslot.data_ptr(), self.quads.data_ptr(),
+                             self.groups, self.nchunks, wq, wp, 1 if reverse else 0, 0)
+
+
+def pack_sparse_weights(jobs, device):
+    """ONE launch that (re)builds the packed weights of every planned conv (after an optimizer step or a parameter load)."""
+    if not jobs:
+        return None
+    table = _upload_structs(jobs, device)
+    mx = max(j.groups * j.nchunks for j in jobs) * 32 * 8 * 12
+    return table, len(jobs), mx
+
+
 class ConvOp:
     """depth shift + concat + Conv3d(1,3,3) + InstanceNorm statistics (reference ConvDropoutNormNonlin,
     unetpp_d.py:61-111; LeakyReLU/affine are applied by the consumers)."""
@@ -147,9 +190,14 @@ class ConvOp:
                                       cs * plane, cs, shifts[c], LRELU_SLOPE if s.normed else 1.0, 0))
                 c += 1
         self.chans = _upload_structs(structs, eng.device)
+        self.in_structs = structs
+        self.out_structs = None
         self.shifts = shifts
         self.outs = None
         self.do_dgrad = any(s.needs_grad for s in sources)
+        # load-balanced sparse kernel (conv133_sparse.hip): plans are built with the kernel maps (Engine.set_kernel_masks)
+        self.sp_fwd = self.sp_bwd = None
+        self.sparse_ok = bool(lib().conv133_sparse_eligible(self.cin, cout, di, hi, wi, sd, sh, sw))
 
     def plan_backward(self):
         if not self.do_dgrad:
@@ -169,6 +217,38 @@ class ConvOp:
                     structs.append(OutChan(None, 0, 0, 0))
                 c += 1
         self.outs = _upload_structs(structs, self.eng.device)
+        self.out_structs = structs
+        if self.sp_bwd is not None:
+            self.sp_bwd.table = None
+
+    def build_sparse_plans(self, km):
+        """km: uint8 [Cout, Cin] kernel map (any device) or None.  Plans for the forward and (if it has one) the data gradient."""
+        self.sp_fwd = self.sp_bwd = None
+        if km is None or not self.sparse_ok or not SPARSE2:
+            return
+        kh = km.detach().to("cpu", torch.uint8).numpy()
+        dev = self.eng.device
+        self.sp_fwd = SparsePlan(kh, False, dev)
+        empty = InChan(None, None, None, 0, 0, 0, 1.0, 0)
+        self.sp_fwd.table = _upload_structs([self.in_structs[p] if p >= 0 else empty for p in self.sp_fwd.pslot_host], dev)
+        if self.do_dgrad:
+            self.sp_bwd = SparsePlan(kh, True, dev)
+
+    def sparse_jobs(self):
+        w = self.eng.params[self.w_name]
+        jobs = []
+        if self.sp_fwd is not None:
+            jobs.append(self.sp_fwd.job(w, self.cin, False))
+        if self.sp_bwd is not None:
+            jobs.append(self.sp_bwd.job(w, self.cin, True))
+        return jobs
+
+    def _bwd_table(self):
+        sp = self.sp_bwd
+        if sp.table is None:
+            empty = OutChan(None, 0, 0, 0)
+            sp.table = _upload_structs([self.out_structs[q] if q >= 0 else empty for q in sp.qslot_host], self.eng.device)
+        return sp.table
 
     def use_dense(self):
         """Dense layers (no DSFF map, or a map too dense for the kernel-granular sparse walk to pay) run on the bf16 matrix
@@ -190,6 +270,11 @@ class ConvOp:
             L.conv133_fwd_dense(self.chans.data_ptr(), self.cin, p[self.w_name].data_ptr(), p[self.prefix + ".conv.bias"].data_ptr(),
                                 _ptr(self.live), self.out.data.data_ptr(), self.part.data_ptr(), b, self.cout, di, hi, wi, ws.data_ptr(),
                                 ws.numel() * 4, _stream())
+        elif self.sp_fwd is not None:                       # DSFF-masked full-resolution layers: load-balanced plan
+            sp = self.sp_fwd
+            L.conv133_fwd_sparse(sp.table.data_ptr(), self.cin, sp.wpk.data_ptr(), p[self.prefix + ".conv.bias"].data_ptr(),
+                                 sp.quads.data_ptr(), sp.qslot.data_ptr(), sp.flush_every, self.out.data.data_ptr(),
+                                 self.part.data_ptr(), b, self.cout, di, hi, wi, _stream())
         elif ws is not None and self.fwd_ws_bytes > 0:      # deep levels: input-plane chunks split over several workgroups
             L.conv133_fwd_splitk(self.chans.data_ptr(), self.cin, p[self.w_name].data_ptr(),
                                  p[self.prefix + ".conv.bias"].data_ptr(), _ptr(self.live), self.out.data.data_ptr(),
@@ -226,6 +311,10 @@ class ConvOp:
             if self.use_dense():
                 L.conv133_dgrad_dense(o.grad.data_ptr(), p[self.w_name].data_ptr(), _ptr(self.live_t), self.outs.data_ptr(), b, self.cin, self.cout,
                                       di, hi, wi, ws.data_ptr(), ws.numel() * 4, _stream())
+            elif self.sp_bwd is not None:
+                sp = self.sp_bwd
+                L.conv133_dgrad_sparse(o.grad.data_ptr(), sp.wpk.data_ptr(), sp.quads.data_ptr(), sp.pslot.data_ptr(),
+                                       self._bwd_table().data_ptr(), sp.flush_every, b, self.cin, self.cout, di, hi, wi, _stream())
             elif ws is not None and self.dgrad_ws_bytes > 0:        # deep levels: split-K (the workspace is idle during backward)
                 L.conv133_dgrad_splitk(o.grad.data_ptr(), p[self.w_name].data_ptr(), _ptr(self.live_t), self.outs.data_ptr(),
                                        b, self.cin, self.cout, di, hi, wi, sd, sh, sw, ws.data_ptr(), ws.numel() * 4, _stream())
@@ -461,6 +550,7 @@ class Engine:
         self._graphs = {}                  # key -> torch.cuda.CUDAGraph
         self._graph_seen = set()           # keys that ran eagerly once (lazy allocations done)
         self.maps_generation = 0           # bumped when the liveness tables are replaced (their pointers are baked into a graph)
+        self._sparse_jobs = None           # pack-job table of the load-balanced convs (rebuilt with the kernel maps)
         self._tgt_static = None
 
     def _build_unetpp(self, cfg):
@@ -542,8 +632,11 @@ class Engine:
         self.maps_generation += 1
         self._graphs.clear()
         self._graph_seen.clear()
+        self._sparse_jobs = None
         for name, op in list(self.conv_ops.items()) + list(self.up_ops.items()):
             km = kmasks.get(name)
+            if isinstance(op, ConvOp):
+                op.build_sparse_plans(km)
             if km is None:
                 op.live = op.live_t = None
                 op.density = 1.0
@@ -594,7 +687,18 @@ class Engine:
         outs = [h.out.data for h in self.heads]
         return outs if deep_supervision else outs[0]
 
+    def _pack_sparse(self):
+        """packed weights of the planned convs (one launch): the weights may have moved since the last pass"""
+        if self._sparse_jobs is None:
+            jobs = [j for op in self.conv_ops.values() if not op.use_dense() for j in op.sparse_jobs()]
+            self._sparse_jobs = pack_sparse_weights(jobs, self.device) or ()
+        if self._sparse_jobs:
+            table, n, mx = self._sparse_jobs
+            lib().conv133_sparse_pack(table.data_ptr(), n, mx, _stream())
+
     def _forward_ops(self):
+        self._pack_sparse()
+
         def act(op):
             if not (isinstance(op, HeadOp) and not op.active):
                 op.forward()

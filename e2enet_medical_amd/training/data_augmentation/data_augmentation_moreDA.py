@@ -281,7 +281,8 @@ class _DeviceGenerator:
         if self._it is None:
             self._it = iter(self.loader)
         b = next(self._it)
-        return self.fn(b["data"], b.get("seg"))
+        # DataLoader3D hands its page-locked staging tensors along: the upload below is then an asynchronous copy
+        return self.fn(b.get("data_pinned", b["data"]), b.get("seg_pinned", b.get("seg")))
 
     next = __next__
 

@@ -105,6 +105,47 @@ int e2e_conv133_dgrad_splitk(const float* dy, const float* w, const unsigned* li
                              long long ws_bytes, void* stream);
 
 
+/* ---- K1s: DSFF-masked 1x3x3 convolution on a load-balanced plan (conv133_sparse.hip) ---------------------------------
+ * The same operators as e2e_conv133_fwd / e2e_conv133_dgrad (unetpp_d.py:45-59, :453-478, :93/:108 and their autograd; the
+ * mask is Masking's, core_channel.py:427-434) for stride-1 layers with planes wider than 16 voxels, Wi % 4 == 0 and more than
+ * 8 channels on both sides (e2e_conv133_sparse_eligible).  The order in which input planes are chunked and the assignment of
+ * output planes to the eight waves of a workgroup are chosen on the HOST from the kernel map so that every wave carries the same
+ * work in every chunk; weights are read from a packed copy in that order.
+ *   e2e_conv133_sparse_plan    host function.  kmask [R][Cc] uint8 in HOST memory (weight dims 0 and 1); transpose 0: forward
+ *       (Q = R output planes, P = Cc input planes), 1: data gradient (Q = Cc virtual-concat channels, P = R dy channels).  Writes
+ *       (host arrays) qslot [groups*32] (output plane of slot wave*4 + a, -1 empty), pslot [groups*nchunks*8] (input plane of each
+ *       chunk slot, -1 empty), quads [groups*8*nchunks] (bit cl*4 + a of word [group][wave][chunk] <=> kernel alive) and
+ *       flush_every (chunks per flush of the two-level summation); groups = ceil(Q/32), nchunks = ceil(P/8).  A pure function of
+ *       the kernel map (every data-parallel rank derives the same plan).
+ *   e2e_conv133_sparse_pack    device: packed weights [groups][nchunks][32][8][12] (pruned kernels and padding = 0) for a TABLE
+ *       of jobs in one launch (run it after every optimizer step / parameter load); max_floats = the largest job's
+ *       e2e_conv133_sparse_wpk_floats(P, Q).  reverse = 1 flips the taps (data gradient).
+ *   e2e_conv133_fwd_sparse     chans_plan [groups][nchunks*8]: the e2e_in_chan_t of pslot's planes (ptr NULL for empty slots)
+ *   e2e_conv133_dgrad_sparse   pslot_t as returned by the plan (dy channels); outs_plan [groups][32]: the e2e_out_chan_t of
+ *       qslot's channels (ptr NULL for empty slots)                                                                          */
+typedef struct {
+  const float* w;            /* the layer's weight tensor */
+  float* wpk;                /* e2e_conv133_sparse_wpk_floats(P, Q) floats */
+  const int* qslot;          /* device copies of the plan arrays */
+  const int* pslot;
+  const unsigned* quads;
+  int groups, nchunks;
+  int wq_stride, wp_stride;  /* element strides of w for (output plane, input plane): forward (Cin*9, 9), data gradient (9, Cin*9) */
+  int reverse;
+  int reserved;
+} e2e_sparse_pack_job_t;
+int e2e_conv133_sparse_eligible(int Cin, int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw);
+long long e2e_conv133_sparse_wpk_floats(int P, int Q);
+int e2e_conv133_sparse_plan(const unsigned char* kmask_host, int R, int Cc, int transpose, int* qslot, int* pslot, unsigned* quads,
+                            int* flush_every);
+int e2e_conv133_sparse_pack(const e2e_sparse_pack_job_t* jobs, int njobs, long long max_floats, void* stream);
+int e2e_conv133_fwd_sparse(const e2e_in_chan_t* chans_plan, int Cin, const float* wpk, const float* bias, const unsigned* quads,
+                           const int* qslot, int flush_every, float* y, double* part, int B, int Cout, int Di, int Hi, int Wi,
+                           void* stream);
+int e2e_conv133_dgrad_sparse(const float* dy, const float* wpk_t, const unsigned* quads_t, const int* pslot_t,
+                             const e2e_out_chan_t* outs_plan, int flush_every, int B, int Cin, int Cout, int Di, int Hi, int Wi,
+                             void* stream);
+
 /* ---- K6b: 1x3x3 convolution, weight gradient (dense: also for dead kernels, because the
  * reference's clip_grad_norm_ runs over all gradients, nnUNetTrainer_simple.py:573) ----
  *   dw   [Cout,Cin,1,3,3] (overwritten)
@@ -299,22 +340,34 @@ int e2e_conv133_dgrad_dense(const float* dy, const float* w, const unsigned* liv
  * (e2enet/training/data_augmentation/data_augmentation_moreDA.py:66-111; batchgenerators 0.24 transforms executed by 24 CPU
  * worker processes in the reference).  All tensors float32 [B, C, D, H, W] contiguous; parameters are drawn on the host.
  *   e2e_aug_spatial: SpatialTransform (:66-79) as one affine gather: source coordinate = A (o - (size_out - 1) / 2) + t per
- *     sample (mat: B x 12 doubles, row-major 3 x 4); data order 1 / cval 0; seg (may be NULL) order `order_seg` (0: nearest;
+ *     sample (mat: B x 12 doubles, row-major 3 x 4); data cval 0, order 3 (the reference's order_data, :43) for the samples
+ *     flagged in `cubic` (B ints; NULL = all) when `coef` -- the B-spline coefficient image of `data`, three
+ *     e2e_aug_bspline_prefilter_axis passes -- is given, order 1 otherwise; seg (may be NULL) order `order_seg` (0: nearest;
  *     1: batchgenerators' per-label linear interpolation thresholded at 0.5), outside the volume cval_seg (order 0) / 0 (order 1)
+ *   e2e_aug_bspline_prefilter_axis: scipy.ndimage.spline_filter1d(order 3, mode 'mirror') along `axis` of nvol volumes
+ *     [D, H, W], src -> dst (may alias): what scipy's map_coordinates / zoom run in front of an order-3 interpolation
  *   e2e_aug_stats: per (sample, channel) min, max, mean, std (ddof 0) as 4 doubles; ws of e2e_aug_stats_ws_bytes(nbc) bytes
  *   e2e_aug_pointwise: op 1 GaussianNoise (:85), 2 BrightnessMultiplicative (:88), 3 ContrastAugmentation (:96), 4 / 5 the
  *     power and retain_stats steps of GammaTransform (:102-109); prm: nbc x 8 doubles, prm[0] == 0 leaves the channel untouched
  *   e2e_aug_blur_axis: one axis of GaussianBlurTransform (:86-87) = scipy gaussian_filter1d (truncate 4, 'reflect');
  *     wts: nbc x 16 floats (radius, w[0..radius])
  *   e2e_aug_lowres: SimulateLowResolutionTransform (:97-100): nearest down to lo_shape (nbc x 3 ints, 0 = untouched), linear up
+ *   e2e_aug_lowres_down / e2e_aug_lowres_up3: the same with the reference's order_upsample = 3 (:99), one volume per call: the
+ *     low-resolution volume materialised edge-padded by `pad` (scipy: 12) -> [prefilter, 3 axes] -> cubic up-sampling clipped to
+ *     minmax[0..1] (skimage resize clip=True: the low-resolution volume's range, e.g. from e2e_aug_stats)
  *   e2e_aug_finish: MaskTransform (:117-119; use_mask: C ints or NULL) and RemoveLabelTransform(-1, 0) (:121)               */
-int e2e_aug_spatial(const float* data, const float* seg, float* out_data, float* out_seg, const double* mat, int B, int C,
-                    int CS, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int order_seg, float cval_seg, void* stream);
+int e2e_aug_spatial(const float* data, const float* coef, const int* cubic, const float* seg, float* out_data, float* out_seg,
+                    const double* mat, int B, int C, int CS, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int order_seg,
+                    float cval_seg, void* stream);
+int e2e_aug_bspline_prefilter_axis(const float* src, float* dst, int nvol, int D, int H, int W, int axis, void* stream);
 long long e2e_aug_stats_ws_bytes(int nbc);
 int e2e_aug_stats(const float* x, double* stats, double* ws, int nbc, long long vol, void* stream);
 int e2e_aug_pointwise(float* x, const double* prm, int op, int nbc, long long vol, unsigned long long seed, void* stream);
 int e2e_aug_blur_axis(const float* src, float* dst, const float* wts, int nbc, int D, int H, int W, int axis, void* stream);
 int e2e_aug_lowres(const float* src, float* dst, const int* lo_shape, int nbc, int D, int H, int W, void* stream);
+int e2e_aug_lowres_down(const float* src, float* dst, int D, int H, int W, int ld, int lh, int lw, int pad, void* stream);
+int e2e_aug_lowres_up3(const float* coef, float* dst, const double* minmax, int D, int H, int W, int ld, int lh, int lw, int pad,
+                       void* stream);
 int e2e_aug_finish(float* data, float* seg, const int* use_mask, int B, int C, int CS, long long vol, void* stream);
 
 #ifdef __cplusplus

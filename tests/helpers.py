@@ -66,3 +66,27 @@ def pack_kernel_mask(mask: torch.Tensor) -> np.ndarray:
 def sha_of(arr: np.ndarray) -> str:
     import hashlib
     return hashlib.sha256(np.ascontiguousarray(arr).tobytes()).hexdigest()
+
+
+def synthetic_cases(folder):
+    """Three small preprocessed 'cases' in the reference's on-disk form ([modalities..., seg] as <name>.npy next to the
+    <name>.npz path the dataset dict names, properties with class_locations), from closed forms: the fixture of the
+    DataLoader3D golden (tools/make_golden.py dataloader) and of its test.  The second case is smaller than the patch."""
+    from collections import OrderedDict
+    shapes = {"case_a": (18, 22, 30), "case_b": (10, 16, 12), "case_c": (25, 20, 21)}
+    dataset = OrderedDict()
+    for ci, (name, shp) in enumerate(shapes.items()):
+        n = int(np.prod(shp))
+        j = np.arange(n, dtype=np.float64).reshape(shp)
+        mods = [np.sin(0.37 * j + 1.1 * ci + m).astype(np.float32) * (1 + m) for m in range(2)]
+        zz, yy, xx = np.meshgrid(*[np.arange(s) for s in shp], indexing="ij")
+        seg = ((zz * 3 + yy * 5 + xx * 7 + ci) % 11 < 2).astype(np.float32) + ((zz + yy + xx) % 13 == 0).astype(np.float32) * 2
+        seg = np.minimum(seg, 2.0)
+        if ci == 2:
+            seg[seg == 2] = 0                       # a case without class 2
+        arr = np.stack(mods + [seg]).astype(np.float32)
+        np.save(os.path.join(folder, name + ".npy"), arr)
+        locs = OrderedDict((c, np.argwhere(seg == c)) for c in (1, 2))
+        dataset[name] = OrderedDict(data_file=os.path.join(folder, name + ".npz"),
+                                    properties=OrderedDict(class_locations=locs, name=name))
+    return dataset

@@ -59,12 +59,16 @@ def _logit_bars(spec, params, x):
     Per output head, with c = the fp32 CPU oracle's own largest distance from fp64 (the oracle is bit-identical to the
     reference on these configurations, tests/test_oracle_golden.py):
       * heads 0-2 (full, 1/2, 1/4 resolution) where c <= 1e-4, i.e. where fp32 defines the logits that well:
-        engine within 1e-4 of fp64 (max norm), within 2e-4 of the reference golden, RMS distance <= 1.5x the CPU's;
+        engine within 1e-4 of fp64 (max norm), within 1.2e-4 of the reference golden (measured 6.8-9.3e-5; round 3 allowed
+        2e-4), RMS distance <= 1.5x the CPU's;
       * the 1/8 head, and any head whose CPU evaluation is itself further than 1e-4 from fp64 (InstanceNorms over 8..175
         voxels amplify rounding noise 3-5x per level): same noise class as the CPU path -- max <= 2 c, RMS <= 2x the CPU's,
         within 3 c of the golden.
-    Measured values of every quantity for this build: profiles/r03_parity.json (tools/parity_report.py).  Returns
-    (fp64 logits, bars)."""
+    The distance engine <-> fp32 CPU oracle (= the reference CPU path the north_star names) is printed by every check and
+    recorded by tools/parity_report.py (profiles/r04_parity.json).  It is NOT below 1e-4 everywhere: on config 1 at full
+    resolution the CPU path itself sits 0.6-1.2e-4 from exact arithmetic and the engine 0.75-1.0e-4, so the two fp32
+    evaluations differ by 1.1-1.9e-4 from each other; the assertion made on it is the triangle bound 1e-4 + c.
+    Returns (fp64 logits, bars)."""
     with torch.no_grad():
         ref32 = oracle.forward(spec, params, x)
         ref64 = oracle.forward(spec, {n: p.detach().double() for n, p in params.items()}, x.double())
@@ -73,9 +77,10 @@ def _logit_bars(spec, params, x):
         d = (a.double() - b).abs()
         c_max, c_rms = d.max().item(), d.pow(2).mean().sqrt().item()
         if i < 3 and c_max <= 1e-4:
-            bars.append(_Bar(1e-4, 1.5 * c_rms, 2e-4))
+            bars.append(_Bar(1e-4, 1.5 * c_rms, 1.2e-4))
         else:
             bars.append(_Bar(2.0 * c_max, 2.0 * c_rms, 3.0 * c_max))
+        bars[-1].head, bars[-1].ref32, bars[-1].c_max = i, a, c_max
     return ref64, bars
 
 
@@ -85,11 +90,17 @@ class _Bar(float):
     def __new__(cls, mx, rms, gold):
         o = super().__new__(cls, mx)
         o.rms, o.gold = rms, gold
+        o.head, o.ref32, o.c_max = -1, None, None
         return o
 
     def check(self, got, ref64):
         d = (got.double() - ref64).abs()
         rms, mx = d.pow(2).mean().sqrt().item(), d.max().item()
+        if self.ref32 is not None:            # engine vs the fp32 CPU oracle (the reference CPU path), next to both vs fp64
+            e32 = (got.double() - self.ref32.double()).abs().max().item()
+            print("[logit parity] head %d: engine-fp64 max %.3e rms %.3e | engine-cpu32 max %.3e | cpu32-fp64 max %.3e | bar %.3e"
+                  % (self.head, mx, rms, e32, self.c_max, float(self)))
+            assert e32 <= float(self) + self.c_max, "engine vs fp32 CPU oracle %.3e > %.3e + %.3e" % (e32, float(self), self.c_max)
         assert rms <= self.rms, "rms distance from fp64 %.3e > %.3e" % (rms, self.rms)
         assert mx <= float(self), "max distance from fp64 %.3e > %.3e" % (mx, float(self))
         return True
@@ -619,3 +630,135 @@ def test_nodff_sparse_engine_fastpath_and_predict_vs_oracle():
                                                   mirror_axes=(0, 1, 2), use_gaussian=True)
     assert np.abs(probs - ref_probs).max() <= 2e-5
     assert (seg != ref_seg).mean() < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ configs 3 and 4 at their SURVEY 8d shapes
+BTCV_FULL = dict(patch=(48, 192, 192), cin=1, k=14, pools=[(1, 2, 2), (2, 2, 2), (2, 2, 2), (2, 2, 2), (1, 2, 2)], batch=2)
+CONV_ENTRIES = ["conv133_fwd", "conv133_fwd_splitk", "conv133_fwd_dense", "conv133_dgrad", "conv133_dgrad_splitk", "conv133_dgrad_dense",
+                "conv133_wgrad", "convT_fwd", "convT_dgrad", "convT_wgrad"]
+
+
+def test_config3_btcv_full_shape_vs_oracle_and_dsff_update_replay():
+    """BASELINE config 3 at the shape SURVEY section 8d gives it: [2, 1, 48, 192, 192], pools [[1,2,2],[2,2,2]x3,[1,2,2]], 14
+    classes, base 32, DSFF density 0.2 (He init under torch.manual_seed(0), masks under random.seed(0); reference
+    nnUNetTrainer_simple.py:292-301, :588-651).  The 192-wide / 48-deep planes and the (1,2,2) kernels at base width 32 meet the
+    size-dependent kernel dispatch here: all four logit heads within 1e-4 of the fp32 CPU oracle, loss within 5e-5, a sample of
+    parameter gradients against the oracle's, every kernel variant dispatched is recorded, and one Masking.truncate_weights()
+    (core_channel.py:556-611) on the trained-one-step weights is replayed bit-exactly by the oracle's death / growth rule."""
+    import bench
+    from e2enet_medical_amd.training.fused_optim import FusedClipSGD
+    dev = torch.device("cuda")
+    C = BTCV_FULL
+    net, opt, mask, fused = bench.build(dev, C["patch"], cin=C["cin"], k=C["k"], pools=C["pools"])
+    x, _ = bench.synthetic_batch(dev, C["patch"], C["batch"], seed=300, cin=C["cin"], k=C["k"])
+    eng = net.engine(x)
+    with KernelLog(CONV_ENTRIES) as kl:
+        outs = eng.forward(x, True)
+        targets = [seeded_labels((o.shape[0], 1) + tuple(o.shape[2:]), C["k"], seed=310 + i) for i, o in enumerate(outs)]
+        assert [tuple(o.shape[2:]) for o in outs] == [(48, 192, 192), (48, 96, 96), (24, 48, 48), (12, 24, 24)]
+        w = oracle.ds_weights(5)
+        loss = eng.loss_backward([t.cuda() for t in targets], w, batch_dice=False)
+        torch.cuda.synchronize()
+    variants = sorted({(n, k.split(" wgs=")[0]) for n, k in kl.log})
+    print("[config 3 kernel variants]")
+    for n, k in variants:
+        print("   %-22s %s" % (n, k))
+    fams = {k.split("<")[0].split(" ")[0] for _, k in variants}
+    assert {"conv133_kernel", "conv133_dense_bf3", "convT_fwd_bf3", "convT_dgrad_bf3"} <= fams, fams
+    # ---- the CPU oracle on the identical batch (forward + loss, fp32)
+    spec = oracle.make_spec(C["cin"], bench.BASE, C["k"], C["pools"])
+    params = {n: p.detach().cpu().clone() for n, p in net.named_parameters()}
+    for n, m in mask.masks.items():
+        assert float((params[n] * (1 - m.cpu())).abs().max()) == 0.0
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), 16)))
+    with torch.no_grad():
+        ref = oracle.forward(spec, params, x.cpu())
+        ref_loss = oracle.deep_supervision_loss(ref, targets, w, False)
+    for i, (o, r) in enumerate(zip(outs, ref)):
+        err = (o.cpu() - r).abs().max().item()
+        print("[config 3] head %d max|dlogit| vs cpu32 %.3e" % (i, err))
+        assert o.shape == r.shape and err <= 1e-4, "head %d: max|dlogit| %.3e" % (i, err)
+    assert abs(loss.item() - ref_loss.item()) <= 5e-5
+    del ref
+    # gradients on the first sample alone (the oracle's autograd graph of the full batch would hold ~30 GB on the host): every
+    # tensor in the fp32 noise class of a network this deep (relative L2; a wrong tap, shift, stride or mask is O(1)); the
+    # full-resolution and head tensors, whose sums run over millions of voxels, tightly
+    x1, t1 = x[:1].contiguous(), [t[:1].contiguous() for t in targets]
+    eng1 = net.engine(x1)
+    eng1.forward(x1, True)
+    loss1 = eng1.loss_backward([t.cuda() for t in t1], w, batch_dice=False)
+    leaves = {n: p.clone().requires_grad_(True) for n, p in params.items()}
+    ref_loss1 = oracle.deep_supervision_loss(oracle.forward(spec, leaves, x1.cpu()), t1, w, False)
+    assert abs(loss1.item() - ref_loss1.item()) <= 5e-5
+    ref_loss1.backward()
+    worst = (0.0, None)
+    for n in params:
+        rg = leaves[n].grad
+        nrm = rg.norm().item()
+        if nrm <= 1e-6:
+            continue
+        rel = (eng1.grads[n].cpu() - rg).norm().item() / nrm
+        if rel > worst[0]:
+            worst = (rel, n)
+        tight = n.startswith("seg_outputs") or n.startswith("loc0.4") or n == "up0.4.weight"
+        assert rel <= (2e-3 if tight else 1e-1), (n, rel)
+    print("[config 3] worst gradient tensor rel-L2 vs cpu32 (B = 1): %.3e (%s)" % worst)
+    del leaves
+    # ---- one optimizer step, then the DSFF update on the device, replayed by the oracle's rule on the same weights and draws
+    fused.step(eng.grads, mask.masks)
+    names = list(mask.masks.keys())
+    pre_w = {n: net.get_parameter(n).detach().cpu().clone() for n in names}
+    pre_m = {n: mask.masks[n].cpu().clone() for n in names}
+    state = random.getstate()
+    mask.truncate_weights()
+    random.setstate(state)
+    rep, nd = {}, {}
+    for n in names:
+        rep[n], nd[n] = oracle.kernel_death(pre_m[n].clone(), pre_w[n] * pre_m[n], mask.death_rate)
+    changed = 0
+    for n in names:
+        rep[n] = oracle.kernel_growth(rep[n], nd[n])
+        got = mask.masks[n].cpu()
+        assert torch.equal(got, rep[n]), "DSFF update: mask indices of %s differ from the oracle's replay" % n
+        assert int(got.sum().item()) == int(pre_m[n].sum().item())             # nnz conserved
+        changed += int((got != pre_m[n]).sum().item())
+        assert float((net.get_parameter(n).detach().cpu() * (1 - got)).abs().max()) == 0.0
+    assert changed > 0
+    # the plan picks the new kernel maps up at its next forward and still agrees with itself
+    outs2 = eng.forward(x, True)
+    assert all(torch.isfinite(o).all() for o in outs2)
+
+
+def test_config4_amos_volume_tiles_vs_oracle():
+    """BASELINE config 4 (reference neural_network.py:286-426, :500-565) at its SURVEY 8d size: crops of the [1, 220, 400, 400]
+    benchmark volume at patch 128^3, 16 classes, base 32, density 0.2, 8 mirrors -- an interior tile of the volume's own
+    tile grid, and a corner region wide enough for two overlapping tiles (Gaussian overlap-add) -- through predict_3D against
+    oracle.predict_tiled on the same crop: probabilities within 2e-5, segmentations equal up to 1e-3 of the voxels."""
+    import bench
+    from e2enet_medical_amd.utilities.nd_softmax import softmax_helper
+    dev = torch.device("cuda")
+    net, _, mask, _ = bench.build(dev, bench.PATCH, cin=1, k=16, seed=1)
+    net.inference_apply_nonlin = softmax_helper
+    net.eval()
+    net.do_ds = False
+    vol = torch.randn((1, 220, 400, 400), generator=torch.Generator().manual_seed(7)).numpy()      # the benchmark's volume
+    steps = net._compute_steps_for_sliding_window(bench.PATCH, vol.shape[1:], 0.5)
+    assert [len(s) for s in steps] == [3, 6, 6]
+    sx, sy, sz = steps[0][1], steps[1][2], steps[2][3]                                           # an interior tile of the grid
+    crops = [vol[:, sx:sx + 128, sy:sy + 128, sz:sz + 128], vol[:, 220 - 128:, 400 - 128:, 400 - 176:]]
+    spec = oracle.make_spec(1, bench.BASE, 16, bench.POOLS)
+    params = {n: p.detach().cpu().clone() for n, p in net.named_parameters()}
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), 16)))
+    kw = dict(do_mirroring=True, mirror_axes=(0, 1, 2), use_sliding_window=True, step_size=0.5, patch_size=bench.PATCH,
+              use_gaussian=True, verbose=False)
+    for ci, crop in enumerate(crops):
+        crop = np.ascontiguousarray(crop)
+        seg, probs = net.predict_3D(crop, **kw)
+        with torch.no_grad():
+            rseg, rprobs = oracle.predict_tiled(lambda t: F.softmax(oracle.forward(spec, params, t, do_ds=False), 1), crop, 16,
+                                                bench.PATCH, 0.5, True, (0, 1, 2), True)
+        err = float(np.abs(probs - rprobs).max())
+        print("[config 4] crop %d %s: max|dprob| %.3e, argmax mismatch %.2e" % (ci, crop.shape[1:], err, float((seg != rseg).mean())))
+        assert seg.shape == crop.shape[1:] and probs.shape == (16,) + crop.shape[1:]
+        assert err <= 2e-5
+        assert (seg != rseg).mean() <= 1e-3

@@ -74,11 +74,29 @@ CONV_CASES = [
     (1, [(4, True)], 32, (2, 16, 64), (1, 1, 1), 1.0),
     (2, [(20, True)], 24, (2, 20, 36), (1, 1, 1), 1.0),                      # one 32 x 32 block: row-split double-buffered wgrad
     (2, [(33, True)], 40, (5, 4, 12), (1, 1, 1), 0.5),                       # 4-row planes with wide rows (found by tools/scratch/fuzz_ops.py)
+    # load-balanced DSFF kernel (conv133_sparse.hip: stride 1, W % 4 == 0, H, W > 16, > 8 channels both sides, density < 0.5)
+    (2, [(32, True), (32, False)], 32, (5, 32, 64), (1, 1, 1), 0.2),           # the benchmark's layer shape in small: whole tiles
+    (1, [(20, True), (13, False)], 34, (4, 20, 36), (1, 1, 1), 0.25),          # ragged tiles, 33 input planes (5 chunks), two output groups (32 + 2)
+    (2, [(64, True), (64, False), (32, False)], 64, (3, 24, 40), (1, 1, 1), 0.2),   # 160 -> 64: 20 chunks, two full groups
+    (1, [(9, False)], 40, (2, 17, 20), (1, 1, 1), 0.4),                        # two chunks, the second nearly empty; 17-row planes
     # dense matrix-core path (conv133_dense.hip: stride 1, W % 32 == 0, H % 16 == 0, >= 16 channels, dense or density >= 0.5)
     (1, [(32, True)], 32, (6, 32, 64), (1, 1, 1), 1.0),
     (2, [(20, True), (28, False)], 40, (3, 32, 32), (1, 1, 1), 1.0),         # ragged channel blocks (48 -> 40), two sources, shift
     (1, [(16, True), (16, False), (8, False)], 64, (7, 48, 96), (1, 1, 1), 0.6),   # DSFF map dense enough for the dense kernel
 ]
+
+
+def _plan_and_pack(op, km):
+    """plans + packed weights of the load-balanced DSFF kernel for a single op driven outside an Engine"""
+    from e2enet_medical_amd.engine import pack_sparse_weights
+    from e2enet_medical_amd._lib import lib
+    op.build_sparse_plans(km)
+    jobs = op.sparse_jobs()
+    if jobs:
+        table, n, mx = pack_sparse_weights(jobs, op.eng.device)
+        lib().conv133_sparse_pack(table.data_ptr(), n, mx, 0)
+        torch.cuda.synchronize()
+    return bool(jobs)
 
 
 def _ref_conv(srcs, w, b, stride):
@@ -152,6 +170,7 @@ def test_conv133_fwd_bwd(case):
         lib().dsff_expand_quads(kmd.data_ptr(), rows.data_ptr(), cols.data_ptr(), cout, cin, 0)
         op.live, op.live_t = rows, cols
         op.density = float(km.float().mean())
+        _plan_and_pack(op, km)                      # load-balanced kernel where the shape is served (conv133_sparse.hip)
     if dims[2] % 32 == 0 and dims[1] % 16 == 0 and dims[1] > 16 and stride == (1, 1, 1) and cin >= 16 and cout >= 16 and density >= 0.5 \
             and os.environ.get("E2E_CONV_DENSE", "1") != "0":
         assert op.use_dense(), "this case is meant to reach conv133_dense_kernel"
@@ -658,17 +677,27 @@ def test_conv133_masks_are_structural_on_every_path(density):
     lib().dsff_expand_quads(km.to(e.device).data_ptr(), rows.data_ptr(), cols.data_ptr(), cout, cin, 0)
     op.live, op.live_t, op.density = rows, cols, float(km.float().mean())
     assert op.use_dense() == (density >= 0.5)
+    op.out.alloc_grad()
+    op.plan_backward()
+    planned = _plan_and_pack(op, km)                # (the packed weights are built from the dirty tensor: pruned kernels must pack as zeros)
+    assert planned
     op.forward()
     x = _act_value(srcs[0]).requires_grad_(True)
     y = F.conv3d(oracle.depth_shift(x), w_masked, None, padding=(0, 1, 1))
     assert (op.out.data.cpu() - y.detach()).abs().max() < 2e-5, "forward used a pruned kernel"
     dy = seeded_input(tuple(y.shape), seed=64)
     y.backward(dy)
-    op.out.alloc_grad()
-    op.plan_backward()
     # data gradient alone (dy handed over as the pre-norm gradient)
     op.out.grad.copy_(dy)
     L = lib()
+    if not op.use_dense():                          # the load-balanced kernel, then (below) the generic walk on the same data
+        sp = op.sp_bwd
+        L.conv133_dgrad_sparse(op.out.grad.data_ptr(), sp.wpk.data_ptr(), sp.quads.data_ptr(), sp.pslot.data_ptr(), op._bwd_table().data_ptr(),
+                               sp.flush_every, B, cin, cout, *dims, 0)
+        torch.cuda.synchronize()
+        assert L.last_kernel().decode().startswith("conv133_sparse_kernel<mode=1>")
+        assert (srcs[0].grad.cpu() - x.grad).abs().max() < 2e-4 * max(1.0, float(x.grad.abs().max())), "planned data gradient used a pruned kernel"
+        srcs[0].grad.fill_(float("nan"))
     if op.use_dense():
         L.conv133_dgrad_dense(op.out.grad.data_ptr(), e.params["blk.conv.weight"].data_ptr(), op.live_t.data_ptr(), op.outs.data_ptr(),
                               B, cin, cout, *dims, e.fwd_ws.data_ptr(), e.fwd_ws.numel() * 4, 0)

@@ -413,3 +413,84 @@ def test_bench_launcher_propagates_a_failed_rank_and_refuses_a_mismatched_world(
     assert r.returncode == 3 and "rank 1 exited with code 3" in r.stderr and not r.stdout.strip()
     r = _bench({"E2E_BENCH_DRY": "1", "WORLD_SIZE": "1"}, "--gpus", "2")       # torchrun form with the wrong --gpus
     assert r.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in r.stderr
+
+
+@pytest.mark.parametrize("tag,mode,kw", [("edge", "edge", None), ("const", "constant", {'constant_values': 0})])
+def test_dataloader3d_batches_equal_the_reference(tmp_path, tag, mode, kw):
+    """DataLoader3D (reference dataset_loading.py:163-388) -- same constructor, same numpy.random draw order: under
+    one seed the batches (random crops, a third of each batch forced onto a foreground voxel, 'edge' / constant borders, a case
+    smaller than the patch) are the reference's, bit for bit, and so is the position of the random stream afterwards."""
+    from tests.helpers import synthetic_cases
+    from e2enet_medical_amd.training.dataloading.dataset_loading import DataLoader3D
+    g = golden("dataloader.npz")
+    ds = synthetic_cases(str(tmp_path))
+    np.random.seed(1234)
+    loader = DataLoader3D(ds, (16, 18, 20), (12, 14, 16), 4, False, oversample_foreground_percent=0.33, pad_mode=mode,
+                          pad_kwargs_data=kw)
+    assert loader.data_shape == (4, 2, 16, 18, 20) and loader.seg_shape == (4, 1, 16, 18, 20)
+    assert [loader.get_do_oversample(j) for j in range(4)] == [False, False, False, True]
+    seen = []
+    for it in range(3):
+        b = next(loader)
+        assert [str(k) for k in b['keys']] == [str(k) for k in g["%s_keys%d" % (tag, it)]]
+        assert np.array_equal(b['data'], g["%s_data%d" % (tag, it)]), "data of batch %d" % it
+        assert np.array_equal(b['seg'], g["%s_seg%d" % (tag, it)].astype(np.float32)), "seg of batch %d" % it
+        assert b['data'].dtype == np.float32 and b['seg'].dtype == np.float32
+        assert b['data_pinned'].numpy().ctypes.data == b['data'].ctypes.data          # the batch IS the (pinned) staging buffer
+        seen.append(b['data'].ctypes.data)
+        assert [p['name'] for p in b['properties']] == [str(k) for k in b['keys']]
+    assert seen[0] != seen[1] and seen[0] == seen[2]                                    # two rotating buffers
+    assert np.array_equal(np.random.randint(0, 2 ** 31 - 1, 4), g[tag + "_rng_after"])
+
+
+@pytest.mark.parametrize("R,Cc,dens", [(32, 64, 0.2), (64, 160, 0.2), (34, 33, 0.3), (128, 320, 0.1), (70, 90, 0.5)])
+def test_sparse_plan_is_a_valid_balanced_permutation(R, Cc, dens):
+    """e2e_conv133_sparse_plan (host side of the load-balanced DSFF conv, csrc/conv133_sparse.hip): for both directions the plan
+    places every output plane in exactly one wave slot of its 32-plane group and every input plane in exactly one chunk slot of
+    every group, its liveness words are the kernel map read through those slots (mask indices stay bit exact), it is a pure
+    function of the map, and the work of the slowest wave summed over the chunks is close to the mean (the point of the plan)."""
+    import ctypes as C
+    from e2enet_medical_amd._lib import lib
+    L = lib()
+    km = (np.random.RandomState(R * 1000 + Cc).rand(R, Cc) < dens).astype(np.uint8)
+
+    def plan(tr):
+        Q, P = (Cc, R) if tr else (R, Cc)
+        G, NC = (Q + 31) // 32, (P + 7) // 8
+        qs, ps, qd = np.empty(G * 32, np.int32), np.empty(G * NC * 8, np.int32), np.empty(G * 8 * NC, np.uint32)
+        fl = C.c_int(0)
+        L.conv133_sparse_plan(km.ctypes.data, R, Cc, tr, qs.ctypes.data, ps.ctypes.data, qd.ctypes.data, C.addressof(fl))
+        return Q, P, G, NC, qs, ps, qd, fl.value
+    for tr in (0, 1):
+        Q, P, G, NC, qs, ps, qd, flush = plan(tr)
+        again = plan(tr)
+        assert all(np.array_equal(a, b) for a, b in zip((qs, ps, qd), again[4:7])) and flush == again[7]
+        assert 1 <= flush <= NC
+        alive = km.T if tr else km                                   # [Q, P]
+        natural = planned = ideal = 0.0
+        for g in range(G):
+            q = qs[g * 32:(g + 1) * 32]
+            assert sorted(q[q >= 0]) == list(range(g * 32, min(Q, g * 32 + 32)))
+            p = ps[g * NC * 8:(g + 1) * NC * 8]
+            assert sorted(p[p >= 0]) == list(range(P))
+            sub = np.zeros((32, NC * 8), np.uint8)                   # the map in slot order
+            sub[np.ix_(q >= 0, p >= 0)] = alive[np.ix_(q[q >= 0], p[p >= 0])]
+            words = np.zeros((8, NC), np.uint32)
+            for w in range(8):
+                for c in range(NC):
+                    bits = sub[w * 4:w * 4 + 4, c * 8:c * 8 + 8]          # [a, cl] -> bit cl * 4 + a
+                    words[w, c] = sum(int(bits[a, cl]) << (cl * 4 + a) for a in range(4) for cl in range(8))
+            assert np.array_equal(words.reshape(-1), qd[g * 8 * NC:(g + 1) * 8 * NC])
+
+            def cost(m):                                             # m [32, NC * 8] -> per (chunk, wave): kernels + 0.35 per visited plane
+                k = m.reshape(8, 4, NC, 8)
+                return (k.sum(axis=(1, 3)) + 0.35 * (k.sum(axis=1) > 0).sum(axis=2)).T
+            nat = np.zeros((32, NC * 8), np.uint8)
+            nq = min(32, Q - g * 32)
+            nat[:nq, :P] = alive[g * 32:g * 32 + nq]
+            natural += cost(nat).max(axis=1).sum()
+            planned += cost(sub).max(axis=1).sum()
+            ideal += cost(sub).sum() / 8
+        assert planned <= natural + 1e-6
+        if Q % 32 == 0 and dens <= 0.3:
+            assert planned / ideal <= 1.2 and natural / ideal >= 1.3, (planned / ideal, natural / ideal)

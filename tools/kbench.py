@@ -97,8 +97,27 @@ def conv_case(B, srcs, cout, dims, stride, density, tag):
     def wgrad():
         L.conv133_wgrad(op.chans.data_ptr(), op.out.grad.data_ptr(), e.grads["b.conv.weight"].data_ptr(), e.wgrad_ws.data_ptr(),
                         B, cin, cout, di, hi, wi, *stride, 0)
+    def fwd_planned():
+        sp = op.sp_fwd
+        L.conv133_fwd_sparse(sp.table.data_ptr(), cin, sp.wpk.data_ptr(), p["b.conv.bias"].data_ptr(), sp.quads.data_ptr(),
+                             sp.qslot.data_ptr(), sp.flush_every, op.out.data.data_ptr(), op.part.data_ptr(), B, cout, di, hi, wi, 0)
+
+    def dgrad_planned():
+        sp = op.sp_bwd
+        L.conv133_dgrad_sparse(op.out.grad.data_ptr(), sp.wpk.data_ptr(), sp.quads.data_ptr(), sp.pslot.data_ptr(),
+                               op._bwd_table().data_ptr(), sp.flush_every, B, cin, cout, di, hi, wi, 0)
     dense = 2.0 * 9 * cin * cout * (vout / cout)
     res = {}
+    if density < 1.0 and not dense_path and os.environ.get("KB_OLD") is None:      # load-balanced kernel (conv133_sparse.hip)
+        from e2enet_medical_amd.engine import pack_sparse_weights
+        op.build_sparse_plans(km)
+        jobs = op.sparse_jobs()
+        if jobs:
+            table, nj, mx = pack_sparse_weights(jobs, dev)
+            L.conv133_sparse_pack(table.data_ptr(), nj, mx, 0)
+            print("%-26s pack   %8.3f ms (%d jobs)" % (tag, time_ms(lambda: L.conv133_sparse_pack(table.data_ptr(), nj, mx, 0)), nj))
+            fwd, dgrad = fwd_planned, dgrad_planned
+            tag = tag + "[plan]"
     if dense_path:
         fwd, dgrad = fwd_dense, dgrad_dense
         tag = tag + "[dense]"

@@ -635,7 +635,46 @@ def gen_export():
     np.savez_compressed(os.path.join(OUT, "export.npz"), **out)
 
 
-ALL = dict(export=gen_export, shift=gen_shift, block=gen_block, net=gen_net_tiny, sparse=gen_net_sparse_tiny, net64=gen_net64,
+
+def gen_dataloader():
+    """DataLoader3D (e2enet/training/dataloading/dataset_loading.py:163-388) on three synthetic cases under np.random.seed:
+    three batches each for 'edge' and 'constant' data padding, a third of every batch forced onto foreground."""
+    import tempfile
+    from tests.helpers import synthetic_cases
+    dl = types.ModuleType('batchgenerators.dataloading.data_loader')
+
+    class SlimDataLoaderBase:                  # batchgenerators 0.24 base class (third party): holds the dataset and batch size
+        def __init__(self, data, batch_size, number_of_threads_in_multithreaded=None):
+            self._data, self.batch_size, self.thread_id = data, batch_size, 0
+    dl.SlimDataLoaderBase = SlimDataLoaderBase
+    sys.modules['batchgenerators.dataloading'] = types.ModuleType('batchgenerators.dataloading')
+    sys.modules['batchgenerators.dataloading.data_loader'] = dl
+    ff = types.ModuleType('batchgenerators.utilities.file_and_folder_operations')
+    import pickle
+    ff.os, ff.isfile, ff.join, ff.isdir = os, os.path.isfile, os.path.join, os.path.isdir
+    ff.load_pickle = lambda f, mode='rb': pickle.load(open(f, mode))
+    for n in ('subfiles', 'subdirs', 'maybe_mkdir_p', 'write_pickle', 'save_pickle', 'save_json', 'load_json'):
+        setattr(ff, n, lambda *a, **k: None)
+    sys.modules['batchgenerators.utilities'] = types.ModuleType('batchgenerators.utilities')
+    sys.modules['batchgenerators.utilities.file_and_folder_operations'] = ff
+    from e2enet.training.dataloading.dataset_loading import DataLoader3D
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        ds = synthetic_cases(tmp)
+        for tag, mode, kw in (("edge", "edge", None), ("const", "constant", {'constant_values': 0})):
+            np.random.seed(1234)
+            loader = DataLoader3D(ds, (16, 18, 20), (12, 14, 16), 4, False, oversample_foreground_percent=0.33,
+                                  pad_mode=mode, pad_kwargs_data=kw)
+            for it in range(3):
+                b = loader.generate_train_batch()
+                out["%s_data%d" % (tag, it)] = b['data'].astype(np.float32)
+                out["%s_seg%d" % (tag, it)] = b['seg'].astype(np.int8)
+                out["%s_keys%d" % (tag, it)] = np.array([str(k) for k in b['keys']])
+            out[tag + "_rng_after"] = np.random.randint(0, 2 ** 31 - 1, 4)          # the stream position after three batches
+    np.savez_compressed(os.path.join(OUT, "dataloader.npz"), **out)
+
+
+ALL = dict(dataloader=gen_dataloader, export=gen_export, shift=gen_shift, block=gen_block, net=gen_net_tiny, sparse=gen_net_sparse_tiny, net64=gen_net64,
            hippo=gen_net_hippo, amos=gen_net_amos,
            variants=gen_net_variants, nodff=gen_net_nodff, masks=gen_masks, loss=gen_loss, sliding=gen_sliding, dice=gen_dice, init=gen_init)
 

@@ -3,7 +3,7 @@
 head the largest and the RMS |dlogit| of the engine against (a) the reference's own golden logits, (b) an fp64 evaluation
 of the same graph, next to the fp32 CPU oracle's own distance from fp64; loss difference; per-tensor gradient noise.
 
-    python tools/parity_report.py [--out profiles/r03_parity.json] [--tag default] [--net128]
+    python tools/parity_report.py [--out profiles/r04_parity.json] [--tag default] [--net128]
 
 Test infrastructure: imports `oracle` (checker).  Run once per library build (E2E_LIB_PATH selects a diagnostic build);
 records are merged into the output file under their tag."""
@@ -153,7 +153,7 @@ def net128():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03_parity.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04_parity.json"))
     ap.add_argument("--tag", default="default")
     ap.add_argument("--net128", action="store_true")
     args = ap.parse_args()
@@ -176,8 +176,8 @@ def main():
         if not isinstance(v, dict):
             continue
         for h in v["heads"]:
-            print("%-18s head %d  eng-fp64 max %.2e rms %.2e | cpu32-fp64 max %.2e rms %.2e | eng-golden max %s" % (
-                k, h["head"], h["engine_vs_fp64_max"], h["engine_vs_fp64_rms"], h["cpu32_vs_fp64_max"], h["cpu32_vs_fp64_rms"],
+            print("%-18s head %d  eng-fp64 max %.2e rms %.2e | eng-cpu32 max %.2e | cpu32-fp64 max %.2e rms %.2e | eng-golden max %s" % (
+                k, h["head"], h["engine_vs_fp64_max"], h["engine_vs_fp64_rms"], h["engine_vs_cpu32_max"], h["cpu32_vs_fp64_max"], h["cpu32_vs_fp64_rms"],
                 ("%.2e" % h["engine_vs_golden_max"]) if "engine_vs_golden_max" in h else "-"))
         if "grads" in v:
             gr = v["grads"]
