@@ -139,6 +139,10 @@ def conv_work(eng, mask):
         by_ptr[op.chans.data_ptr()] = rec
         if op.outs is not None:
             by_ptr[op.outs.data_ptr()] = rec
+        if op.sp_fwd is not None:                        # load-balanced kernel: plane / destination tables in plan order
+            by_ptr[op.sp_fwd.table.data_ptr()] = rec
+        if op.sp_bwd is not None and op.out_structs is not None:
+            by_ptr[op._bwd_table().data_ptr()] = rec
     return by_ptr
 
 
@@ -499,8 +503,8 @@ def main():
 
     # ---- instrumented steps (outside the timed region): HIP events around the conv entry points --------------------
     # (_splitk: the deep levels' forward / data gradient, same kernel + a sum kernel; _dense: the unmasked layers on the matrix cores)
-    names = ["conv133_fwd", "conv133_fwd_splitk", "conv133_fwd_dense", "conv133_dgrad", "conv133_dgrad_splitk", "conv133_dgrad_dense",
-             "conv133_wgrad"]
+    names = ["conv133_fwd", "conv133_fwd_splitk", "conv133_fwd_dense", "conv133_fwd_sparse", "conv133_dgrad", "conv133_dgrad_splitk",
+             "conv133_dgrad_dense", "conv133_dgrad_sparse", "conv133_sparse_pack", "conv133_wgrad"]
     if args.op_profile:
         names += ["in_stats_finalize", "in_lrelu_bwd", "convT_fwd", "convT_dgrad", "convT_wgrad", "maxpool_fwd", "maxpool_bwd",
                   "head1x1_fwd", "head1x1_dgrad", "head1x1_wgrad", "dc_ce_reduce", "dc_ce_grad", "grad_sqnorm", "sgd_clip_mask_step"]
@@ -549,20 +553,23 @@ def main():
             out["metric"] = "voxels/sec (inference forward only), 128^3 patch 32ch density=0.2"
         work = conv_work(eng, mask)
         ev = [(e0.elapsed_time(e1), work[a[0]]) for e0, e1, a in timers["conv133_fwd"].events + timers["conv133_fwd_splitk"].events +
-              timers["conv133_fwd_dense"].events]
+              timers["conv133_fwd_dense"].events + timers["conv133_fwd_sparse"].events]
+        ev += [(e0.elapsed_time(e1), work[a[4]]) for e0, e1, a in timers["conv133_dgrad_sparse"].events]
+        pack_ms = timers["conv133_sparse_pack"].total_ms()            # weight packing of the planned layers: counted with the family
         ev += [(e0.elapsed_time(e1), work[a[3]]) for e0, e1, a in timers["conv133_dgrad"].events + timers["conv133_dgrad_splitk"].events]
         ev += [(e0.elapsed_time(e1), work[a[3]]) for e0, e1, a in timers["conv133_dgrad_dense"].events]
         if ev:
-            ms = sum(t for t, _ in ev)
+            ms = sum(t for t, _ in ev) + pack_ms
             byt = sum(w["bytes"] for _, w in ev)
             fl = sum(w["flops_live"] for _, w in ev)
             gbs = byt / (ms * 1e-3) / 1e9
             out["roofline"] = {
-                "bound": "hbm", "kernel": "conv133_kernel + conv133_dense_kernel: every launch of e2e_conv133_fwd* and e2e_conv133_dgrad* "
-                                          "(depth shift + concat + 1x3x3 conv, forward and data gradient; DSFF-masked layers on the "
-                                          "sparse VALU walk, unmasked layers on the bf16 matrix pipe with fp32-exact operands)",
+                "bound": "hbm", "kernel": "conv133_sparse_kernel + conv133_kernel + conv133_dense_kernel: every launch of e2e_conv133_fwd* and "
+                                          "e2e_conv133_dgrad* (depth shift + concat + 1x3x3 conv, forward and data gradient; DSFF-masked "
+                                          "layers on the sparse VALU walk -- load-balanced plan at full resolution -- incl. their weight "
+                                          "packing launch, unmasked layers on the bf16 matrix pipe with fp32-exact operands)",
                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                "traffic": pmc_traffic("conv133_kernel", "conv133_dense_kernel"),
+                "traffic": pmc_traffic("conv133_kernel", "conv133_dense_kernel", "conv133_sparse_kernel"),
                 "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" % TRAFFIC_FILE,
                 "algorithmic_bytes_per_launch": byt / len(ev), "launches_per_step": len(ev) // isteps,
                 "avg_ms": ms / len(ev), "ms_per_step": ms / isteps, "share_of_step": (ms / isteps) / ms_step,

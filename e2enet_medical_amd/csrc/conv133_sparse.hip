@@ -30,6 +30,17 @@
 #include <vector>
 #include <algorithm>
 
+// phase stamps (s_memtime), diagnostic build -DE2E_CONV_DEBUG with E2E_CONV_DBG=8: [0] prologue [1] commit + load wait [2] barrier 1
+// [3] request setup [4] walk [5] flush + barrier 2 [6] epilogue [7] waves
+#ifdef E2E_CONV_DEBUG
+__device__ unsigned long long g_sparse_stamps[1024 * 8];
+#define SSTAMP(var) const unsigned long long var = __builtin_readcyclecounter()
+#define SSTAMP_ADD(i, a, b) st_acc[i] += (b) - (a)
+#else
+#define SSTAMP(var)
+#define SSTAMP_ADD(i, a, b)
+#endif
+
 namespace {
 
 constexpr int TH = 16, TW = 32, LX = 8, PH = 2, PW = 4, OPW = 4, NW = 8, CK = 8, OCG = 32;
@@ -95,6 +106,10 @@ __global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams
 
   int item = e2e::xcd_remap(blockIdx.x, p.padded_total);
   if (item >= p.total) return;
+#ifdef E2E_CONV_DEBUG
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  SSTAMP(t_begin);
   const int g = item % p.groups;
   item /= p.groups;
   const int n = item / p.tiles_per_n, tile_in_n = item - n * p.tiles_per_n;
@@ -265,16 +280,22 @@ __global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams
   request_weights(0, 0, true);
   request_weights(0, 1, true);
   unsigned m_cur = load_uniform(qrow);
+  SSTAMP(t_pro);
+  SSTAMP_ADD(0, t_begin, t_pro);
 
   int until_flush = p.flush_every;
   for (int c = 0; c < p.nchunks; ++c) {
     const bool more = c + 1 < p.nchunks;
     const unsigned m_next = more ? load_uniform(qrow + c + 1) : 0u;
+    SSTAMP(t0);
     commit();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's LDS-DMA share of the chunk's weights has landed
+    SSTAMP(t1);
     __syncthreads();
+    SSTAMP(t2);
     request_begin(more ? c + 1 : c);
     const float* wbuf = wl + (c & 1) * WCHUNK + (wave * OPW) * CK * WSLOT;
+    SSTAMP(t3);
 #pragma unroll
     for (int cl = 0; cl < CK; ++cl) {
       if (cl < NUP) request_plane(cl, more);
@@ -312,6 +333,7 @@ __global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams
       }
     }
     m_cur = m_next;
+    SSTAMP(t4);
     if (--until_flush == 0 || !more) {
       until_flush = p.flush_every;
 #pragma unroll
@@ -322,7 +344,10 @@ __global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams
           for (int j = 0; j < PW; ++j) { acc2[a][i][j] += acc[a][i][j]; acc[a][i][j] = 0.f; }
     }
     __syncthreads();
+    SSTAMP(t5);
+    SSTAMP_ADD(1, t0, t1); SSTAMP_ADD(2, t1, t2); SSTAMP_ADD(3, t2, t3); SSTAMP_ADD(4, t3, t4); SSTAMP_ADD(5, t4, t5);
   }
+  SSTAMP(t_epi);
 
   // ---- epilogue --------------------------------------------------------------------------------------------------------------
   if (MODE == 0) {
@@ -398,6 +423,13 @@ __global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams
       }
     }
   }
+#ifdef E2E_CONV_DEBUG
+  SSTAMP(t_end);
+  SSTAMP_ADD(6, t_epi, t_end);
+  st_acc[7] = 1;
+  if (lane == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_sparse_stamps[(blockIdx.x & 1023) * 8 + i], st_acc[i]);
+#endif
 }
 
 // ---- weight packing: one launch for a table of (layer, direction) jobs --------------------------------------------------------
@@ -439,31 +471,22 @@ int sparse_launch(int mode, SparseParams p, hipStream_t st) {
   e2e::note_kernel("conv133_sparse_kernel<mode=%d> wgs=%d groups=%d chunks=%d flush=%d", mode, p.padded_total, p.groups, p.nchunks, p.flush_every);
   if (mode == 0) hipLaunchKernelGGL((conv133_sparse_kernel<0>), dim3(p.padded_total), dim3(NW * 64), dyn, st, p);
   else hipLaunchKernelGGL((conv133_sparse_kernel<1>), dim3(p.padded_total), dim3(NW * 64), dyn, st, p);
+#ifdef E2E_CONV_DEBUG
+  static const int dbg = getenv("E2E_CONV_DBG") ? atoi(getenv("E2E_CONV_DBG")) : 0;
+  if (dbg & 8) {
+    (void)hipStreamSynchronize(st);
+    static unsigned long long hh[1024 * 8], zz[1024 * 8];
+    (void)hipMemcpyFromSymbol(hh, HIP_SYMBOL(g_sparse_stamps), sizeof(hh));
+    unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 1024 * 8; ++i) h[i & 7] += hh[i];
+    const double w = h[7] ? (double)h[7] : 1.0;
+    fprintf(stderr, "[conv133_sparse MODE %d P %d Q %d] per-wave cycles: pro %.0f commit %.0f bar1 %.0f prefetch %.0f walk %.0f bar2 %.0f epi %.0f (waves %.0f)\n",
+            mode, p.P, p.Q, h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[6] / w, w);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sparse_stamps), zz, sizeof(zz));
+  }
+#endif
   return e2e::check_launch("conv133_sparse_kernel");
 }
-
-// ---- host: the load-balanced plan ---------------------------------------------------------------------------------------------
-// cost of a (chunk, wave) cell: live kernels + 0.35 per visited plane (neighbourhood rows are read once per visited plane)
-struct Balancer {
-  int P, nchunks;
-  const unsigned char* live;      // [32 slots][P]: kernel (slot, plane) alive
-  std::vector<int> chunk_of;      // plane -> chunk
-  std::vector<int> fill;          // planes per chunk
-  std::vector<float> load;        // [nchunks][8]
-  float cell(int wave, int plane) const {
-    int k = 0;
-    for (int a = 0; a < OPW; ++a) k += live[(wave * OPW + a) * P + plane];
-    return k ? (float)k + 0.35f : 0.f;
-  }
-  float chunk_max(int c) const {
-    float m = 0.f;
-    for (int w = 0; w < NW; ++w) m = std::max(m, load[c * NW + w]);
-    return m;
-  }
-  void add(int c, int plane, float sign) {
-    for (int w = 0; w < NW; ++w) load[c * NW + w] += sign * cell(w, plane);
-  }
-};
 
 }  // namespace
 
@@ -485,11 +508,12 @@ extern "C" int e2e_conv133_sparse_plan(const unsigned char* kmask, int R, int Cc
   E2E_REQUIRE(kmask && qslot && pslot && quads && R > 0 && Cc > 0, "conv133_sparse_plan: bad arguments");
   const int Q = transpose ? Cc : R, P = transpose ? R : Cc;
   const int groups = e2e::cdiv(Q, OCG), nchunks = e2e::cdiv(P, CK);
+  const int NWG = groups * NW;                           // waves of all groups: they share ONE chunking of the input planes
   auto alive = [&](int q, int pp) -> unsigned char { return transpose ? kmask[(long long)pp * Cc + q] : kmask[(long long)q * Cc + pp]; };
   long long nlive = 0;
+  // -- output planes to waves, per 32-plane group: longest-processing-time first on the planes' live counts
   for (int g = 0; g < groups; ++g) {
     const int q0 = g * OCG, nq = std::min(OCG, Q - q0);
-    // -- output planes to waves: longest-processing-time first on the planes' live counts
     std::vector<int> cnt(nq, 0), order(nq);
     for (int i = 0; i < nq; ++i) {
       for (int pp = 0; pp < P; ++pp) cnt[i] += alive(q0 + i, pp);
@@ -507,60 +531,89 @@ extern "C" int e2e_conv133_sparse_plan(const unsigned char* kmask, int R, int Cc
       qs[best * OPW + wfill[best]++] = q0 + i;
       wload[best] += cnt[i];
     }
-    // -- input planes to chunks
-    std::vector<unsigned char> live((size_t)OCG * P, 0);
-    for (int s = 0; s < OCG; ++s)
-      if (qs[s] >= 0)
-        for (int pp = 0; pp < P; ++pp) live[(size_t)s * P + pp] = alive(qs[s], pp);
-    Balancer b;
-    b.P = P; b.nchunks = nchunks; b.live = live.data();
-    b.chunk_of.assign(P, -1); b.fill.assign(nchunks, 0); b.load.assign((size_t)nchunks * NW, 0.f);
-    std::vector<int> porder(P), pcnt(P, 0);
-    for (int pp = 0; pp < P; ++pp) {
-      for (int s = 0; s < OCG; ++s) pcnt[pp] += live[(size_t)s * P + pp];
-      porder[pp] = pp;
-    }
-    std::stable_sort(porder.begin(), porder.end(), [&](int a, int bb) { return pcnt[a] > pcnt[bb]; });
-    for (int pp : porder) {                              // greedy: the chunk whose slowest wave grows least (ties: the lighter chunk)
-      int best = -1;
-      float bmax = 0.f, bsum = 0.f;
-      for (int c = 0; c < nchunks; ++c) {
-        if (b.fill[c] >= CK) continue;
-        float mx = 0.f, sm = 0.f;
-        for (int w = 0; w < NW; ++w) { const float v = b.load[c * NW + w] + b.cell(w, pp); mx = std::max(mx, v); sm += v; }
-        if (best < 0 || mx < bmax || (mx == bmax && sm < bsum)) { best = c; bmax = mx; bsum = sm; }
+  }
+  // -- input planes to chunks.  The groups of a layer are separate workgroups that run side by side on the same tile: with one
+  // common plane order they request the same planes at the same time and share them through L2 (per-group orders were measured:
+  // 160 -> 64 @64^3 forward 0.387 -> 0.424 ms, the input was fetched once per group).  Cost of a (chunk, wave) cell: live
+  // kernels + 0.35 per visited plane; objective: sum over chunks and groups of the slowest wave of the group.
+  std::vector<float> cell((size_t)NWG * P, 0.f);          // [wave of any group][plane]
+  for (int g = 0; g < groups; ++g)
+    for (int w = 0; w < NW; ++w)
+      for (int pp = 0; pp < P; ++pp) {
+        int k = 0;
+        for (int a = 0; a < OPW; ++a) {
+          const int q = qslot[g * OCG + w * OPW + a];
+          if (q >= 0) k += alive(q, pp);
+        }
+        cell[(size_t)(g * NW + w) * P + pp] = k ? (float)k + 0.35f : 0.f;
       }
-      b.chunk_of[pp] = best;
-      b.fill[best]++;
-      b.add(best, pp, 1.f);
+  std::vector<int> chunk_of(P, -1), fill(nchunks, 0);
+  std::vector<float> load((size_t)nchunks * NWG, 0.f);
+  auto chunk_cost = [&](int c) {
+    float tot = 0.f;
+    for (int g = 0; g < groups; ++g) {
+      float m = 0.f;
+      for (int w = 0; w < NW; ++w) m = std::max(m, load[(size_t)c * NWG + g * NW + w]);
+      tot += m;
     }
-    // pair swaps between chunks (fixed pseudo-random sequence: the plan is a pure function of the kernel map)
-    unsigned long long rng = 0x9e3779b97f4a7c15ull ^ ((unsigned long long)P * 1315423911ull + (unsigned long long)g);
-    auto next = [&]() { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return (unsigned)(rng >> 33); };
-    const int tries = nchunks > 1 ? 400 * nchunks : 0;
-    for (int t = 0; t < tries; ++t) {
-      const int p1 = (int)(next() % (unsigned)P), p2 = (int)(next() % (unsigned)P);
-      const int c1 = b.chunk_of[p1], c2 = b.chunk_of[p2];
-      if (c1 == c2) continue;
-      const float before = b.chunk_max(c1) + b.chunk_max(c2);
-      b.add(c1, p1, -1.f); b.add(c2, p2, -1.f); b.add(c1, p2, 1.f); b.add(c2, p1, 1.f);
-      const float after = b.chunk_max(c1) + b.chunk_max(c2);
-      if (after < before) { b.chunk_of[p1] = c2; b.chunk_of[p2] = c1; }
-      else { b.add(c1, p2, -1.f); b.add(c2, p1, -1.f); b.add(c1, p1, 1.f); b.add(c2, p2, 1.f); }
+    return tot;
+  };
+  auto add = [&](int c, int pp, float sign) {
+    for (int w = 0; w < NWG; ++w) load[(size_t)c * NWG + w] += sign * cell[(size_t)w * P + pp];
+  };
+  std::vector<int> porder(P);
+  std::vector<float> pw(P, 0.f);
+  for (int pp = 0; pp < P; ++pp) {
+    for (int w = 0; w < NWG; ++w) pw[pp] += cell[(size_t)w * P + pp];
+    porder[pp] = pp;
+  }
+  std::stable_sort(porder.begin(), porder.end(), [&](int a, int b) { return pw[a] > pw[b]; });
+  for (int pp : porder) {                                  // greedy: the chunk whose cost grows least (ties: the lighter chunk)
+    int best = -1;
+    float bcost = 0.f, bsum = 0.f;
+    for (int c = 0; c < nchunks; ++c) {
+      if (fill[c] >= CK) continue;
+      const float before = chunk_cost(c);
+      add(c, pp, 1.f);
+      const float grow = chunk_cost(c) - before;
+      float sm = 0.f;
+      for (int w = 0; w < NWG; ++w) sm += load[(size_t)c * NWG + w];
+      add(c, pp, -1.f);
+      if (best < 0 || grow < bcost || (grow == bcost && sm < bsum)) { best = c; bcost = grow; bsum = sm; }
     }
-    // -- emit: planes of a chunk in ascending order (deterministic), liveness words
+    chunk_of[pp] = best;
+    fill[best]++;
+    add(best, pp, 1.f);
+  }
+  // pair swaps between chunks (fixed pseudo-random sequence: the plan is a pure function of the kernel map)
+  unsigned long long rng = 0x9e3779b97f4a7c15ull ^ ((unsigned long long)P * 1315423911ull + (unsigned long long)Q);
+  auto next = [&]() { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return (unsigned)(rng >> 33); };
+  const int tries = nchunks > 1 ? 400 * nchunks : 0;
+  for (int t = 0; t < tries; ++t) {
+    const int p1 = (int)(next() % (unsigned)P), p2 = (int)(next() % (unsigned)P);
+    const int c1 = chunk_of[p1], c2 = chunk_of[p2];
+    if (c1 == c2) continue;
+    const float before = chunk_cost(c1) + chunk_cost(c2);
+    add(c1, p1, -1.f); add(c2, p2, -1.f); add(c1, p2, 1.f); add(c2, p1, 1.f);
+    if (chunk_cost(c1) + chunk_cost(c2) < before) { chunk_of[p1] = c2; chunk_of[p2] = c1; }
+    else { add(c1, p2, -1.f); add(c2, p1, -1.f); add(c1, p1, 1.f); add(c2, p2, 1.f); }
+  }
+  // -- emit: planes of a chunk in ascending order, the same table for every group; liveness words per (group, wave, chunk)
+  std::vector<int> ps0((size_t)nchunks * CK, -1), at(nchunks, 0);
+  for (int pp = 0; pp < P; ++pp) { const int c = chunk_of[pp]; ps0[(size_t)c * CK + at[c]++] = pp; }
+  for (int g = 0; g < groups; ++g) {
     int* ps = pslot + (long long)g * nchunks * CK;
-    for (int i = 0; i < nchunks * CK; ++i) ps[i] = -1;
-    std::vector<int> at(nchunks, 0);
-    for (int pp = 0; pp < P; ++pp) { const int c = b.chunk_of[pp]; ps[c * CK + at[c]++] = pp; }
+    for (int i = 0; i < nchunks * CK; ++i) ps[i] = ps0[i];
     for (int w = 0; w < NW; ++w)
       for (int c = 0; c < nchunks; ++c) {
         unsigned word = 0u;
         for (int cl = 0; cl < CK; ++cl) {
-          const int pp = ps[c * CK + cl];
+          const int pp = ps0[(size_t)c * CK + cl];
           if (pp < 0) continue;
-          for (int a = 0; a < OPW; ++a)
-            if (qs[w * OPW + a] >= 0 && live[(size_t)(w * OPW + a) * P + pp]) word |= 1u << (cl * 4 + a);
+          for (int a = 0; a < OPW; ++a) {
+            const int q = qslot[g * OCG + w * OPW + a];
+            if (q >= 0 && alive(q, pp)) word |= 1u << (cl * 4 + a);
+          }
         }
         quads[((long long)g * NW + w) * nchunks + c] = word;
       }

@@ -283,11 +283,11 @@ def test_config5_amos_density_whole_net(dens):
 FULL_CONV = [
     # (case of test_gpu_ops.test_conv133_fwd_bwd, expected kernel substrings: fwd, wgrad, dgrad)
     ("loc L0 64->32 @128^3 B=2 d=0.2", (2, [(32, True), (32, False)], 32, (128, 128, 128), (1, 1, 1), 0.2),
-     "tile=16x32", "conv133_wgrad_bf3 chunks=128 pairs=2", "mode=1"),
+     "conv133_sparse_kernel<mode=0>", "conv133_wgrad_bf3 chunks=128 pairs=2", "conv133_sparse_kernel<mode=1>"),
     ("c0.b1 32->32 @128^3 dense", (2, [(32, True)], 32, (128, 128, 128), (1, 1, 1), 1.0),
      "conv133_dense_bf3<mode=0>", "conv133_wgrad_bf3", "conv133_dense_bf3<mode=1>"),
     ("loc L1 160->64 @64^3 d=0.2", (2, [(64, True), (64, False), (32, False)], 64, (64, 64, 64), (1, 1, 1), 0.2),
-     "tile=16x32", "conv133_wgrad_bf3", "mode=1"),
+     "conv133_sparse_kernel<mode=0>", "conv133_wgrad_bf3", "conv133_sparse_kernel<mode=1>"),
     ("c1.b0 32->64 s2 @128^3", (1, [(32, True)], 64, (128, 128, 128), (2, 2, 2), 1.0),
      "s=2x2", "conv133_wgrad_s2", "mode=2"),
 ]
@@ -295,10 +295,11 @@ FULL_CONV = [
 
 @pytest.mark.parametrize("name,case,k_fwd,k_wgrad,k_dgrad", FULL_CONV, ids=[c[0] for c in FULL_CONV])
 def test_conv133_at_benchmarked_shapes(name, case, k_fwd, k_wgrad, k_dgrad):
-    with KernelLog(["conv133_fwd", "conv133_fwd_dense", "conv133_wgrad", "conv133_dgrad", "conv133_dgrad_dense"]) as kl:
+    with KernelLog(["conv133_fwd", "conv133_fwd_dense", "conv133_fwd_sparse", "conv133_wgrad", "conv133_dgrad", "conv133_dgrad_dense",
+                    "conv133_dgrad_sparse"]) as kl:
         ops.test_conv133_fwd_bwd(case)
-    fwd = kl.of("conv133_fwd") + kl.of("conv133_fwd_dense")
-    dgr = kl.of("conv133_dgrad") + kl.of("conv133_dgrad_dense")
+    fwd = kl.of("conv133_fwd") + kl.of("conv133_fwd_dense") + kl.of("conv133_fwd_sparse")
+    dgr = kl.of("conv133_dgrad") + kl.of("conv133_dgrad_dense") + kl.of("conv133_dgrad_sparse")
     assert all(k_fwd in k for k in fwd) and fwd, kl.log
     assert all(k_wgrad in k for k in kl.of("conv133_wgrad")) and kl.of("conv133_wgrad"), kl.log
     assert all(k_dgrad in k for k in dgr) and dgr, kl.log
@@ -634,7 +635,8 @@ def test_nodff_sparse_engine_fastpath_and_predict_vs_oracle():
 
 # ------------------------------------------------------------------------------------------------ configs 3 and 4 at their SURVEY 8d shapes
 BTCV_FULL = dict(patch=(48, 192, 192), cin=1, k=14, pools=[(1, 2, 2), (2, 2, 2), (2, 2, 2), (2, 2, 2), (1, 2, 2)], batch=2)
-CONV_ENTRIES = ["conv133_fwd", "conv133_fwd_splitk", "conv133_fwd_dense", "conv133_dgrad", "conv133_dgrad_splitk", "conv133_dgrad_dense",
+CONV_ENTRIES = ["conv133_fwd", "conv133_fwd_splitk", "conv133_fwd_dense", "conv133_fwd_sparse", "conv133_dgrad", "conv133_dgrad_splitk",
+                "conv133_dgrad_dense", "conv133_dgrad_sparse",
                 "conv133_wgrad", "convT_fwd", "convT_dgrad", "convT_wgrad"]
 
 
@@ -664,7 +666,7 @@ def test_config3_btcv_full_shape_vs_oracle_and_dsff_update_replay():
     for n, k in variants:
         print("   %-22s %s" % (n, k))
     fams = {k.split("<")[0].split(" ")[0] for _, k in variants}
-    assert {"conv133_kernel", "conv133_dense_bf3", "convT_fwd_bf3", "convT_dgrad_bf3"} <= fams, fams
+    assert {"conv133_kernel", "conv133_sparse_kernel", "conv133_dense_bf3", "convT_fwd_bf3", "convT_dgrad_bf3"} <= fams, fams
     # ---- the CPU oracle on the identical batch (forward + loss, fp32)
     spec = oracle.make_spec(C["cin"], bench.BASE, C["k"], C["pools"])
     params = {n: p.detach().cpu().clone() for n, p in net.named_parameters()}

@@ -446,8 +446,8 @@ def test_dataloader3d_batches_equal_the_reference(tmp_path, tag, mode, kw):
 @pytest.mark.parametrize("R,Cc,dens", [(32, 64, 0.2), (64, 160, 0.2), (34, 33, 0.3), (128, 320, 0.1), (70, 90, 0.5)])
 def test_sparse_plan_is_a_valid_balanced_permutation(R, Cc, dens):
     """e2e_conv133_sparse_plan (host side of the load-balanced DSFF conv, csrc/conv133_sparse.hip): for both directions the plan
-    places every output plane in exactly one wave slot of its 32-plane group and every input plane in exactly one chunk slot of
-    every group, its liveness words are the kernel map read through those slots (mask indices stay bit exact), it is a pure
+    places every output plane in exactly one wave slot of its 32-plane group and every input plane in exactly one chunk slot (the
+    same chunking for every group), its liveness words are the kernel map read through those slots (mask indices stay bit exact), it is a pure
     function of the map, and the work of the slowest wave summed over the chunks is close to the mean (the point of the plan)."""
     import ctypes as C
     from e2enet_medical_amd._lib import lib
@@ -492,5 +492,7 @@ def test_sparse_plan_is_a_valid_balanced_permutation(R, Cc, dens):
             planned += cost(sub).max(axis=1).sum()
             ideal += cost(sub).sum() / 8
         assert planned <= natural + 1e-6
+        for g in range(1, G):                                        # ONE chunking of the input planes for all groups of a layer
+            assert np.array_equal(ps[:NC * 8], ps[g * NC * 8:(g + 1) * NC * 8])           # (they share the staged planes through L2)
         if Q % 32 == 0 and dens <= 0.3:
-            assert planned / ideal <= 1.2 and natural / ideal >= 1.3, (planned / ideal, natural / ideal)
+            assert natural / ideal >= 1.3 and (planned / ideal <= 1.2 if G == 1 else planned <= 0.87 * natural), (planned / ideal, natural / ideal)

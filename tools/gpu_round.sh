@@ -4,6 +4,7 @@
 #   gpurun --timeout 1500 -- 'bash tools/gpu_round.sh <tag> [tests] [bench] [prof] [kbench "<kbench args>"]'
 #
 #   tests   python -m pytest tests -m gpu -x -q                          -> gpurun_out/<tag>/tests.log
+#   ktests "<expr>"   the same with -k <expr>                            -> gpurun_out/<tag>/ktests.log
 #   bench   python bench.py --steps 20 --warmup 5                        -> gpurun_out/<tag>/bench.json
 #   prof    tools/prof_bench.sh <tag> (rocprofv3 --kernel-trace --stats, default + one-stream; FETCH_SIZE / WRITE_SIZE passes)
 #   kbench  python tools/kbench.py <args> (single-kernel timings)        -> gpurun_out/<tag>/kbench.log
@@ -17,7 +18,8 @@ cd $R
 mkdir -p gpurun_out/$TAG
 while [ $# -gt 0 ]; do
   case $1 in
-    tests)  timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > gpurun_out/$TAG/tests.log ;;
+    tests)  timeout 1500 python -m pytest tests -m gpu -x -q --tb=short -rs 2>&1 | grep -v "curr_density\|amdgpu.ids" | tail -150 > gpurun_out/$TAG/tests.log ;;
+    ktests) shift; timeout 1500 python -m pytest tests -m gpu -x -q --tb=short -k "$1" 2>&1 | grep -v "curr_density\|amdgpu.ids" | tail -150 > gpurun_out/$TAG/ktests.log ;;
     bench)  timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench.err ;;
     prof)   bash tools/prof_bench.sh $TAG 2>&1 | tail -20 > gpurun_out/$TAG/prof.log ;;
     kbench) shift; timeout 600 python tools/kbench.py $1 > gpurun_out/$TAG/kbench.log 2>&1 ;;
