@@ -33,11 +33,11 @@ class ParamEntry(C.Structure):
 class SparsePackJob(C.Structure):
     """e2e_sparse_pack_job_t"""
     _fields_ = [("w", C.c_void_p), ("wpk", C.c_void_p), ("qslot", C.c_void_p), ("pslot", C.c_void_p), ("quads", C.c_void_p),
-                ("groups", C.c_int), ("nchunks", C.c_int), ("wq_stride", C.c_int), ("wp_stride", C.c_int),
-                ("reverse", C.c_int), ("reserved", C.c_int)]
+                ("woff", C.c_void_p), ("groups", C.c_int), ("nchunks", C.c_int), ("wq_stride", C.c_int), ("wp_stride", C.c_int),
+                ("reverse", C.c_int), ("kmax", C.c_int)]
 
 
-assert C.sizeof(InChan) == 48 and C.sizeof(OutChan) == 24 and C.sizeof(ParamEntry) == 40 and C.sizeof(SparsePackJob) == 64
+assert C.sizeof(InChan) == 48 and C.sizeof(OutChan) == 24 and C.sizeof(ParamEntry) == 40 and C.sizeof(SparsePackJob) == 72
 
 P, I, F, LL = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 
@@ -55,11 +55,11 @@ SIGNATURES = {
     "e2e_conv133_dgrad_splitk": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, P, LL, P]),
     "e2e_conv133_dense_ws_bytes": (LL, [I, I, I, I, I, I, I, I, I]),
     "e2e_conv133_sparse_eligible": (I, [I, I, I, I, I, I, I, I]),
-    "e2e_conv133_sparse_wpk_floats": (LL, [I, I]),
-    "e2e_conv133_sparse_plan": (I, [P, I, I, I, P, P, P, P]),
+    "e2e_conv133_sparse_wpk_floats": (LL, [I, I, I]),
+    "e2e_conv133_sparse_plan": (I, [P, I, I, I, P, P, P, P, P, P]),
     "e2e_conv133_sparse_pack": (I, [P, I, LL, P]),
-    "e2e_conv133_fwd_sparse": (I, [P, I, P, P, P, P, I, P, P, I, I, I, I, I, P]),
-    "e2e_conv133_dgrad_sparse": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P]),
+    "e2e_conv133_fwd_sparse": (I, [P, I, P, P, P, P, I, P, I, P, P, I, I, I, I, I, P]),
+    "e2e_conv133_dgrad_sparse": (I, [P, P, P, P, I, P, P, I, I, I, I, I, I, I, P]),
     "e2e_conv133_fwd_dense": (I, [P, I, P, P, P, P, P, I, I, I, I, I, P, LL, P]),
     "e2e_conv133_dgrad_dense": (I, [P, P, P, P, I, I, I, I, I, I, P, LL, P]),
     "e2e_conv133_wgrad_ws_bytes": (LL, [I, I, I, I, I, I, I, I, I]),

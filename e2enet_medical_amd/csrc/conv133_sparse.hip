@@ -11,10 +11,14 @@
 // input planes are chunked and the assignment of output planes to waves are free, so the host picks them per 32-plane group
 // such that every (chunk, wave) cell carries nearly the same work (e2e_conv133_sparse_plan: longest-processing-time assignment
 // + pair swaps; sum over chunks of the slowest wave drops from 1.48x to 1.15x of the mean).  What follows from the plan:
-//   * weights are read from a PACKED copy in plan order, [group][chunk][32 output slots][8 plane slots][12] floats with pruned
-//     kernels and padding as zeros (e2e_conv133_sparse_pack: one launch for all layers of a network, after every optimizer step):
-//     a chunk's weights are one contiguous 12 KB block that goes global -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPRs,
-//     no ds_write), double buffered;
+//   * weights are read from a PACKED copy that holds the LIVE kernels only, in the order the waves walk them:
+//     [group][chunk][kmax kernel slots][12 floats], wave w's list starting at slot woff[group][chunk][w]
+//     (e2e_conv133_sparse_pack: one launch for all layers of a network, after every optimizer step).  A chunk's block (2-4 KB at
+//     density 0.2 instead of 12 KB) goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write), double
+//     buffered; the walk reads a wave's kernels one after the other;
+//   * the LDS that the dense weight image would take holds a SECOND image of the staged planes: a wave commits the planes of
+//     chunk c + 1 right after its walk of chunk c, so there is ONE barrier per chunk and the waves that finish a chunk early
+//     spend the wait for the slowest on their share of the staging instead of idling;
 //   * the plane table, the destination table and the liveness words arrive in plan order (built by the caller);
 //   * a neighbourhood row is read as ds_read_b128 + ds_read_b64 (the compiler merged the halo halves of two rows into one
 //     ds_read2_b64, whose accesses are banked mod 32 and collide 2-way: SQ_LDS_BANK_CONFLICT was 39 % of the LDS cycles);
@@ -30,8 +34,8 @@
 #include <vector>
 #include <algorithm>
 
-// phase stamps (s_memtime), diagnostic build -DE2E_CONV_DEBUG with E2E_CONV_DBG=8: [0] prologue [1] commit + load wait [2] barrier 1
-// [3] request setup [4] walk [5] flush + barrier 2 [6] epilogue [7] waves
+// phase stamps (s_memtime), diagnostic build -DE2E_CONV_DEBUG with E2E_CONV_DBG=8: [0] prologue (incl. first chunk) [1] commit of the
+// next chunk + load wait [2] the barrier [3] request setup [4] walk [5] flush [6] epilogue [7] waves
 #ifdef E2E_CONV_DEBUG
 __device__ unsigned long long g_sparse_stamps[1024 * 8];
 #define SSTAMP(var) const unsigned long long var = __builtin_readcyclecounter()
@@ -57,15 +61,16 @@ struct SparseParams {
   const e2e_in_chan_t* chans;   // MODE 0: [groups][ppad] plane descriptors in plan order (ptr == null: empty slot)
   const float* xin;             // MODE 1: dy [B, P, D, H, W]
   const int* pslot;             // MODE 1: [groups][ppad] dy channel of each chunk slot (-1: empty)
-  const float* wpk;             // [groups][nchunks][32][8][12]
+  const float* wpk;             // [groups][nchunks][kmax][12]: the live kernels of a chunk, wave by wave in walk order
   const unsigned* quads;        // [groups][8 waves][nchunks]: bit cl * 4 + a
+  const int* woff;              // [groups][nchunks][8]: first kernel slot of each wave's list
   const int* qslot;             // MODE 0: [groups][32] output plane of slot wave * 4 + a (-1: empty)
   const e2e_out_chan_t* outs;   // MODE 1: [groups][32] destinations in plan order (ptr == null: nothing to store)
   const float* bias;
   float* y;
   double* part;
   int P, Q, B, D, H, W;
-  int nchunks, ppad, groups, flush_every;
+  int nchunks, ppad, groups, flush_every, kmax, uw;      // uw: 16-byte units of a chunk's weight block per wave
   int tiles_x, tiles_y, tiles_per_n, total, padded_total;
 };
 
@@ -79,6 +84,8 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef const f32x4_t __attribute__((address_space(1)))* gfloat4_p;
 typedef const volatile f32x2_t __attribute__((address_space(3)))* lds_v2_p;      // (volatile: not merged into ds_read2_b64)
+typedef const f32x4_t __attribute__((address_space(3)))* lds_v4_p;
+typedef const float __attribute__((address_space(3)))* lds_f_p;
 
 template <class T>
 __device__ __forceinline__ T load_uniform(const T* ptr) {
@@ -91,10 +98,11 @@ __device__ __forceinline__ T load_uniform(const T* ptr) {
 
 template <int MODE>
 __global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams p) {
-  __shared__ __attribute__((aligned(16))) float lds_raw[CK * CHS + 4];
-  __shared__ __attribute__((aligned(16))) float wl[2 * WCHUNK];
+  constexpr int IMG = CK * CHS + 4;                     // one image of a chunk's planes (+ 4 guard floats in front)
+  __shared__ __attribute__((aligned(16))) float lds_raw[2 * IMG];
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-  PlaneDesc* tab = reinterpret_cast<PlaneDesc*>(dyn_lds);
+  float* const wl = reinterpret_cast<float*>(dyn_lds);              // 2 x kmax x 12 floats
+  PlaneDesc* tab = reinterpret_cast<PlaneDesc*>(dyn_lds + (size_t)2 * p.kmax * WSLOT * 4);
   float* const lds = lds_raw + 4;
 
   const int tid = threadIdx.x;
@@ -227,7 +235,8 @@ __global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams
   float pd_a = 1.f, pd_b = 0.f, pd_slope = 1.f;
   bool pd_ok = false;
   unsigned pf_blo = 0, pf_bhi = 0;
-  const float* wblock = p.wpk + (long long)g * p.nchunks * WCHUNK;
+  const int wstride = p.kmax * WSLOT;                    // floats of a chunk's weight block
+  const float* wblock = p.wpk + (long long)g * p.nchunks * wstride;
   auto request_begin = [&](int c) {
     const PlaneDesc ds = tab[c * CK + wave];
     const unsigned long long bb = (unsigned long long)ds.base;
@@ -244,17 +253,18 @@ __global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams
     const unsigned off = live && pd_ok ? (unsigned)su_goff[k] : 0u;
     v4[k] = *reinterpret_cast<gfloat4_p>(base + off);
   };
-  // a chunk's weight block = 768 float4 units; wave w moves units [96 w, 96 w + 96): one full and one half LDS-DMA instruction
+  // a chunk's weight block = 3 kmax float4 units; wave w moves units [uw w, uw w + uw) with up to two LDS-DMA instructions
   // (LDS destination = wave-uniform base + 16 * lane)
   auto request_weights = [&](int c, int half, bool live) {
-    if (!live) return;                                    // (wave-uniform)
-    const float* src = wblock + (long long)c * WCHUNK + (wave * 96 + half * 64 + lane) * 4;
-    float* dst = wl + (c & 1) * WCHUNK + (wave * 96 + half * 64) * 4;
-    if (half == 0 || lane < 32)
+    if (!live || half * 64 >= p.uw) return;               // (wave-uniform)
+    const int u = wave * p.uw + half * 64 + lane;
+    const float* src = wblock + (long long)c * wstride + u * 4;
+    float* dst = wl + (c & 1) * wstride + (wave * p.uw + half * 64) * 4;
+    if (half * 64 + lane < p.uw && u < 3 * p.kmax)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   };
-  auto commit = [&]() {
-    float* pl = lds + wave * CHS;
+  auto commit = [&](int img) {
+    float* pl = lds + img * IMG + wave * CHS;
 #pragma unroll
     for (int i = 0; i < NUP; ++i) {
       if ((i + 1) * 64 > UPP && lane + 64 * i >= UPP) continue;
@@ -274,12 +284,17 @@ __global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams
   };
 
   const unsigned* qrow = p.quads + ((long long)g * NW + wave) * p.nchunks;
+  const int* orow = p.woff + (long long)g * p.nchunks * NW + wave;
   request_begin(0);
 #pragma unroll
   for (int k = 0; k < NUP; ++k) request_plane(k, true);
   request_weights(0, 0, true);
   request_weights(0, 1, true);
   unsigned m_cur = load_uniform(qrow);
+  int o_cur = load_uniform(orow);
+  commit(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's LDS-DMA share of the first weight block has landed
+  __syncthreads();
   SSTAMP(t_pro);
   SSTAMP_ADD(0, t_begin, t_pro);
 
@@ -287,14 +302,12 @@ __global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams
   for (int c = 0; c < p.nchunks; ++c) {
     const bool more = c + 1 < p.nchunks;
     const unsigned m_next = more ? load_uniform(qrow + c + 1) : 0u;
-    SSTAMP(t0);
-    commit();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's LDS-DMA share of the chunk's weights has landed
-    SSTAMP(t1);
-    __syncthreads();
+    const int o_next = more ? load_uniform(orow + (c + 1) * NW) : 0;
     SSTAMP(t2);
     request_begin(more ? c + 1 : c);
-    const float* wbuf = wl + (c & 1) * WCHUNK + (wave * OPW) * CK * WSLOT;
+    // this wave's kernels of the chunk, one after the other (LDS byte address, wave-uniform)
+    unsigned wq = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)(wl + (c & 1) * wstride + o_cur * WSLOT);
+    const float* tp0 = lane_tp + (c & 1) * IMG;
     SSTAMP(t3);
 #pragma unroll
     for (int cl = 0; cl < CK; ++cl) {
@@ -303,7 +316,7 @@ __global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams
       const unsigned nib = (m_cur >> (cl * 4)) & 15u;
       if (nib) {
         float nb[NR][NCL];
-        const float* tp = lane_tp + cl * CHS;
+        const float* tp = tp0 + cl * CHS;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
           // (the halo pair as its own ds_read_b64: merged with the next row's into a ds_read2_b64 -- what the compiler does with
@@ -316,10 +329,11 @@ __global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams
 #pragma unroll
         for (int a = 0; a < OPW; ++a) {
           if (nib & (1u << a)) {
-            const float* wp = wbuf + (a * CK + cl) * WSLOT;
-            const float4 w0v = *reinterpret_cast<const float4*>(wp);
-            const float4 w1v = *reinterpret_cast<const float4*>(wp + 4);
-            const float wk[9] = {w0v.x, w0v.y, w0v.z, w0v.w, w1v.x, w1v.y, w1v.z, w1v.w, wp[8]};
+            const lds_f_p wp = (lds_f_p)(unsigned long long)wq;
+            const f32x4_t w0v = *(lds_v4_p)wp;
+            const f32x4_t w1v = *(lds_v4_p)(wp + 4);
+            const float wk[9] = {w0v[0], w0v[1], w0v[2], w0v[3], w1v[0], w1v[1], w1v[2], w1v[3], wp[8]};
+            wq += WSLOT * 4;
 #pragma unroll
             for (int i = 0; i < PH; ++i)
 #pragma unroll
@@ -333,6 +347,7 @@ __global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams
       }
     }
     m_cur = m_next;
+    o_cur = o_next;
     SSTAMP(t4);
     if (--until_flush == 0 || !more) {
       until_flush = p.flush_every;
@@ -343,9 +358,16 @@ __global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams
 #pragma unroll
           for (int j = 0; j < PW; ++j) { acc2[a][i][j] += acc[a][i][j]; acc[a][i][j] = 0.f; }
     }
-    __syncthreads();
     SSTAMP(t5);
-    SSTAMP_ADD(1, t0, t1); SSTAMP_ADD(2, t1, t2); SSTAMP_ADD(3, t2, t3); SSTAMP_ADD(4, t3, t4); SSTAMP_ADD(5, t4, t5);
+    if (more) {
+      commit((c + 1) & 1);                                // into the other image: nobody reads it before the barrier below
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // ... and this wave's share of the next weight block has landed
+      SSTAMP(t6);
+      __syncthreads();
+      SSTAMP(t7);
+      SSTAMP_ADD(1, t5, t6); SSTAMP_ADD(2, t6, t7);
+    }
+    SSTAMP_ADD(3, t2, t3); SSTAMP_ADD(4, t3, t4); SSTAMP_ADD(5, t4, t5);
   }
   SSTAMP(t_epi);
 
@@ -433,6 +455,8 @@ __global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams
 }
 
 // ---- weight packing: one launch for a table of (layer, direction) jobs --------------------------------------------------------
+// thread = (group, chunk, output slot, plane slot, tap); a live kernel's 12-float slot lands at woff[wave] + its rank in the wave's
+// walk order (ascending bit index of the liveness word); pruned kernels are not stored at all
 __global__ __launch_bounds__(256) void sparse_pack_kernel(const e2e_sparse_pack_job_t* __restrict__ jobs) {
   const e2e_sparse_pack_job_t jb = jobs[blockIdx.y];
   const long long total = (long long)jb.groups * jb.nchunks * WCHUNK;
@@ -440,15 +464,15 @@ __global__ __launch_bounds__(256) void sparse_pack_kernel(const e2e_sparse_pack_
     const int t = (int)(idx % WSLOT), cl = (int)((idx / WSLOT) % CK), ql = (int)((idx / (WSLOT * CK)) % OCG);
     const long long gc = idx / WCHUNK;
     const int c = (int)(gc % jb.nchunks), g = (int)(gc / jb.nchunks);
+    const int wave = ql >> 2, bit = cl * 4 + (ql & 3);
+    const unsigned word = jb.quads[((long long)g * NW + wave) * jb.nchunks + c];
+    if (!((word >> bit) & 1u)) continue;
+    const int q = jb.qslot[g * OCG + ql];
+    const int pp = jb.pslot[((long long)g * jb.nchunks + c) * CK + cl];
+    const int slot = jb.woff[(gc) * NW + wave] + __popc(word & ((1u << bit) - 1u));
     float v = 0.f;
-    if (t < 9) {
-      const int q = jb.qslot[g * OCG + ql];
-      const int pp = jb.pslot[((long long)g * jb.nchunks + c) * CK + cl];
-      const unsigned word = jb.quads[((long long)g * NW + (ql >> 2)) * jb.nchunks + c];
-      if (q >= 0 && pp >= 0 && ((word >> (cl * 4 + (ql & 3))) & 1u))
-        v = jb.w[(long long)q * jb.wq_stride + (long long)pp * jb.wp_stride + (jb.reverse ? 8 - t : t)];
-    }
-    jb.wpk[idx] = v;
+    if (t < 9 && q >= 0 && pp >= 0) v = jb.w[(long long)q * jb.wq_stride + (long long)pp * jb.wp_stride + (jb.reverse ? 8 - t : t)];
+    jb.wpk[(gc * jb.kmax + slot) * WSLOT + t] = v;
   }
 }
 
@@ -467,8 +491,16 @@ int sparse_launch(int mode, SparseParams p, hipStream_t st) {
   p.total = p.B * p.tiles_per_n * p.groups;
   p.padded_total = (p.total + 7) & ~7;
   if (p.flush_every < 1) p.flush_every = 1;
-  const size_t dyn = (size_t)p.ppad * sizeof(PlaneDesc);
-  e2e::note_kernel("conv133_sparse_kernel<mode=%d> wgs=%d groups=%d chunks=%d flush=%d", mode, p.padded_total, p.groups, p.nchunks, p.flush_every);
+  p.uw = e2e::cdiv(3 * p.kmax, NW);
+  const size_t dyn = (size_t)2 * p.kmax * WSLOT * 4 + (size_t)p.ppad * sizeof(PlaneDesc);
+  static bool attr_set = false;
+  if (!attr_set) {                                        // static 55 KB + dynamic: beyond the default 64 KB for dense maps / many planes
+    (void)hipFuncSetAttribute((const void*)conv133_sparse_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv133_sparse_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    attr_set = true;
+  }
+  E2E_REQUIRE(dyn <= 100 * 1024 && p.uw <= 128, "conv133_sparse: %zu bytes of dynamic LDS (kmax %d, %d planes) not served", dyn, p.kmax, p.ppad);
+  e2e::note_kernel("conv133_sparse_kernel<mode=%d> wgs=%d groups=%d chunks=%d flush=%d kmax=%d", mode, p.padded_total, p.groups, p.nchunks, p.flush_every, p.kmax);
   if (mode == 0) hipLaunchKernelGGL((conv133_sparse_kernel<0>), dim3(p.padded_total), dim3(NW * 64), dyn, st, p);
   else hipLaunchKernelGGL((conv133_sparse_kernel<1>), dim3(p.padded_total), dim3(NW * 64), dyn, st, p);
 #ifdef E2E_CONV_DEBUG
@@ -480,7 +512,7 @@ int sparse_launch(int mode, SparseParams p, hipStream_t st) {
     unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < 1024 * 8; ++i) h[i & 7] += hh[i];
     const double w = h[7] ? (double)h[7] : 1.0;
-    fprintf(stderr, "[conv133_sparse MODE %d P %d Q %d] per-wave cycles: pro %.0f commit %.0f bar1 %.0f prefetch %.0f walk %.0f bar2 %.0f epi %.0f (waves %.0f)\n",
+    fprintf(stderr, "[conv133_sparse MODE %d P %d Q %d] per-wave cycles: pro %.0f commit %.0f barrier %.0f prefetch %.0f walk %.0f flush %.0f epi %.0f (waves %.0f)\n",
             mode, p.P, p.Q, h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[6] / w, w);
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sparse_stamps), zz, sizeof(zz));
   }
@@ -499,13 +531,13 @@ extern "C" int e2e_conv133_sparse_eligible(int Cin, int Cout, int Di, int Hi, in
   return 1;
 }
 
-extern "C" long long e2e_conv133_sparse_wpk_floats(int P, int Q) {
-  return (long long)e2e::cdiv(Q, OCG) * e2e::cdiv(P, CK) * WCHUNK;
+extern "C" long long e2e_conv133_sparse_wpk_floats(int P, int Q, int kmax) {
+  return (long long)e2e::cdiv(Q, OCG) * e2e::cdiv(P, CK) * kmax * WSLOT;
 }
 
 extern "C" int e2e_conv133_sparse_plan(const unsigned char* kmask, int R, int Cc, int transpose, int* qslot, int* pslot,
-                                       unsigned* quads, int* flush_every) {
-  E2E_REQUIRE(kmask && qslot && pslot && quads && R > 0 && Cc > 0, "conv133_sparse_plan: bad arguments");
+                                       unsigned* quads, int* woff, int* kmax, int* flush_every) {
+  E2E_REQUIRE(kmask && qslot && pslot && quads && woff && kmax && R > 0 && Cc > 0, "conv133_sparse_plan: bad arguments");
   const int Q = transpose ? Cc : R, P = transpose ? R : Cc;
   const int groups = e2e::cdiv(Q, OCG), nchunks = e2e::cdiv(P, CK);
   const int NWG = groups * NW;                           // waves of all groups: they share ONE chunking of the input planes
@@ -618,6 +650,18 @@ extern "C" int e2e_conv133_sparse_plan(const unsigned char* kmask, int R, int Cc
         quads[((long long)g * NW + w) * nchunks + c] = word;
       }
   }
+  // -- the live kernels of a chunk are stored wave by wave: first slot of every wave's list, and the largest chunk (block size)
+  int km = 1;
+  for (int g = 0; g < groups; ++g)
+    for (int c = 0; c < nchunks; ++c) {
+      int at_slot = 0;
+      for (int w = 0; w < NW; ++w) {
+        woff[((long long)g * nchunks + c) * NW + w] = at_slot;
+        at_slot += __builtin_popcount(quads[((long long)g * NW + w) * nchunks + c]);
+      }
+      km = std::max(km, at_slot);
+    }
+  *kmax = km;
   if (flush_every != nullptr) {
     // flush the chunk accumulators into the outer ones once a chain holds about as many products as a dense chunk (72)
     const double per_plane_chunk = Q > 0 ? (double)nlive / ((double)Q * nchunks) : (double)CK;   // live kernels per output plane and chunk
@@ -636,23 +680,23 @@ extern "C" int e2e_conv133_sparse_pack(const e2e_sparse_pack_job_t* jobs, int nj
 }
 
 extern "C" int e2e_conv133_fwd_sparse(const e2e_in_chan_t* chans_plan, int Cin, const float* wpk, const float* bias, const unsigned* quads,
-                                      const int* qslot, int flush_every, float* y, double* part, int B, int Cout, int Di, int Hi,
-                                      int Wi, void* stream) {
-  E2E_REQUIRE(chans_plan && wpk && quads && qslot && y, "conv133_fwd_sparse: null pointer");
+                                      const int* woff, int kmax, const int* qslot, int flush_every, float* y, double* part, int B,
+                                      int Cout, int Di, int Hi, int Wi, void* stream) {
+  E2E_REQUIRE(chans_plan && wpk && quads && woff && kmax > 0 && qslot && y, "conv133_fwd_sparse: bad arguments");
   E2E_REQUIRE(e2e_conv133_sparse_eligible(Cin, Cout, Di, Hi, Wi, 1, 1, 1), "conv133_fwd_sparse: shape not served");
   SparseParams p{};
-  p.chans = chans_plan; p.wpk = wpk; p.bias = bias; p.quads = quads; p.qslot = qslot; p.y = y; p.part = part;
+  p.chans = chans_plan; p.wpk = wpk; p.bias = bias; p.quads = quads; p.woff = woff; p.kmax = kmax; p.qslot = qslot; p.y = y; p.part = part;
   p.P = Cin; p.Q = Cout; p.B = B; p.D = Di; p.H = Hi; p.W = Wi; p.flush_every = flush_every;
   return sparse_launch(0, p, (hipStream_t)stream);
 }
 
-extern "C" int e2e_conv133_dgrad_sparse(const float* dy, const float* wpk_t, const unsigned* quads_t, const int* pslot_t,
-                                        const e2e_out_chan_t* outs_plan, int flush_every, int B, int Cin, int Cout, int Di, int Hi,
-                                        int Wi, void* stream) {
-  E2E_REQUIRE(dy && wpk_t && quads_t && pslot_t && outs_plan, "conv133_dgrad_sparse: null pointer");
+extern "C" int e2e_conv133_dgrad_sparse(const float* dy, const float* wpk_t, const unsigned* quads_t, const int* woff_t, int kmax_t,
+                                        const int* pslot_t, const e2e_out_chan_t* outs_plan, int flush_every, int B, int Cin, int Cout,
+                                        int Di, int Hi, int Wi, void* stream) {
+  E2E_REQUIRE(dy && wpk_t && quads_t && woff_t && kmax_t > 0 && pslot_t && outs_plan, "conv133_dgrad_sparse: bad arguments");
   E2E_REQUIRE(e2e_conv133_sparse_eligible(Cin, Cout, Di, Hi, Wi, 1, 1, 1), "conv133_dgrad_sparse: shape not served");
   SparseParams p{};
-  p.xin = dy; p.wpk = wpk_t; p.quads = quads_t; p.pslot = pslot_t; p.outs = outs_plan;
+  p.xin = dy; p.wpk = wpk_t; p.quads = quads_t; p.woff = woff_t; p.kmax = kmax_t; p.pslot = pslot_t; p.outs = outs_plan;
   p.P = Cout; p.Q = Cin; p.B = B; p.D = Di; p.H = Hi; p.W = Wi; p.flush_every = flush_every;
   return sparse_launch(1, p, (hipStream_t)stream);
 }

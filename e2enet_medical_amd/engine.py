@@ -128,22 +128,24 @@ class SparsePlan:
         qslot = np.empty(self.groups * 32, dtype=np.int32)
         pslot = np.empty(self.groups * self.nchunks * 8, dtype=np.int32)
         quads = np.empty(self.groups * 8 * self.nchunks, dtype=np.uint32)
-        flush = C.c_int(1)
+        woff = np.empty(self.groups * self.nchunks * 8, dtype=np.int32)
+        flush, kmax = C.c_int(1), C.c_int(1)
         km_host = np.ascontiguousarray(km_host, dtype=np.uint8)
         L.conv133_sparse_plan(km_host.ctypes.data, r, cc, 1 if transpose else 0, qslot.ctypes.data, pslot.ctypes.data,
-                              quads.ctypes.data, C.addressof(flush))
-        self.flush_every = int(flush.value)
+                              quads.ctypes.data, woff.ctypes.data, C.addressof(kmax), C.addressof(flush))
+        self.flush_every, self.kmax = int(flush.value), int(kmax.value)
+        self.woff = torch.from_numpy(woff).to(device)
         self.qslot_host, self.pslot_host = qslot, pslot
         self.qslot = torch.from_numpy(qslot).to(device)
         self.pslot = torch.from_numpy(pslot).to(device)
         self.quads = torch.from_numpy(quads.view(np.int32)).to(device)
-        self.wpk = torch.zeros(int(L.conv133_sparse_wpk_floats(self.P, self.Q)), dtype=torch.float32, device=device)
+        self.wpk = torch.zeros(int(L.conv133_sparse_wpk_floats(self.P, self.Q, self.kmax)), dtype=torch.float32, device=device)
         self.table = None           # forward: plane descriptors in plan order; data gradient: destinations in plan order
 
     def job(self, w, cin, reverse):
         wq, wp = (9, cin * 9) if reverse else (cin * 9, 9)
         return SparsePackJob(w.data_ptr(), self.wpk.data_ptr(), self.qslot.data_ptr(), self.pslot.data_ptr(), self.quads.data_ptr(),
-                             self.groups, self.nchunks, wq, wp, 1 if reverse else 0, 0)
+                             self.woff.data_ptr(), self.groups, self.nchunks, wq, wp, 1 if reverse else 0, self.kmax)
 
 
 def pack_sparse_weights(jobs, device):
@@ -273,7 +275,7 @@ class ConvOp:
         elif self.sp_fwd is not None:                       # DSFF-masked full-resolution layers: load-balanced plan
             sp = self.sp_fwd
             L.conv133_fwd_sparse(sp.table.data_ptr(), self.cin, sp.wpk.data_ptr(), p[self.prefix + ".conv.bias"].data_ptr(),
-                                 sp.quads.data_ptr(), sp.qslot.data_ptr(), sp.flush_every, self.out.data.data_ptr(),
+                                 sp.quads.data_ptr(), sp.woff.data_ptr(), sp.kmax, sp.qslot.data_ptr(), sp.flush_every, self.out.data.data_ptr(),
                                  self.part.data_ptr(), b, self.cout, di, hi, wi, _stream())
         elif ws is not None and self.fwd_ws_bytes > 0:      # deep levels: input-plane chunks split over several workgroups
             L.conv133_fwd_splitk(self.chans.data_ptr(), self.cin, p[self.w_name].data_ptr(),
@@ -313,7 +315,7 @@ class ConvOp:
                                       di, hi, wi, ws.data_ptr(), ws.numel() * 4, _stream())
             elif self.sp_bwd is not None:
                 sp = self.sp_bwd
-                L.conv133_dgrad_sparse(o.grad.data_ptr(), sp.wpk.data_ptr(), sp.quads.data_ptr(), sp.pslot.data_ptr(),
+                L.conv133_dgrad_sparse(o.grad.data_ptr(), sp.wpk.data_ptr(), sp.quads.data_ptr(), sp.woff.data_ptr(), sp.kmax, sp.pslot.data_ptr(),
                                        self._bwd_table().data_ptr(), sp.flush_every, b, self.cin, self.cout, di, hi, wi, _stream())
             elif ws is not None and self.dgrad_ws_bytes > 0:        # deep levels: split-K (the workspace is idle during backward)
                 L.conv133_dgrad_splitk(o.grad.data_ptr(), p[self.w_name].data_ptr(), _ptr(self.live_t), self.outs.data_ptr(),

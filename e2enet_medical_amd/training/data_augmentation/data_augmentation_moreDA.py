@@ -13,9 +13,12 @@ Parameter draws follow each transform's own order of random calls as far as it i
 to be bit-compatible with).  Parity is unpinned by construction; each kernel is tested against scipy / numpy given the drawn
 parameters (tests/test_gpu_augment.py, oracle/augment.py).
 
-Deviations, all stated where they happen: data interpolation order 1 instead of the cubic spline (``order_data=3``) in the
-spatial transform and in the up-sampling half of SimulateLowResolution; elastic deformation (switched off by the trainer,
-nnUNetTrainer_simple.py:730), the cascade / pyramid transforms, ``dummy_2D`` and region targets are not built.
+Data interpolation follows the reference's orders: ``order_data=3`` (cubic B-spline, scipy ``map_coordinates`` semantics: mirror
+prefilter + 64-tap gather) in the spatial transform and ``order_upsample=3`` in SimulateLowResolution (scipy ``zoom`` with
+``grid_mode``, edge pre-padding by 12, clipped to the low-resolution range like skimage's ``resize``); ``order_data=1`` selects
+the linear kernels.  Not built, and rejected when asked for: elastic deformation (switched off by the trainer,
+nnUNetTrainer_simple.py:730), the cascade / pyramid transforms, ``dummy_2D``, region targets, additive brightness, independent
+per-axis scaling, random crops.
 """
 from typing import Iterable, Optional, Sequence
 
@@ -49,6 +52,8 @@ class DeviceAugmenter:
                  deep_supervision_scales=None, seed: Optional[int] = None, device="cuda"):
         self.params = dict(default_3D_augmentation_params if params is None else params)
         p = self.params
+        if params is None:
+            p["do_elastic"] = False        # the table default is True; the trainer, the only caller in the reference, switches it off (:730)
         if p.get("do_elastic"):
             raise NotImplementedError("elastic deformation is not built (the trainer switches it off, nnUNetTrainer_simple.py:730)")
         if p.get("dummy_2D") or p.get("move_last_seg_chanel_to_data"):
@@ -57,8 +62,13 @@ class DeviceAugmenter:
             raise NotImplementedError("border_mode_data must be 'constant'")
         if order_seg not in (0, 1):
             raise NotImplementedError("order_seg 0 or 1")
-        # order_data: the reference asks batchgenerators for a cubic spline (3); the gather kernel interpolates linearly
-        self.order_data_requested, self.order_seg = order_data, order_seg
+        if order_data not in (1, 3):
+            raise NotImplementedError("order_data 1 (linear) or 3 (cubic B-spline, the reference's default)")
+        for key, off in (("do_additive_brightness", False), ("independent_scale_factor_for_each_axis", False), ("random_crop", False)):
+            if p.get(key, off) not in (off, None):
+                raise NotImplementedError("augmentation parameter %s=%r is not built" % (key, p.get(key)))
+        self.order_data, self.order_seg = int(order_data), order_seg
+        self.order_upsample = 3 if order_data == 3 else 1         # the reference passes order_upsample=3 (:99)
         self.patch_size = tuple(int(v) for v in patch_size)
         self.border_val_seg = float(border_val_seg)
         self.ds_scales = deep_supervision_scales
@@ -153,7 +163,20 @@ class DeviceAugmenter:
         out = torch.empty((B, C, Do, Ho, Wo), dtype=torch.float32, device=self.device)
         oseg = torch.empty((B, seg.shape[1], Do, Ho, Wo), dtype=torch.float32, device=self.device) if seg is not None else None
         mat = self._prm(draws["mat"])
-        L.aug_spatial(data.data_ptr(), seg.data_ptr() if seg is not None else None, out.data_ptr(),
+        coef = cubic = None
+        mod = np.asarray(draws["modified"], dtype=bool)
+        if self.order_data == 3 and mod.any():
+            # cubic B-spline coefficients of the samples the transform moves (an untouched sample is an integer crop: exact copy).
+            # scipy's prefilter, one recursive pass per axis; the raw batch stays as it is (order-1 seg path, centre crops)
+            coef = torch.empty_like(data)
+            for b in np.nonzero(mod)[0]:
+                src = data[b]
+                for ax in (0, 1, 2):
+                    L.aug_bspline_prefilter_axis(src.data_ptr(), coef[b].data_ptr(), C, Di, Hi, Wi, ax, _stream())
+                    src = coef[b]
+            cubic = torch.from_numpy(mod.astype(np.int32)).to(self.device)
+        L.aug_spatial(data.data_ptr(), coef.data_ptr() if coef is not None else None, cubic.data_ptr() if cubic is not None else None,
+                      seg.data_ptr() if seg is not None else None, out.data_ptr(),
                       oseg.data_ptr() if oseg is not None else None, mat.data_ptr(), B, C, seg.shape[1] if seg is not None else 0,
                       Di, Hi, Wi, Do, Ho, Wo, self.order_seg, self.border_val_seg, _stream())
         # a sample the spatial transform did not touch is a centre crop: exact for data and seg alike (order-1 seg at integer
@@ -206,7 +229,26 @@ class DeviceAugmenter:
                     lo[i] = np.round(np.array([Do, Ho, Wo]) * z).astype(int)
             if tmp is None:
                 tmp = torch.empty_like(out)
-            L.aug_lowres(out.data_ptr(), tmp.data_ptr(), torch.from_numpy(lo).to(self.device).data_ptr(), nbc, Do, Ho, Wo, _stream())
+            if self.order_upsample == 3:
+                # per touched channel: nearest down-sampling into an edge-padded scratch volume, its range (skimage clips the
+                # up-sampled result to it), spline prefilter, cubic up-sampling; untouched channels are copied
+                PAD = 12
+                tmp.copy_(out)
+                ov, tv = out.view(nbc, Do, Ho, Wo), tmp.view(nbc, Do, Ho, Wo)
+                big = int(max((l[0] + 2 * PAD) * (l[1] + 2 * PAD) * (l[2] + 2 * PAD) for l in lo))
+                scratch = torch.empty(big, dtype=torch.float32, device=self.device)
+                st = torch.empty(4, dtype=torch.float64, device=self.device)
+                ws = torch.empty(L.aug_stats_ws_bytes(1) // 8, dtype=torch.float64, device=self.device)
+                for i in np.nonzero(lo[:, 0])[0]:
+                    ld, lh, lw = (int(v) for v in lo[i])
+                    pd, ph, pw = ld + 2 * PAD, lh + 2 * PAD, lw + 2 * PAD
+                    L.aug_lowres_down(ov[i].data_ptr(), scratch.data_ptr(), Do, Ho, Wo, ld, lh, lw, PAD, _stream())
+                    L.aug_stats(scratch.data_ptr(), st.data_ptr(), ws.data_ptr(), 1, pd * ph * pw, _stream())
+                    for ax in (0, 1, 2):
+                        L.aug_bspline_prefilter_axis(scratch.data_ptr(), scratch.data_ptr(), 1, pd, ph, pw, ax, _stream())
+                    L.aug_lowres_up3(scratch.data_ptr(), tv[i].data_ptr(), st.data_ptr(), Do, Ho, Wo, ld, lh, lw, PAD, _stream())
+            else:
+                L.aug_lowres(out.data_ptr(), tmp.data_ptr(), torch.from_numpy(lo).to(self.device).data_ptr(), nbc, Do, Ho, Wo, _stream())
             out, tmp = tmp, out
         for key, inv in (("gamma_inv", 1.0), ("gamma", 0.0)):
             g = draws[key]
@@ -303,6 +345,8 @@ def get_moreDA_augmentation(dataloader_train, dataloader_val, patch_size, params
         dev = aug.device
         data = torch.as_tensor(data, dtype=torch.float32).to(dev).contiguous()
         seg = torch.as_tensor(seg, dtype=torch.float32).to(dev).contiguous()
+        if params.get("selected_data_channels") is not None:              # DataChannelSelectionTransform (:154-155)
+            data = data[:, list(params["selected_data_channels"])].contiguous()
         if params.get("selected_seg_channels") is not None:
             seg = seg[:, list(params["selected_seg_channels"])].contiguous()
         lib().aug_finish(data.data_ptr(), seg.data_ptr(), None, data.shape[0], data.shape[1], seg.shape[1],

@@ -114,12 +114,14 @@ int e2e_conv133_dgrad_splitk(const float* dy, const float* w, const unsigned* li
  *   e2e_conv133_sparse_plan    host function.  kmask [R][Cc] uint8 in HOST memory (weight dims 0 and 1); transpose 0: forward
  *       (Q = R output planes, P = Cc input planes), 1: data gradient (Q = Cc virtual-concat channels, P = R dy channels).  Writes
  *       (host arrays) qslot [groups*32] (output plane of slot wave*4 + a, -1 empty), pslot [groups*nchunks*8] (input plane of each
- *       chunk slot, -1 empty), quads [groups*8*nchunks] (bit cl*4 + a of word [group][wave][chunk] <=> kernel alive) and
+ *       chunk slot, -1 empty; the same chunking for every group: they share the staged planes through L2), quads
+ *       [groups*8*nchunks] (bit cl*4 + a of word [group][wave][chunk] <=> kernel alive), woff [groups*nchunks*8] (first slot of
+ *       each wave's kernel list inside the chunk's packed block), kmax (slots of a block = the most live kernels of any chunk) and
  *       flush_every (chunks per flush of the two-level summation); groups = ceil(Q/32), nchunks = ceil(P/8).  A pure function of
  *       the kernel map (every data-parallel rank derives the same plan).
- *   e2e_conv133_sparse_pack    device: packed weights [groups][nchunks][32][8][12] (pruned kernels and padding = 0) for a TABLE
- *       of jobs in one launch (run it after every optimizer step / parameter load); max_floats = the largest job's
- *       e2e_conv133_sparse_wpk_floats(P, Q).  reverse = 1 flips the taps (data gradient).
+ *   e2e_conv133_sparse_pack    device: packed weights [groups][nchunks][kmax][12] -- only the LIVE kernels, wave by wave in walk
+ *       order -- for a TABLE of jobs in one launch (run it after every optimizer step / parameter load).  reverse = 1 flips the
+ *       taps (data gradient).
  *   e2e_conv133_fwd_sparse     chans_plan [groups][nchunks*8]: the e2e_in_chan_t of pslot's planes (ptr NULL for empty slots)
  *   e2e_conv133_dgrad_sparse   pslot_t as returned by the plan (dy channels); outs_plan [groups][32]: the e2e_out_chan_t of
  *       qslot's channels (ptr NULL for empty slots)                                                                          */
@@ -129,22 +131,23 @@ typedef struct {
   const int* qslot;          /* device copies of the plan arrays */
   const int* pslot;
   const unsigned* quads;
+  const int* woff;
   int groups, nchunks;
   int wq_stride, wp_stride;  /* element strides of w for (output plane, input plane): forward (Cin*9, 9), data gradient (9, Cin*9) */
   int reverse;
-  int reserved;
+  int kmax;
 } e2e_sparse_pack_job_t;
 int e2e_conv133_sparse_eligible(int Cin, int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw);
-long long e2e_conv133_sparse_wpk_floats(int P, int Q);
+long long e2e_conv133_sparse_wpk_floats(int P, int Q, int kmax);
 int e2e_conv133_sparse_plan(const unsigned char* kmask_host, int R, int Cc, int transpose, int* qslot, int* pslot, unsigned* quads,
-                            int* flush_every);
-int e2e_conv133_sparse_pack(const e2e_sparse_pack_job_t* jobs, int njobs, long long max_floats, void* stream);
+                            int* woff, int* kmax, int* flush_every);
+int e2e_conv133_sparse_pack(const e2e_sparse_pack_job_t* jobs, int njobs, long long max_threads, void* stream);
 int e2e_conv133_fwd_sparse(const e2e_in_chan_t* chans_plan, int Cin, const float* wpk, const float* bias, const unsigned* quads,
-                           const int* qslot, int flush_every, float* y, double* part, int B, int Cout, int Di, int Hi, int Wi,
-                           void* stream);
-int e2e_conv133_dgrad_sparse(const float* dy, const float* wpk_t, const unsigned* quads_t, const int* pslot_t,
-                             const e2e_out_chan_t* outs_plan, int flush_every, int B, int Cin, int Cout, int Di, int Hi, int Wi,
-                             void* stream);
+                           const int* woff, int kmax, const int* qslot, int flush_every, float* y, double* part, int B, int Cout,
+                           int Di, int Hi, int Wi, void* stream);
+int e2e_conv133_dgrad_sparse(const float* dy, const float* wpk_t, const unsigned* quads_t, const int* woff_t, int kmax_t,
+                             const int* pslot_t, const e2e_out_chan_t* outs_plan, int flush_every, int B, int Cin, int Cout, int Di,
+                             int Hi, int Wi, void* stream);
 
 /* ---- K6b: 1x3x3 convolution, weight gradient (dense: also for dead kernels, because the
  * reference's clip_grad_norm_ runs over all gradients, nnUNetTrainer_simple.py:573) ----

@@ -3,9 +3,9 @@
 numpy / scipy restatement of the batchgenerators 0.24 transforms that reference
 e2enet/training/data_augmentation/data_augmentation_moreDA.py:66-121 composes (third party, absent from the image and from
 /root/reference: PARITY UNPINNED -- no golden could be generated; each function states the batchgenerators routine it follows).
-Where the device path deviates from the reference on purpose (linear instead of cubic interpolation of the data, linear
-up-sampling in the low-resolution simulation) this file restates the DEVICE's choice, so that the kernels are checked against an
-independent implementation of the same arithmetic.
+Data interpolation orders are parameters (the reference: order_data = 3 in SpatialTransform, order_upsample = 3 in
+SimulateLowResolution; order 1 is the device's other mode): scipy.ndimage itself is the independent implementation the kernels are
+checked against.
 """
 import numpy as np
 from scipy import ndimage
@@ -19,8 +19,9 @@ def coordinate_mesh(patch_size, mat):
     return (m[:, :3] @ c + m[:, 3:4]).reshape((3,) + tuple(patch_size))
 
 
-def spatial(data, seg, mats, patch_size, order_seg=1, cval_seg=-1.0):
-    """SpatialTransform per sample: data map_coordinates(order=1, mode='constant', cval=0) [reference: order 3]; seg either
+def spatial(data, seg, mats, patch_size, order_seg=1, cval_seg=-1.0, order_data=3):
+    """SpatialTransform per sample: data map_coordinates(order=order_data, mode='constant', cval=0) [batchgenerators
+    interpolate_img: img.astype(float) in, .astype(img.dtype) out; the reference passes order_data=3]; seg either
     order 0 with cval, or interpolate_img(is_seg=True, order=1): per label (ascending) a linear interpolation of the binary mask
     with the same cval, assigned where >= 0.5."""
     B = data.shape[0]
@@ -29,7 +30,7 @@ def spatial(data, seg, mats, patch_size, order_seg=1, cval_seg=-1.0):
     for b in range(B):
         coords = coordinate_mesh(patch_size, mats[b])
         for c in range(data.shape[1]):
-            out[b, c] = ndimage.map_coordinates(data[b, c].astype(float), coords, order=1, mode='constant', cval=0.0).astype(np.float32)
+            out[b, c] = ndimage.map_coordinates(data[b, c].astype(float), coords, order=order_data, mode='constant', cval=0.0).astype(np.float32)
         if seg is not None:
             for c in range(seg.shape[1]):
                 img = seg[b, c]
@@ -79,13 +80,15 @@ def _resize(img, shape, order):
     return ndimage.zoom(img, np.array(shape, dtype=float) / np.array(img.shape), order=order, mode='nearest', grid_mode=True)
 
 
-def low_resolution(x, zoom):
-    """augment_linear_downsampling_scipy on one channel: nearest down to round(shape * zoom), then up-sampling back [order 1
-    here like the device; the reference passes order_upsample=3]"""
+def low_resolution(x, zoom, order_upsample=3):
+    """augment_linear_downsampling_scipy on one channel: nearest down to round(shape * zoom), then up-sampling back with
+    skimage resize(order_upsample, mode='edge', anti_aliasing=False) [the reference passes order_upsample=3]; resize's default
+    clip=True clamps the result to the range of its input (a no-op for order <= 1)"""
     shp = np.array(x.shape)
     target = np.round(shp * zoom).astype(int)
-    down = _resize(x.astype(float), target, 0)
-    return _resize(down, shp, 1).astype(np.float32)
+    down = _resize(x.astype(np.float32), target, 0)
+    up = _resize(down, shp, order_upsample)
+    return np.clip(up, down.min(), down.max()).astype(np.float32)
 
 
 def mirror(data, seg, axes_flags):

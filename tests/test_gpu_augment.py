@@ -46,17 +46,43 @@ def _mats(a, B, in_shape, angles, scales):
     return m
 
 
-@pytest.mark.parametrize("order_seg", [0, 1])
-def test_spatial_transform_vs_scipy(order_seg):
-    a = _aug(order_seg=order_seg)
+@pytest.mark.parametrize("order_seg,order_data", [(0, 3), (1, 3), (1, 1)])
+def test_spatial_transform_vs_scipy(order_seg, order_data):
+    """order_data 3 = the reference's cubic B-spline (data_augmentation_moreDA.py:43): scipy's mirror prefilter and 64-tap gather
+    on the device against scipy.ndimage.map_coordinates itself; order 1 = the linear mode."""
+    a = _aug(order_seg=order_seg, order_data=order_data)
     data, seg = _raw()
     d = _blank(a, 2, 3)
     d["mat"] = _mats(a, 2, data.shape[2:], [(0.3, -0.2, 0.4), (0.0, 0.5, -0.1)], [1.3, 0.75])
     out, oseg = a.apply(torch.from_numpy(data).cuda(), torch.from_numpy(seg).cuda(), d)
-    ref, rseg = oaug.spatial(data, seg, d["mat"], a.patch_size, order_seg, -1.0)
+    ref, rseg = oaug.spatial(data, seg, d["mat"], a.patch_size, order_seg, -1.0, order_data)
     rdat, rseg = oaug.finish(ref, rseg, None)
-    assert np.abs(out.cpu().numpy() - rdat).max() <= 2e-5
+    err = np.abs(out.cpu().numpy() - rdat).max()
+    print("[spatial order_data %d] max |device - scipy| = %.3e" % (order_data, err))
+    assert err <= (2e-5 if order_data == 1 else 3e-5)          # (coefficients are stored in fp32 between the prefilter passes)
+    assert (out.cpu().numpy() == 0).mean() > 0.01               # part of the patch lies outside the loaded volume: cval
     assert (oseg.cpu().numpy() != rseg).mean() <= 2e-4          # label decisions exactly on a 0.5 / half-voxel boundary
+
+
+@pytest.mark.parametrize("shape", [(3, 9, 11, 13), (2, 24, 40, 330), (1, 40, 5, 64), (2, 1, 3, 700)])
+def test_bspline_prefilter_is_scipy_spline_filter(shape):
+    """e2e_aug_bspline_prefilter_axis x 3 = scipy.ndimage.spline_filter(order=3, mode='mirror') (what map_coordinates / zoom run in
+    front of an order-3 interpolation, also for mode='constant' and the pre-padded 'nearest'); rows longer than 320 voxels take the
+    16-lines-per-block form of the contiguous-axis kernel, a length-1 axis is left alone."""
+    from scipy import ndimage
+    from e2enet_medical_amd._lib import lib
+    x = np.random.RandomState(5).standard_normal(shape).astype(np.float32)
+    t = torch.from_numpy(x).cuda()
+    o = torch.empty_like(t)
+    src = t
+    for ax in (0, 1, 2):
+        lib().aug_bspline_prefilter_axis(src.data_ptr(), o.data_ptr(), shape[0], *shape[1:], ax, 0)
+        src = o
+    torch.cuda.synchronize()
+    assert torch.equal(t.cpu(), torch.from_numpy(x))            # the source is not touched
+    for v in range(shape[0]):
+        ref = ndimage.spline_filter(x[v].astype(np.float64), 3, mode='mirror')
+        assert np.abs(o[v].cpu().numpy() - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max())
 
 
 def test_unmodified_sample_is_a_centre_crop():
@@ -87,7 +113,7 @@ def test_intensity_transforms_vs_numpy_scipy():
     s = torch.from_numpy(seg).cuda()
 
     def run(**kw):
-        d = dict(_blank(a, B, C), mat=ident)
+        d = dict(_blank(a, B, C), mat=ident, modified=np.zeros(B, dtype=bool))      # an untouched sample: exact integer crop
         d.update(kw)
         return a.apply(x, s, d)[0].cpu().numpy()
     # blur (per channel sigma, one channel untouched)
@@ -119,16 +145,23 @@ def test_intensity_transforms_vs_numpy_scipy():
             for c in range(C):
                 ref = data[b, c] if g[b, c] == 0 else oaug.gamma(data[b, c], g[b, c], inv, True)
                 assert np.abs(got[b, c] - ref).max() <= 5e-5, (key, b, c, np.abs(got[b, c] - ref).max())
-    # low-resolution simulation
+    # low-resolution simulation: the reference's cubic up-sampling (order_upsample = 3, clipped to the low-resolution range), and linear
     z = np.array([[0.5, 0.0, 0.8], [0.66, 0.93, 0.0]])
-    got = run(zoom=z)
-    for b in range(B):
-        for c in range(C):
-            ref = data[b, c] if z[b, c] == 0 else oaug.low_resolution(data[b, c], z[b, c])
-            assert np.abs(got[b, c] - ref).max() <= 2e-6
+    for order, aa in ((3, a), (1, _aug(order_data=1))):
+        d = dict(_blank(aa, B, C), mat=ident, zoom=z, modified=np.zeros(B, dtype=bool))
+        got = aa.apply(x, s, d)[0].cpu().numpy()
+        for b in range(B):
+            for c in range(C):
+                ref = data[b, c] if z[b, c] == 0 else oaug.low_resolution(data[b, c], z[b, c], order)
+                assert np.abs(got[b, c] - ref).max() <= (2e-6 if order == 1 else 2e-5), (order, b, c, np.abs(got[b, c] - ref).max())
+        if order == 3:                                          # the clip matters here: the cubic overshoots the low-resolution range somewhere
+            lo = oaug._resize(data[0, 0], np.round(np.array(data.shape[2:]) * 0.5).astype(int), 0)
+            raw = oaug._resize(lo, data.shape[2:], 3)
+            assert (raw > lo.max()).any() or (raw < lo.min()).any()
+            assert got[0, 0].max() <= np.float32(lo.max()) and got[0, 0].min() >= np.float32(lo.min())
     # mirror + mask + remove label
     a2 = _aug(params={"mask_was_used_for_normalization": {0: True, 1: False, 2: True}})
-    d = dict(_blank(a2, B, C), mat=ident, mirror=np.array([[True, False, True], [False, True, False]]))
+    d = dict(_blank(a2, B, C), mat=ident, mirror=np.array([[True, False, True], [False, True, False]]), modified=np.zeros(B, dtype=bool))
     out, oseg = a2.apply(x, s, d)
     for b in range(B):
         rd, rs = oaug.mirror(data[b], seg[b], d["mirror"][b])
@@ -140,7 +173,7 @@ def test_gaussian_noise_statistics_and_determinism():
     a = _aug(patch=(32, 32, 32))
     data = np.zeros((1, 2, 32, 32, 32), np.float32)
     ident = np.concatenate([np.eye(3), np.full((3, 1), 15.5)], 1).reshape(1, 12)
-    d = dict(_blank(a, 1, 2), mat=ident, noise=np.array([[0.07, 0.0]]), noise_seed=123)
+    d = dict(_blank(a, 1, 2), mat=ident, noise=np.array([[0.07, 0.0]]), noise_seed=123, modified=np.zeros(1, dtype=bool))
     x = torch.from_numpy(data).cuda()
     o1 = a.apply(x, None, d)[0].cpu().numpy()
     o2 = a.apply(x, None, d)[0].cpu().numpy()

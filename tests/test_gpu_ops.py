@@ -692,7 +692,7 @@ def test_conv133_masks_are_structural_on_every_path(density):
     L = lib()
     if not op.use_dense():                          # the load-balanced kernel, then (below) the generic walk on the same data
         sp = op.sp_bwd
-        L.conv133_dgrad_sparse(op.out.grad.data_ptr(), sp.wpk.data_ptr(), sp.quads.data_ptr(), sp.pslot.data_ptr(), op._bwd_table().data_ptr(),
+        L.conv133_dgrad_sparse(op.out.grad.data_ptr(), sp.wpk.data_ptr(), sp.quads.data_ptr(), sp.woff.data_ptr(), sp.kmax, sp.pslot.data_ptr(), op._bwd_table().data_ptr(),
                                sp.flush_every, B, cin, cout, *dims, 0)
         torch.cuda.synchronize()
         assert L.last_kernel().decode().startswith("conv133_sparse_kernel<mode=1>")

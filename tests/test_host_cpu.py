@@ -458,8 +458,16 @@ def test_sparse_plan_is_a_valid_balanced_permutation(R, Cc, dens):
         Q, P = (Cc, R) if tr else (R, Cc)
         G, NC = (Q + 31) // 32, (P + 7) // 8
         qs, ps, qd = np.empty(G * 32, np.int32), np.empty(G * NC * 8, np.int32), np.empty(G * 8 * NC, np.uint32)
-        fl = C.c_int(0)
-        L.conv133_sparse_plan(km.ctypes.data, R, Cc, tr, qs.ctypes.data, ps.ctypes.data, qd.ctypes.data, C.addressof(fl))
+        wo = np.empty(G * NC * 8, np.int32)
+        fl, kmx = C.c_int(0), C.c_int(0)
+        L.conv133_sparse_plan(km.ctypes.data, R, Cc, tr, qs.ctypes.data, ps.ctypes.data, qd.ctypes.data, wo.ctypes.data,
+                              C.addressof(kmx), C.addressof(fl))
+        # the packed block of a chunk holds the live kernels wave by wave: offsets are the running popcount, kmax the largest chunk
+        pc = np.array([bin(int(v)).count("1") for v in qd]).reshape(G, 8, NC)
+        want = np.cumsum(pc, axis=1) - pc                            # [G, wave, chunk] exclusive prefix over the waves
+        assert np.array_equal(wo.reshape(G, NC, 8), want.transpose(0, 2, 1))
+        assert kmx.value == max(1, int(pc.sum(axis=1).max()))
+        assert L.conv133_sparse_wpk_floats(P, Q, kmx.value) == G * NC * kmx.value * 12
         return Q, P, G, NC, qs, ps, qd, fl.value
     for tr in (0, 1):
         Q, P, G, NC, qs, ps, qd, flush = plan(tr)

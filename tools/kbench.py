@@ -100,11 +100,11 @@ def conv_case(B, srcs, cout, dims, stride, density, tag):
     def fwd_planned():
         sp = op.sp_fwd
         L.conv133_fwd_sparse(sp.table.data_ptr(), cin, sp.wpk.data_ptr(), p["b.conv.bias"].data_ptr(), sp.quads.data_ptr(),
-                             sp.qslot.data_ptr(), sp.flush_every, op.out.data.data_ptr(), op.part.data_ptr(), B, cout, di, hi, wi, 0)
+                             sp.woff.data_ptr(), sp.kmax, sp.qslot.data_ptr(), sp.flush_every, op.out.data.data_ptr(), op.part.data_ptr(), B, cout, di, hi, wi, 0)
 
     def dgrad_planned():
         sp = op.sp_bwd
-        L.conv133_dgrad_sparse(op.out.grad.data_ptr(), sp.wpk.data_ptr(), sp.quads.data_ptr(), sp.pslot.data_ptr(),
+        L.conv133_dgrad_sparse(op.out.grad.data_ptr(), sp.wpk.data_ptr(), sp.quads.data_ptr(), sp.woff.data_ptr(), sp.kmax, sp.pslot.data_ptr(),
                                op._bwd_table().data_ptr(), sp.flush_every, B, cin, cout, di, hi, wi, 0)
     dense = 2.0 * 9 * cin * cout * (vout / cout)
     res = {}
