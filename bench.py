@@ -554,7 +554,7 @@ def main():
         work = conv_work(eng, mask)
         ev = [(e0.elapsed_time(e1), work[a[0]]) for e0, e1, a in timers["conv133_fwd"].events + timers["conv133_fwd_splitk"].events +
               timers["conv133_fwd_dense"].events + timers["conv133_fwd_sparse"].events]
-        ev += [(e0.elapsed_time(e1), work[a[4]]) for e0, e1, a in timers["conv133_dgrad_sparse"].events]
+        ev += [(e0.elapsed_time(e1), work[a[6]]) for e0, e1, a in timers["conv133_dgrad_sparse"].events]
         pack_ms = timers["conv133_sparse_pack"].total_ms()            # weight packing of the planned layers: counted with the family
         ev += [(e0.elapsed_time(e1), work[a[3]]) for e0, e1, a in timers["conv133_dgrad"].events + timers["conv133_dgrad_splitk"].events]
         ev += [(e0.elapsed_time(e1), work[a[3]]) for e0, e1, a in timers["conv133_dgrad_dense"].events]

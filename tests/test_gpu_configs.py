@@ -697,7 +697,7 @@ def test_config3_btcv_full_shape_vs_oracle_and_dsff_update_replay():
     for n in params:
         rg = leaves[n].grad
         nrm = rg.norm().item()
-        if nrm <= 1e-6:
+        if nrm <= 1e-6 or n.endswith(".conv.bias"):      # a conv bias in front of an InstanceNorm has an exactly-zero gradient: both sides hold noise
             continue
         rel = (eng1.grads[n].cpu() - rg).norm().item() / nrm
         if rel > worst[0]:
