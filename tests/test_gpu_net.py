@@ -668,12 +668,28 @@ def test_full_size_128_training_properties():
     for n in g1:
         assert torch.equal(g1[n] * 0.5, eng.grads[n]), "linearity: " + n
 
-    # (b) liveness-skipping data gradient against dense execution of the same (masked) weights by the SAME kernel (the matrix-core
-    # conv path is switched off for this comparison: without kernel maps every served layer would go to conv133_dense_kernel)
+    # (b) liveness-skipping data gradient against dense execution of the same (masked) weights by the SAME kernel, conv133_kernel
+    # (the matrix-core conv path and the load-balanced plans are switched off for this comparison: without kernel maps every
+    # served layer would go to conv133_dense_kernel, and a plan walks the planes in another order)
     from e2enet_medical_amd import engine as engine_mod
+
+    def noise_class(a, b, what):
+        num = sum((a[n].double() - b[n].double()).pow(2).sum().item() for n in b)
+        den = sum(v.double().pow(2).sum().item() for v in b.values())
+        typical = (den / len(b)) ** 0.5           # (tensors whose gradient is analytically zero are measured against the typical tensor)
+        worst = max(((a[n] - v).norm() / max(v.norm().item(), 1e-2 * typical)).item() for n, v in b.items())
+        print("[%s] global rel-L2 %.3e, worst tensor %.3e" % (what, (num / den) ** 0.5, worst))
+        assert (num / den) ** 0.5 <= 5e-3 and worst <= 5e-2, what
     engine_mod.DENSE_ENABLED = False
     try:
         eng.forward(x, True)
+        eng.backward(gl)
+        assert any(op.sp_fwd is not None for op in eng.conv_ops.values()), "the full-resolution masked layers run on plans"
+        planned = {n: v.clone() for n, v in eng.grads.items()}
+        engine_mod.SPARSE2 = False
+        mask._push_liveness()                       # (the plan picks the maps up at its next forward)
+        eng.forward(x, True)
+        assert all(op.sp_fwd is None for op in eng.conv_ops.values())
         eng.backward(gl)
         sparse = {n: v.clone() for n, v in eng.grads.items()}
         net.set_kernel_masks(None)
@@ -682,20 +698,19 @@ def test_full_size_128_training_properties():
         for n, v in eng.grads.items():
             ref = v
             assert (sparse[n] - ref).abs().max().item() <= 2e-4 * max(ref.abs().max().item(), 1e-6), "sparse vs dense backward: " + n
+        # (b1) the load-balanced plans (another plane order per chunk, another assignment of planes to waves) against the plain
+        # walk: equality in the fp32 noise class of this graph (InstanceNorms over 64 voxels at the bottleneck)
+        noise_class(planned, sparse, "planned kernel vs plain sparse walk backward")
     finally:
         engine_mod.DENSE_ENABLED = True
+        engine_mod.SPARSE2 = True
+    mask._push_liveness()
     # (b2) the same masked weights through the matrix-core conv kernel (bf16 x 3 operands) wherever it is served: another
     # summation order, so equality only in the fp32 noise class of this graph (InstanceNorms over 64 voxels at the bottleneck)
+    net.set_kernel_masks(None)
     eng.forward(x, True)
     eng.backward(gl)
-    num = sum((sparse[n].double() - v.double()).pow(2).sum().item() for n, v in eng.grads.items())
-    den = sum(v.double().pow(2).sum().item() for v in eng.grads.values())
-    # per tensor against its own size, tensors whose gradient is analytically zero (conv biases in front of an InstanceNorm:
-    # pure rounding noise) measured against the typical tensor instead
-    typical = (den / len(eng.grads)) ** 0.5
-    worst = max(((sparse[n] - v).norm() / max(v.norm().item(), 1e-2 * typical)).item() for n, v in eng.grads.items())
-    print("[dense-kernel vs sparse-walk backward] global rel-L2 %.3e, worst tensor %.3e" % ((num / den) ** 0.5, worst))
-    assert (num / den) ** 0.5 <= 5e-3 and worst <= 5e-2
+    noise_class(sparse, {n: v.clone() for n, v in eng.grads.items()}, "dense-kernel vs sparse-walk backward")
     mask._push_liveness()
 
     # (c) ten iterations
