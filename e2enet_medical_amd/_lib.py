@@ -24,6 +24,13 @@ class OutChan(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("nstride", C.c_longlong), ("dshift", C.c_int), ("accumulate", C.c_int)]
 
 
+class InSumChan(C.Structure):
+    """e2e_in_sum_chan_t"""
+    _fields_ = [("y", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
+                ("part", C.c_void_p), ("nstride", C.c_longlong), ("part_nstride", C.c_longlong), ("ab_nstride", C.c_int),
+                ("slope", C.c_float)]
+
+
 class ParamEntry(C.Structure):
     """e2e_param_t"""
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("momentum", C.c_void_p), ("mask", C.c_void_p),
@@ -37,7 +44,7 @@ class SparsePackJob(C.Structure):
                 ("reverse", C.c_int), ("kmax", C.c_int)]
 
 
-assert C.sizeof(InChan) == 48 and C.sizeof(OutChan) == 24 and C.sizeof(ParamEntry) == 40 and C.sizeof(SparsePackJob) == 72
+assert C.sizeof(InChan) == 48 and C.sizeof(OutChan) == 24 and C.sizeof(ParamEntry) == 40 and C.sizeof(SparsePackJob) == 72 and C.sizeof(InSumChan) == 72
 
 P, I, F, LL = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 
@@ -59,19 +66,20 @@ SIGNATURES = {
     "e2e_conv133_sparse_plan": (I, [P, I, I, I, P, P, P, P, P, P]),
     "e2e_conv133_sparse_pack": (I, [P, I, LL, P]),
     "e2e_conv133_fwd_sparse": (I, [P, I, P, P, P, P, I, P, I, P, P, I, I, I, I, I, P]),
-    "e2e_conv133_dgrad_sparse": (I, [P, P, P, P, I, P, P, I, I, I, I, I, I, I, P]),
+    "e2e_conv133_dgrad_sparse": (I, [P, P, P, P, I, P, P, P, I, I, I, I, I, I, I, P]),
     "e2e_conv133_fwd_dense": (I, [P, I, P, P, P, P, P, I, I, I, I, I, P, LL, P]),
     "e2e_conv133_dgrad_dense": (I, [P, P, P, P, I, I, I, I, I, I, P, LL, P]),
     "e2e_conv133_wgrad_ws_bytes": (LL, [I, I, I, I, I, I, I, I, I]),
     "e2e_conv133_wgrad": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "e2e_in_stats_finalize": (I, [P, I, P, P, F, P, P, P, P, I, I, P]),
-    "e2e_in_lrelu_bwd": (I, [P, P, P, P, P, P, F, P, P, P, P, I, I, LL, P]),
+    "e2e_in_lrelu_bwd": (I, [P, P, P, P, P, P, F, P, P, P, P, I, I, LL, P, I, P]),
     "e2e_convT_fwd": (I, [P, P, P, F, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "e2e_convT_dgrad": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
     "e2e_convT_wgrad_ws_bytes": (LL, [I, I, I, I, I, I, I, I, I]),
     "e2e_convT_wgrad": (I, [P, P, P, F, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "e2e_maxpool_fwd": (I, [P, P, P, F, P, I, I, I, I, I, I, I, I, P]),
-    "e2e_maxpool_bwd": (I, [P, P, P, F, P, P, I, I, I, I, I, I, I, I, I, P]),
+    "e2e_maxpool_bwd_num_records": (I, [I, I, I, I, I, I]),
+    "e2e_maxpool_bwd": (I, [P, P, P, F, P, P, I, I, I, I, I, I, I, I, I, P, P, P, P]),
     "e2e_head1x1_fwd": (I, [P, P, P, F, P, P, I, I, I, LL, P]),
     "e2e_head1x1_dgrad": (I, [P, P, P, I, I, I, I, LL, P]),
     "e2e_head1x1_wgrad_ws_bytes": (LL, [I, I, I, LL]),
@@ -110,7 +118,7 @@ SIGNATURES = {
     "e2e_aug_finish": (I, [P, P, P, I, I, I, LL, P]),
 }
 
-_NO_STATUS = {"e2e_last_error", "e2e_abi_version", "e2e_last_kernel", "e2e_conv133_num_partials", "e2e_conv133_wgrad_ws_bytes", "e2e_conv133_dense_ws_bytes", "e2e_conv133_sparse_eligible", "e2e_conv133_sparse_wpk_floats", "e2e_conv133_fwd_ws_bytes", "e2e_conv133_dgrad_ws_bytes",
+_NO_STATUS = {"e2e_last_error", "e2e_abi_version", "e2e_last_kernel", "e2e_conv133_num_partials", "e2e_conv133_wgrad_ws_bytes", "e2e_conv133_dense_ws_bytes", "e2e_conv133_sparse_eligible", "e2e_conv133_sparse_wpk_floats", "e2e_maxpool_bwd_num_records", "e2e_conv133_fwd_ws_bytes", "e2e_conv133_dgrad_ws_bytes",
               "e2e_convT_wgrad_ws_bytes", "e2e_head1x1_wgrad_ws_bytes", "e2e_loss_ws_bytes", "e2e_aug_stats_ws_bytes"}
 
 

@@ -25,7 +25,10 @@
 //   * the two-level summation flushes after `flush_every` chunks (a chain of ~18 products: every chunk at density >= 0.2, fewer
 //     flushes for sparser maps; the noise against fp64 stays below the torch-CPU conv's);
 //   * an accumulating data gradient loads the old dx values in its PROLOGUE into the outer accumulators (they are free until the
-//     first flush): no read-modify-write round trip in the epilogue.
+//     first flush): no read-modify-write round trip in the epilogue;
+//   * a data gradient that is the LAST writer of a gradient buffer also forms the InstanceNorm-backward sums of that buffer's
+//     producer in its epilogue (e2e_in_sum_chan_t): this kernel is VALU bound, the extra read of y rides on idle HBM bandwidth,
+//     and the producer's e2e_in_lrelu_bwd drops its first streaming pass over (dz, y).
 // Everything else (16 x 32 tile, 8 waves x 4 output planes, 2 x 4 micro-tile per lane, register-prefetched float4 plane staging
 // with normalise-on-load, quad-nibble walk unrolled over the eight plane slots, fp64 statistics records) is conv133_kernel's.
 #include "e2e_common.h"
@@ -66,6 +69,7 @@ struct SparseParams {
   const int* woff;              // [groups][nchunks][8]: first kernel slot of each wave's list
   const int* qslot;             // MODE 0: [groups][32] output plane of slot wave * 4 + a (-1: empty)
   const e2e_out_chan_t* outs;   // MODE 1: [groups][32] destinations in plan order (ptr == null: nothing to store)
+  const e2e_in_sum_chan_t* insum;   // MODE 1, optional: [groups][32] fused InstanceNorm-backward sums of the channels written last here
   const float* bias;
   float* y;
   double* part;
@@ -192,9 +196,12 @@ __global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams
       for (int j = 0; j < PW; ++j) { acc[a][i][j] = 0.f; acc2[a][i][j] = 0.f; }
   // data gradient: gradient of virtual-concat channel q at (shifted) depth d goes to depth d - s(q) of its source; the slices that
   // receive nothing are zero-filled by the workgroups of the slices that fall outside (conv133_kernel's rule).  Wave-uniform.
-  // mode: 0 store, 1 accumulate (the old values are the initial outer accumulators), 2 zero fill, 3 nothing to do
+  // mode: 0 store, 1 accumulate (the old values are the initial outer accumulators), 2 zero fill, 3 nothing to do, 4 nothing to
+  // store but the slice holds final values of earlier writers (an accumulating launch whose depth falls outside: dd = that slice)
+  int dd_out = 0;
   auto destination = [&](const e2e_out_chan_t& oc, int& mode) -> float* {
     mode = 3;
+    dd_out = 0;
     if (oc.ptr == nullptr) return nullptr;
     int dd = d - oc.dshift;
     bool zero_fill = false;
@@ -207,7 +214,8 @@ __global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams
       dd = d - lo;
       zero_fill = true;
     }
-    if (zero_fill && oc.accumulate) return nullptr;
+    dd_out = dd;
+    if (zero_fill && oc.accumulate) { mode = 4; return nullptr; }
     mode = zero_fill ? 2 : (oc.accumulate ? 1 : 0);
     return oc.ptr + (long long)n * oc.nstride + (long long)dd * plane;
   };
@@ -435,14 +443,53 @@ __global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams
       int mode;
       float* xp = destination(ocs[a], mode);
       if (mode == 3) continue;
+      const int dd = dd_out;
+      if (mode != 4) {
+#pragma unroll
+        for (int i = 0; i < PH; ++i) {
+          const int oh = oh0 + i;
+          if (oh >= p.H || ow0 >= p.W) continue;
+          float4 val = make_float4(acc2[a][i][0], acc2[a][i][1], acc2[a][i][2], acc2[a][i][3]);
+          if (mode == 2) val = make_float4(0.f, 0.f, 0.f, 0.f);
+          *reinterpret_cast<float4*>(xp + (long long)oh * p.W + ow0) = val;
+        }
+      }
+      // ---- fused first pass of the InstanceNorm + LeakyReLU backward (instnorm.hip: in_bwd_reduce_kernel) for channels whose
+      // gradient buffer this launch writes last: the values just stored (or, in an untouched slice, found) are final.  One
+      // record per (channel, destination slice, tile), written by exactly one wave of the launch.
+      if (p.insum == nullptr) continue;
+      const e2e_in_sum_chan_t sc = load_uniform(p.insum + slot0 + a);
+      if (sc.y == nullptr) continue;
+      double* rec = sc.part + (long long)n * sc.part_nstride + (((long long)dd * p.tiles_y + ty) * p.tiles_x + tx) * 2;
+      if (mode == 2) {                                      // a zero-filled slice adds nothing
+        if (lane == 0) { rec[0] = 0.0; rec[1] = 0.0; }
+        continue;
+      }
+      const long long ci = (long long)n * sc.ab_nstride;
+      const float ca = load_uniform(sc.scale + ci), cb = load_uniform(sc.shift + ci);
+      const float mu = load_uniform(sc.mean + ci), rs = load_uniform(sc.rstd + ci);
+      const float* yp = sc.y + (long long)n * sc.nstride + (long long)dd * plane;
+      const float* op = ocs[a].ptr + (long long)n * ocs[a].nstride + (long long)dd * plane;
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int i = 0; i < PH; ++i) {
         const int oh = oh0 + i;
         if (oh >= p.H || ow0 >= p.W) continue;
-        float4 val = make_float4(acc2[a][i][0], acc2[a][i][1], acc2[a][i][2], acc2[a][i][3]);
-        if (mode == 2) val = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(xp + (long long)oh * p.W + ow0) = val;
+        const float4 yv = *reinterpret_cast<const float4*>(yp + (long long)oh * p.W + ow0);
+        float4 dzv = make_float4(acc2[a][i][0], acc2[a][i][1], acc2[a][i][2], acc2[a][i][3]);
+        if (mode == 4) dzv = *reinterpret_cast<const float4*>(op + (long long)oh * p.W + ow0);
+        const float ys[4] = {yv.x, yv.y, yv.z, yv.w}, dz[4] = {dzv.x, dzv.y, dzv.z, dzv.w};
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+          const float u = fmaf(ca, ys[j], cb);
+          const float du = u > 0.f ? dz[j] : dz[j] * sc.slope;
+          s1 += du;
+          s2 = fmaf(du, (ys[j] - mu) * rs, s2);
+        }
       }
+      s1 = e2e::wave_sum_dpp(s1);
+      s2 = e2e::wave_sum_dpp(s2);
+      if (lane == 0) { rec[0] = (double)s1; rec[1] = (double)s2; }
     }
   }
 #ifdef E2E_CONV_DEBUG
@@ -694,12 +741,12 @@ extern "C" int e2e_conv133_fwd_sparse(const e2e_in_chan_t* chans_plan, int Cin, 
 }
 
 extern "C" int e2e_conv133_dgrad_sparse(const float* dy, const float* wpk_t, const unsigned* quads_t, const int* woff_t, int kmax_t,
-                                        const int* pslot_t, const e2e_out_chan_t* outs_plan, int flush_every, int B, int Cin, int Cout,
-                                        int Di, int Hi, int Wi, void* stream) {
+                                        const int* pslot_t, const e2e_out_chan_t* outs_plan, const e2e_in_sum_chan_t* insum_plan,
+                                        int flush_every, int B, int Cin, int Cout, int Di, int Hi, int Wi, void* stream) {
   E2E_REQUIRE(dy && wpk_t && quads_t && woff_t && kmax_t > 0 && pslot_t && outs_plan, "conv133_dgrad_sparse: bad arguments");
   E2E_REQUIRE(e2e_conv133_sparse_eligible(Cin, Cout, Di, Hi, Wi, 1, 1, 1), "conv133_dgrad_sparse: shape not served");
   SparseParams p{};
-  p.xin = dy; p.wpk = wpk_t; p.quads = quads_t; p.woff = woff_t; p.kmax = kmax_t; p.pslot = pslot_t; p.outs = outs_plan;
+  p.xin = dy; p.wpk = wpk_t; p.quads = quads_t; p.woff = woff_t; p.kmax = kmax_t; p.pslot = pslot_t; p.outs = outs_plan; p.insum = insum_plan;
   p.P = Cout; p.Q = Cin; p.B = B; p.D = Di; p.H = Hi; p.W = Wi; p.flush_every = flush_every;
   return sparse_launch(1, p, (hipStream_t)stream);
 }

@@ -179,15 +179,27 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(float* __restrict__ d
   if (threadIdx.x == 0) atomicAdd(&sums[(long long)nc * 3 + 2], sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
-__global__ void in_bwd_params_kernel(const double* __restrict__ sums, float* __restrict__ dgamma,
+// first pass done by the last writers of dz (conv133_sparse.hip): add their tile records up, one wave per (n, c), fixed order
+__global__ __launch_bounds__(64) void in_bwd_tile_sums_kernel(const double* __restrict__ part, double* __restrict__ sums, int np) {
+  const int nc = blockIdx.x;
+  const double* p = part + (long long)nc * np * 2;
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < np; i += 64) { a += p[2 * i]; b += p[2 * i + 1]; }
+  a = e2e::wave_sum_d(a);
+  b = e2e::wave_sum_d(b);
+  if (threadIdx.x == 0) { sums[(long long)nc * 3] = a; sums[(long long)nc * 3 + 1] = b; sums[(long long)nc * 3 + 2] = 0.0; }
+}
+
+__global__ void in_bwd_params_kernel(double* __restrict__ sums, float* __restrict__ dgamma,
                                      float* __restrict__ dbeta, float* __restrict__ dbias, int B, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double s1 = 0.0, s2 = 0.0, s3 = 0.0;
   for (int n = 0; n < B; ++n) {
-    s1 += sums[((long long)n * C + c) * 3 + 0];
-    s2 += sums[((long long)n * C + c) * 3 + 1];
-    s3 += sums[((long long)n * C + c) * 3 + 2];
+    const double* r = sums + ((long long)n * C + c) * 3;
+    s1 += r[0];
+    s2 += r[1];
+    s3 += r[2];
   }
   dbeta[c] = (float)s1;
   dgamma[c] = (float)s2;
@@ -208,18 +220,24 @@ extern "C" int e2e_in_stats_finalize(const double* part, int np, const float* ga
 
 extern "C" int e2e_in_lrelu_bwd(float* dz_dy, const float* y, const float* mean, const float* rstd,
                                 const float* gamma, const float* beta, float slope, float* dgamma, float* dbeta,
-                                float* dbias, float* sums, int B, int C, long long spatial, void* stream) {
+                                float* dbias, float* sums, int B, int C, long long spatial, const double* tile_sums, int np,
+                                void* stream) {
   E2E_REQUIRE(dz_dy && y && mean && rstd && gamma && beta && dgamma && dbeta && sums, "in_lrelu_bwd: null pointer");
   E2E_REQUIRE(B > 0 && C > 0 && spatial > 0, "in_lrelu_bwd: bad dims");
   hipStream_t st = (hipStream_t)stream;
   double* ds = reinterpret_cast<double*>(sums);
-  e2e::zero_async(ds, (size_t)B * C * 3 * sizeof(double), st);
   long long blocks = e2e::cdivll(spatial, 256 * 4 * 4);
   if (blocks > 256) blocks = 256;
   if (blocks < 1) blocks = 1;
   dim3 grid((unsigned)blocks, B * C);
-  hipLaunchKernelGGL(in_bwd_reduce_kernel, grid, dim3(256), 0, st, dz_dy, y, mean, rstd, gamma, beta, slope, ds, C,
-                     spatial);
+  if (tile_sums == nullptr) {
+    e2e::zero_async(ds, (size_t)B * C * 3 * sizeof(double), st);
+    hipLaunchKernelGGL(in_bwd_reduce_kernel, grid, dim3(256), 0, st, dz_dy, y, mean, rstd, gamma, beta, slope, ds, C,
+                       spatial);
+  } else {
+    E2E_REQUIRE(np > 0, "in_lrelu_bwd: tile_sums without a record count");
+    hipLaunchKernelGGL(in_bwd_tile_sums_kernel, dim3(B * C), dim3(64), 0, st, tile_sums, ds, np);
+  }
   hipLaunchKernelGGL(in_bwd_apply_kernel, grid, dim3(256), 0, st, dz_dy, y, mean, rstd, gamma, beta, slope, ds, C,
                      spatial);
   hipLaunchKernelGGL(in_bwd_params_kernel, dim3(e2e::cdiv(C, 64)), dim3(64), 0, st, ds, dgamma, dbeta, dbias, B, C);

@@ -96,44 +96,80 @@ __global__ __launch_bounds__(256) void maxpool_fwd_w2_kernel(const float* __rest
   *reinterpret_cast<float2*>(y + (long long)nc * Do * Ho * Wo + ((long long)dq * Ho + ho) * Wo + wp * 2) = make_float2(m0, m1);
 }
 
+// Fused first pass of the source's InstanceNorm + LeakyReLU backward (round 4): when this launch is the LAST writer of dx -- the
+// engine issues the pooling backward behind the other consumers' data gradients for that purpose -- every thread holds the final
+// dz of the cells of its windows next to their pre-norm values y (it re-reads them for the argmax anyway) and the block writes
+//   sum dz lrelu'(u),  sum dz lrelu'(u) xhat      (u = a y + b, xhat = (y - mean) rstd; instnorm.hip: in_bwd_reduce_kernel)
+// of its cells to part[(nc * gridDim.x + blockIdx.x) * 2 ..]: one record per block, plain stores, added up in a fixed order by
+// e2e_in_lrelu_bwd.  HBM-bound kernel: the sums cost no extra traffic.
 __global__ __launch_bounds__(256) void maxpool_bwd_w2_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, float slope,
                                                              const float* __restrict__ dy, float* __restrict__ dx,
                                                              int accumulate, int D, int H, int W, int kd, int kh, int Do, int Ho,
-                                                             int Wo) {
+                                                             int Wo, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             double* __restrict__ part) {
   const int nc = blockIdx.y;
   const long long pairs = (long long)Do * Ho * (Wo / 2);
   const long long pi = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (pi >= pairs) return;
-  const int wp = (int)(pi % (Wo / 2));
-  const long long r = pi / (Wo / 2);
-  const int ho = (int)(r % Ho), dq = (int)(r / Ho);
-  float a = 1.f, b = 0.f, sl = 1.f;
-  if (scale) { a = scale[nc]; b = shift[nc]; sl = slope; }
-  const float* xp = x + (long long)nc * D * H * W;
-  float* dxp = dx + (long long)nc * D * H * W;
-  float m0 = -INFINITY, m1 = -INFINITY;
-  int b0 = 0, b1 = 0;
-  for (int i = 0; i < kd; ++i)
-    for (int j = 0; j < kh; ++j) {
-      const float4 q = *reinterpret_cast<const float4*>(xp + ((long long)(dq * kd + i) * H + (ho * kh + j)) * W + wp * 4);
-      const float v0 = e2e::in_act(q.x, a, b, sl), v1 = e2e::in_act(q.y, a, b, sl);
-      const float v2 = e2e::in_act(q.z, a, b, sl), v3 = e2e::in_act(q.w, a, b, sl);
-      const int base = (i * kh + j) * 2;
-      if (v0 > m0 || v0 != v0) { m0 = v0; b0 = base; }
-      if (v1 > m0 || v1 != v1) { m0 = v1; b0 = base + 1; }
-      if (v2 > m1 || v2 != v2) { m1 = v2; b1 = base; }
-      if (v3 > m1 || v3 != v3) { m1 = v3; b1 = base + 1; }
+  const bool active = pi < pairs;
+  float s1 = 0.f, s2 = 0.f;
+  if (active) {
+    const int wp = (int)(pi % (Wo / 2));
+    const long long r = pi / (Wo / 2);
+    const int ho = (int)(r % Ho), dq = (int)(r / Ho);
+    float a = 1.f, b = 0.f, sl = 1.f;
+    if (scale) { a = scale[nc]; b = shift[nc]; sl = slope; }
+    float mu = 0.f, rs = 0.f;
+    if (part != nullptr) { mu = mean[nc]; rs = rstd[nc]; }
+    const float* xp = x + (long long)nc * D * H * W;
+    float* dxp = dx + (long long)nc * D * H * W;
+    float m0 = -INFINITY, m1 = -INFINITY;
+    int b0 = 0, b1 = 0;
+    for (int i = 0; i < kd; ++i)
+      for (int j = 0; j < kh; ++j) {
+        const float4 q = *reinterpret_cast<const float4*>(xp + ((long long)(dq * kd + i) * H + (ho * kh + j)) * W + wp * 4);
+        const float v0 = e2e::in_act(q.x, a, b, sl), v1 = e2e::in_act(q.y, a, b, sl);
+        const float v2 = e2e::in_act(q.z, a, b, sl), v3 = e2e::in_act(q.w, a, b, sl);
+        const int base = (i * kh + j) * 2;
+        if (v0 > m0 || v0 != v0) { m0 = v0; b0 = base; }
+        if (v1 > m0 || v1 != v1) { m0 = v1; b0 = base + 1; }
+        if (v2 > m1 || v2 != v2) { m1 = v2; b1 = base; }
+        if (v3 > m1 || v3 != v3) { m1 = v3; b1 = base + 1; }
+      }
+    const float2 g = *reinterpret_cast<const float2*>(dy + (long long)nc * Do * Ho * Wo + ((long long)dq * Ho + ho) * Wo + wp * 2);
+    for (int i = 0; i < kd; ++i)
+      for (int j = 0; j < kh; ++j) {
+        const int base = (i * kh + j) * 2;
+        const long long off = ((long long)(dq * kd + i) * H + (ho * kh + j)) * W + wp * 4;
+        float4* dst = reinterpret_cast<float4*>(dxp + off);
+        float4 v = make_float4(b0 == base ? g.x : 0.f, b0 == base + 1 ? g.x : 0.f, b1 == base ? g.y : 0.f, b1 == base + 1 ? g.y : 0.f);
+        if (accumulate) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        *dst = v;
+        if (part != nullptr) {
+          const float4 q = *reinterpret_cast<const float4*>(xp + off);        // (the read of the argmax loop: L1 / L2 hit)
+          const float ys[4] = {q.x, q.y, q.z, q.w}, dz[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float u = fmaf(a, ys[e], b);
+            const float du = u > 0.f ? dz[e] : dz[e] * sl;
+            s1 += du;
+            s2 = fmaf(du, (ys[e] - mu) * rs, s2);
+          }
+        }
+      }
+  }
+  if (part != nullptr) {
+    double d1 = e2e::wave_sum_d((double)s1), d2 = e2e::wave_sum_d((double)s2);
+    __shared__ double sh[2][4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { sh[0][wave] = d1; sh[1][wave] = d2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double* rec = part + ((long long)nc * gridDim.x + blockIdx.x) * 2;
+      rec[0] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+      rec[1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
     }
-  const float2 g = *reinterpret_cast<const float2*>(dy + (long long)nc * Do * Ho * Wo + ((long long)dq * Ho + ho) * Wo + wp * 2);
-  for (int i = 0; i < kd; ++i)
-    for (int j = 0; j < kh; ++j) {
-      const int base = (i * kh + j) * 2;
-      float4* dst = reinterpret_cast<float4*>(dxp + ((long long)(dq * kd + i) * H + (ho * kh + j)) * W + wp * 4);
-      float4 v = make_float4(b0 == base ? g.x : 0.f, b0 == base + 1 ? g.x : 0.f, b1 == base ? g.y : 0.f, b1 == base + 1 ? g.y : 0.f);
-      if (accumulate) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-      *dst = v;
-    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ 1x1x1 head
@@ -410,11 +446,20 @@ extern "C" int e2e_maxpool_fwd(const float* x, const float* scale, const float* 
   return e2e::check_launch("maxpool_fwd_kernel");
 }
 
+// records per (n, c) that a fused launch writes; 0: this shape cannot carry the fused sums (cells outside every window, or the
+// generic kernel)
+extern "C" int e2e_maxpool_bwd_num_records(int D, int H, int W, int kd, int kh, int kw) {
+  if (kd < 1 || kh < 1 || kw != 2 || (W % 4) != 0 || D % kd || H % kh) return 0;
+  return (int)e2e::cdivll((long long)(D / kd) * (H / kh) * (W / 4), 256);
+}
+
 extern "C" int e2e_maxpool_bwd(const float* x, const float* scale, const float* shift, float slope, const float* dy,
                                float* dx, int accumulate, int B, int C, int D, int H, int W, int kd, int kh, int kw,
-                               void* stream) {
+                               const float* mean, const float* rstd, double* tile_sums, void* stream) {
   E2E_REQUIRE(x && dy && dx, "maxpool_bwd: null pointer");
   E2E_REQUIRE(kd >= 1 && kh >= 1 && kw >= 1 && D >= kd && H >= kh && W >= kw, "maxpool_bwd: bad dims");
+  E2E_REQUIRE(tile_sums == nullptr || (mean && rstd && scale && e2e_maxpool_bwd_num_records(D, H, W, kd, kh, kw) > 0),
+              "maxpool_bwd: fused InstanceNorm-backward sums need a normalised source and a shape of e2e_maxpool_bwd_num_records");
   hipStream_t st = (hipStream_t)stream;
   const int Do = D / kd, Ho = H / kh, Wo = W / kw;
   if (!accumulate && (D % kd || H % kh || W % kw)) {   // cells outside every window receive no gradient
@@ -423,7 +468,7 @@ extern "C" int e2e_maxpool_bwd(const float* x, const float* scale, const float* 
   if (kw == 2 && (W % 4) == 0) {
     dim3 grid2((unsigned)e2e::cdivll((long long)Do * Ho * (Wo / 2), 256), B * C);
     hipLaunchKernelGGL(maxpool_bwd_w2_kernel, grid2, dim3(256), 0, st, x, scale, shift, slope, dy, dx, accumulate, D, H, W, kd, kh,
-                       Do, Ho, Wo);
+                       Do, Ho, Wo, mean, rstd, tile_sums);
     return e2e::check_launch("maxpool_bwd_w2_kernel");
   }
   dim3 grid((unsigned)e2e::cdivll((long long)Do * Ho * Wo, 256), B * C);

@@ -21,7 +21,7 @@ import torch
 
 import numpy as np
 
-from ._lib import lib, InChan, OutChan, ParamEntry, SparsePackJob
+from ._lib import lib, InChan, OutChan, ParamEntry, SparsePackJob, InSumChan
 
 LRELU_SLOPE = 0.01
 IN_EPS = 1e-5
@@ -42,6 +42,10 @@ def _lane_divs(voxels):
     if LANE_DIVS is not None:
         return LANE_DIVS
     return (8, 512) if voxels <= (1 << 20) else (64,)
+# fused first pass of the InstanceNorm backward in the LAST writer of a gradient buffer.  1 (default): the pooling backward, which
+# is issued behind the other consumers for that purpose (an HBM-bound kernel that reads y and the final dz anyway: free);
+# 2: also the load-balanced conv data gradient (measured: +1.4 ms on those launches against -1.0 ms of in_bwd_reduce: a loss); 0: off
+FUSE_IN_SUMS = int(os.environ.get("E2E_FUSE_IN_SUMS", "1"))
 SPARSE2 = os.environ.get("E2E_CONV_SPARSE2", "1") != "0"         # load-balanced kernel for the DSFF-masked full-resolution layers
 DENSE_ENABLED = True          # tests switch the matrix-core conv path off to compare the sparse walk with itself
 
@@ -99,6 +103,9 @@ class Act:
         self.grad: Optional[torch.Tensor] = None
         self.needs_grad = True
         self._grad_written = False                          # plan-time bookkeeping
+        self.producer = None                                # the ConvOp whose pre-norm output this is (normed tensors)
+        self.last_writer = None                             # the op that touches .grad last in the backward pass
+        self.sums_ready = False                             # set by a last writer that formed the InstanceNorm-backward sums
 
     @property
     def spatial(self):
@@ -108,10 +115,11 @@ class Act:
         if self.grad is None and self.needs_grad:
             self.grad = torch.empty(self.shape, dtype=torch.float32, device=self.data.device)
 
-    def claim_grad_write(self) -> int:
+    def claim_grad_write(self, op=None) -> int:
         """Plan-time: returns the accumulate flag for the next writer (in backward order)."""
         acc = 1 if self._grad_written else 0
         self._grad_written = True
+        self.last_writer = op
         return acc
 
 
@@ -172,6 +180,9 @@ class ConvOp:
         sd, sh, sw = self.stride
         self.out_dims = ((di - 1) // sd + 1, (hi - 1) // sh + 1, (wi - 1) // sw + 1)
         self.out = Act(prefix, (b, cout) + self.out_dims, True, eng.device)
+        self.out.producer = self
+        self.own_sums = None    # [B, Cout, own_np, 2] fp64 records of the InstanceNorm-backward sums, written by the last writer of out.grad
+        self.own_np = 0
         self.np = lib().conv133_num_partials(*self.out_dims, sh, sw)
         self.part = torch.empty(b * cout * self.np * 3, dtype=torch.float64, device=eng.device)      # (count, mean, M2), fp64
         self.w_name = prefix + ".conv.weight"
@@ -204,22 +215,24 @@ class ConvOp:
     def plan_backward(self):
         if not self.do_dgrad:
             return
-        structs = []
+        structs, srcmap = [], []
         c = 0
         for s in self.sources:
             cs = s.shape[1]
             plane = s.spatial
             if s.needs_grad:
                 s.alloc_grad()
-                acc = s.claim_grad_write()
+                acc = s.claim_grad_write(self)
             for k in range(cs):
                 if s.needs_grad:
                     structs.append(OutChan(s.grad.data_ptr() + 4 * k * plane, cs * plane, self.shifts[c], acc))
                 else:
                     structs.append(OutChan(None, 0, 0, 0))
+                srcmap.append((s, k))
                 c += 1
         self.outs = _upload_structs(structs, self.eng.device)
         self.out_structs = structs
+        self.out_srcs = srcmap
         if self.sp_bwd is not None:
             self.sp_bwd.table = None
 
@@ -250,6 +263,25 @@ class ConvOp:
         if sp.table is None:
             empty = OutChan(None, 0, 0, 0)
             sp.table = _upload_structs([self.out_structs[q] if q >= 0 else empty for q in sp.qslot_host], self.eng.device)
+            # fused InstanceNorm-backward sums: for the normalised sources whose gradient buffer THIS op writes last the kernel
+            # also forms sum dz lrelu' and sum dz lrelu' xhat of their producer (its e2e_in_lrelu_bwd then skips the first pass)
+            sp.fused_srcs = [s for s in self.sources if FUSE_IN_SUMS >= 2 and s.needs_grad and s.normed and s.last_writer is self
+                             and s.producer is not None and s.producer.own_sums is not None]
+            sp.insum = None
+            if sp.fused_srcs:
+                none = InSumChan(None, None, None, None, None, None, 0, 0, 0, 0.0)
+                rows = []
+                for q in sp.qslot_host:
+                    s, k = self.out_srcs[q] if q >= 0 else (None, 0)
+                    if s is None or not any(s is f for f in sp.fused_srcs):
+                        rows.append(none)
+                        continue
+                    cs = s.shape[1]
+                    npr = s.producer.own_np
+                    rows.append(InSumChan(s.data.data_ptr() + 4 * k * s.spatial, s.scale.data_ptr() + 4 * k, s.shift.data_ptr() + 4 * k,
+                                          s.mean.data_ptr() + 4 * k, s.rstd.data_ptr() + 4 * k, s.producer.own_sums.data_ptr() + 16 * k * npr,
+                                          cs * s.spatial, 2 * cs * npr, cs, LRELU_SLOPE))
+                sp.insum = _upload_structs(rows, self.eng.device)
         return sp.table
 
     def use_dense(self):
@@ -299,12 +331,15 @@ class ConvOp:
         di, hi, wi = self.in_dims
         sd, sh, sw = self.stride
         L = lib()
-        # dz (w.r.t. the post-activation output) -> dy (w.r.t. the pre-norm conv output), in place
+        # dz (w.r.t. the post-activation output) -> dy (w.r.t. the pre-norm conv output), in place; the first pass (two sums per
+        # instance) has already been done by the last writer of dz where that writer could (conv133_sparse.hip)
+        ready = o.sums_ready
+        o.sums_ready = False
         L.in_lrelu_bwd(o.grad.data_ptr(), o.data.data_ptr(), o.mean.data_ptr(), o.rstd.data_ptr(),
                        p[self.prefix + ".instnorm.weight"].data_ptr(), p[self.prefix + ".instnorm.bias"].data_ptr(),
                        LRELU_SLOPE, g[self.prefix + ".instnorm.weight"].data_ptr(),
                        g[self.prefix + ".instnorm.bias"].data_ptr(), g[self.prefix + ".conv.bias"].data_ptr(),
-                       e.in_sums.data_ptr(), b, self.cout, o.spatial, _stream())
+                       e.in_sums.data_ptr(), b, self.cout, o.spatial, self.own_sums.data_ptr() if ready else None, self.own_np, _stream())
         late = WGRAD_LATE and getattr(e, "_wg_active", None) is not None and o.data.numel() > WGRAD_STREAM_MAX_ELEMS
         if not late:
             self._wgrad(e, L, g, o, b, di, hi, wi, sd, sh, sw, o.data.numel())
@@ -315,8 +350,11 @@ class ConvOp:
                                       di, hi, wi, ws.data_ptr(), ws.numel() * 4, _stream())
             elif self.sp_bwd is not None:
                 sp = self.sp_bwd
+                table = self._bwd_table()
                 L.conv133_dgrad_sparse(o.grad.data_ptr(), sp.wpk.data_ptr(), sp.quads.data_ptr(), sp.woff.data_ptr(), sp.kmax, sp.pslot.data_ptr(),
-                                       self._bwd_table().data_ptr(), sp.flush_every, b, self.cin, self.cout, di, hi, wi, _stream())
+                                       table.data_ptr(), _ptr(sp.insum), sp.flush_every, b, self.cin, self.cout, di, hi, wi, _stream())
+                for s in sp.fused_srcs:
+                    s.sums_ready = True
             elif ws is not None and self.dgrad_ws_bytes > 0:        # deep levels: split-K (the workspace is idle during backward)
                 L.conv133_dgrad_splitk(o.grad.data_ptr(), p[self.w_name].data_ptr(), _ptr(self.live_t), self.outs.data_ptr(),
                                        b, self.cin, self.cout, di, hi, wi, sd, sh, sw, ws.data_ptr(), ws.numel() * 4, _stream())
@@ -375,7 +413,7 @@ class UpOp:
 
     def plan_backward(self):
         self.src.alloc_grad()
-        self.acc = self.src.claim_grad_write()
+        self.acc = self.src.claim_grad_write(self)
 
     def forward(self):
         s = self.src
@@ -411,7 +449,7 @@ class PoolOp:
 
     def plan_backward(self):
         self.src.alloc_grad()
-        self.acc = self.src.claim_grad_write()
+        self.acc = self.src.claim_grad_write(self)
 
     def forward(self):
         s = self.src
@@ -422,8 +460,13 @@ class PoolOp:
     def backward(self):
         s = self.src
         b, c, d, h, w = s.shape
+        fuse = FUSE_IN_SUMS >= 1 and s.normed and s.last_writer is self and s.producer is not None and s.producer.own_sums is not None
         lib().maxpool_bwd(s.data.data_ptr(), _ptr(s.scale), _ptr(s.shift), LRELU_SLOPE, self.out.grad.data_ptr(),
-                          s.grad.data_ptr(), self.acc, b, c, d, h, w, *self.kernel, _stream())
+                          s.grad.data_ptr(), self.acc, b, c, d, h, w, *self.kernel,
+                          s.mean.data_ptr() if fuse else None, s.rstd.data_ptr() if fuse else None,
+                          s.producer.own_sums.data_ptr() if fuse else None, _stream())
+        if fuse:
+            s.sums_ready = True
 
 
 class HeadOp:
@@ -438,7 +481,7 @@ class HeadOp:
 
     def plan_backward(self):
         self.src.alloc_grad()
-        self.acc = self.src.claim_grad_write()
+        self.acc = self.src.claim_grad_write(self)
 
     def forward(self):
         s = self.src
@@ -543,6 +586,7 @@ class Engine:
         self._fwd_ws = [torch.empty(fws // 4, dtype=torch.float32, device=self.device) if fws > 0 else None for _ in range(nl)]
         self._in_sums, self._wgrad_ws = [None] * nl, [None] * nl
         self._lane = 0
+        self._bwd_order = self._backward_order()
         self._plan_lanes()
         self.pre_forward_hook = None       # callable(): set by the owning network, brings masks / parameters up to date
         self._eval_counts = None
@@ -733,10 +777,28 @@ class Engine:
         self._deps_bwd, self._ev_bwd = None, None
         self._lane_streams = None
 
+    def _backward_order(self):
+        """The reverse op list, except that a pooling backward is issued LAST among the writers of its source's gradient buffer
+        (right in front of the source's producer): maxpool_bwd is an HBM-bound pass that reads the source's pre-norm values and
+        the final dz of every cell anyway, so as last writer it forms the first pass of the producer's InstanceNorm backward at
+        no cost (FUSE_IN_SUMS).  For a buffer with two writers the sum is the same to the bit (a + b = b + a); with three (levels
+        >= 1: transposed conv, conv, pool) the fp32 association changes."""
+        order = list(reversed(range(len(self.ops))))
+        if FUSE_IN_SUMS < 1:
+            return order
+        index = {id(op): i for i, op in enumerate(self.ops)}
+        for i, op in enumerate(self.ops):
+            prod = getattr(op.src, "producer", None) if isinstance(op, PoolOp) else None
+            if prod is None or id(prod) not in index:
+                continue
+            order.remove(i)
+            order.insert(order.index(index[id(prod)]), i)
+        return order
+
     def _plan_lanes_backward(self):
         last = {}                              # gradient buffer -> op that touched it last (in backward order)
         self._deps_bwd = [None] * len(self.ops)
-        for i in reversed(range(len(self.ops))):
+        for i in self._bwd_order:
             op = self.ops[i]
             touched = [op.out] + [a for a in self._reads(op) if a.grad is not None]
             self._deps_bwd[i] = sorted({last[id(a)] for a in touched
@@ -836,14 +898,14 @@ class Engine:
     def prepare_backward(self):
         if self._backward_ready:
             return
-        for op in reversed(self.ops):          # backward order: first writer of a gradient buffer overwrites
+        for op in (self.ops[i] for i in self._bwd_order):      # backward order: first writer of a gradient buffer overwrites
             op.out.alloc_grad()
             op.plan_backward()
         # all parameter gradients live in ONE flat buffer (each tensor at a 256-byte aligned offset), laid out in the
         # order the backward pass completes them: the data-parallel all-reduce runs on it in place, and a prefix of the
         # buffer can be reduced while the rest of the backward pass is still running (grad_bucket_hook)
         order, seen = [], set()
-        for op in reversed(self.ops):
+        for op in (self.ops[i] for i in self._bwd_order):
             if isinstance(op, ConvOp):
                 produced = [op.w_name, op.prefix + ".conv.bias", op.prefix + ".instnorm.weight", op.prefix + ".instnorm.bias"]
             elif isinstance(op, (UpOp, HeadOp)):
@@ -876,6 +938,18 @@ class Engine:
         self._wgrad_ws = [torch.empty((ws + 3) // 4, dtype=torch.float32, device=self.device) for _ in range(len(self.lane_divs) + 1)]
         cmax = max(op.cout for op in self.conv_ops.values())
         self._in_sums = [torch.empty(self.batch * cmax * 3, dtype=torch.float64, device=self.device) for _ in range(len(self.lane_divs) + 1)]
+        for op in self.conv_ops.values():       # records of the fused InstanceNorm-backward sums, laid out for the buffer's last writer
+            d_, h_, w_ = op.out_dims
+            lw = op.out.last_writer
+            op.own_sums, op.own_np = None, 0
+            if isinstance(lw, PoolOp) and FUSE_IN_SUMS >= 1:
+                op.own_np = int(lib().maxpool_bwd_num_records(d_, h_, w_, *lw.kernel))
+            elif isinstance(lw, ConvOp) and FUSE_IN_SUMS >= 2 and lw.sparse_ok:
+                op.own_np = d_ * ((h_ + 15) // 16) * ((w_ + 31) // 32)          # the 16 x 32 tiles of conv133_sparse_kernel
+            if op.own_np > 0:
+                op.own_sums = torch.zeros(self.batch * op.cout * op.own_np * 2, dtype=torch.float64, device=self.device)
+            if op.sp_bwd is not None:
+                op.sp_bwd.table = None          # (who writes a buffer last is known only now)
         self._plan_lanes_backward()
         self._loss_buffers()
         self._backward_ready = True
@@ -890,6 +964,8 @@ class Engine:
                     h.out.grad.zero_()
                 else:
                     h.out.grad.copy_(g)
+        for op in self.conv_ops.values():       # (a pass that was abandoned between a writer and its producer)
+            op.out.sums_ready = False
         hook = self.grad_bucket_hook
         main = torch.cuda.current_stream()
         if WGRAD_STREAM and not self._graph_ok() and not torch.cuda.is_current_stream_capturing():
@@ -918,7 +994,7 @@ class Engine:
                     main.wait_stream(side)
                 hook(*self._bucket_after_op[id(op)])           # gradients in flat[lo:hi] are final
         try:
-            self._exec(reversed(range(len(self.ops))), self._deps_bwd, self._ev_bwd, act, checkpoint)
+            self._exec(self._bwd_order, self._deps_bwd, self._ev_bwd, act, checkpoint)
         finally:
             if side is not None:
                 main.wait_stream(side)

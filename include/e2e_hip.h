@@ -58,6 +58,25 @@ typedef struct {
   int accumulate;
 } e2e_out_chan_t;
 
+/* One channel of a fused InstanceNorm-backward reduction (round 4): the LAST writer of a gradient buffer holds the final dz of
+ * every element it stores and writes, per 16 x 32 tile of every depth slice, this channel's  sum dz * lrelu'(u)  and
+ * sum dz * lrelu'(u) * xhat  (u = scale * y + shift, xhat = (y - mean) * rstd; autograd of unetpp_d.py:99-100, :111) -- the
+ * first pass of e2e_in_lrelu_bwd, which then only adds the tile records up (fixed order: deterministic) and runs its apply pass.
+ * Records: part[((n * C + c) * np + tile) * 2 + {0, 1}], np = e2e_conv133_num_partials(D, H, W, 1, 1), every record of a
+ * channel is written exactly once per launch (plain stores).  y == NULL: nothing to do for this channel.                    */
+typedef struct {
+  const float* y;        /* pre-norm plane of this channel (batch item 0) */
+  const float* scale;    /* per-(n, c) coefficients of the channel at n = 0 ... */
+  const float* shift;
+  const float* mean;
+  const float* rstd;
+  double* part;          /* tile records of (n = 0, c) */
+  long long nstride;     /* floats between batch items of y */
+  long long part_nstride;   /* doubles between batch items of part (= 2 * C * np) */
+  int ab_nstride;        /* elements between batch items of the coefficients (= C) */
+  float slope;
+} e2e_in_sum_chan_t;
+
 /* ---- K1: 1x3x3 convolution, forward ------------------------------------------------
  * Replaces: torch_shift.forward (unetpp_d.py:45-59) + torch.cat (unetpp_d.py:453-478) +
  * nn.Conv3d k(1,3,3) pad(0,1,1) stride (sd,sh,sw) bias (unetpp_d.py:93,108) and the
@@ -124,7 +143,8 @@ int e2e_conv133_dgrad_splitk(const float* dy, const float* w, const unsigned* li
  *       taps (data gradient).
  *   e2e_conv133_fwd_sparse     chans_plan [groups][nchunks*8]: the e2e_in_chan_t of pslot's planes (ptr NULL for empty slots)
  *   e2e_conv133_dgrad_sparse   pslot_t as returned by the plan (dy channels); outs_plan [groups][32]: the e2e_out_chan_t of
- *       qslot's channels (ptr NULL for empty slots)                                                                          */
+ *       qslot's channels (ptr NULL for empty slots); insum_plan (optional, same order): channels whose gradient buffer this
+ *       launch writes LAST also get their InstanceNorm-backward sums here (e2e_in_sum_chan_t)                                                                          */
 typedef struct {
   const float* w;            /* the layer's weight tensor */
   float* wpk;                /* e2e_conv133_sparse_wpk_floats(P, Q) floats */
@@ -146,8 +166,8 @@ int e2e_conv133_fwd_sparse(const e2e_in_chan_t* chans_plan, int Cin, const float
                            const int* woff, int kmax, const int* qslot, int flush_every, float* y, double* part, int B, int Cout,
                            int Di, int Hi, int Wi, void* stream);
 int e2e_conv133_dgrad_sparse(const float* dy, const float* wpk_t, const unsigned* quads_t, const int* woff_t, int kmax_t,
-                             const int* pslot_t, const e2e_out_chan_t* outs_plan, int flush_every, int B, int Cin, int Cout, int Di,
-                             int Hi, int Wi, void* stream);
+                             const int* pslot_t, const e2e_out_chan_t* outs_plan, const e2e_in_sum_chan_t* insum_plan /* [groups][32] or NULL */,
+                             int flush_every, int B, int Cin, int Cout, int Di, int Hi, int Wi, void* stream);
 
 /* ---- K6b: 1x3x3 convolution, weight gradient (dense: also for dead kernels, because the
  * reference's clip_grad_norm_ runs over all gradients, nnUNetTrainer_simple.py:573) ----
@@ -170,10 +190,12 @@ int e2e_in_stats_finalize(const double* part, int np, const float* gamma, const 
  * Given dz = dL/d(lrelu(IN(y))) and the saved pre-norm y, overwrite dz with dy = dL/dy and
  * produce dgamma, dbeta (accumulated over the batch) and dbias = sum(dy).
  *   sums  workspace of B*C*3 doubles (s1 = sum du, s2 = sum du*xhat, s3 = sum dy)
+ *   tile_sums  NULL: the first pass (s1, s2) runs here.  Otherwise the per-tile records [B][C][np][2] that the last writers of
+ *              dz have produced (e2e_in_sum_chan_t): they are added up in a fixed order and only the apply pass runs
  */
 int e2e_in_lrelu_bwd(float* dz_dy, const float* y, const float* mean, const float* rstd, const float* gamma,
                      const float* beta, float slope, float* dgamma, float* dbeta, float* dbias, float* sums,
-                     int B, int C, long long spatial, void* stream);
+                     int B, int C, long long spatial, const double* tile_sums, int np, void* stream);
 
 /* ---- K3: transposed convolution, kernel == stride in {1,2}^3, no bias ------------------
  * Replaces: nn.ConvTranspose3d(Cin,Cout,k,k,bias=False) (unetpp_d.py:521-522).
@@ -199,9 +221,13 @@ int e2e_convT_wgrad(const float* x, const float* scale, const float* shift, floa
 int e2e_maxpool_fwd(const float* x, const float* scale, const float* shift, float slope, float* y, int B, int C,
                     int D, int H, int W, int kd, int kh, int kw, void* stream);
 /* dx [B,C,D,H,W] (w.r.t. the post-activation input; first maximum in scan order wins, as ATen). */
+/* mean / rstd / tile_sums (all NULL: plain pooling backward): when this launch writes dx LAST it also forms the per-block records
+ * of the source's InstanceNorm-backward sums (see e2e_in_sum_chan_t; records [B*C][e2e_maxpool_bwd_num_records(..)][2], consumed
+ * by e2e_in_lrelu_bwd(tile_sums, np)); e2e_maxpool_bwd_num_records returns 0 for shapes that cannot carry them.            */
+int e2e_maxpool_bwd_num_records(int D, int H, int W, int kd, int kh, int kw);
 int e2e_maxpool_bwd(const float* x, const float* scale, const float* shift, float slope, const float* dy,
                     float* dx, int accumulate, int B, int C, int D, int H, int W, int kd, int kh, int kw,
-                    void* stream);
+                    const float* mean, const float* rstd, double* tile_sums, void* stream);
 
 /* ---- K5: 1x1x1 segmentation head, no bias ----------------------------------------------
  * Replaces: nn.Conv3d(C,K,1,bias=False) (unetpp_d.py:394-401, used :480-483). */

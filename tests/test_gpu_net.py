@@ -902,3 +902,60 @@ def test_two_lane_issue_matches_single_stream(monkeypatch):
             assert all(torch.equal(a, b) for a, b in zip(o1, o2)) and torch.equal(l1, l2), cfg
             bad = [n for n in g1 if not torch.equal(g1[n], g2[n])]
             assert not bad, (cfg, bad[:4])
+
+
+def test_fused_instancenorm_backward_sums_match_the_two_pass_form():
+    """Round 4: the op that writes a gradient buffer LAST also forms the two per-instance sums of the InstanceNorm + LeakyReLU
+    backward of that buffer's producer (autograd of unetpp_d.py:99-100, :111) as per-block / per-tile records, and the producer's
+    e2e_in_lrelu_bwd adds the records up (fixed order) and runs its apply pass only.  Level 1 (default): the pooling backward,
+    issued behind the other consumers' data gradients for this purpose; level 2: also conv133_sparse_kernel<1> (depth-shifted
+    channels at the volume border -- slices that launch does not touch -- included).  Same arithmetic, another summation order
+    of the fp32 partials below the fp64 sums (and, with three writers, of the fp32 accumulation into the buffer): every
+    parameter gradient agrees with the two-pass form to 5e-5 of its scale."""
+    from e2enet_medical_amd.training.network_training.sparselearning.core_channel import Masking, CosineDecay
+    from e2enet_medical_amd import engine as engine_mod
+    torch.manual_seed(3)
+    net = build_net((16, 64, 64), 2, 16, 3, [(2, 2, 2)] * 3 + [(1, 2, 2)] * 2, 64)
+    opt = torch.optim.SGD(net.parameters(), 1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)
+
+    class A:
+        adv = False
+        fix = False
+        update_frequency = 1000
+        final_density = 0.05
+    random.seed(4)
+    mask = Masking(opt, death_rate=0.5, death_mode='magnitude', death_rate_decay=CosineDecay(0.5, 10), growth_mode='random',
+                   redistribution_mode='none', args=A())
+    mask.add_module(net, sparse_init='uniform', density=0.25)
+    x = seeded_input((2, 2, 16, 64, 64), seed=9).cuda()
+    w = oracle.ds_weights(5)
+    grads, targets = {}, None
+    try:
+        for level in (1, 2, 0):
+            engine_mod.FUSE_IN_SUMS = level
+            net._engines.clear()                                # the issue order and the record buffers belong to the plan
+            eng = net.engine(x)
+            outs = eng.forward(x, True)
+            if targets is None:
+                targets = [seeded_labels((o.shape[0], 1) + tuple(o.shape[2:]), 3, seed=60 + i).cuda() for i, o in enumerate(outs)]
+            eng.loss_backward(targets, w, batch_dice=False)
+            by_pool = sum(1 for op in eng.conv_ops.values() if op.own_sums is not None and isinstance(op.out.last_writer, engine_mod.PoolOp))
+            by_conv = sum(len(op.sp_bwd.fused_srcs) for op in eng.conv_ops.values() if op.sp_bwd is not None and op.sp_bwd.table is not None)
+            print("[fused sums level %d] %d buffers by the pooling backward, %d by the planned data gradient" % (level, by_pool, by_conv))
+            assert (by_pool > 0) == (level >= 1) and (by_conv > 0) == (level >= 2)
+            assert all(not op.out.sums_ready for op in eng.conv_ops.values())                    # every producer consumed its sums
+            grads[level] = {n: v.clone() for n, v in eng.grads.items()}
+    finally:
+        engine_mod.FUSE_IN_SUMS = 1
+        net._engines.clear()
+    for level in (1, 2):
+        worst = (0.0, None)
+        for n, v in grads[0].items():
+            if n.endswith(".conv.bias"):            # analytically zero (a bias in front of an InstanceNorm): both sides hold rounding noise
+                continue
+            scale = max(v.abs().max().item(), 1e-6)
+            err = (grads[level][n] - v).abs().max().item() / scale
+            if err > worst[0]:
+                worst = (err, n)
+        print("[fused InstanceNorm-backward sums, level %d, vs two passes] worst tensor %.3e of its scale (%s)" % ((level,) + worst))
+        assert worst[0] <= 5e-5, (level, worst)

@@ -693,7 +693,7 @@ def test_conv133_masks_are_structural_on_every_path(density):
     if not op.use_dense():                          # the load-balanced kernel, then (below) the generic walk on the same data
         sp = op.sp_bwd
         L.conv133_dgrad_sparse(op.out.grad.data_ptr(), sp.wpk.data_ptr(), sp.quads.data_ptr(), sp.woff.data_ptr(), sp.kmax, sp.pslot.data_ptr(), op._bwd_table().data_ptr(),
-                               sp.flush_every, B, cin, cout, *dims, 0)
+                               None, sp.flush_every, B, cin, cout, *dims, 0)
         torch.cuda.synchronize()
         assert L.last_kernel().decode().startswith("conv133_sparse_kernel<mode=1>")
         assert (srcs[0].grad.cpu() - x.grad).abs().max() < 2e-4 * max(1.0, float(x.grad.abs().max())), "planned data gradient used a pruned kernel"

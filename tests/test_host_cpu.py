@@ -383,7 +383,19 @@ def test_lane_plan_orders_every_cross_lane_dependency(graph, divs, monkeypatch):
             out.append((a.name, list(last.get(id(a), []))))
             last.setdefault(id(a), []).append(i)
         return out
-    replay(list(reversed(range(len(eng.ops)))), eng._deps_bwd, bwd_touch)
+    # the backward issue order: the reverse op list with every pooling backward moved behind the other writers of its source's
+    # gradient buffer, right in front of the source's producer (Engine._backward_order: it forms that producer's InstanceNorm sums)
+    order = list(eng._bwd_order)
+    assert sorted(order) == list(range(len(eng.ops)))
+    pos = {i: k for k, i in enumerate(order)}
+    for i, op in enumerate(eng.ops):
+        if isinstance(op, E.PoolOp) and op.src.producer is not None:
+            assert pos[i] + 1 == pos[producer[id(op.src)]], "pooling backward sits right in front of its source's producer"
+            assert op.src.last_writer is op
+        else:
+            # everything else keeps the reverse order among itself
+            assert all(pos[i] < pos[j] for j in range(i) if not isinstance(eng.ops[j], E.PoolOp)) or isinstance(op, E.PoolOp)
+    replay(order, eng._deps_bwd, bwd_touch)
     assert any(eng._deps_fwd) and any(eng._deps_bwd)
 
 

@@ -105,7 +105,7 @@ def conv_case(B, srcs, cout, dims, stride, density, tag):
     def dgrad_planned():
         sp = op.sp_bwd
         L.conv133_dgrad_sparse(op.out.grad.data_ptr(), sp.wpk.data_ptr(), sp.quads.data_ptr(), sp.woff.data_ptr(), sp.kmax, sp.pslot.data_ptr(),
-                               op._bwd_table().data_ptr(), sp.flush_every, B, cin, cout, di, hi, wi, 0)
+                               op._bwd_table().data_ptr(), None, sp.flush_every, B, cin, cout, di, hi, wi, 0)
     dense = 2.0 * 9 * cin * cout * (vout / cout)
     res = {}
     if density < 1.0 and not dense_path and os.environ.get("KB_OLD") is None:      # load-balanced kernel (conv133_sparse.hip)
