@@ -125,9 +125,14 @@ __global__ __launch_bounds__(256) void maxpool_bwd_w2_kernel(const float* __rest
     float* dxp = dx + (long long)nc * D * H * W;
     float m0 = -INFINITY, m1 = -INFINITY;
     int b0 = 0, b1 = 0;
-    for (int i = 0; i < kd; ++i)
-      for (int j = 0; j < kh; ++j) {
+    float4 qs[2][2];                                        // the window rows (kd, kh <= 2), kept for the fused sums
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (i >= kd || j >= kh) continue;
         const float4 q = *reinterpret_cast<const float4*>(xp + ((long long)(dq * kd + i) * H + (ho * kh + j)) * W + wp * 4);
+        qs[i][j] = q;
         const float v0 = e2e::in_act(q.x, a, b, sl), v1 = e2e::in_act(q.y, a, b, sl);
         const float v2 = e2e::in_act(q.z, a, b, sl), v3 = e2e::in_act(q.w, a, b, sl);
         const int base = (i * kh + j) * 2;
@@ -137,8 +142,11 @@ __global__ __launch_bounds__(256) void maxpool_bwd_w2_kernel(const float* __rest
         if (v3 > m1 || v3 != v3) { m1 = v3; b1 = base + 1; }
       }
     const float2 g = *reinterpret_cast<const float2*>(dy + (long long)nc * Do * Ho * Wo + ((long long)dq * Ho + ho) * Wo + wp * 2);
-    for (int i = 0; i < kd; ++i)
-      for (int j = 0; j < kh; ++j) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (i >= kd || j >= kh) continue;
         const int base = (i * kh + j) * 2;
         const long long off = ((long long)(dq * kd + i) * H + (ho * kh + j)) * W + wp * 4;
         float4* dst = reinterpret_cast<float4*>(dxp + off);
@@ -146,7 +154,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_w2_kernel(const float* __rest
         if (accumulate) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
         *dst = v;
         if (part != nullptr) {
-          const float4 q = *reinterpret_cast<const float4*>(xp + off);        // (the read of the argmax loop: L1 / L2 hit)
+          const float4 q = qs[i][j];
           const float ys[4] = {q.x, q.y, q.z, q.w}, dz[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -449,7 +457,7 @@ extern "C" int e2e_maxpool_fwd(const float* x, const float* scale, const float* 
 // records per (n, c) that a fused launch writes; 0: this shape cannot carry the fused sums (cells outside every window, or the
 // generic kernel)
 extern "C" int e2e_maxpool_bwd_num_records(int D, int H, int W, int kd, int kh, int kw) {
-  if (kd < 1 || kh < 1 || kw != 2 || (W % 4) != 0 || D % kd || H % kh) return 0;
+  if (kd < 1 || kh < 1 || kd > 2 || kh > 2 || kw != 2 || (W % 4) != 0 || D % kd || H % kh) return 0;
   return (int)e2e::cdivll((long long)(D / kd) * (H / kh) * (W / 4), 256);
 }
 
@@ -465,7 +473,7 @@ extern "C" int e2e_maxpool_bwd(const float* x, const float* scale, const float* 
   if (!accumulate && (D % kd || H % kh || W % kw)) {   // cells outside every window receive no gradient
     e2e::zero_async(dx, (size_t)B * C * D * H * W * sizeof(float), st);
   }
-  if (kw == 2 && (W % 4) == 0) {
+  if (kw == 2 && (W % 4) == 0 && kd <= 2 && kh <= 2) {
     dim3 grid2((unsigned)e2e::cdivll((long long)Do * Ho * (Wo / 2), 256), B * C);
     hipLaunchKernelGGL(maxpool_bwd_w2_kernel, grid2, dim3(256), 0, st, x, scale, shift, slope, dy, dx, accumulate, D, H, W, kd, kh,
                        Do, Ho, Wo, mean, rstd, tile_sums);
