@@ -259,6 +259,7 @@ def sliding_window_record(device, rank=0, world=1):
     net.do_ds = False
     if world > 1 or os.environ.get("E2E_FORCE_DIST") == "1":
         net.shard_tiles(rank, world, None, force=world == 1)
+        net.time_sharding = True                     # collective_wait_ms in the record (one extra device sync per volume)
     vol = torch.randn((1, 220, 400, 400), generator=torch.Generator().manual_seed(7)).numpy()
     kw = dict(do_mirroring=True, mirror_axes=(0, 1, 2), use_sliding_window=True, step_size=0.5, patch_size=PATCH,
               use_gaussian=True, verbose=False)

@@ -128,6 +128,109 @@ __global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams
   const int tx = tile_in_n % p.tiles_x, ty = (tile_in_n / p.tiles_x) % p.tiles_y, d = tile_in_n / (p.tiles_x * p.tiles_y);
   const int h0 = ty * TH, w0 = tx * TW;
 
+  // ---- staging geometry: a wave stages one whole plane of each chunk, a lane NUP float4 groups of it --------------------------
+  int su_lds[NUP], su_goff[NUP];
+  bool su_ok[NUP];
+#pragma unroll
+  for (int i = 0; i < NUP; ++i) {
+    int u = lane + 64 * i;
+    if (u >= UPP) u = UPP - 1;
+    const int r = u / NQ, q = u - r * NQ;
+    const int hi = h0 - 1 + r, gc = w0 - 4 + 4 * q;
+    const bool ok = (unsigned)hi < (unsigned)p.H && gc >= 0 && gc + 3 < p.W;
+    su_lds[i] = r * PITCH + 4 * q - 3;
+    su_goff[i] = ok ? (hi * p.W + gc) * 4 : 0;
+    su_ok[i] = ok;
+  }
+
+  // ---- staging: planes through registers (prefetched one chunk ahead), weights by LDS-DMA into the other weight buffer ---------
+  f32x4_t v4[NUP];
+  float pd_a = 1.f, pd_b = 0.f, pd_slope = 1.f;
+  bool pd_ok = false;
+  unsigned pf_blo = 0, pf_bhi = 0;
+  const int wstride = p.kmax * WSLOT;                    // floats of a chunk's weight block
+  const float* wblock = p.wpk + (long long)g * p.nchunks * wstride;
+  auto request_begin = [&](int c) {
+    const PlaneDesc ds = tab[c * CK + wave];
+    const unsigned long long bb = (unsigned long long)ds.base;
+    pf_blo = __builtin_amdgcn_readfirstlane((unsigned)bb);
+    pf_bhi = __builtin_amdgcn_readfirstlane((unsigned)(bb >> 32));
+    pd_a = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ds.a)));
+    pd_b = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ds.b)));
+    pd_slope = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ds.slope)));
+    pd_ok = __builtin_amdgcn_readfirstlane(ds.valid) != 0;
+  };
+  auto request_plane = [&](int k, bool live) {           // k: compile-time
+    const char __attribute__((address_space(1)))* base =
+        (const char __attribute__((address_space(1)))*)(((unsigned long long)pf_bhi << 32) | pf_blo);
+    const unsigned off = live && pd_ok ? (unsigned)su_goff[k] : 0u;
+    v4[k] = *reinterpret_cast<gfloat4_p>(base + off);
+  };
+  // a chunk's weight block = 3 kmax float4 units; wave w moves units [uw w, uw w + uw) with up to two LDS-DMA instructions
+  // (LDS destination = wave-uniform base + 16 * lane)
+  auto request_weights = [&](int c, int half, bool live) {
+    if (!live || half * 64 >= p.uw) return;               // (wave-uniform)
+    const int u = wave * p.uw + half * 64 + lane;
+    const float* src = wblock + (long long)c * wstride + u * 4;
+    float* dst = wl + (c & 1) * wstride + (wave * p.uw + half * 64) * 4;
+    if (half * 64 + lane < p.uw && u < 3 * p.kmax)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+  auto commit = [&](int img) {
+    float* pl = lds + img * IMG + wave * CHS;
+#pragma unroll
+    for (int i = 0; i < NUP; ++i) {
+      if ((i + 1) * 64 > UPP && lane + 64 * i >= UPP) continue;
+      float* dst = pl + su_lds[i];
+      if (!pd_ok) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[e] = 0.f;
+      } else if (MODE == 0) {
+        const float ae = su_ok[i] ? pd_a : 0.f, be = su_ok[i] ? pd_b : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[e] = e2e::in_act(v4[i][e], ae, be, pd_slope);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[e] = su_ok[i] ? v4[i][e] : 0.f;
+      }
+    }
+  };
+
+  // ---- the first chunk is requested before anything else: this wave's plane descriptor comes straight from the plan tables on
+  // the scalar path, the loads are in flight while the descriptor table of the remaining chunks is built (the prologue was 11 %
+  // of a wave's life in the forward, 21 % in a 4-chunk data gradient: three dependent round trips -- table, barrier, first loads)
+  {
+    gfloat_p base = (gfloat_p)p.wpk;                      // always dereferenceable
+    bool ok = false;
+    if (MODE == 0) {
+      const e2e_in_chan_t ch = load_uniform(p.chans + (long long)g * p.ppad + wave);
+      const int din = d - ch.dshift;
+      if (ch.ptr != nullptr && (unsigned)din < (unsigned)p.D) {
+        ok = true;
+        base = (gfloat_p)(ch.ptr + (long long)n * ch.nstride + (long long)din * plane);
+        if (ch.scale != nullptr) {
+          pd_a = load_uniform(ch.scale + (long long)n * ch.ab_nstride);
+          pd_b = load_uniform(ch.shift + (long long)n * ch.ab_nstride);
+          pd_slope = ch.slope;
+        }
+      }
+    } else {
+      const int c = load_uniform(p.pslot + (long long)g * p.ppad + wave);
+      if (c >= 0) {
+        ok = true;
+        base = (gfloat_p)(p.xin + (((long long)n * p.P + c) * p.D + d) * plane);
+      }
+    }
+    const unsigned long long bb = (unsigned long long)base;
+    pf_blo = (unsigned)bb;
+    pf_bhi = (unsigned)(bb >> 32);
+    pd_ok = ok;
+  }
+#pragma unroll
+  for (int k = 0; k < NUP; ++k) request_plane(k, true);
+  request_weights(0, 0, true);
+  request_weights(0, 1, true);
+
   // ---- plane table of this (group, batch item, depth slice) ------------------------------------------------------------------
   for (int pl = tid; pl < p.ppad; pl += NW * 64) {
     PlaneDesc ds;
@@ -153,21 +256,6 @@ __global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams
       }
     }
     tab[pl] = ds;
-  }
-
-  // ---- staging geometry: a wave stages one whole plane of each chunk, a lane NUP float4 groups of it --------------------------
-  int su_lds[NUP], su_goff[NUP];
-  bool su_ok[NUP];
-#pragma unroll
-  for (int i = 0; i < NUP; ++i) {
-    int u = lane + 64 * i;
-    if (u >= UPP) u = UPP - 1;
-    const int r = u / NQ, q = u - r * NQ;
-    const int hi = h0 - 1 + r, gc = w0 - 4 + 4 * q;
-    const bool ok = (unsigned)hi < (unsigned)p.H && gc >= 0 && gc + 3 < p.W;
-    su_lds[i] = r * PITCH + 4 * q - 3;
-    su_goff[i] = ok ? (hi * p.W + gc) * 4 : 0;
-    su_ok[i] = ok;
   }
 
   // ---- epilogue operands, requested up front --------------------------------------------------------------------------------
@@ -236,68 +324,10 @@ __global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams
     }
   }
 
-  __syncthreads();                                      // the plane table is complete
-
-  // ---- staging: planes through registers (prefetched one chunk ahead), weights by LDS-DMA into the other weight buffer ---------
-  f32x4_t v4[NUP];
-  float pd_a = 1.f, pd_b = 0.f, pd_slope = 1.f;
-  bool pd_ok = false;
-  unsigned pf_blo = 0, pf_bhi = 0;
-  const int wstride = p.kmax * WSLOT;                    // floats of a chunk's weight block
-  const float* wblock = p.wpk + (long long)g * p.nchunks * wstride;
-  auto request_begin = [&](int c) {
-    const PlaneDesc ds = tab[c * CK + wave];
-    const unsigned long long bb = (unsigned long long)ds.base;
-    pf_blo = __builtin_amdgcn_readfirstlane((unsigned)bb);
-    pf_bhi = __builtin_amdgcn_readfirstlane((unsigned)(bb >> 32));
-    pd_a = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ds.a)));
-    pd_b = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ds.b)));
-    pd_slope = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ds.slope)));
-    pd_ok = __builtin_amdgcn_readfirstlane(ds.valid) != 0;
-  };
-  auto request_plane = [&](int k, bool live) {           // k: compile-time
-    const char __attribute__((address_space(1)))* base =
-        (const char __attribute__((address_space(1)))*)(((unsigned long long)pf_bhi << 32) | pf_blo);
-    const unsigned off = live && pd_ok ? (unsigned)su_goff[k] : 0u;
-    v4[k] = *reinterpret_cast<gfloat4_p>(base + off);
-  };
-  // a chunk's weight block = 3 kmax float4 units; wave w moves units [uw w, uw w + uw) with up to two LDS-DMA instructions
-  // (LDS destination = wave-uniform base + 16 * lane)
-  auto request_weights = [&](int c, int half, bool live) {
-    if (!live || half * 64 >= p.uw) return;               // (wave-uniform)
-    const int u = wave * p.uw + half * 64 + lane;
-    const float* src = wblock + (long long)c * wstride + u * 4;
-    float* dst = wl + (c & 1) * wstride + (wave * p.uw + half * 64) * 4;
-    if (half * 64 + lane < p.uw && u < 3 * p.kmax)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-  };
-  auto commit = [&](int img) {
-    float* pl = lds + img * IMG + wave * CHS;
-#pragma unroll
-    for (int i = 0; i < NUP; ++i) {
-      if ((i + 1) * 64 > UPP && lane + 64 * i >= UPP) continue;
-      float* dst = pl + su_lds[i];
-      if (!pd_ok) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dst[e] = 0.f;
-      } else if (MODE == 0) {
-        const float ae = su_ok[i] ? pd_a : 0.f, be = su_ok[i] ? pd_b : 0.f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dst[e] = e2e::in_act(v4[i][e], ae, be, pd_slope);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dst[e] = su_ok[i] ? v4[i][e] : 0.f;
-      }
-    }
-  };
+  // (no barrier for the plane table: it is first read after the barrier behind the first chunk's commit)
 
   const unsigned* qrow = p.quads + ((long long)g * NW + wave) * p.nchunks;
   const int* orow = p.woff + (long long)g * p.nchunks * NW + wave;
-  request_begin(0);
-#pragma unroll
-  for (int k = 0; k < NUP; ++k) request_plane(k, true);
-  request_weights(0, 0, true);
-  request_weights(0, 1, true);
   unsigned m_cur = load_uniform(qrow);
   int o_cur = load_uniform(orow);
   commit(0);

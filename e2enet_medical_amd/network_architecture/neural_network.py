@@ -273,7 +273,7 @@ class SegmentationNetwork(NeuralNetwork):
                 accumulate(ti, predict_tile(ti))
         else:
             from ..parallel import run_tiles_sharded
-            self.last_shard_stats = {}
+            self.last_shard_stats = {"time": bool(getattr(self, "time_sharding", False))}      # (timing costs a device sync: benchmark only)
             run_tiles_sharded(num_tiles, rank, world, self.tile_group, predict_tile, accumulate, (K, px, py, pz), dev,
                               pipelined=os.environ.get("E2E_SW_BLOCKING") != "1", stats=self.last_shard_stats)
 

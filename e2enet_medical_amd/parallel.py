@@ -62,10 +62,13 @@ def run_tiles_sharded(num_tiles: int, rank: int, world: int, group, predict_tile
     fp32 sums -- and the result -- are bit-identical to the single-process loop.  Two group buffers are live (2 x world
     patches: 2.1 GB at K = 16, 128^3, 8 ranks) instead of every tile of the volume (14.5 GB for the AMOS-shaped benchmark volume).
     ``pipelined=False``: the former blocking form (all local tiles, one all-gather of everything, then the overlap-add);
-    kept for A/B timing.  ``stats`` (dict) receives tile counts and, for CUDA tensors, the time the compute stream spent
-    waiting for collectives."""
+    kept for A/B timing.  ``stats`` (dict) receives tile counts; with ``stats["time"]`` set (the benchmark does) it also receives
+    the time the compute stream spent waiting for collectives -- that costs two events per group and ONE device synchronisation
+    at the end, which an ordinary inference call does not pay.  Returns None in both forms (the result is what ``accumulate``
+    has been handed)."""
     if stats is None:
         stats = {}
+    timed = bool(stats.get("time"))
     mine_tiles = partition_tiles(num_tiles, rank, world)
     stats.update(tiles_total=num_tiles, tiles_local=len(mine_tiles), world=world, pipelined=bool(pipelined))
     if not pipelined:
@@ -77,7 +80,7 @@ def run_tiles_sharded(num_tiles: int, rank: int, world: int, group, predict_tile
         for ti in range(num_tiles):
             owner, slot = tile_slot(ti, world)
             accumulate(ti, gathered[owner, slot])
-        return gathered
+        return None
     ngroups = slots_per_rank(num_tiles, world)
     send = [torch.zeros(tuple(patch_shape), dtype=dtype, device=device) for _ in range(2)]
     recv = [torch.empty((world,) + tuple(patch_shape), dtype=dtype, device=device) for _ in range(2)]
@@ -85,7 +88,7 @@ def run_tiles_sharded(num_tiles: int, rank: int, world: int, group, predict_tile
     waits = []
 
     def drain(g, handle):
-        if cuda:
+        if cuda and timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             handle.wait()                       # the compute stream waits for the collective; the host does not
@@ -110,12 +113,12 @@ def run_tiles_sharded(num_tiles: int, rank: int, world: int, group, predict_tile
         pending = (g, handle)
     if pending is not None:
         drain(*pending)
-    if cuda and waits:
+    if waits:
         torch.cuda.synchronize()
         stats["collective_wait_ms"] = sum(a.elapsed_time(b) for a, b in waits)
     stats["groups"] = ngroups
     stats["exchange_buffer_bytes"] = 2 * (world + 1) * int(torch.tensor(patch_shape).prod()) * 4
-    return recv
+    return None
 
 
 def allreduce_mean_gradients(grads: Dict[str, torch.Tensor], names: List[str], group=None, flat: torch.Tensor = None,
