@@ -569,7 +569,9 @@ int sparse_launch(int mode, SparseParams p, hipStream_t st) {
   p.padded_total = (p.total + 7) & ~7;
   if (p.flush_every < 1) p.flush_every = 1;
   p.uw = e2e::cdiv(3 * p.kmax, NW);
-  const size_t dyn = (size_t)2 * p.kmax * WSLOT * 4 + (size_t)p.ppad * sizeof(PlaneDesc);
+  size_t dyn = (size_t)2 * p.kmax * WSLOT * 4 + (size_t)p.ppad * sizeof(PlaneDesc);
+  static const int pad_kb = getenv("E2E_SPARSE_LDS_PAD_KB") ? atoi(getenv("E2E_SPARSE_LDS_PAD_KB")) : 0;   // occupancy experiment
+  dyn += (size_t)pad_kb * 1024;
   static bool attr_set = false;
   if (!attr_set) {                                        // static 55 KB + dynamic: beyond the default 64 KB for dense maps / many planes
     (void)hipFuncSetAttribute((const void*)conv133_sparse_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
