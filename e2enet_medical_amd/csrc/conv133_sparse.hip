@@ -75,6 +75,7 @@ struct SparseParams {
   double* part;
   int P, Q, B, D, H, W;
   int nchunks, ppad, groups, flush_every, kmax, uw;      // uw: 16-byte units of a chunk's weight block per wave
+  int dbg;                                               // diagnostic build: 1 no walk, 2 no plane loads, 4 no stores
   int tiles_x, tiles_y, tiles_per_n, total, padded_total;
 };
 
@@ -102,12 +103,12 @@ __device__ __forceinline__ T load_uniform(const T* ptr) {
 
 template <int MODE>
 __global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams p) {
-  constexpr int IMG = CK * CHS + 4;                     // one image of a chunk's planes (+ 4 guard floats in front)
+  constexpr int IMG = CK * CHS;                         // one image of a chunk's planes
   __shared__ __attribute__((aligned(16))) float lds_raw[2 * IMG];
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
   float* const wl = reinterpret_cast<float*>(dyn_lds);              // 2 x kmax x 12 floats
   PlaneDesc* tab = reinterpret_cast<PlaneDesc*>(dyn_lds + (size_t)2 * p.kmax * WSLOT * 4);
-  float* const lds = lds_raw + 4;
+  float* const lds = lds_raw;
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -128,19 +129,26 @@ __global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams
   const int tx = tile_in_n % p.tiles_x, ty = (tile_in_n / p.tiles_x) % p.tiles_y, d = tile_in_n / (p.tiles_x * p.tiles_y);
   const int h0 = ty * TH, w0 = tx * TW;
 
-  // ---- staging geometry: a wave stages one whole plane of each chunk, a lane NUP float4 groups of it --------------------------
+  // ---- staging geometry: a wave stages one whole plane of each chunk; a lane loads the NUP CONSECUTIVE aligned float4 groups
+  // 3 lane .. 3 lane + 2 of the plane's IH x NQ groups (group (r, q) = image row r, global columns w0 - 4 + 4 q ..).  The LDS image
+  // is shifted by one column against those groups (its column 0 is the left halo, so that every lane's neighbourhood rows start
+  // 16-byte aligned): image unit (r, q) = the last element of group q and the first three of group q + 1 -- the lane's own next
+  // group, or, for its last one, the first group of lane + 1 (one cross-lane move per element).  Written as aligned
+  // ds_write_b128; the straight copy of the global groups needed four ds_write_b32 per group at a lane stride of four words:
+  // 4-way bank conflicts, 96 instead of 24 LDS-array cycles per wave and chunk, a third of this kernel's LDS time.
   int su_lds[NUP], su_goff[NUP];
-  bool su_ok[NUP];
+  bool su_ok[NUP], su_wr[NUP];
 #pragma unroll
   for (int i = 0; i < NUP; ++i) {
-    int u = lane + 64 * i;
-    if (u >= UPP) u = UPP - 1;
+    const int u0 = 3 * lane + i;
+    const int u = u0 < UPP ? u0 : UPP - 1;                // (idle lanes: harmless duplicate loads, no writes)
     const int r = u / NQ, q = u - r * NQ;
     const int hi = h0 - 1 + r, gc = w0 - 4 + 4 * q;
     const bool ok = (unsigned)hi < (unsigned)p.H && gc >= 0 && gc + 3 < p.W;
-    su_lds[i] = r * PITCH + 4 * q - 3;
+    su_lds[i] = r * PITCH + 4 * q;
     su_goff[i] = ok ? (hi * p.W + gc) * 4 : 0;
     su_ok[i] = ok;
+    su_wr[i] = u0 < UPP && q < NQ - 1;
   }
 
   // ---- staging: planes through registers (prefetched one chunk ahead), weights by LDS-DMA into the other weight buffer ---------
@@ -163,7 +171,11 @@ __global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams
   auto request_plane = [&](int k, bool live) {           // k: compile-time
     const char __attribute__((address_space(1)))* base =
         (const char __attribute__((address_space(1)))*)(((unsigned long long)pf_bhi << 32) | pf_blo);
+#ifdef E2E_CONV_DEBUG
+    const unsigned off = live && pd_ok && !(p.dbg & 2) ? (unsigned)su_goff[k] : 0u;
+#else
     const unsigned off = live && pd_ok ? (unsigned)su_goff[k] : 0u;
+#endif
     v4[k] = *reinterpret_cast<gfloat4_p>(base + off);
   };
   // a chunk's weight block = 3 kmax float4 units; wave w moves units [uw w, uw w + uw) with up to two LDS-DMA instructions
@@ -178,21 +190,26 @@ __global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams
   };
   auto commit = [&](int img) {
     float* pl = lds + img * IMG + wave * CHS;
+    float t[NUP][4];
 #pragma unroll
     for (int i = 0; i < NUP; ++i) {
-      if ((i + 1) * 64 > UPP && lane + 64 * i >= UPP) continue;
-      float* dst = pl + su_lds[i];
-      if (!pd_ok) {
+      const float ae = su_ok[i] ? pd_a : 0.f, be = su_ok[i] ? pd_b : 0.f;   // out-of-image groups stage zeros
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dst[e] = 0.f;
-      } else if (MODE == 0) {
-        const float ae = su_ok[i] ? pd_a : 0.f, be = su_ok[i] ? pd_b : 0.f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dst[e] = e2e::in_act(v4[i][e], ae, be, pd_slope);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dst[e] = su_ok[i] ? v4[i][e] : 0.f;
+      for (int e = 0; e < 4; ++e) {
+        if (!pd_ok) t[i][e] = 0.f;
+        else if (MODE == 0) t[i][e] = e2e::in_act(v4[i][e], ae, be, pd_slope);
+        else t[i][e] = su_ok[i] ? v4[i][e] : 0.f;
       }
+    }
+    float nx[3];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) nx[e] = __shfl_down(t[0][e], 1, 64);        // the first group of lane + 1 follows this lane's last
+#pragma unroll
+    for (int i = 0; i < NUP; ++i) {
+      if (!su_wr[i]) continue;
+      const float4 val = i + 1 < NUP ? make_float4(t[i][3], t[(i + 1) % NUP][0], t[(i + 1) % NUP][1], t[(i + 1) % NUP][2])
+                                     : make_float4(t[i][3], nx[0], nx[1], nx[2]);
+      *reinterpret_cast<float4*>(pl + su_lds[i]) = val;
     }
   };
 
@@ -274,14 +291,20 @@ __global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams
   }
 
   // ---- accumulators; an accumulating data gradient starts its outer accumulators from the old dx values -----------------------
-  float acc[OPW][PH][PW], acc2[OPW][PH][PW];
+  // Accumulators as aligned register PAIRS over adjacent output columns: a tap with an even column offset (kw = 0, 2) is one
+  // v_pk_fma_f32 per pair (the weight is broadcast by op_sel, the two neighbourhood values are an aligned pair of the row's
+  // ds_read registers), kw = 1 (odd offset: no aligned pair) stays two v_fma_f32: 48 instead of 72 VALU instructions per kernel.
+  // A packed FMA costs ~4 SIMD cycles at any occupancy, a plain one 2.3 with two waves issuing but 4.3 when a wave issues alone
+  // (tools/scratch/fma_rate.hip) -- which in this kernel (four waves per SIMD, each in an FMA burst a third of its life) is the
+  // common case.
+  f32x2_t accp[OPW][PH][PW / 2], acc2p[OPW][PH][PW / 2];
   const int oh0 = h0 + ly * PH, ow0 = w0 + lx * PW;
 #pragma unroll
   for (int a = 0; a < OPW; ++a)
 #pragma unroll
     for (int i = 0; i < PH; ++i)
 #pragma unroll
-      for (int j = 0; j < PW; ++j) { acc[a][i][j] = 0.f; acc2[a][i][j] = 0.f; }
+      for (int j = 0; j < PW / 2; ++j) { accp[a][i][j] = f32x2_t{0.f, 0.f}; acc2p[a][i][j] = f32x2_t{0.f, 0.f}; }
   // data gradient: gradient of virtual-concat channel q at (shifted) depth d goes to depth d - s(q) of its source; the slices that
   // receive nothing are zero-filled by the workgroups of the slices that fall outside (conv133_kernel's rule).  Wave-uniform.
   // mode: 0 store, 1 accumulate (the old values are the initial outer accumulators), 2 zero fill, 3 nothing to do, 4 nothing to
@@ -318,7 +341,7 @@ __global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams
         const int oh = oh0 + i;
         if (oh < p.H && ow0 < p.W) {
           const float4 o = *reinterpret_cast<const float4*>(xp + (long long)oh * p.W + ow0);
-          acc2[a][i][0] = o.x; acc2[a][i][1] = o.y; acc2[a][i][2] = o.z; acc2[a][i][3] = o.w;
+          acc2p[a][i][0] = f32x2_t{o.x, o.y}; acc2p[a][i][1] = f32x2_t{o.z, o.w};
         }
       }
     }
@@ -351,7 +374,11 @@ __global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams
     for (int cl = 0; cl < CK; ++cl) {
       if (cl < NUP) request_plane(cl, more);
       else if (cl < NUP + 2) request_weights(c + 1, cl - NUP, more);
+#ifdef E2E_CONV_DEBUG
+      const unsigned nib = (p.dbg & 1) ? 0u : (m_cur >> (cl * 4)) & 15u;
+#else
       const unsigned nib = (m_cur >> (cl * 4)) & 15u;
+#endif
       if (nib) {
         float nb[NR][NCL];
         const float* tp = tp0 + cl * CHS;
@@ -373,13 +400,24 @@ __global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams
             const float wk[9] = {w0v[0], w0v[1], w0v[2], w0v[3], w1v[0], w1v[1], w1v[2], w1v[3], wp[8]};
             wq += WSLOT * 4;
 #pragma unroll
-            for (int i = 0; i < PH; ++i)
+            for (int kh = 0; kh < 3; ++kh) {
 #pragma unroll
-              for (int j = 0; j < PW; ++j)
+              for (int kw = 0; kw < 3; kw += 2) {
+                const f32x2_t wv = {wk[kh * 3 + kw], wk[kh * 3 + kw]};
 #pragma unroll
-                for (int kh = 0; kh < 3; ++kh)
+                for (int i = 0; i < PH; ++i)
 #pragma unroll
-                  for (int kw = 0; kw < 3; ++kw) acc[a][i][j] = fmaf(wk[kh * 3 + kw], nb[i + kh][j + kw], acc[a][i][j]);
+                  for (int j = 0; j < PW / 2; ++j) {
+                    const f32x2_t bv = {nb[i + kh][2 * j + kw], nb[i + kh][2 * j + kw + 1]};
+                    accp[a][i][j] = __builtin_elementwise_fma(wv, bv, accp[a][i][j]);
+                  }
+              }
+#pragma unroll
+              for (int i = 0; i < PH; ++i)
+#pragma unroll
+                for (int j = 0; j < PW; ++j)
+                  accp[a][i][j >> 1][j & 1] = fmaf(wk[kh * 3 + 1], nb[i + kh][j + 1], accp[a][i][j >> 1][j & 1]);
+            }
           }
         }
       }
@@ -394,7 +432,7 @@ __global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams
 #pragma unroll
         for (int i = 0; i < PH; ++i)
 #pragma unroll
-          for (int j = 0; j < PW; ++j) { acc2[a][i][j] += acc[a][i][j]; acc[a][i][j] = 0.f; }
+          for (int j = 0; j < PW / 2; ++j) { acc2p[a][i][j] += accp[a][i][j]; accp[a][i][j] = f32x2_t{0.f, 0.f}; }
     }
     SSTAMP(t5);
     if (more) {
@@ -410,6 +448,13 @@ __global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams
   SSTAMP(t_epi);
 
   // ---- epilogue --------------------------------------------------------------------------------------------------------------
+  float acc2[OPW][PH][PW];
+#pragma unroll
+  for (int a = 0; a < OPW; ++a)
+#pragma unroll
+    for (int i = 0; i < PH; ++i)
+#pragma unroll
+      for (int j = 0; j < PW; ++j) acc2[a][i][j] = acc2p[a][i][j >> 1][j & 1];
   if (MODE == 0) {
     float psum[OPW];
     const long long out_n = (long long)p.Q * p.D * plane;
@@ -427,6 +472,9 @@ __global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams
           acc2[a][i][j] += bqs[a];
           if (oh < p.H && ow0 + j < p.W) s += acc2[a][i][j];
         }
+#ifdef E2E_CONV_DEBUG
+        if (p.dbg & 4) continue;
+#endif
         if (oh < p.H && ow0 < p.W)
           *reinterpret_cast<float4*>(yp + (long long)oh * p.W + ow0) = make_float4(acc2[a][i][0], acc2[a][i][1], acc2[a][i][2], acc2[a][i][3]);
       }
@@ -568,6 +616,10 @@ int sparse_launch(int mode, SparseParams p, hipStream_t st) {
   p.total = p.B * p.tiles_per_n * p.groups;
   p.padded_total = (p.total + 7) & ~7;
   if (p.flush_every < 1) p.flush_every = 1;
+#ifdef E2E_CONV_DEBUG
+  static const int dbg_knob = getenv("E2E_CONV_DBG") ? atoi(getenv("E2E_CONV_DBG")) : 0;
+  p.dbg = dbg_knob;
+#endif
   p.uw = e2e::cdiv(3 * p.kmax, NW);
   size_t dyn = (size_t)2 * p.kmax * WSLOT * 4 + (size_t)p.ppad * sizeof(PlaneDesc);
   static const int pad_kb = getenv("E2E_SPARSE_LDS_PAD_KB") ? atoi(getenv("E2E_SPARSE_LDS_PAD_KB")) : 0;   // occupancy experiment
@@ -583,8 +635,7 @@ int sparse_launch(int mode, SparseParams p, hipStream_t st) {
   if (mode == 0) hipLaunchKernelGGL((conv133_sparse_kernel<0>), dim3(p.padded_total), dim3(NW * 64), dyn, st, p);
   else hipLaunchKernelGGL((conv133_sparse_kernel<1>), dim3(p.padded_total), dim3(NW * 64), dyn, st, p);
 #ifdef E2E_CONV_DEBUG
-  static const int dbg = getenv("E2E_CONV_DBG") ? atoi(getenv("E2E_CONV_DBG")) : 0;
-  if (dbg & 8) {
+  if (p.dbg & 8) {
     (void)hipStreamSynchronize(st);
     static unsigned long long hh[1024 * 8], zz[1024 * 8];
     (void)hipMemcpyFromSymbol(hh, HIP_SYMBOL(g_sparse_stamps), sizeof(hh));
