@@ -31,6 +31,10 @@
 #include "e2e_common.h"
 #include <cstdlib>
 
+// raw buffer loads (the clang builtin __builtin_amdgcn_raw_buffer_load_b128 of this toolchain lowers to a splatted dword load)
+__device__ float __attribute__((ext_vector_type(4))) llvm_raw_buffer_load_v4f32(int __attribute__((ext_vector_type(4))) rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ float llvm_raw_buffer_load_f32(int __attribute__((ext_vector_type(4))) rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+
 namespace {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -38,6 +42,7 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 typedef const f32x4_t __attribute__((address_space(1)))* gf4_p;
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int TH = 4, TW = 32;
 constexpr int XROWS = TH + 2;
@@ -580,12 +585,375 @@ __global__ __launch_bounds__(768, 3) void conv133_wgrad_bf3v2_kernel(e2e::WgBf3P
   }
 }
 
+// ---- v4: matrix waves and staging waves (producer / consumer) ---------------------------------------------------------------
+// v2's twelve waves all do both jobs in lockstep behind one barrier: the three waves of a SIMD read their fragments together,
+// convert together and issue matrix instructions together, so the phases add up (timing with phases switched off: matrix
+// instructions alone 0.56 ms, + fragment reads 0.74, + conversion 0.90 on 64->32 @128^3 x 2).  tools/scratch/mfma_overlap.hip:
+// the matrix instructions of one wave and the vector instructions of ANOTHER wave of the same SIMD do overlap.  So: eight waves,
+// two per SIMD, 256 registers each.
+//   * waves 0-3 (one per SIMD): matrix wave r owns tile row r, both 16-pixel K blocks, all nine taps (9 x 16 accumulator
+//     registers), 108 matrix instructions per tile and nothing else but its fragment reads: dy row r once per K block (three
+//     v2 waves read it), x rows r .. r+2 one kernel row at a time, double-buffered in registers and requested one phase
+//     (18 matrix instructions) ahead; the dy words of the next K block two phases ahead.
+//   * waves 4-7: staging wave s loads, normalises, splits and commits 8 input channels (6 rounds, lane -> (channel, row,
+//     quad)), 8 dy channels (4 rounds) and their halo (1 round) of tile t+1 while the matrix waves work on tile t, and has the
+//     loads of tile t+2 in flight.
+//   * one barrier per tile; the matrix waves take it in front of their LAST phase (all reads of the tile's image have landed,
+//     18 matrix instructions still to issue) and request the next tile's first fragments right behind it.
+// Same LDS images, split and summation order per accumulator as v2 (bit-identical results).
+#ifndef E2E_WG4_STAGE_PRIO
+#define E2E_WG4_STAGE_PRIO 2
+#endif
+#ifdef E2E_CONV_DEBUG
+__device__ unsigned long long g_wg4_stamps[8];   // matrix wave 0: [0] loop, [1] barrier; staging wave 4: [2] loop, [3] barrier, [4] request, [5] convert; [7] workgroups
+#define WG4_T() __builtin_readcyclecounter()
+#endif
+__device__ __forceinline__ void bf3v4_mma(unsigned char* lds, f32x16 (&acc)[9], int ntiles, int wr, int lane) {
+  const int fr = lane & 31, fh8 = lane >> 5;
+  const int a_off = XB2 + fr * CSTR2 + wr * YROWB + (8 + 8 * fh8) * 2;          // + 32 bytes per K block
+  const int b_off = fr * CSTR2 + wr * XROWB + 8 * fh8 * 2;                      // + kh rows
+  u32x4_t r_an[3];
+  unsigned r_prev[3], r_next[3];
+  bf16x8 bq[2][3];
+  auto read_a = [&](const unsigned char* img, int half) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const unsigned char* ap = img + a_off + half * 32 + s * SSTR2;
+      r_an[s] = *reinterpret_cast<const u32x4_t*>(ap);
+      r_prev[s] = *reinterpret_cast<const unsigned*>(ap - 4);
+      r_next[s] = *reinterpret_cast<const unsigned*>(ap + 16);
+    }
+  };
+  auto read_b = [&](const unsigned char* img, int half, int kh, bf16x8 (&b)[3]) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s) b[s] = *reinterpret_cast<const bf16x8*>(img + b_off + kh * XROWB + half * 32 + s * SSTR2);
+  };
+  __syncthreads();                                            // image of the first tile committed
+#ifdef E2E_CONV_DEBUG
+  unsigned long long s_bar = 0;
+  const unsigned long long s_t0 = WG4_T();
+#endif
+  read_a(lds, 0);
+  read_b(lds, 0, 0, bq[0]);
+  for (int t = 0; t < ntiles; ++t) {
+    const unsigned char* const img = lds + (t & 1) * BUF2;
+    const unsigned char* const imgn = lds + ((t & 1) ^ 1) * BUF2;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      bf16x8 afr[3][3];                                       // [kw][piece]
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const u32x4_t an = r_an[s];
+        const u32x4_t k0 = u32x4_t{__builtin_amdgcn_alignbit(an[1], an[0], 16), __builtin_amdgcn_alignbit(an[2], an[1], 16),
+                                   __builtin_amdgcn_alignbit(an[3], an[2], 16), __builtin_amdgcn_alignbit(r_next[s], an[3], 16)};
+        const u32x4_t k2 = u32x4_t{__builtin_amdgcn_alignbit(an[0], r_prev[s], 16), __builtin_amdgcn_alignbit(an[1], an[0], 16),
+                                   __builtin_amdgcn_alignbit(an[2], an[1], 16), __builtin_amdgcn_alignbit(an[3], an[2], 16)};
+        afr[0][s] = __builtin_bit_cast(bf16x8, k0);
+        afr[1][s] = __builtin_bit_cast(bf16x8, an);
+        afr[2][s] = __builtin_bit_cast(bf16x8, k2);
+      }
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int ph = half * 3 + kh, cur = ph & 1;
+        __builtin_amdgcn_sched_barrier(0);
+        if (ph == 5) {
+#ifdef E2E_CONV_DEBUG
+          asm volatile("s_waitcnt lgkmcnt(0)");
+          const unsigned long long s_b0 = WG4_T();
+          __syncthreads();
+          s_bar += WG4_T() - s_b0;
+#else
+          __syncthreads();                                    // every read of this image has landed; tile t+1 is committed
+#endif
+          if (t + 1 < ntiles) {
+            read_a(imgn, 0);
+            read_b(imgn, 0, 0, bq[cur ^ 1]);
+          }
+        } else {
+          if (kh < 2) read_b(img, half, kh + 1, bq[cur ^ 1]);
+          else read_b(img, 1, 0, bq[cur ^ 1]);
+          if (ph == 1) read_a(img, 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          f32x16 a = acc[kh * 3 + kw];
+          // small terms first: lo*hi, mid*mid, hi*lo, then mid*hi, hi*mid, then hi*hi
+          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[kw][2], bq[cur][0], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[kw][1], bq[cur][1], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[kw][0], bq[cur][2], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[kw][1], bq[cur][0], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[kw][0], bq[cur][1], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[kw][0], bq[cur][0], a, 0, 0, 0);
+          acc[kh * 3 + kw] = a;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+#ifdef E2E_CONV_DEBUG
+  if (wr == 0 && lane == 0) { atomicAdd(&g_wg4_stamps[0], WG4_T() - s_t0); atomicAdd(&g_wg4_stamps[1], s_bar); atomicAdd(&g_wg4_stamps[7], 1ull); }
+#endif
+  if (ntiles & 1) __syncthreads();                            // the staging waves run their tiles in pairs
+}
+
+// The staging wave is ONE instruction stream per SIMD (a lone wave issues a vector instruction every ~5 cycles at best), so its
+// length per tile is what the kernel runs at once the matrix waves are fed: tile coordinates advance by counters (no
+// divisions), every address is a per-lane constant plus a per-tile scalar, dy comes through a buffer descriptor (lanes outside
+// the plane read zeros: no predicate at commit time), the input's zero fill rides in the per-lane (scale, shift) pair.
+__device__ __forceinline__ void bf3v4_stage(const e2e::WgBf3Params& p, unsigned char* lds, int n, int tile_lo, int ntiles, int cg, int ob,
+                                            int sw, int lane) {
+  const int obase = ob * 32, cbase = cg * 32;
+  const int in_plane = p.Hi * p.Wi;                           // (host: Di * Hi * Wi < 2^29, Cout * Do * Hi * Wi < 2^29)
+  // the staging waves are the younger half of the workgroup and lose every issue arbitration against their SIMD's matrix wave,
+  // which has slack (it waits at the barrier): static priority for the staging stream
+  __builtin_amdgcn_s_setprio(E2E_WG4_STAGE_PRIO);
+  // ---- input: round j, lane l -> item 64 j + l = (channel of this wave, row, quad); descriptors per lane ----
+  gfloat_p xbase[6];
+  float xa[6], xb[6], xsl[6];
+  int xdsh[6], xro[6], xgc[6], xoff[6], xdst[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int item = j * 64 + lane;
+    const int chl = item / 48, rem = item - chl * 48;
+    const int x_r = rem >> 3, x_q = rem & 7;
+    const int c = cbase + sw * 8 + chl;
+    const bool val = c < p.Cin;
+    const e2e_in_chan_t* chd = p.chans + (val ? c : 0);
+    xdsh[j] = val ? chd->dshift : (1 << 30);                  // an absent channel fails the depth test of every tile
+    xbase[j] = (gfloat_p)(chd->ptr + (long long)n * chd->nstride);
+    xa[j] = 1.f; xb[j] = 0.f; xsl[j] = 1.f;
+    if (val && chd->scale != nullptr) {
+      xa[j] = chd->scale[(long long)n * chd->ab_nstride];
+      xb[j] = chd->shift[(long long)n * chd->ab_nstride];
+      xsl[j] = chd->slope;
+    }
+    xro[j] = x_r - 1;
+    xgc[j] = 4 * x_q;
+    xoff[j] = (x_r - 1) * p.Wi + 4 * x_q - (val ? chd->dshift : 0) * in_plane;
+    xdst[j] = (sw * 8 + chl) * CSTR2 + x_r * XROWB + x_q * 8;
+  }
+  // ---- dy: round j, lane l -> (channel 2 j + l / 32 of this wave, row, quad); halo: lane -> (channel, row, side) ----
+  const int y_grp = lane & 31, y_r = y_grp >> 3, y_q = y_grp & 7;
+  const int h_ch = lane >> 3, h_r = (lane >> 1) & 3, h_side = lane & 1;
+  // buffer descriptor of this batch item's dy: base, stride 0, bytes, raw 32-bit format; a lane whose offset has bit 31 set is
+  // out of range and reads zeros
+  const unsigned long long dya = (unsigned long long)(p.dy + (long long)n * p.Cout * p.Do * in_plane);
+  const i32x4_t dyr = {__builtin_amdgcn_readfirstlane((int)dya), __builtin_amdgcn_readfirstlane((int)(dya >> 32) & 0xffff),
+                       __builtin_amdgcn_readfirstlane(p.Cout * p.Do * in_plane * 4), 0x00020000};
+  int yoff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int o = obase + sw * 8 + 2 * j + (lane >> 5);
+    yoff[j] = o < p.Cout ? ((o * p.Do) * in_plane + y_r * p.Wi + 4 * y_q) * 4 : (int)0x80000000;
+  }
+  // the halo's descriptor starts one float earlier: the left neighbour of column 0 of row 0 would be a negative lane offset
+  const i32x4_t dyh = {__builtin_amdgcn_readfirstlane((int)(dya - 4)), __builtin_amdgcn_readfirstlane((int)((dya - 4) >> 32) & 0xffff),
+                       __builtin_amdgcn_readfirstlane(p.Cout * p.Do * in_plane * 4 + 4), 0x00020000};
+  const int ho_ = obase + sw * 8 + h_ch;
+  const int hoff = ho_ < p.Cout ? ((ho_ * p.Do) * in_plane + h_r * p.Wi + (h_side ? TW + 1 : 0)) * 4 : (int)0x80000000;
+
+  struct Pos { int tx, ty, d; };
+  auto advance = [&](Pos& q, bool go) {                       // branch-free: scalar selects only (one basic block per tile)
+    const int tx = q.tx + 1;
+    const bool wx = tx == p.tiles_x;
+    const int ty = q.ty + (wx ? 1 : 0);
+    const bool wy = ty == p.tiles_y;
+    q.tx = go ? (wx ? 0 : tx) : q.tx;
+    q.ty = go ? (wy ? 0 : ty) : q.ty;
+    q.d = go ? q.d + (wy ? 1 : 0) : q.d;
+  };
+
+  // two register sets: the loads of tile t+2 are issued BEFORE tile t+1 is converted (a full tile of latency cover)
+  f32x4_t vx[2][6], vy[2][4];
+  float vh[2] = {0.f, 0.f};
+  float ta[2][6], tb[2][6];                                   // (scale, shift) of the lane for the tile in registers; (0, 0) outside
+  auto prefetch = [&](const int rs, const Pos& q) {
+    const int h0 = q.ty * TH, w0 = q.tx * TW;
+    const int dd = q.d * p.sd;
+    const int S = dd * in_plane + h0 * p.Wi + w0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const bool ok = (unsigned)(h0 + xro[j]) < (unsigned)p.Hi && xgc[j] < p.Wi - w0 && (unsigned)(dd - xdsh[j]) < (unsigned)p.Di;
+      const unsigned off = ok ? (unsigned)(S + xoff[j]) : 0u;
+      vx[rs][j] = *reinterpret_cast<gf4_p>(xbase[j] + off);
+      ta[rs][j] = ok ? xa[j] : 0.f;
+      tb[rs][j] = ok ? xb[j] : 0.f;
+    }
+    const int sy = (q.d * in_plane + h0 * p.Wi + w0) * 4;
+    const bool rowok = h0 + y_r < p.Hi && 4 * y_q < p.Wi - w0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vy[rs][j] = llvm_raw_buffer_load_v4f32(dyr, rowok ? yoff[j] : (int)0x80000000, sy, 0);
+    const bool hok = h0 + h_r < p.Hi && (unsigned)(w0 + (h_side ? TW : -1)) < (unsigned)p.Wi;
+    vh[rs] = llvm_raw_buffer_load_f32(dyh, hok ? hoff : (int)0x80000000, sy, 0);
+  };
+  auto commit = [&](const int rs, int buf) {
+    unsigned char* const xs = lds + buf * BUF2;
+    unsigned char* const ys = xs + XB2;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float u = fmaf(vx[rs][j][e], ta[rs][j], tb[rs][j]);
+        v[e] = fmaxf(u, u * xsl[j]);                          // LeakyReLU with 0 <= slope <= 1 (the engine's contract)
+      }
+      u32x2_t hi2, mid2, lo2;
+      split4(v, hi2, mid2, lo2);
+      unsigned char* dst = xs + xdst[j];
+      *reinterpret_cast<u32x2_t*>(dst) = hi2;
+      *reinterpret_cast<u32x2_t*>(dst + SSTR2) = mid2;
+      *reinterpret_cast<u32x2_t*>(dst + 2 * SSTR2) = lo2;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ol = sw * 8 + 2 * j + (lane >> 5);
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = vy[rs][j][e];
+      u32x2_t hi2, mid2, lo2;
+      split4(v, hi2, mid2, lo2);
+      unsigned char* dst = ys + ol * CSTR2 + y_r * YROWB + (8 + 4 * y_q) * 2;
+      *reinterpret_cast<u32x2_t*>(dst) = hi2;
+      *reinterpret_cast<u32x2_t*>(dst + SSTR2) = mid2;
+      *reinterpret_cast<u32x2_t*>(dst + 2 * SSTR2) = lo2;
+    }
+    {
+      const int ol = sw * 8 + h_ch;
+      const float v = vh[rs];
+      const unsigned u = __builtin_bit_cast(unsigned, v);
+      const float r1 = v - __builtin_bit_cast(float, u & 0xffff0000u);
+      const unsigned m = __builtin_bit_cast(unsigned, r1);
+      const float r2 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+      const unsigned l = __builtin_bit_cast(unsigned, r2);
+      unsigned char* dst = ys + ol * CSTR2 + h_r * YROWB + (h_side ? 40 : 7) * 2;
+      *reinterpret_cast<unsigned short*>(dst) = (unsigned short)(u >> 16);
+      *reinterpret_cast<unsigned short*>(dst + SSTR2) = (unsigned short)(m >> 16);
+      *reinterpret_cast<unsigned short*>(dst + 2 * SSTR2) = (unsigned short)(l >> 16);
+    }
+  };
+
+  Pos far;
+  far.tx = tile_lo % p.tiles_x;
+  const int tq = tile_lo / p.tiles_x;
+  far.ty = tq % p.tiles_y;
+  far.d = tq / p.tiles_y;
+  prefetch(0, far);
+  commit(0, 0);
+  advance(far, ntiles > 1);
+  prefetch(1, far);
+  __syncthreads();                                            // image of the first tile committed
+#ifdef E2E_CONV_DEBUG
+  unsigned long long s_bar = 0, s_req = 0, s_cvt = 0;
+  const unsigned long long s_t0 = WG4_T();
+#define WG4_SEG(acc_, body_) { const unsigned long long s_a = WG4_T(); body_; acc_ += WG4_T() - s_a; }
+#else
+#define WG4_SEG(acc_, body_) { body_; }
+#endif
+  for (int t = 0; t < ntiles; t += 2) {
+    // registers of set 1 hold tile t+1: request tile t+2 into set 0, then convert tile t+1 into the image the matrix waves are
+    // not reading.  Past the end the last tile is staged again into the image nobody reads (no branch around the loads; an odd
+    // run ends with one barrier the matrix waves answer behind their loop).
+    advance(far, t + 2 < ntiles);
+    WG4_SEG(s_req, prefetch(0, far));
+    __builtin_amdgcn_sched_barrier(0);                        // the requests stay in front of the conversion
+    WG4_SEG(s_cvt, commit(1, 1));
+    WG4_SEG(s_bar, __syncthreads());
+    advance(far, t + 3 < ntiles);
+    WG4_SEG(s_req, prefetch(1, far));
+    __builtin_amdgcn_sched_barrier(0);
+    WG4_SEG(s_cvt, commit(0, 0));
+    WG4_SEG(s_bar, __syncthreads());
+  }
+#ifdef E2E_CONV_DEBUG
+  if (sw == 0 && lane == 0) { atomicAdd(&g_wg4_stamps[2], WG4_T() - s_t0); atomicAdd(&g_wg4_stamps[3], s_bar); atomicAdd(&g_wg4_stamps[4], s_req); atomicAdd(&g_wg4_stamps[5], s_cvt); }
+#endif
+}
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv133_wgrad_bf3v4_kernel(e2e::WgBf3Params p) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF2];
+  const int segs = p.segs;
+  const int n = blockIdx.x / segs, seg = blockIdx.x - n * segs;
+  const int cg = blockIdx.y % p.cblocks, ob = blockIdx.y / p.cblocks;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile_lo = seg * p.tiles_per_chunk;
+  int tile_hi = tile_lo + p.tiles_per_chunk;
+  if (tile_hi > p.tiles_per_n) tile_hi = p.tiles_per_n;
+  const int ntiles = tile_hi - tile_lo;
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  if (ntiles > 0) {
+    if (wave < 4) bf3v4_mma(lds, acc, ntiles, wave, lane);
+    else bf3v4_stage(p, lds, n, tile_lo, ntiles, cg, ob, wave - 4, lane);
+  }
+
+  // ---- sum of the four matrix waves through LDS, fixed tree: (0 + 2) + (1 + 3) ----
+  __syncthreads();
+  float* const red = reinterpret_cast<float*>(lds);           // regions of 144 x 64 floats
+  auto put = [&](int region) {
+    float* dst = red + region * (144 * 64) + lane;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dst[(t * 16 + i) * 64] = acc[t][i];
+  };
+  auto add = [&](int region) {
+    const float* src = red + region * (144 * 64) + lane;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] += src[(t * 16 + i) * 64];
+  };
+  if (wave == 2 || wave == 3) put(wave - 2);
+  __syncthreads();
+  if (wave < 2) add(wave);
+  __syncthreads();
+  if (wave == 1) put(0);
+  __syncthreads();
+  if (wave == 0) {
+    add(0);
+    // C/D layout of v_mfma_f32_32x32x16: column (in channel) = lane & 31, row (out channel) = (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
+    float* sp = p.slab + (long long)blockIdx.x * p.Cout * p.Cin * 9;
+    const int c = cg * 32 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int o = ob * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+      if (o < p.Cout && c < p.Cin) {
+        float* dst = sp + ((long long)o * p.Cin + c) * 9;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) dst[t] = acc[t][i];
+      }
+    }
+  }
+}
+
 }  // namespace
 
 namespace e2e {
 
 int launch_wgrad_bf3(const WgBf3Params& p, int nchunks, int pairs, hipStream_t st) {
-  static const int variant = getenv("E2E_WG_BF3") ? atoi(getenv("E2E_WG_BF3")) : 2;       // 2: v2 (default), 1: v1 (A/B)
+  static const int variant = getenv("E2E_WG_BF3") ? atoi(getenv("E2E_WG_BF3")) : 4;       // 4: v4 (default), 2: v2, 1: v1 (A/B)
+  // v4 addresses with 32-bit element offsets inside one batch item's channel block / dy block
+  const bool fits32 = (long long)p.Di * p.Hi * p.Wi < (1ll << 29) && (long long)p.Cout * p.Do * p.Hi * p.Wi < (1ll << 29);
+  if (variant == 4 && fits32) {
+    hipLaunchKernelGGL(conv133_wgrad_bf3v4_kernel, dim3(nchunks, pairs), dim3(512), 0, st, p);
+#ifdef E2E_CONV_DEBUG
+    if (getenv("E2E_WG_STAMPS")) {
+      (void)hipStreamSynchronize(st);
+      unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wg4_stamps), sizeof(h));
+      const double w = h[7] ? (double)h[7] : 1.0, tl = (double)p.tiles_per_chunk;
+      fprintf(stderr, "[wgrad bf3v4 %d->%d] per tile, counter ticks: matrix wave loop %.0f (barrier wait %.0f) | staging wave loop %.0f: request %.0f convert %.0f barrier wait %.0f\n",
+              p.Cin, p.Cout, h[0] / w / tl, h[1] / w / tl, h[2] / w / tl, h[4] / w / tl, h[5] / w / tl, h[3] / w / tl);
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wg4_stamps), z, sizeof(z));
+    }
+#endif
+    return check_launch("conv133_wgrad_bf3v4_kernel");
+  }
   if (variant == 1) {
     hipLaunchKernelGGL(conv133_wgrad_bf3_kernel, dim3(nchunks, pairs), dim3(512), 0, st, p);
     return check_launch("conv133_wgrad_bf3_kernel");
