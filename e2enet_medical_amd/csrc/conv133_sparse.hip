@@ -401,8 +401,9 @@ __global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams
             wq += WSLOT * 4;
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
-#pragma unroll
-              for (int kw = 0; kw < 3; kw += 2) {
+              // taps in the order kw = 0, 1, 2 (the summation order of every kernel since round 1): the even column offsets as
+              // packed pairs, the odd one lane by lane
+              auto pair_tap = [&](int kw) {
                 const f32x2_t wv = {wk[kh * 3 + kw], wk[kh * 3 + kw]};
 #pragma unroll
                 for (int i = 0; i < PH; ++i)
@@ -411,12 +412,14 @@ __global__ __launch_bounds__(NW * 64, 4) void conv133_sparse_kernel(SparseParams
                     const f32x2_t bv = {nb[i + kh][2 * j + kw], nb[i + kh][2 * j + kw + 1]};
                     accp[a][i][j] = __builtin_elementwise_fma(wv, bv, accp[a][i][j]);
                   }
-              }
+              };
+              pair_tap(0);
 #pragma unroll
               for (int i = 0; i < PH; ++i)
 #pragma unroll
                 for (int j = 0; j < PW; ++j)
                   accp[a][i][j >> 1][j & 1] = fmaf(wk[kh * 3 + 1], nb[i + kh][j + 1], accp[a][i][j >> 1][j & 1]);
+              pair_tap(2);
             }
           }
         }
