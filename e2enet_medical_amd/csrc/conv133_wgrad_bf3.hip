@@ -602,7 +602,7 @@ __global__ __launch_bounds__(768, 3) void conv133_wgrad_bf3v2_kernel(e2e::WgBf3P
 //     18 matrix instructions still to issue) and request the next tile's first fragments right behind it.
 // Same LDS images, split and summation order per accumulator as v2 (bit-identical results).
 #ifndef E2E_WG4_STAGE_PRIO
-#define E2E_WG4_STAGE_PRIO 2
+#define E2E_WG4_STAGE_PRIO 0
 #endif
 #ifdef E2E_CONV_DEBUG
 __device__ unsigned long long g_wg4_stamps[8];   // matrix wave 0: [0] loop, [1] barrier; staging wave 4: [2] loop, [3] barrier, [4] request, [5] convert; [7] workgroups
@@ -705,9 +705,7 @@ __device__ __forceinline__ void bf3v4_stage(const e2e::WgBf3Params& p, unsigned 
                                             int sw, int lane) {
   const int obase = ob * 32, cbase = cg * 32;
   const int in_plane = p.Hi * p.Wi;                           // (host: Di * Hi * Wi < 2^29, Cout * Do * Hi * Wi < 2^29)
-  // the staging waves are the younger half of the workgroup and lose every issue arbitration against their SIMD's matrix wave,
-  // which has slack (it waits at the barrier): static priority for the staging stream
-  __builtin_amdgcn_s_setprio(E2E_WG4_STAGE_PRIO);
+  __builtin_amdgcn_s_setprio(E2E_WG4_STAGE_PRIO);             // (A/B knob: priorities 0..3 measured equal, tools/scratch/wg_prio.sh)
   // ---- input: round j, lane l -> item 64 j + l = (channel of this wave, row, quad); descriptors per lane ----
   gfloat_p xbase[6];
   float xa[6], xb[6], xsl[6];
