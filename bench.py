@@ -50,7 +50,7 @@ FP32_PEAK_TF = 157.3           # fp32 vector FMA peak = fp32-input MFMA peak (MI
 BF16_PEAK_TF = 2500.0          # dense bf16 MFMA peak (MI355X_MICROARCH.md; the 5 PF headline figure includes 2:1 sparsity)
 FWD_BYTES_PER_VOXEL = 5393.0   # BASELINE.md section 3 / SURVEY section 8(d): algorithmic fwd bytes per voxel at 32 ch
 TRAIN_BYTES_PER_VOXEL = 3 * FWD_BYTES_PER_VOXEL
-TRAFFIC_FILE = "r03_pmc_traffic.json"
+TRAFFIC_FILE = "r04_pmc_traffic.json"
 
 
 def build(device, patch=PATCH, cin=CIN, k=K, seed=0, density=DENSITY, pools=None, update_frequency=1200):
