@@ -586,7 +586,7 @@ def main():
             fl = sum(work[a[0]]["flops_dense"] for _, _, a in wt.events)
             tf = fl / (ms * 1e-3) / 1e12
             out["roofline_secondary"] = {
-                "bound": "mfma", "kernel": "conv133_wgrad_bf3v4 (bf16 MFMA, six bf16 products per fp32 product) / v2 / s2 / smallc (fp32 MFMA) "
+                "bound": "mfma", "kernel": "conv133_wgrad_bf3v5 (bf16 MFMA, six bf16 products per fp32 product) / v2 / s2 / smallc (fp32 MFMA) "
                                            "+ slab reduce: every launch of e2e_conv133_wgrad (dense weight gradient)",
                 "achieved": tf, "peak": BF16_PEAK_TF / 6.0, "unit": "TFLOP/s", "frac": tf / (BF16_PEAK_TF / 6.0),
                 "note": "fp32-equivalent dense FLOPs / time; peak = the dense bf16 MFMA peak (2500 TFLOP/s) / 6, the rate an fp32 "

@@ -929,14 +929,330 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+// ---- v5: one wave per SIMD, the staging stream dealt into the matrix-instruction gaps ------------------------------------------
+// v4's two streams are arbitrated by the hardware and both end up issue-bound on their shared SIMD (matrix pipe 66 % busy).  Here
+// the workgroup is four waves (one per SIMD, 512 registers): wave r owns tile row r with all nine taps AND a quarter of the
+// staging.  A tile is six phases of 18 matrix instructions; each phase carries a fixed share of the other work, spread over its
+// gaps by sched_group_barrier (one matrix instruction, then up to five others):
+//   phase 0: request the input pieces of tile t+2 (registers of the set that held tile t)
+//   phases 1-4: convert and commit tile t+1 (requested during tile t-1) into the image not being read
+//   phase 5: barrier first (all commits done, every read of this image landed), then the dy requests of tile t+2 and the first
+//            fragment reads of tile t+1
+// plus, in every phase, the fragment reads of the next phase.  Same images, split, order per accumulator and reduction tree as
+// v2 / v4 (bit-identical results).
+#define WG5_GAP1() __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x0b6, WG5_FILL, 0);
+#define WG5_GAP6() WG5_GAP1() WG5_GAP1() WG5_GAP1() WG5_GAP1() WG5_GAP1() WG5_GAP1()
+#ifndef WG5_FILL
+#define WG5_FILL 5
+#endif
+#ifndef WG5_DIAG
+#define WG5_DIAG 0                 // timing-only builds: 1 no conversion / commit, 2 no global requests, 4 no fragment reads
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv133_wgrad_bf3v5_kernel(e2e::WgBf3Params p) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF2];
+  const int segs = p.segs;
+  const int n = blockIdx.x / segs, seg = blockIdx.x - n * segs;
+  const int cg = blockIdx.y % p.cblocks, ob = blockIdx.y / p.cblocks;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile_lo = seg * p.tiles_per_chunk;
+  int tile_hi = tile_lo + p.tiles_per_chunk;
+  if (tile_hi > p.tiles_per_n) tile_hi = p.tiles_per_n;
+  const int ntiles = tile_hi - tile_lo;
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  if (ntiles > 0) {
+    const int sw = wave, wr = wave;
+    const int obase = ob * 32, cbase = cg * 32;
+    const int in_plane = p.Hi * p.Wi;                         // (host: Di * Hi * Wi < 2^29, Cout * Do * Hi * Wi < 2^29)
+    // ---- staging share of this wave (as bf3v4_stage) ----
+    gfloat_p xbase[6];
+    float xa[6], xb[6], xsl[6];
+    int xdsh[6], xro[6], xgc[6], xoff[6], xdst[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int item = j * 64 + lane;
+      const int chl = item / 48, rem = item - chl * 48;
+      const int x_r = rem >> 3, x_q = rem & 7;
+      const int c = cbase + sw * 8 + chl;
+      const bool val = c < p.Cin;
+      const e2e_in_chan_t* chd = p.chans + (val ? c : 0);
+      xdsh[j] = val ? chd->dshift : (1 << 30);
+      xbase[j] = (gfloat_p)(chd->ptr + (long long)n * chd->nstride);
+      xa[j] = 1.f; xb[j] = 0.f; xsl[j] = 1.f;
+      if (val && chd->scale != nullptr) {
+        xa[j] = chd->scale[(long long)n * chd->ab_nstride];
+        xb[j] = chd->shift[(long long)n * chd->ab_nstride];
+        xsl[j] = chd->slope;
+      }
+      xro[j] = x_r - 1;
+      xgc[j] = 4 * x_q;
+      xoff[j] = (x_r - 1) * p.Wi + 4 * x_q - (val ? chd->dshift : 0) * in_plane;
+      xdst[j] = (sw * 8 + chl) * CSTR2 + x_r * XROWB + x_q * 8;
+    }
+    const int y_grp = lane & 31, y_r = y_grp >> 3, y_q = y_grp & 7;
+    const int h_ch = lane >> 3, h_r = (lane >> 1) & 3, h_side = lane & 1;
+    const unsigned long long dya = (unsigned long long)(p.dy + (long long)n * p.Cout * p.Do * in_plane);
+    const i32x4_t dyr = {__builtin_amdgcn_readfirstlane((int)dya), __builtin_amdgcn_readfirstlane((int)(dya >> 32) & 0xffff),
+                         __builtin_amdgcn_readfirstlane(p.Cout * p.Do * in_plane * 4), 0x00020000};
+    const i32x4_t dyh = {__builtin_amdgcn_readfirstlane((int)(dya - 4)), __builtin_amdgcn_readfirstlane((int)((dya - 4) >> 32) & 0xffff),
+                         __builtin_amdgcn_readfirstlane(p.Cout * p.Do * in_plane * 4 + 4), 0x00020000};
+    int yoff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int o = obase + sw * 8 + 2 * j + (lane >> 5);
+      yoff[j] = o < p.Cout ? ((o * p.Do) * in_plane + y_r * p.Wi + 4 * y_q) * 4 : (int)0x80000000;
+    }
+    const int ho_ = obase + sw * 8 + h_ch;
+    const int hoff = ho_ < p.Cout ? ((ho_ * p.Do) * in_plane + h_r * p.Wi + (h_side ? TW + 1 : 0)) * 4 : (int)0x80000000;
+    const int ydst = y_r * YROWB + (8 + 4 * y_q) * 2;
+    const int hdst = (sw * 8 + h_ch) * CSTR2 + h_r * YROWB + (h_side ? 40 : 7) * 2;
+
+    struct Pos { int tx, ty, d; };
+    auto advance = [&](Pos& q, bool go) {
+      const int tx = q.tx + 1;
+      const bool wx = tx == p.tiles_x;
+      const int ty = q.ty + (wx ? 1 : 0);
+      const bool wy = ty == p.tiles_y;
+      q.tx = go ? (wx ? 0 : tx) : q.tx;
+      q.ty = go ? (wy ? 0 : ty) : q.ty;
+      q.d = go ? q.d + (wy ? 1 : 0) : q.d;
+    };
+    f32x4_t vx[2][6], vy[2][4];
+    float vh[2] = {0.f, 0.f};
+    float ta[2][6], tb[2][6];
+    auto request_x = [&](const int rs, const Pos& q) {
+      const int h0 = q.ty * TH, w0 = q.tx * TW;
+      const int dd = q.d * p.sd;
+      const int S = dd * in_plane + h0 * p.Wi + w0;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const bool ok = (unsigned)(h0 + xro[j]) < (unsigned)p.Hi && xgc[j] < p.Wi - w0 && (unsigned)(dd - xdsh[j]) < (unsigned)p.Di;
+        const unsigned off = ok ? (unsigned)(S + xoff[j]) : 0u;
+        vx[rs][j] = *reinterpret_cast<gf4_p>(xbase[j] + off);
+        ta[rs][j] = ok ? xa[j] : 0.f;
+        tb[rs][j] = ok ? xb[j] : 0.f;
+      }
+    };
+    auto request_y = [&](const int rs, const Pos& q) {
+      const int h0 = q.ty * TH, w0 = q.tx * TW;
+      const int sy = (q.d * in_plane + h0 * p.Wi + w0) * 4;
+      const bool rowok = h0 + y_r < p.Hi && 4 * y_q < p.Wi - w0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) vy[rs][j] = llvm_raw_buffer_load_v4f32(dyr, rowok ? yoff[j] : (int)0x80000000, sy, 0);
+      const bool hok = h0 + h_r < p.Hi && (unsigned)(w0 + (h_side ? TW : -1)) < (unsigned)p.Wi;
+      vh[rs] = llvm_raw_buffer_load_f32(dyh, hok ? hoff : (int)0x80000000, sy, 0);
+    };
+    auto commit_x = [&](const int rs, const int j, unsigned char* img) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float u = fmaf(vx[rs][j][e], ta[rs][j], tb[rs][j]);
+        v[e] = fmaxf(u, u * xsl[j]);                          // LeakyReLU with 0 <= slope <= 1 (the engine's contract)
+      }
+      u32x2_t hi2, mid2, lo2;
+      split4(v, hi2, mid2, lo2);
+      unsigned char* dst = img + xdst[j];
+      *reinterpret_cast<u32x2_t*>(dst) = hi2;
+      *reinterpret_cast<u32x2_t*>(dst + SSTR2) = mid2;
+      *reinterpret_cast<u32x2_t*>(dst + 2 * SSTR2) = lo2;
+    };
+    auto commit_y = [&](const int rs, const int j, unsigned char* img) {
+      const int ol = sw * 8 + 2 * j + (lane >> 5);
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = vy[rs][j][e];
+      u32x2_t hi2, mid2, lo2;
+      split4(v, hi2, mid2, lo2);
+      unsigned char* dst = img + XB2 + ol * CSTR2 + ydst;
+      *reinterpret_cast<u32x2_t*>(dst) = hi2;
+      *reinterpret_cast<u32x2_t*>(dst + SSTR2) = mid2;
+      *reinterpret_cast<u32x2_t*>(dst + 2 * SSTR2) = lo2;
+    };
+    auto commit_h = [&](const int rs, unsigned char* img) {
+      const float v = vh[rs];
+      const unsigned u = __builtin_bit_cast(unsigned, v);
+      const float r1 = v - __builtin_bit_cast(float, u & 0xffff0000u);
+      const unsigned m = __builtin_bit_cast(unsigned, r1);
+      const float r2 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+      const unsigned l = __builtin_bit_cast(unsigned, r2);
+      unsigned char* dst = img + XB2 + hdst;
+      *reinterpret_cast<unsigned short*>(dst) = (unsigned short)(u >> 16);
+      *reinterpret_cast<unsigned short*>(dst + SSTR2) = (unsigned short)(m >> 16);
+      *reinterpret_cast<unsigned short*>(dst + 2 * SSTR2) = (unsigned short)(l >> 16);
+    };
+    // ---- matrix side (as bf3v4_mma) ----
+    const int fr = lane & 31, fh8 = lane >> 5;
+    const int a_off = XB2 + fr * CSTR2 + wr * YROWB + (8 + 8 * fh8) * 2;
+    const int b_off = fr * CSTR2 + wr * XROWB + 8 * fh8 * 2;
+    u32x4_t r_an[3];
+    unsigned r_prev[3], r_next[3];
+    bf16x8 bq[2][3];
+    auto read_a = [&](const unsigned char* img, int half) {
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const unsigned char* ap = img + a_off + half * 32 + s * SSTR2;
+        r_an[s] = *reinterpret_cast<const u32x4_t*>(ap);
+        r_prev[s] = *reinterpret_cast<const unsigned*>(ap - 4);
+        r_next[s] = *reinterpret_cast<const unsigned*>(ap + 16);
+      }
+    };
+    auto read_b = [&](const unsigned char* img, int half, int kh, bf16x8 (&b)[3]) {
+#pragma unroll
+      for (int s = 0; s < 3; ++s) b[s] = *reinterpret_cast<const bf16x8*>(img + b_off + kh * XROWB + half * 32 + s * SSTR2);
+    };
+
+    // ---- prologue: tile 0 committed, tile 1 in the registers of set 1 ----
+    Pos far;
+    far.tx = tile_lo % p.tiles_x;
+    const int tq = tile_lo / p.tiles_x;
+    far.ty = tq % p.tiles_y;
+    far.d = tq / p.tiles_y;
+    request_x(0, far);
+    request_y(0, far);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) commit_x(0, j, lds);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) commit_y(0, j, lds);
+    commit_h(0, lds);
+    advance(far, ntiles > 1);
+    request_x(1, far);
+    request_y(1, far);
+    advance(far, ntiles > 2);
+    request_x(0, far);                                        // tile 2: its dy follows in phase 0 of tile 0
+    __syncthreads();
+    read_a(lds, 0);
+    read_b(lds, 0, 0, bq[0]);
+
+    auto tile = [&](const int t, const int rs) {               // rs: the register set that holds tile t+1
+      const unsigned char* const img = lds + (t & 1) * BUF2;
+      unsigned char* const imgn = lds + ((t & 1) ^ 1) * BUF2;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        bf16x8 afr[3][3];                                     // [kw][piece]
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int ph = half * 3 + kh, cur = ph & 1;
+          __builtin_amdgcn_sched_barrier(0);
+          if (kh == 0) {                                      // (inside the phase: the shifts are dealt into its gaps too)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+              const u32x4_t an = r_an[s];
+              const u32x4_t k0 = u32x4_t{__builtin_amdgcn_alignbit(an[1], an[0], 16), __builtin_amdgcn_alignbit(an[2], an[1], 16),
+                                         __builtin_amdgcn_alignbit(an[3], an[2], 16), __builtin_amdgcn_alignbit(r_next[s], an[3], 16)};
+              const u32x4_t k2 = u32x4_t{__builtin_amdgcn_alignbit(an[0], r_prev[s], 16), __builtin_amdgcn_alignbit(an[1], an[0], 16),
+                                         __builtin_amdgcn_alignbit(an[2], an[1], 16), __builtin_amdgcn_alignbit(an[3], an[2], 16)};
+              afr[0][s] = __builtin_bit_cast(bf16x8, k0);
+              afr[1][s] = __builtin_bit_cast(bf16x8, an);
+              afr[2][s] = __builtin_bit_cast(bf16x8, k2);
+            }
+          }
+          if (ph == 5) {
+            __syncthreads();                                  // tile t+1 committed; every read of this image has landed
+            if (t + 1 < ntiles && !(WG5_DIAG & 4)) {
+              read_a(imgn, 0);
+              read_b(imgn, 0, 0, bq[cur ^ 1]);
+            }
+            // the set of tile t+1 is free (committed in phases 1-4): the input of tile t+3 goes there, a tile and a half ahead of
+            // its conversion; past the end the last tile is requested and staged again
+            advance(far, t + 3 < ntiles);
+            if (!(WG5_DIAG & 2)) request_x(rs, far);
+          } else {
+            if (!(WG5_DIAG & 4)) {
+              if (kh < 2) read_b(img, half, kh + 1, bq[cur ^ 1]);
+              else read_b(img, 1, 0, bq[cur ^ 1]);
+              if (ph == 1) read_a(img, 1);
+            }
+            if (ph == 0) {
+              if (!(WG5_DIAG & 2)) request_y(rs ^ 1, far);     // dy of tile t+2 (its input was requested in phase 5 of tile t-1)
+            } else if (WG5_DIAG & 1) {
+            } else if (ph == 1) {
+              commit_x(rs, 0, imgn); commit_x(rs, 1, imgn);
+            } else if (ph == 2) {
+              commit_x(rs, 2, imgn); commit_x(rs, 3, imgn); commit_h(rs, imgn);
+            } else if (ph == 3) {
+              commit_x(rs, 4, imgn); commit_x(rs, 5, imgn); commit_y(rs, 0, imgn);
+            } else {
+              commit_y(rs, 1, imgn); commit_y(rs, 2, imgn); commit_y(rs, 3, imgn);
+            }
+          }
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            f32x16 a = acc[kh * 3 + kw];
+            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[kw][2], bq[cur][0], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[kw][1], bq[cur][1], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[kw][0], bq[cur][2], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[kw][1], bq[cur][0], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[kw][0], bq[cur][1], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[kw][0], bq[cur][0], a, 0, 0, 0);
+            acc[kh * 3 + kw] = a;
+          }
+          WG5_GAP6() WG5_GAP6() WG5_GAP6()
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    };
+    for (int t = 0; t < ntiles; t += 2) {
+      tile(t, 1);
+      if (t + 1 < ntiles) tile(t + 1, 0);
+    }
+  }
+
+  // ---- sum of the four waves through LDS, fixed tree: (0 + 2) + (1 + 3) ----
+  __syncthreads();
+  float* const red = reinterpret_cast<float*>(lds);           // regions of 144 x 64 floats
+  auto put = [&](int region) {
+    float* dst = red + region * (144 * 64) + lane;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dst[(t * 16 + i) * 64] = acc[t][i];
+  };
+  auto add = [&](int region) {
+    const float* src = red + region * (144 * 64) + lane;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] += src[(t * 16 + i) * 64];
+  };
+  if (wave >= 2) put(wave - 2);
+  __syncthreads();
+  if (wave < 2) add(wave);
+  __syncthreads();
+  if (wave == 1) put(0);
+  __syncthreads();
+  if (wave == 0) {
+    add(0);
+    float* sp = p.slab + (long long)blockIdx.x * p.Cout * p.Cin * 9;
+    const int c = cg * 32 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int o = ob * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+      if (o < p.Cout && c < p.Cin) {
+        float* dst = sp + ((long long)o * p.Cin + c) * 9;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) dst[t] = acc[t][i];
+      }
+    }
+  }
+}
+
 }  // namespace
 
 namespace e2e {
 
 int launch_wgrad_bf3(const WgBf3Params& p, int nchunks, int pairs, hipStream_t st) {
-  static const int variant = getenv("E2E_WG_BF3") ? atoi(getenv("E2E_WG_BF3")) : 4;       // 4: v4 (default), 2: v2, 1: v1 (A/B)
+  static const int variant = getenv("E2E_WG_BF3") ? atoi(getenv("E2E_WG_BF3")) : 5;       // 5: v5 (default), 4: v4, 2: v2, 1: v1 (A/B)
   // v4 addresses with 32-bit element offsets inside one batch item's channel block / dy block
   const bool fits32 = (long long)p.Di * p.Hi * p.Wi < (1ll << 29) && (long long)p.Cout * p.Do * p.Hi * p.Wi < (1ll << 29);
+  if (variant >= 5 && fits32) {
+    hipLaunchKernelGGL(conv133_wgrad_bf3v5_kernel, dim3(nchunks, pairs), dim3(256), 0, st, p);
+    return check_launch("conv133_wgrad_bf3v5_kernel");
+  }
   if (variant == 4 && fits32) {
     hipLaunchKernelGGL(conv133_wgrad_bf3v4_kernel, dim3(nchunks, pairs), dim3(512), 0, st, p);
 #ifdef E2E_CONV_DEBUG

@@ -25,9 +25,9 @@ if len(sys.argv) > 1:
     torch.cuda.synchronize()
     torch.save(e.grads["b.conv.weight"].cpu(), sys.argv[1])
 else:
-    for v in ("2", "4"):
+    for v in ("2", os.environ.get("WG_NEW", "4")):
         subprocess.check_call([sys.executable, __file__, "/tmp/wg_%s.pt" % v], env=dict(os.environ, E2E_WG_BF3=v))
-    a, b = torch.load("/tmp/wg_2.pt"), torch.load("/tmp/wg_4.pt")
+    a, b = torch.load("/tmp/wg_2.pt"), torch.load("/tmp/wg_%s.pt" % os.environ.get("WG_NEW", "4"))
     d = (a - b).abs()[:, :, 0]
     print("max |v2|", float(a.abs().max()), "max diff", float(d.max()))
     print("by tap (kh, kw):\n", d.amax(dim=(0, 1)))
