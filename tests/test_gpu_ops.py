@@ -516,6 +516,62 @@ def test_conv133_wgrad_alternative_paths_forced(variant):
     assert "passed" in r.stdout
 
 
+_WG_CHILD = r"""
+import sys, torch
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, %(root)r + "/tools")
+import kbench
+from e2enet_medical_amd._lib import lib
+from e2enet_medical_amd.engine import Act, ConvOp
+torch.manual_seed(0)
+out = {}
+for tag, (B, srcs, cout, dims) in {"ragged": (2, [(33, True), (20, False)], 40, (3, 20, 36)), "whole": (1, [(32, True), (32, False)], 32, (9, 32, 64)),
+                                   "one_tile_runs": (1, [(16, False)], 16, (1, 20, 32))}.items():
+    dev = torch.device("cuda")
+    acts = []
+    for i, (c, normed) in enumerate(srcs):
+        a = Act("s%%d" %% i, (B, c) + dims, normed, dev)
+        a.data.normal_()
+        if normed:
+            a.scale.uniform_(0.5, 1.5); a.shift.normal_()
+        acts.append(a)
+    cin = sum(c for c, _ in srcs)
+    e = kbench.Stub(); e.device = dev
+    e.params = {"b.conv.weight": torch.randn(cout, cin, 1, 3, 3, device=dev), "b.conv.bias": torch.zeros(cout, device=dev),
+                "b.instnorm.weight": torch.ones(cout, device=dev), "b.instnorm.bias": torch.zeros(cout, device=dev)}
+    e.grads = {k: torch.zeros_like(v) for k, v in e.params.items()}
+    op = ConvOp(e, "b", acts, cout, (1, 1, 1))
+    e.wgrad_ws = torch.empty(max(op.wgrad_ws_bytes() // 4, 1), dtype=torch.float32, device=dev)
+    op.out.alloc_grad(); op.plan_backward(); op.out.grad.normal_()
+    lib().conv133_wgrad(op.chans.data_ptr(), op.out.grad.data_ptr(), e.grads["b.conv.weight"].data_ptr(), e.wgrad_ws.data_ptr(), B, cin, cout, *dims, 1, 1, 1, 0)
+    torch.cuda.synchronize()
+    assert (lib().last_kernel() or b"").startswith(b"conv133_wgrad_bf3"), lib().last_kernel()
+    out[tag] = e.grads["b.conv.weight"].cpu()
+torch.save(out, sys.argv[1])
+"""
+
+
+def test_conv133_wgrad_bf3_variants_are_bit_identical(tmp_path):
+    """The three forms of the bf16x3 weight gradient (E2E_WG_BF3 = 5: one wave per SIMD, the default; 4: matrix waves + staging
+    waves; 2: twelve waves) use the same split, the same order per accumulator and the same reduction tree: their results must be
+    EQUAL, bit for bit (ragged channel blocks and tiles, depth shifts, a run of a single tile).  The knob is read once per
+    process: one child per variant."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for v in ("5", "4", "2"):
+        f = str(tmp_path / ("wg_%s.pt" % v))
+        r = subprocess.run([sys.executable, "-c", _WG_CHILD % {"root": root}, f], env=dict(os.environ, E2E_WG_BF3=v),
+                           capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        res[v] = torch.load(f)
+    for tag in res["5"]:
+        assert float(res["5"][tag].abs().max()) > 0
+        assert torch.equal(res["5"][tag], res["2"][tag]), "v5 vs v2: %s" % tag
+        assert torch.equal(res["4"][tag], res["2"][tag]), "v4 vs v2: %s" % tag
+
+
 @pytest.mark.parametrize("shape", [(2, 1, 16, 32, 32), (1, 1, 40, 56, 40), (2, 2, 7, 9, 13)])
 def test_ds_target_gather_vs_oracle(shape):
     """Deep-supervision targets gathered on the device against the oracle (scipy's zoom, order 0): bit exact."""
