@@ -51,6 +51,9 @@ BF16_PEAK_TF = 2500.0          # dense bf16 MFMA peak (MI355X_MICROARCH.md; the 
 FWD_BYTES_PER_VOXEL = 5393.0   # BASELINE.md section 3 / SURVEY section 8(d): algorithmic fwd bytes per voxel at 32 ch
 TRAIN_BYTES_PER_VOXEL = 3 * FWD_BYTES_PER_VOXEL
 TRAFFIC_FILE = "r04_pmc_traffic.json"
+# measured outside this process (profiles/r04_pmc_sq_bf3.txt): context for the fractions, not a live number
+CLOCK_NOTE = ("peaks are the 2.4 GHz figures of the guide; SQ busy cycles / kernel time put the shader clock at 1.5-1.6 GHz under "
+              "this kernel family with all 256 CUs busy (2.35 GHz when the same launch is confined to 64 CUs): power-limited")
 
 
 def build(device, patch=PATCH, cin=CIN, k=K, seed=0, density=DENSITY, pools=None, update_frequency=1200):
@@ -579,6 +582,7 @@ def main():
                           "the serial kernel time with the overlapped step)" % isteps,
                 "fma": {"achieved": fl / (ms * 1e-3) / 1e12, "peak": FP32_PEAK_TF, "unit": "TFLOP/s",
                         "frac": fl / (ms * 1e-3) / 1e12 / FP32_PEAK_TF, "flops": "live (DSFF-masked) FLOPs from the kernel maps"},
+                "clock_note": CLOCK_NOTE,
             }
         wt = timers["conv133_wgrad"]
         if wt.events:
@@ -593,7 +597,8 @@ def main():
                         "product rebuilt from six bf16 products can reach; against the fp32 MFMA / vector peak (157.3) the fraction "
                         "is %.3f" % (tf / FP32_PEAK_TF),
                 "traffic": pmc_traffic("conv133_wgrad"), "launches_per_step": len(wt.events) // isteps,
-                "avg_ms": ms / len(wt.events), "ms_per_step": ms / isteps, "share_of_step": (ms / isteps) / ms_step}
+                "avg_ms": ms / len(wt.events), "ms_per_step": ms / isteps, "share_of_step": (ms / isteps) / ms_step,
+                "clock_note": CLOCK_NOTE}
         if args.op_profile:
             prof = {k: round(t.total_ms() / isteps, 3) for k, t in timers.items() if t.events}
             out["op_ms_per_step"] = dict(sorted(prof.items(), key=lambda kv: -kv[1]))
