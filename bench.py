@@ -596,7 +596,9 @@ def main():
                 "note": "fp32-equivalent dense FLOPs / time; peak = the dense bf16 MFMA peak (2500 TFLOP/s) / 6, the rate an fp32 "
                         "product rebuilt from six bf16 products can reach; against the fp32 MFMA / vector peak (157.3) the fraction "
                         "is %.3f" % (tf / FP32_PEAK_TF),
-                "traffic": pmc_traffic("conv133_wgrad"), "launches_per_step": len(wt.events) // isteps,
+                "traffic": pmc_traffic("conv133_wgrad"),
+                "algorithmic_bytes_per_launch": sum(work[a[0]]["bytes"] for _, _, a in wt.events) / len(wt.events),
+                "launches_per_step": len(wt.events) // isteps,
                 "avg_ms": ms / len(wt.events), "ms_per_step": ms / isteps, "share_of_step": (ms / isteps) / ms_step,
                 "clock_note": CLOCK_NOTE}
         if args.op_profile:
