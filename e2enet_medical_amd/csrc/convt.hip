@@ -446,25 +446,32 @@ __device__ __forceinline__ void split3(float v, unsigned& h, unsigned& m, unsign
 // (S1 >> 16) | (S0 & 0xffff0000): the bf16 (truncated) pieces of two values in one word, `lo` in the low half
 __device__ __forceinline__ unsigned pack_hi16(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
 
-template <int KDH, int NCB>     // KDH = kd * kh (output rows per input voxel row), KT = 2 * KDH
-__global__ __launch_bounds__(256 * NCB) void convT_wgrad_bf3_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+// TPX = input voxels per tile: 64 (one 138 KB workgroup per CU) or, for KDH = 4, 32: two 77 KB workgroups per CU, one converting
+// and committing its tile while the other issues its matrix instructions (the phases of ONE workgroup are serial: commit, barrier,
+// matrix phase, barrier, with a single LDS image).
+template <int KDH, int NCB, int TPX>     // KDH = kd * kh (output rows per input voxel row), KT = 2 * KDH
+__global__ __launch_bounds__(256 * NCB, TPX == 32 ? 2 : 1) void convT_wgrad_bf3_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                                    const float* __restrict__ shift, float slope,
                                                                    const float* __restrict__ dy, float* __restrict__ slab,
                                                                    int B, int Cin, int Cout, int D, int H, int W, int kd, int kh,
                                                                    int tiles_per_chunk, int cgroups) {
   constexpr int KT = 2 * KDH;
-  constexpr int RS = WG_TPX * 2 + 16;                  // bytes per staged row (64 voxels bf16 + 16: odd multiple of 16, conflict-free b128)
+  constexpr int RS = TPX * 2 + 16;                     // bytes per staged row (TPX voxels bf16 + 16: odd multiple of 16, conflict-free b128)
+  constexpr int ZG = TPX / 4;                          // float4 groups per input channel row
+  constexpr int ZIT = 8 * ZG / 64;                     // wave iterations over its 8 input channels
+  constexpr int VP = TPX / 2;                          // voxel pairs (= float4 of dy) per output row
   constexpr int ZP = NCB * 32 * RS, YP = KT * 32 * RS;  // bytes per piece
   constexpr int YCW = 32 / (4 * NCB);                  // dy channels staged per wave
-  constexpr int YIT = KDH * 32 / 64;                   // wave iterations per dy channel (KDH rows x 32 voxel pairs)
-  static_assert(KDH == 2 || KDH == 4, "kd*kh in {2,4}");
+  constexpr int YIT = KDH * VP / 64;                   // wave iterations per dy channel (KDH rows x VP voxel pairs)
+  static_assert((KDH == 2 || KDH == 4) && (TPX == 64 || (TPX == 32 && KDH == 4)), "kd*kh in {2,4}; 32-voxel tiles for kd*kh = 4");
+  static_assert((TPX == 32 ? 2 : 1) * 3 * (NCB * 32 + 2 * KDH * 32) * RS <= 163840, "LDS budget");
   __shared__ __attribute__((aligned(16))) unsigned char zs[3 * ZP];     // [piece][channel][voxel] bf16
   __shared__ __attribute__((aligned(16))) unsigned char ds[3 * YP];     // [piece][tap][out channel][voxel] bf16
 
   const int chunk = blockIdx.x;
   const int cg = blockIdx.y % cgroups, ob = blockIdx.y / cgroups;
   const long long spatial = (long long)D * H * W;
-  const long long tiles_per_n = e2e::cdivll(spatial, WG_TPX);
+  const long long tiles_per_n = e2e::cdivll(spatial, TPX);
   const long long total_tiles = tiles_per_n * B;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -482,15 +489,15 @@ __global__ __launch_bounds__(256 * NCB) void convT_wgrad_bf3_kernel(const float*
   if (tile_hi > total_tiles) tile_hi = total_tiles;
 
   // z: each wave stages 8 channels x 64 voxels = 128 float4 -> 2 iterations; lane -> (channel k = g / 16, group g % 16)
-  f32x4_t vz[2], vy[YCW][YIT];
-  float za[2], zb[2];
+  f32x4_t vz[ZIT], vy[YCW][YIT];
+  float za[ZIT], zb[ZIT];
   // (=> spatial % 64 == 0 as well: no ragged last tile; the fast path keeps per-lane byte offsets in 32 bits: 96 spatial x 4 B)
-  const bool row_tiles = (W % WG_TPX) == 0 && spatial < (1ll << 24);
+  const bool row_tiles = (W % TPX) == 0 && spatial < (1ll << 24);
   long long yoff[YIT];
 #pragma unroll
   for (int it = 0; it < YIT; ++it) {
     const int g = lane + 64 * it;
-    const int rr = g >> 5, vp = g & 31;
+    const int rr = g / VP, vp = g % VP;
     const int i = rr / kh, j = rr - i * kh;
     yoff[it] = ((long long)i * Ho + j) * Wo + 4 * vp;
   }
@@ -498,13 +505,13 @@ __global__ __launch_bounds__(256 * NCB) void convT_wgrad_bf3_kernel(const float*
   // never change; the normalise-on-load coefficients change only with the batch item.  (s_memtime stamps: issuing the ten
   // float4 loads of a tile with per-lane 64-bit index arithmetic, two integer divisions and four coefficient loads took
   // ~2500 cycles, as long as the tile's matrix phase.)
-  unsigned zoffb[2], yoffb[YCW][YIT];
-  bool zcok[2];
+  unsigned zoffb[ZIT], yoffb[YCW][YIT];
+  bool zcok[ZIT];
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
+  for (int it = 0; it < ZIT; ++it) {
     const int g = lane + 64 * it;
-    zcok[it] = cbase + wave * 8 + (g >> 4) < Cin;
-    zoffb[it] = zcok[it] ? (unsigned)(((long long)(wave * 8 + (g >> 4)) * spatial + (g & 15) * 4) * 4) : 0u;
+    zcok[it] = cbase + wave * 8 + g / ZG < Cin;
+    zoffb[it] = zcok[it] ? (unsigned)(((long long)(wave * 8 + g / ZG) * spatial + (g % ZG) * 4) * 4) : 0u;
   }
 #pragma unroll
   for (int k = 0; k < YCW; ++k)
@@ -514,13 +521,13 @@ __global__ __launch_bounds__(256 * NCB) void convT_wgrad_bf3_kernel(const float*
   int cur_n = -1;
   auto prefetch = [&](long long tile) {
     const int n = (int)((unsigned)tile / (unsigned)tiles_per_n);
-    const long long vbase = (tile - (long long)n * tiles_per_n) * WG_TPX;
+    const long long vbase = (tile - (long long)n * tiles_per_n) * TPX;
     if (row_tiles) {
       if (n != cur_n) {
         cur_n = n;
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          const int c = cbase + wave * 8 + ((lane + 64 * it) >> 4);
+        for (int it = 0; it < ZIT; ++it) {
+          const int c = cbase + wave * 8 + (lane + 64 * it) / ZG;
           za[it] = 1.f; zb[it] = 0.f;
           if (scale != nullptr && c < Cin) { za[it] = scale[(long long)n * Cin + c]; zb[it] = shift[(long long)n * Cin + c]; }
         }
@@ -532,7 +539,7 @@ __global__ __launch_bounds__(256 * NCB) void convT_wgrad_bf3_kernel(const float*
       const char* yb8 = reinterpret_cast<const char*>(dy + ((long long)n * Cout + ych) * ospatial +
                                                       ((long long)dv * kd * Ho + (long long)hv * kh) * Wo + 2 * w0);
 #pragma unroll
-      for (int it = 0; it < 2; ++it) vz[it] = *reinterpret_cast<gf4_p>((gfloat_p)(zb8 + zoffb[it]));
+      for (int it = 0; it < ZIT; ++it) vz[it] = *reinterpret_cast<gf4_p>((gfloat_p)(zb8 + zoffb[it]));
 #pragma unroll
       for (int k = 0; k < YCW; ++k)
 #pragma unroll
@@ -540,10 +547,10 @@ __global__ __launch_bounds__(256 * NCB) void convT_wgrad_bf3_kernel(const float*
       return;
     }
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < ZIT; ++it) {
       const int g = lane + 64 * it;
-      const int c = cbase + wave * 8 + (g >> 4);
-      const long long vi = vbase + (g & 15) * 4;
+      const int c = cbase + wave * 8 + g / ZG;
+      const long long vi = vbase + (g % ZG) * 4;
       const bool ok = c < Cin && vi + 3 < spatial;
       const long long off = ok ? ((long long)n * Cin + c) * spatial + vi : 0;
       vz[it] = *reinterpret_cast<gf4_p>((gfloat_p)x + off);
@@ -555,8 +562,8 @@ __global__ __launch_bounds__(256 * NCB) void convT_wgrad_bf3_kernel(const float*
       const int o = ob * 32 + wave * YCW + k;
 #pragma unroll
       for (int it = 0; it < YIT; ++it) {
-        const int g = lane + 64 * it;                 // (row rr = g / 32, voxel pair vp = g % 32)
-        const int rr = g >> 5, vp = g & 31;
+        const int g = lane + 64 * it;                 // (row rr = g / VP, voxel pair vp = g % VP)
+        const int rr = g / VP, vp = g % VP;
         const long long vi = vbase + 2 * vp;
         const bool ok = o < Cout && vi + 1 < spatial;
         long long off = 0;
@@ -572,14 +579,14 @@ __global__ __launch_bounds__(256 * NCB) void convT_wgrad_bf3_kernel(const float*
   };
   auto commit = [&](long long tile) {
     const int n = (int)((unsigned)tile / (unsigned)tiles_per_n);
-    const long long vbase = (tile - (long long)n * tiles_per_n) * WG_TPX;
+    const long long vbase = (tile - (long long)n * tiles_per_n) * TPX;
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < ZIT; ++it) {
       const int g = lane + 64 * it;
-      const int cl = wave * 8 + (g >> 4);
-      const long long vi = vbase + (g & 15) * 4;
+      const int cl = wave * 8 + g / ZG;
+      const long long vi = vbase + (g % ZG) * 4;
       const bool ok = cbase + cl < Cin && vi + 3 < spatial;
-      unsigned char* dst = zs + cl * RS + (g & 15) * 8;
+      unsigned char* dst = zs + cl * RS + (g % ZG) * 8;
       unsigned h[4], m[4], l[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -597,7 +604,7 @@ __global__ __launch_bounds__(256 * NCB) void convT_wgrad_bf3_kernel(const float*
 #pragma unroll
       for (int it = 0; it < YIT; ++it) {
         const int g = lane + 64 * it;
-        const int rr = g >> 5, vp = g & 31;
+        const int rr = g / VP, vp = g % VP;
         const bool ok = ob * 32 + ol < Cout && vbase + 2 * vp + 1 < spatial;
         const f32x4_t q = vy[k][it];                  // (k=0,v) (k=1,v) (k=0,v+1) (k=1,v+1)
         unsigned h[4], m[4], l[4];
@@ -637,7 +644,7 @@ __global__ __launch_bounds__(256 * NCB) void convT_wgrad_bf3_kernel(const float*
       const unsigned char* ap = zs + (cbl * 32 + ch * 16 + li) * RS + lk * 16;
       const unsigned char* bp = ds + (oh * 16 + li) * RS + lk * 16;
 #pragma unroll
-      for (int kb = 0; kb < WG_TPX / 32; ++kb) {
+      for (int kb = 0; kb < TPX / 32; ++kb) {
         bf16x8_t af[3];
 #pragma unroll
         for (int sp = 0; sp < 3; ++sp) af[sp] = *reinterpret_cast<const bf16x8_t*>(ap + sp * ZP + kb * 64);
@@ -1295,11 +1302,11 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   if (w == 0 && e < numel) out[e] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
-inline int wgrad_chunks(long long total_tiles, int pairs, int* tiles_per_chunk) {
-  // aim at ~256 workgroups (one 84 KB workgroup per CU, equal work each) and keep the slabs few: every chunk is a slab
-  // the reduction has to read (1024 chunks cost 14 % more on the 64 -> 32 @64^3 layer); at least 8 tiles per chunk
+inline int wgrad_chunks(long long total_tiles, int pairs, int* tiles_per_chunk, int per_cu = 1) {
+  // aim at ~256 workgroups (one 84 KB workgroup per CU, equal work each; per_cu = 2: 512) and keep the slabs few: every chunk is
+  // a slab the reduction has to read (1024 chunks cost 14 % more on the 64 -> 32 @64^3 layer); at least 8 tiles per chunk
   static const int target = getenv("E2E_CT_WG_TARGET") ? atoi(getenv("E2E_CT_WG_TARGET")) : 256;
-  long long want = target / (pairs > 0 ? pairs : 1);
+  long long want = (long long)target * per_cu / (pairs > 0 ? pairs : 1);
   if (want < 1) want = 1;
   long long tpc = e2e::cdivll(total_tiles, want);
   if (tpc < 8) tpc = 8;
@@ -1426,6 +1433,14 @@ extern "C" int e2e_convT_dgrad(const float* dy, const float* w, const unsigned* 
   return e2e::check_launch("convT_dgrad_kernel");
 }
 
+// 32-voxel tiles of the bf16x3 weight gradient (two workgroups per CU; kd * kh = 4 only): measured SLOWER than one workgroup
+// per CU with 64-voxel tiles on every level but the 8^3 one (0.215 -> 0.27 ms at 64 -> 32 @64^3, profiles/r04_convt_wgrad_tiles.txt:
+// twice the barriers and slabs per matrix instruction); off unless E2E_CT_TPX32=1
+static bool convT_bf3_tpx32(int kd, int kh) {
+  static const int on = getenv("E2E_CT_TPX32") ? atoi(getenv("E2E_CT_TPX32")) : 0;
+  static const int use_bf3 = getenv("E2E_CT_BF3") ? atoi(getenv("E2E_CT_BF3")) : 1;
+  return on && use_bf3 && kd * kh == 4;
+}
 static bool convT_use_v2(int D, int H, int W, int kd, int kh, int kw) {
   return kw == 2 && (kd * kh == 2 || kd * kh == 4) && (W % 2) == 0 && ((long long)D * H * W) % 4 == 0;
 }
@@ -1436,7 +1451,9 @@ extern "C" long long e2e_convT_wgrad_ws_bytes(int B, int Cin, int Cout, int D, i
   int tpc;
   int pairs = e2e::cdiv(Cin, 32) * e2e::cdiv(Cout, 32);
   if (convT_use_v2(D, H, W, kd, kh, kw)) pairs = e2e::cdiv(Cin, 32 * convT_v2_ncb(Cin)) * e2e::cdiv(Cout, 32);
-  const int nchunks = wgrad_chunks(total_tiles, pairs, &tpc);
+  int nchunks = wgrad_chunks(total_tiles, pairs, &tpc);
+  if (convT_use_v2(D, H, W, kd, kh, kw) && convT_bf3_tpx32(kd, kh))
+    nchunks = wgrad_chunks(e2e::cdivll((long long)D * H * W, 32) * B, pairs, &tpc, 2);
   return (long long)nchunks * Cin * Cout * kd * kh * kw * (long long)sizeof(float);
 }
 
@@ -1456,16 +1473,18 @@ extern "C" int e2e_convT_wgrad(const float* x, const float* scale, const float* 
     const int ncb = convT_v2_ncb(Cin);
     const int cgroups = e2e::cdiv(Cin, 32 * ncb);
     const int pairs2 = cgroups * e2e::cdiv(Cout, 32);
-    const int nch = wgrad_chunks(total_tiles, pairs2, &tpc);
+    const bool tpx32 = convT_bf3_tpx32(kd, kh);
+    const int nch = tpx32 ? wgrad_chunks(e2e::cdivll((long long)D * H * W, 32) * B, pairs2, &tpc, 2) : wgrad_chunks(total_tiles, pairs2, &tpc);
     dim3 grid2(nch, pairs2);
     const int kdh = kd * kh;
     static const int use_bf3 = getenv("E2E_CT_BF3") ? atoi(getenv("E2E_CT_BF3")) : 1;
     if (use_bf3) {
-      e2e::note_kernel("convT_wgrad_bf3<%d,%d> chunks=%d pairs=%d", kdh, ncb, nch, pairs2);
-#define LAUNCH_B3(KDH, NCB) hipLaunchKernelGGL((convT_wgrad_bf3_kernel<KDH, NCB>), grid2, dim3(256 * NCB), 0, st, x, scale, shift, \
-                                               slope, dy, slab, B, Cin, Cout, D, H, W, kd, kh, tpc, cgroups)
-      if (kdh == 4) { if (ncb == 2) LAUNCH_B3(4, 2); else LAUNCH_B3(4, 1); }
-      else { if (ncb == 2) LAUNCH_B3(2, 2); else LAUNCH_B3(2, 1); }
+      e2e::note_kernel("convT_wgrad_bf3<%d,%d> chunks=%d pairs=%d%s", kdh, ncb, nch, pairs2, tpx32 ? " tpx=32" : "");
+#define LAUNCH_B3(KDH, NCB, TPX) hipLaunchKernelGGL((convT_wgrad_bf3_kernel<KDH, NCB, TPX>), grid2, dim3(256 * NCB), 0, st, x, scale, shift, \
+                                                    slope, dy, slab, B, Cin, Cout, D, H, W, kd, kh, tpc, cgroups)
+      if (kdh == 4 && tpx32) { if (ncb == 2) LAUNCH_B3(4, 2, 32); else LAUNCH_B3(4, 1, 32); }
+      else if (kdh == 4) { if (ncb == 2) LAUNCH_B3(4, 2, 64); else LAUNCH_B3(4, 1, 64); }
+      else { if (ncb == 2) LAUNCH_B3(2, 2, 64); else LAUNCH_B3(2, 1, 64); }
 #undef LAUNCH_B3
       hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)e2e::cdivll(numel_all, 64)), dim3(256), 0, st, slab, dw, numel_all, nch);
       return e2e::check_launch("convT_wgrad_bf3");
