@@ -1134,6 +1134,32 @@ inline bool use_bf3(int Cin, int Hi, int Wi, int sh, int sw) {
   return on && Cin > 4 && use_v3(Cin, Hi, Wi, sh, sw);
 }
 inline int bf3_pairs(int Cin, int Cout) { return e2e::cdiv(Cin, 32) * e2e::cdiv(Cout, 32); }
+// planes 16..31 voxels wide: the same kernel on 8 x 16-pixel tiles (conv133_wgrad_bf3v5_kernel<1>; round 4, they ran on the fp32
+// MFMA v2 kernel); E2E_WG_W16=0 or E2E_WG_BF3 < 5 keeps v2.  32-bit element offsets inside one batch item (as v5).
+inline bool use_bf3_w16(int Cin, int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw) {
+  static const int bf3 = getenv("E2E_WG_BF3") ? atoi(getenv("E2E_WG_BF3")) : 5;
+  static const int on = getenv("E2E_WG_W16") ? atoi(getenv("E2E_WG_W16")) : 1;
+  const long long Do = (Di - 1) / sd + 1;
+  return bf3 >= 5 && on && Cin > 4 && sh == 1 && sw == 1 && (Wi % 4) == 0 && Wi >= 16 && Wi < 32 && Hi >= 8 &&
+         (long long)Di * Hi * Wi < (1ll << 29) && (long long)Cout * Do * Hi * Wi < (1ll << 29);
+}
+inline int plan_w16(WgParams& p, int pairs) {
+  p.tiles_x = e2e::cdiv(p.Wo, 16);
+  p.tiles_y = e2e::cdiv(p.Ho, 8);
+  p.tiles_d = p.Do;
+  p.tiles_per_n = p.tiles_d * p.tiles_y * p.tiles_x;
+  p.total_tiles = (long long)p.tiles_per_n * p.B;
+  long long want = 256 / (pairs > 0 ? pairs : 1);            // one workgroup per CU
+  if (want < p.B) want = p.B;
+  int segs = (int)(want / p.B);
+  int tpc = e2e::cdiv(p.tiles_per_n, segs);
+  if (tpc < 4) tpc = 4;
+  if (tpc > p.tiles_per_n) tpc = p.tiles_per_n;
+  segs = e2e::cdiv(p.tiles_per_n, tpc);
+  p.tiles_per_chunk = tpc;
+  p.cblocks_segs = segs;
+  return segs * p.B;
+}
 
 // network input layer (Cin <= 4): stride 1, rows multiples of 4 floats, planes at least one 8 x 32 tile
 inline bool use_smallc(int Cin, int Hi, int Wi, int sh, int sw) {
@@ -1197,6 +1223,8 @@ extern "C" long long e2e_conv133_wgrad_ws_bytes(int B, int Cin, int Cout, int Di
     nchunks = plan_v3(p, bf3_pairs(Cin, Cout));
   } else if (use_v3(Cin, Hi, Wi, sh, sw)) {
     nchunks = plan_v3(p, v3_pairs(Cin, Cout)) * (v3_ksplit(Cin, Cout) ? 2 : 1);
+  } else if (use_bf3_w16(Cin, Cout, Di, Hi, Wi, sd, sh, sw)) {
+    nchunks = plan_w16(p, bf3_pairs(Cin, Cout));
   } else if (use_v2(Hi, Wi, sh, sw)) {
     const int pairs = e2e::cdiv(Cin, 32 * v2_ncb(Cin, p.Ho, p.Wo)) * e2e::cdiv(Cout, 32);
     plan(p, pick(p.Ho, p.Wo, false), pairs, &nchunks, 512);
@@ -1278,6 +1306,21 @@ extern "C" int e2e_conv133_wgrad(const e2e_in_chan_t* chans, const float* dy, fl
     } else if (wide) hipLaunchKernelGGL((conv133_wgrad_v3_kernel<1, 2, 1>), dim3(nchunks, pairs), dim3(512), 0, st, p);
     else hipLaunchKernelGGL((conv133_wgrad_v3_kernel<2, 1, 1>), dim3(nchunks, pairs), dim3(512), 0, st, p);
     rc = e2e::check_launch("conv133_wgrad_v3_kernel");
+    if (rc != E2E_OK) return rc;
+    hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)e2e::cdivll(numel, 64)), dim3(256), 0, st, p.slab, dw, numel,
+                       nchunks);
+    return e2e::check_launch("wgrad_slab_reduce_kernel");
+  }
+  if (use_bf3_w16(Cin, Cout, Di, Hi, Wi, sd, sh, sw)) {
+    const int pairs = bf3_pairs(Cin, Cout);
+    nchunks = plan_w16(p, pairs);
+    e2e::WgBf3Params q{};
+    q.chans = chans; q.dy = dy; q.slab = p.slab;
+    q.B = B; q.Cin = Cin; q.Cout = Cout; q.Di = Di; q.Hi = Hi; q.Wi = Wi; q.Do = p.Do; q.sd = sd;
+    q.tiles_x = p.tiles_x; q.tiles_y = p.tiles_y; q.tiles_per_n = p.tiles_per_n; q.tiles_per_chunk = p.tiles_per_chunk;
+    q.segs = p.cblocks_segs; q.cblocks = e2e::cdiv(Cin, 32); q.geom = 1;
+    e2e::note_kernel("conv133_wgrad_bf3w16 chunks=%d pairs=%d", nchunks, pairs);
+    rc = e2e::launch_wgrad_bf3(q, nchunks, pairs, st);
     if (rc != E2E_OK) return rc;
     hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)e2e::cdivll(numel, 64)), dim3(256), 0, st, p.slab, dw, numel,
                        nchunks);

@@ -682,7 +682,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #ifndef WG5_DIAG
 #define WG5_DIAG 0                 // timing-only builds: 1 no conversion / commit, 2 no global requests, 4 no fragment reads
 #endif
+// G = 0: 4 x 32-pixel tiles (planes at least 32 wide; the two K blocks of a wave are the halves of its tile row).
+// G = 1: 8 x 16-pixel tiles for planes 16..31 wide (verdict item 2: these ran on fp32 MFMA): the two K blocks of wave r are the tile
+//        rows 2r and 2r+1; dy rows of 48 B (pixels at entries 8..23, halos at 7 and 24 -- entry 24 shares the unused head of the
+//        next row), input rows of 32 B, the same 400 B channel stride: same images, same pipeline, 5 + 4 + 2 pieces per wave.
+template <int G>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv133_wgrad_bf3v5_kernel(e2e::WgBf3Params p) {
+  constexpr int GTH = G ? 8 : 4, GTW = G ? 16 : 32;         // tile
+  constexpr int NX = G ? 5 : 6, NH = G ? 2 : 1;             // input / halo pieces per wave (dy: 4)
+  constexpr int XIT = G ? 40 : 48, XQS = G ? 2 : 3;         // items (rows x quads) per input channel, log2 quads per row
+  constexpr int GXROWB = G ? 32 : 64, GYROWB = G ? 48 : 96; // bytes per staged input / dy row
+  static_assert((GTH + 2) * GXROWB + 16 <= CSTR2 && GTH * GYROWB + 16 <= CSTR2, "channel stride");
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF2];
   const int segs = p.segs;
   const int n = blockIdx.x / segs, seg = blockIdx.x - n * segs;
@@ -704,14 +714,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int obase = ob * 32, cbase = cg * 32;
     const int in_plane = p.Hi * p.Wi;                         // (host: Di * Hi * Wi < 2^29, Cout * Do * Hi * Wi < 2^29)
     // ---- staging share of this wave (as bf3v4_stage) ----
-    gfloat_p xbase[6];
-    float xa[6], xb[6], xsl[6];
-    int xdsh[6], xro[6], xgc[6], xoff[6], xdst[6];
+    gfloat_p xbase[NX];
+    float xa[NX], xb[NX], xsl[NX];
+    int xdsh[NX], xro[NX], xgc[NX], xoff[NX], xdst[NX];
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
+    for (int j = 0; j < NX; ++j) {
       const int item = j * 64 + lane;
-      const int chl = item / 48, rem = item - chl * 48;
-      const int x_r = rem >> 3, x_q = rem & 7;
+      const int chl = item / XIT, rem = item - chl * XIT;
+      const int x_r = rem >> XQS, x_q = rem & ((1 << XQS) - 1);
       const int c = cbase + sw * 8 + chl;
       const bool val = c < p.Cin;
       const e2e_in_chan_t* chd = p.chans + (val ? c : 0);
@@ -726,10 +736,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       xro[j] = x_r - 1;
       xgc[j] = 4 * x_q;
       xoff[j] = (x_r - 1) * p.Wi + 4 * x_q - (val ? chd->dshift : 0) * in_plane;
-      xdst[j] = (sw * 8 + chl) * CSTR2 + x_r * XROWB + x_q * 8;
+      xdst[j] = (sw * 8 + chl) * CSTR2 + x_r * GXROWB + x_q * 8;
     }
-    const int y_grp = lane & 31, y_r = y_grp >> 3, y_q = y_grp & 7;
-    const int h_ch = lane >> 3, h_r = (lane >> 1) & 3, h_side = lane & 1;
+    const int y_grp = lane & 31, y_r = y_grp >> XQS, y_q = y_grp & ((1 << XQS) - 1);
+    const int h_side = lane & 1, h_r = (lane >> 1) & (GTH - 1);   // halo round k: channel (lane / (2 GTH)) + (8 / NH) k
     const unsigned long long dya = (unsigned long long)(p.dy + (long long)n * p.Cout * p.Do * in_plane);
     const i32x4_t dyr = {__builtin_amdgcn_readfirstlane((int)dya), __builtin_amdgcn_readfirstlane((int)(dya >> 32) & 0xffff),
                          __builtin_amdgcn_readfirstlane(p.Cout * p.Do * in_plane * 4), 0x00020000};
@@ -741,10 +751,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const int o = obase + sw * 8 + 2 * j + (lane >> 5);
       yoff[j] = o < p.Cout ? ((o * p.Do) * in_plane + y_r * p.Wi + 4 * y_q) * 4 : (int)0x80000000;
     }
-    const int ho_ = obase + sw * 8 + h_ch;
-    const int hoff = ho_ < p.Cout ? ((ho_ * p.Do) * in_plane + h_r * p.Wi + (h_side ? TW + 1 : 0)) * 4 : (int)0x80000000;
-    const int ydst = y_r * YROWB + (8 + 4 * y_q) * 2;
-    const int hdst = (sw * 8 + h_ch) * CSTR2 + h_r * YROWB + (h_side ? 40 : 7) * 2;
+    int hoff[NH], hdst[NH];
+#pragma unroll
+    for (int k2 = 0; k2 < NH; ++k2) {
+      const int h_ch = lane / (2 * GTH) + (8 / NH) * k2;
+      const int ho_ = obase + sw * 8 + h_ch;
+      hoff[k2] = ho_ < p.Cout ? ((ho_ * p.Do) * in_plane + h_r * p.Wi + (h_side ? GTW + 1 : 0)) * 4 : (int)0x80000000;
+      hdst[k2] = (sw * 8 + h_ch) * CSTR2 + h_r * GYROWB + (h_side ? 8 + GTW : 7) * 2;
+    }
+    const int ydst = y_r * GYROWB + (8 + 4 * y_q) * 2;
 
     struct Pos { int tx, ty, d; };
     auto advance = [&](Pos& q, bool go) {
@@ -756,15 +771,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       q.ty = go ? (wy ? 0 : ty) : q.ty;
       q.d = go ? q.d + (wy ? 1 : 0) : q.d;
     };
-    f32x4_t vx[2][6], vy[2][4];
-    float vh[2] = {0.f, 0.f};
-    float ta[2][6], tb[2][6];
+    f32x4_t vx[2][NX], vy[2][4];
+    float vh[2][NH];
+    float ta[2][NX], tb[2][NX];
     auto request_x = [&](const int rs, const Pos& q) {
-      const int h0 = q.ty * TH, w0 = q.tx * TW;
+      const int h0 = q.ty * GTH, w0 = q.tx * GTW;
       const int dd = q.d * p.sd;
       const int S = dd * in_plane + h0 * p.Wi + w0;
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
+      for (int j = 0; j < NX; ++j) {
         const bool ok = (unsigned)(h0 + xro[j]) < (unsigned)p.Hi && xgc[j] < p.Wi - w0 && (unsigned)(dd - xdsh[j]) < (unsigned)p.Di;
         const unsigned off = ok ? (unsigned)(S + xoff[j]) : 0u;
         vx[rs][j] = *reinterpret_cast<gf4_p>(xbase[j] + off);
@@ -773,13 +788,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
     };
     auto request_y = [&](const int rs, const Pos& q) {
-      const int h0 = q.ty * TH, w0 = q.tx * TW;
+      const int h0 = q.ty * GTH, w0 = q.tx * GTW;
       const int sy = (q.d * in_plane + h0 * p.Wi + w0) * 4;
       const bool rowok = h0 + y_r < p.Hi && 4 * y_q < p.Wi - w0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) vy[rs][j] = llvm_raw_buffer_load_v4f32(dyr, rowok ? yoff[j] : (int)0x80000000, sy, 0);
-      const bool hok = h0 + h_r < p.Hi && (unsigned)(w0 + (h_side ? TW : -1)) < (unsigned)p.Wi;
-      vh[rs] = llvm_raw_buffer_load_f32(dyh, hok ? hoff : (int)0x80000000, sy, 0);
+      const bool hok = h0 + h_r < p.Hi && (unsigned)(w0 + (h_side ? GTW : -1)) < (unsigned)p.Wi;
+#pragma unroll
+      for (int k2 = 0; k2 < NH; ++k2) vh[rs][k2] = llvm_raw_buffer_load_f32(dyh, hok ? hoff[k2] : (int)0x80000000, sy, 0);
     };
     auto commit_x = [&](const int rs, const int j, unsigned char* img) {
       float v[4];
@@ -807,29 +823,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       *reinterpret_cast<u32x2_t*>(dst + SSTR2) = mid2;
       *reinterpret_cast<u32x2_t*>(dst + 2 * SSTR2) = lo2;
     };
-    auto commit_h = [&](const int rs, unsigned char* img) {
-      const float v = vh[rs];
+    auto commit_h = [&](const int rs, const int k2, unsigned char* img) {
+      const float v = vh[rs][k2];
       const unsigned u = __builtin_bit_cast(unsigned, v);
       const float r1 = v - __builtin_bit_cast(float, u & 0xffff0000u);
       const unsigned m = __builtin_bit_cast(unsigned, r1);
       const float r2 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
       const unsigned l = __builtin_bit_cast(unsigned, r2);
-      unsigned char* dst = img + XB2 + hdst;
+      unsigned char* dst = img + XB2 + hdst[k2];
       *reinterpret_cast<unsigned short*>(dst) = (unsigned short)(u >> 16);
       *reinterpret_cast<unsigned short*>(dst + SSTR2) = (unsigned short)(m >> 16);
       *reinterpret_cast<unsigned short*>(dst + 2 * SSTR2) = (unsigned short)(l >> 16);
     };
     // ---- matrix side (as bf3v4_mma) ----
     const int fr = lane & 31, fh8 = lane >> 5;
-    const int a_off = XB2 + fr * CSTR2 + wr * YROWB + (8 + 8 * fh8) * 2;
-    const int b_off = fr * CSTR2 + wr * XROWB + 8 * fh8 * 2;
+    // K block `half` of this wave: G = 0 the column half of tile row wr (+32 B), G = 1 tile row 2 wr + half (+ one row)
+    constexpr int AH = G ? GYROWB : 32, BH = 32;
+    const int a_off = XB2 + fr * CSTR2 + (G ? 2 : 1) * wr * GYROWB + (8 + 8 * fh8) * 2;
+    const int b_off = fr * CSTR2 + (G ? 2 : 1) * wr * GXROWB + 8 * fh8 * 2;
     u32x4_t r_an[3];
     unsigned r_prev[3], r_next[3];
     bf16x8 bq[2][3];
     auto read_a = [&](const unsigned char* img, int half) {
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
-        const unsigned char* ap = img + a_off + half * 32 + s * SSTR2;
+        const unsigned char* ap = img + a_off + half * AH + s * SSTR2;
         r_an[s] = *reinterpret_cast<const u32x4_t*>(ap);
         r_prev[s] = *reinterpret_cast<const unsigned*>(ap - 4);
         r_next[s] = *reinterpret_cast<const unsigned*>(ap + 16);
@@ -837,7 +855,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     auto read_b = [&](const unsigned char* img, int half, int kh, bf16x8 (&b)[3]) {
 #pragma unroll
-      for (int s = 0; s < 3; ++s) b[s] = *reinterpret_cast<const bf16x8*>(img + b_off + kh * XROWB + half * 32 + s * SSTR2);
+      for (int s = 0; s < 3; ++s) b[s] = *reinterpret_cast<const bf16x8*>(img + b_off + kh * GXROWB + half * BH + s * SSTR2);
     };
 
     // ---- prologue: tile 0 committed, tile 1 in the registers of set 1 ----
@@ -849,10 +867,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     request_x(0, far);
     request_y(0, far);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) commit_x(0, j, lds);
+    for (int j = 0; j < NX; ++j) commit_x(0, j, lds);
 #pragma unroll
     for (int j = 0; j < 4; ++j) commit_y(0, j, lds);
-    commit_h(0, lds);
+#pragma unroll
+    for (int k2 = 0; k2 < NH; ++k2) commit_h(0, k2, lds);
     advance(far, ntiles > 1);
     request_x(1, far);
     request_y(1, far);
@@ -907,9 +926,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             } else if (ph == 1) {
               commit_x(rs, 0, imgn); commit_x(rs, 1, imgn);
             } else if (ph == 2) {
-              commit_x(rs, 2, imgn); commit_x(rs, 3, imgn); commit_h(rs, imgn);
+              commit_x(rs, 2, imgn); commit_x(rs, 3, imgn); commit_h(rs, 0, imgn);
             } else if (ph == 3) {
-              commit_x(rs, 4, imgn); commit_x(rs, 5, imgn); commit_y(rs, 0, imgn);
+              commit_x(rs, 4, imgn);
+              if constexpr (G == 0) commit_x(rs, 5, imgn); else commit_h(rs, 1, imgn);
+              commit_y(rs, 0, imgn);
             } else {
               commit_y(rs, 1, imgn); commit_y(rs, 2, imgn); commit_y(rs, 3, imgn);
             }
@@ -983,8 +1004,12 @@ int launch_wgrad_bf3(const WgBf3Params& p, int nchunks, int pairs, hipStream_t s
   static const int variant = getenv("E2E_WG_BF3") ? atoi(getenv("E2E_WG_BF3")) : 5;       // 5: v5 (default), 4: v4, 2: v2 (A/B; 0 = the fp32-MFMA kernels, decided by the caller)
   // v4 addresses with 32-bit element offsets inside one batch item's channel block / dy block
   const bool fits32 = (long long)p.Di * p.Hi * p.Wi < (1ll << 29) && (long long)p.Cout * p.Do * p.Hi * p.Wi < (1ll << 29);
+  if (p.geom == 1) {                                         // 8 x 16 tiles (planes 16..31 wide): v5 only
+    hipLaunchKernelGGL(conv133_wgrad_bf3v5_kernel<1>, dim3(nchunks, pairs), dim3(256), 0, st, p);
+    return check_launch("conv133_wgrad_bf3v5_kernel<1>");
+  }
   if (variant >= 5 && fits32) {
-    hipLaunchKernelGGL(conv133_wgrad_bf3v5_kernel, dim3(nchunks, pairs), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(conv133_wgrad_bf3v5_kernel<0>, dim3(nchunks, pairs), dim3(256), 0, st, p);
     return check_launch("conv133_wgrad_bf3v5_kernel");
   }
   if (variant == 4 && fits32) {

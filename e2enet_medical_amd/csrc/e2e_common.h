@@ -120,6 +120,7 @@ struct WgBf3Params {
   int tiles_x, tiles_y, tiles_per_n, tiles_per_chunk;
   int segs;                    // chunks per batch item
   int cblocks;                 // ceil(Cin / 32)
+  int geom;                    // 0: 4 x 32-pixel tiles, 1: 8 x 16-pixel tiles (planes 16..31 wide; v5 kernel only)
 };
 int launch_wgrad_bf3(const WgBf3Params& p, int nchunks, int pairs, hipStream_t st);
 

@@ -79,6 +79,10 @@ CONV_CASES = [
     (1, [(20, True), (13, False)], 34, (4, 20, 36), (1, 1, 1), 0.25),          # ragged tiles, 33 input planes (5 chunks), two output groups (32 + 2)
     (2, [(64, True), (64, False), (32, False)], 64, (3, 24, 40), (1, 1, 1), 0.2),   # 160 -> 64: 20 chunks, two full groups
     (1, [(9, False)], 40, (2, 17, 20), (1, 1, 1), 0.4),                        # two chunks, the second nearly empty; 17-row planes
+    # planes 16..31 voxels wide: weight gradient on 8 x 16-pixel tiles of the bf16x3 kernel (conv133_wgrad_bf3v5_kernel<1>)
+    (2, [(20, True), (13, False)], 34, (3, 9, 20), (1, 1, 1), 1.0),          # ragged tile rows and columns, 33 + 34 channels, depth shifts
+    (1, [(40, True)], 33, (2, 16, 16), (1, 1, 1), 0.3),                      # whole tiles, two channel blocks each side
+    (1, [(33, True)], 34, (3, 24, 28), (1, 1, 1), 1.0),                      # 28-wide planes: second tile column ragged
     # dense matrix-core path (conv133_dense.hip: stride 1, W % 32 == 0, H % 16 == 0, >= 16 channels, dense or density >= 0.5)
     (1, [(32, True)], 32, (6, 32, 64), (1, 1, 1), 1.0),
     (2, [(20, True), (28, False)], 40, (3, 32, 32), (1, 1, 1), 1.0),         # ragged channel blocks (48 -> 40), two sources, shift
