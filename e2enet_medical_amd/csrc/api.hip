@@ -21,4 +21,4 @@ void note_kernel(const char* fmt, ...) {
 
 extern "C" const char* e2e_last_error(void) { return e2e::g_err; }
 extern "C" const char* e2e_last_kernel(void) { return e2e::g_kernel; }
-extern "C" int e2e_abi_version(void) { return 13; }
+extern "C" int e2e_abi_version(void) { return 14; }

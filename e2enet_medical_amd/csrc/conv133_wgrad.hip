@@ -1127,20 +1127,24 @@ inline int plan_v3(WgParams& p, int pairs) {
   return segs * p.B;
 }
 
-// bf3 (conv133_wgrad_bf3.hip: bf16 matrix pipe, fp32-exact three-piece operands): the shapes v3 serves; E2E_WG_BF3=0 keeps
-// the fp32-MFMA kernels, 1 selects the first bf3 form (A/B runs).  32 x 32 channel blocks, chunks planned like v3's.
-inline bool use_bf3(int Cin, int Hi, int Wi, int sh, int sw) {
+// conv133_wgrad_bf3.hip (bf16 / fp16 matrix pipe, fp32-exact split operands): the shapes v3 serves; E2E_WG_BF3=0 keeps the
+// fp32-MFMA kernels (forced-path tests, A/B runs).  32 x 32 channel blocks, chunks planned like v3's.
+inline bool use_bf3(int Cin, int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw) {
   static const int on = getenv("E2E_WG_BF3") ? atoi(getenv("E2E_WG_BF3")) : 1;
-  return on && Cin > 4 && use_v3(Cin, Hi, Wi, sh, sw);
+  const long long Do = (Di - 1) / sd + 1;                    // the kernel addresses with 32-bit element offsets inside one batch item
+  const bool fits32 = (long long)Di * Hi * Wi < (1ll << 29) && (long long)Cout * Do * Hi * Wi < (1ll << 29);
+  return on && Cin > 4 && fits32 && use_v3(Cin, Hi, Wi, sh, sw);
 }
+// fp16 two-piece operands (round 5) where the caller hands over max |dy|; E2E_WG_H2=0 keeps the bf16 three-piece form (A/B runs)
+inline int wg_h2_env() { static const int v = getenv("E2E_WG_H2") ? atoi(getenv("E2E_WG_H2")) : 1; return v; }
 inline int bf3_pairs(int Cin, int Cout) { return e2e::cdiv(Cin, 32) * e2e::cdiv(Cout, 32); }
 // planes 16..31 voxels wide: the same kernel on 8 x 16-pixel tiles (conv133_wgrad_bf3v5_kernel<1>; round 4, they ran on the fp32
 // MFMA v2 kernel); E2E_WG_W16=0 or E2E_WG_BF3 < 5 keeps v2.  32-bit element offsets inside one batch item (as v5).
 inline bool use_bf3_w16(int Cin, int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw) {
-  static const int bf3 = getenv("E2E_WG_BF3") ? atoi(getenv("E2E_WG_BF3")) : 5;
+  static const int bf3 = getenv("E2E_WG_BF3") ? atoi(getenv("E2E_WG_BF3")) : 1;
   static const int on = getenv("E2E_WG_W16") ? atoi(getenv("E2E_WG_W16")) : 1;
   const long long Do = (Di - 1) / sd + 1;
-  return bf3 >= 5 && on && Cin > 4 && sh == 1 && sw == 1 && (Wi % 4) == 0 && Wi >= 16 && Wi < 32 && Hi >= 8 &&
+  return bf3 && on && Cin > 4 && sh == 1 && sw == 1 && (Wi % 4) == 0 && Wi >= 16 && Wi < 32 && Hi >= 8 &&
          (long long)Di * Hi * Wi < (1ll << 29) && (long long)Cout * Do * Hi * Wi < (1ll << 29);
 }
 inline int plan_w16(WgParams& p, int pairs) {
@@ -1219,7 +1223,7 @@ extern "C" long long e2e_conv133_wgrad_ws_bytes(int B, int Cin, int Cout, int Di
     nchunks = s2_chunks(p.total_tiles, pairs, &p.tiles_per_chunk);
   } else if (use_smallc(Cin, Hi, Wi, sh, sw)) {
     nchunks = 2 * plan_smallc(p, e2e::cdiv(Cout, 32));
-  } else if (use_bf3(Cin, Hi, Wi, sh, sw)) {
+  } else if (use_bf3(Cin, Cout, Di, Hi, Wi, sd, sh, sw)) {
     nchunks = plan_v3(p, bf3_pairs(Cin, Cout));
   } else if (use_v3(Cin, Hi, Wi, sh, sw)) {
     nchunks = plan_v3(p, v3_pairs(Cin, Cout)) * (v3_ksplit(Cin, Cout) ? 2 : 1);
@@ -1236,7 +1240,7 @@ extern "C" long long e2e_conv133_wgrad_ws_bytes(int B, int Cin, int Cout, int Di
 }
 
 extern "C" int e2e_conv133_wgrad(const e2e_in_chan_t* chans, const float* dy, float* dw, void* ws, int B, int Cin,
-                                 int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw, void* stream) {
+                                 int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw, const unsigned* dy_absmax, void* stream) {
   E2E_REQUIRE(chans && dy && dw && ws, "conv133_wgrad: null pointer");
   E2E_REQUIRE((sd == 1 || sd == 2) && (sh == 1 || sh == 2) && (sw == 1 || sw == 2), "conv133_wgrad: stride must be 1 or 2");
   hipStream_t st = (hipStream_t)stream;
@@ -1278,7 +1282,7 @@ extern "C" int e2e_conv133_wgrad(const e2e_in_chan_t* chans, const float* dy, fl
                        nchunks);
     return e2e::check_launch("wgrad_slab_reduce_kernel");
   }
-  if (use_bf3(Cin, Hi, Wi, sh, sw)) {
+  if (use_bf3(Cin, Cout, Di, Hi, Wi, sd, sh, sw)) {
     const int pairs = bf3_pairs(Cin, Cout);
     nchunks = plan_v3(p, pairs);
     e2e::WgBf3Params q{};
@@ -1286,7 +1290,8 @@ extern "C" int e2e_conv133_wgrad(const e2e_in_chan_t* chans, const float* dy, fl
     q.B = B; q.Cin = Cin; q.Cout = Cout; q.Di = Di; q.Hi = Hi; q.Wi = Wi; q.Do = p.Do; q.sd = sd;
     q.tiles_x = p.tiles_x; q.tiles_y = p.tiles_y; q.tiles_per_n = p.tiles_per_n; q.tiles_per_chunk = p.tiles_per_chunk;
     q.segs = p.cblocks_segs; q.cblocks = e2e::cdiv(Cin, 32);
-    e2e::note_kernel("conv133_wgrad_bf3 chunks=%d pairs=%d", nchunks, pairs);
+    q.h2 = wg_h2_env() && dy_absmax != nullptr; q.dy_absmax = dy_absmax;
+    e2e::note_kernel("conv133_wgrad_%s chunks=%d pairs=%d", q.h2 ? "h2" : "bf3", nchunks, pairs);
     rc = e2e::launch_wgrad_bf3(q, nchunks, pairs, st);
     if (rc != E2E_OK) return rc;
     hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)e2e::cdivll(numel, 64)), dim3(256), 0, st, p.slab, dw, numel,
@@ -1319,7 +1324,8 @@ extern "C" int e2e_conv133_wgrad(const e2e_in_chan_t* chans, const float* dy, fl
     q.B = B; q.Cin = Cin; q.Cout = Cout; q.Di = Di; q.Hi = Hi; q.Wi = Wi; q.Do = p.Do; q.sd = sd;
     q.tiles_x = p.tiles_x; q.tiles_y = p.tiles_y; q.tiles_per_n = p.tiles_per_n; q.tiles_per_chunk = p.tiles_per_chunk;
     q.segs = p.cblocks_segs; q.cblocks = e2e::cdiv(Cin, 32); q.geom = 1;
-    e2e::note_kernel("conv133_wgrad_bf3w16 chunks=%d pairs=%d", nchunks, pairs);
+    q.h2 = wg_h2_env() && dy_absmax != nullptr; q.dy_absmax = dy_absmax;
+    e2e::note_kernel("conv133_wgrad_%sw16 chunks=%d pairs=%d", q.h2 ? "h2" : "bf3", nchunks, pairs);
     rc = e2e::launch_wgrad_bf3(q, nchunks, pairs, st);
     if (rc != E2E_OK) return rc;
     hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3((unsigned)e2e::cdivll(numel, 64)), dim3(256), 0, st, p.slab, dw, numel,

@@ -121,6 +121,8 @@ struct WgBf3Params {
   int segs;                    // chunks per batch item
   int cblocks;                 // ceil(Cin / 32)
   int geom;                    // 0: 4 x 32-pixel tiles, 1: 8 x 16-pixel tiles (planes 16..31 wide; v5 kernel only)
+  int h2;                      // 1: fp16 two-piece operands, three products (v5 kernel only); 0: bf16 three-piece, six products
+  const unsigned* dy_absmax;   // h2: bit pattern of max |dy| over the tensor (device; nullptr: dy is taken unscaled)
 };
 int launch_wgrad_bf3(const WgBf3Params& p, int nchunks, int pairs, hipStream_t st);
 

@@ -68,9 +68,11 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float slope,
-                                                            double* __restrict__ sums, int C, long long spatial) {
+                                                            double* __restrict__ sums, int C, long long spatial,
+                                                            unsigned* __restrict__ absmax) {
   const int nc = blockIdx.y;
   const int c = nc % C;
+  if (absmax != nullptr && blockIdx.x == 0 && nc == 0 && threadIdx.x == 0) *absmax = 0u;   // the apply pass (next launch) records max |dy|
   const float mu = mean[nc], rs = rstd[nc], g = gamma[c], b = beta[c];
   const float* dzp = dz + (long long)nc * spatial;
   const float* yp = y + (long long)nc * spatial;
@@ -119,13 +121,16 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const float* __restr
   }
 }
 
-// pass 2: dy = gamma * rstd * (du - s1/N - xhat * s2/N), in place; s3 = sum dy (bias gradient)
+// pass 2: dy = gamma * rstd * (du - s1/N - xhat * s2/N), in place; s3 = sum dy (bias gradient); absmax (optional): the bit
+// pattern of max |dy| over the whole tensor (atomicMax on the unsigned pattern of a non-negative float: order-independent, so
+// deterministic), from which the fp16 two-piece weight gradient takes its power-of-two scale (conv133_wgrad_bf3.hip)
 __global__ __launch_bounds__(256) void in_bwd_apply_kernel(float* __restrict__ dz, const float* __restrict__ y,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float slope,
-                                                           double* __restrict__ sums, int C, long long spatial) {
+                                                           double* __restrict__ sums, int C, long long spatial,
+                                                           unsigned* __restrict__ absmax) {
   const int nc = blockIdx.y;
   const int c = nc % C;
   const float mu = mean[nc], rs = rstd[nc], g = gamma[c], b = beta[c];
@@ -136,6 +141,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(float* __restrict__ d
   float* dzp = dz + (long long)nc * spatial;
   const float* yp = y + (long long)nc * spatial;
   double acc = 0.0;
+  float amax = 0.f;
   const long long stride = (long long)gridDim.x * 256 * 4;
   const bool vec = (spatial % 4) == 0;
   for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < spatial; i += stride) {
@@ -160,7 +166,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(float* __restrict__ d
       const float u = fmaf(g, xh, b);
       const float du = u > 0.f ? dv[k] : dv[k] * slope;
       o[k] = grs * (du - m1 - xh * m2);
-      if (vec || i + k < spatial) part += o[k];
+      if (vec || i + k < spatial) { part += o[k]; amax = fmaxf(amax, fabsf(o[k])); }
     }
     acc += part;
     if (vec) {
@@ -172,16 +178,24 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(float* __restrict__ d
     }
   }
   acc = e2e::wave_sum_d(acc);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
   __shared__ double sh[4];
+  __shared__ float shm[4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane == 0) sh[wave] = acc;
+  if (lane == 0) { sh[wave] = acc; shm[wave] = amax; }
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(&sums[(long long)nc * 3 + 2], sh[0] + sh[1] + sh[2] + sh[3]);
+  if (threadIdx.x == 0) {
+    atomicAdd(&sums[(long long)nc * 3 + 2], sh[0] + sh[1] + sh[2] + sh[3]);
+    if (absmax != nullptr) atomicMax(absmax, __builtin_bit_cast(unsigned, fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3]))));
+  }
 }
 
 // first pass done by the last writers of dz (conv133_sparse.hip): add their tile records up, one wave per (n, c), fixed order
-__global__ __launch_bounds__(64) void in_bwd_tile_sums_kernel(const double* __restrict__ part, double* __restrict__ sums, int np) {
+__global__ __launch_bounds__(64) void in_bwd_tile_sums_kernel(const double* __restrict__ part, double* __restrict__ sums, int np,
+                                                              unsigned* __restrict__ absmax) {
   const int nc = blockIdx.x;
+  if (absmax != nullptr && nc == 0 && threadIdx.x == 0) *absmax = 0u;
   const double* p = part + (long long)nc * np * 2;
   double a = 0.0, b = 0.0;
   for (int i = threadIdx.x; i < np; i += 64) { a += p[2 * i]; b += p[2 * i + 1]; }
@@ -221,7 +235,7 @@ extern "C" int e2e_in_stats_finalize(const double* part, int np, const float* ga
 extern "C" int e2e_in_lrelu_bwd(float* dz_dy, const float* y, const float* mean, const float* rstd,
                                 const float* gamma, const float* beta, float slope, float* dgamma, float* dbeta,
                                 float* dbias, float* sums, int B, int C, long long spatial, const double* tile_sums, int np,
-                                void* stream) {
+                                unsigned* dy_absmax, void* stream) {
   E2E_REQUIRE(dz_dy && y && mean && rstd && gamma && beta && dgamma && dbeta && sums, "in_lrelu_bwd: null pointer");
   E2E_REQUIRE(B > 0 && C > 0 && spatial > 0, "in_lrelu_bwd: bad dims");
   hipStream_t st = (hipStream_t)stream;
@@ -233,13 +247,13 @@ extern "C" int e2e_in_lrelu_bwd(float* dz_dy, const float* y, const float* mean,
   if (tile_sums == nullptr) {
     e2e::zero_async(ds, (size_t)B * C * 3 * sizeof(double), st);
     hipLaunchKernelGGL(in_bwd_reduce_kernel, grid, dim3(256), 0, st, dz_dy, y, mean, rstd, gamma, beta, slope, ds, C,
-                       spatial);
+                       spatial, dy_absmax);
   } else {
     E2E_REQUIRE(np > 0, "in_lrelu_bwd: tile_sums without a record count");
-    hipLaunchKernelGGL(in_bwd_tile_sums_kernel, dim3(B * C), dim3(64), 0, st, tile_sums, ds, np);
+    hipLaunchKernelGGL(in_bwd_tile_sums_kernel, dim3(B * C), dim3(64), 0, st, tile_sums, ds, np, dy_absmax);
   }
   hipLaunchKernelGGL(in_bwd_apply_kernel, grid, dim3(256), 0, st, dz_dy, y, mean, rstd, gamma, beta, slope, ds, C,
-                     spatial);
+                     spatial, dy_absmax);
   hipLaunchKernelGGL(in_bwd_params_kernel, dim3(e2e::cdiv(C, 64)), dim3(64), 0, st, ds, dgamma, dbeta, dbias, B, C);
   return e2e::check_launch("in_lrelu_bwd");
 }

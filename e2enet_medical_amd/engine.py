@@ -181,6 +181,7 @@ class ConvOp:
         self.out_dims = ((di - 1) // sd + 1, (hi - 1) // sh + 1, (wi - 1) // sw + 1)
         self.out = Act(prefix, (b, cout) + self.out_dims, True, eng.device)
         self.out.producer = self
+        self.dy_absmax = torch.zeros(1, dtype=torch.int32, device=eng.device)   # bit pattern of max |dy| (e2e_in_lrelu_bwd -> e2e_conv133_wgrad)
         self.own_sums = None    # [B, Cout, own_np, 2] fp64 records of the InstanceNorm-backward sums, written by the last writer of out.grad
         self.own_np = 0
         self.np = lib().conv133_num_partials(*self.out_dims, sh, sw)
@@ -339,7 +340,8 @@ class ConvOp:
                        p[self.prefix + ".instnorm.weight"].data_ptr(), p[self.prefix + ".instnorm.bias"].data_ptr(),
                        LRELU_SLOPE, g[self.prefix + ".instnorm.weight"].data_ptr(),
                        g[self.prefix + ".instnorm.bias"].data_ptr(), g[self.prefix + ".conv.bias"].data_ptr(),
-                       e.in_sums.data_ptr(), b, self.cout, o.spatial, self.own_sums.data_ptr() if ready else None, self.own_np, _stream())
+                       e.in_sums.data_ptr(), b, self.cout, o.spatial, self.own_sums.data_ptr() if ready else None, self.own_np,
+                       self.dy_absmax.data_ptr(), _stream())
         late = WGRAD_LATE and getattr(e, "_wg_active", None) is not None and o.data.numel() > WGRAD_STREAM_MAX_ELEMS
         if not late:
             self._wgrad(e, L, g, o, b, di, hi, wi, sd, sh, sw, o.data.numel())
@@ -370,7 +372,7 @@ class ConvOp:
     def _wgrad(self, e, L, g, o, b, di, hi, wi, sd, sh, sw, elems):
         with _wgrad_stream(e, elems) as ws:
             L.conv133_wgrad(self.chans.data_ptr(), o.grad.data_ptr(), g[self.w_name].data_ptr(), ws.data_ptr(),
-                            b, self.cin, self.cout, di, hi, wi, sd, sh, sw, _stream())
+                            b, self.cin, self.cout, di, hi, wi, sd, sh, sw, self.dy_absmax.data_ptr(), _stream())
 
     def wgrad_ws_bytes(self):
         di, hi, wi = self.in_dims

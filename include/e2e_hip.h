@@ -175,8 +175,18 @@ int e2e_conv133_dgrad_sparse(const float* dy, const float* wpk_t, const unsigned
  *   ws   workspace of e2e_conv133_wgrad_ws_bytes(...) bytes
  */
 long long e2e_conv133_wgrad_ws_bytes(int B, int Cin, int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw);
+/*   dy_absmax  NULL, or the device word e2e_in_lrelu_bwd(dy_absmax) left behind for this dy (bit pattern of max |dy|).  With it,
+ *              the shapes served by the matrix-pipe kernel run on fp16 two-piece operands (three products per fp32 product, dy
+ *              pre-scaled by the power of two that puts its maximum in [2^14, 2^15)); without it on bf16 three-piece operands
+ *              (six products, no range assumption).  Both are fp32-exact to the last two bits of an operand. */
 int e2e_conv133_wgrad(const e2e_in_chan_t* chans, const float* dy, float* dw, void* ws, int B, int Cin,
-                      int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw, void* stream);
+                      int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw, const unsigned* dy_absmax, void* stream);
+
+/* Diagnostic (the numerics gate of the split-operand matrix paths, tests/test_gpu_ops.py): D[32][32] = A[32][K] Bt[32][K]^T through the
+ * split functions and product orders of the matrix-pipe kernels.  mode 0: bf16 three-piece operands, six products; 1: fp16 two-piece
+ * operands, three products, Bt pre-scaled by the power of two derived from *absmax_b (NULL: unscaled) exactly as dy is in
+ * e2e_conv133_wgrad; 2: fp32-input MFMA (an fp32 FMA chain).  K % 16 == 0.  No reference counterpart (torch computes in fp32). */
+int e2e_diag_split_gemm(const float* A, const float* Bt, float* D, int K, int mode, const unsigned* absmax_b, void* stream);
 
 /* ---- K2: InstanceNorm statistics finalize --------------------------------------------
  * Replaces: nn.InstanceNorm3d(eps, affine, instance statistics) (unetpp_d.py:99,111):
@@ -192,10 +202,11 @@ int e2e_in_stats_finalize(const double* part, int np, const float* gamma, const 
  *   sums  workspace of B*C*3 doubles (s1 = sum du, s2 = sum du*xhat, s3 = sum dy)
  *   tile_sums  NULL: the first pass (s1, s2) runs here.  Otherwise the per-tile records [B][C][np][2] that the last writers of
  *              dz have produced (e2e_in_sum_chan_t): they are added up in a fixed order and only the apply pass runs
+ *   dy_absmax  NULL, or one device word that receives the bit pattern of max |dy| over the tensor (consumed by e2e_conv133_wgrad)
  */
 int e2e_in_lrelu_bwd(float* dz_dy, const float* y, const float* mean, const float* rstd, const float* gamma,
                      const float* beta, float slope, float* dgamma, float* dbeta, float* dbias, float* sums,
-                     int B, int C, long long spatial, const double* tile_sums, int np, void* stream);
+                     int B, int C, long long spatial, const double* tile_sums, int np, unsigned* dy_absmax, void* stream);
 
 /* ---- K3: transposed convolution, kernel == stride in {1,2}^3, no bias ------------------
  * Replaces: nn.ConvTranspose3d(Cin,Cout,k,k,bias=False) (unetpp_d.py:521-522).

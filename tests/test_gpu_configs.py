@@ -283,11 +283,11 @@ def test_config5_amos_density_whole_net(dens):
 FULL_CONV = [
     # (case of test_gpu_ops.test_conv133_fwd_bwd, expected kernel substrings: fwd, wgrad, dgrad)
     ("loc L0 64->32 @128^3 B=2 d=0.2", (2, [(32, True), (32, False)], 32, (128, 128, 128), (1, 1, 1), 0.2),
-     "conv133_sparse_kernel<mode=0>", "conv133_wgrad_bf3 chunks=128 pairs=2", "conv133_sparse_kernel<mode=1>"),
+     "conv133_sparse_kernel<mode=0>", "conv133_wgrad_h2 chunks=128 pairs=2", "conv133_sparse_kernel<mode=1>"),
     ("c0.b1 32->32 @128^3 dense", (2, [(32, True)], 32, (128, 128, 128), (1, 1, 1), 1.0),
-     "conv133_dense_bf3<mode=0>", "conv133_wgrad_bf3", "conv133_dense_bf3<mode=1>"),
+     "conv133_dense_bf3<mode=0>", "conv133_wgrad_h2", "conv133_dense_bf3<mode=1>"),
     ("loc L1 160->64 @64^3 d=0.2", (2, [(64, True), (64, False), (32, False)], 64, (64, 64, 64), (1, 1, 1), 0.2),
-     "conv133_sparse_kernel<mode=0>", "conv133_wgrad_bf3", "conv133_sparse_kernel<mode=1>"),
+     "conv133_sparse_kernel<mode=0>", "conv133_wgrad_h2", "conv133_sparse_kernel<mode=1>"),
     ("c1.b0 32->64 s2 @128^3", (1, [(32, True)], 64, (128, 128, 128), (2, 2, 2), 1.0),
      "s=2x2", "conv133_wgrad_s2", "mode=2"),
 ]

@@ -503,77 +503,127 @@ def test_conv133_persistent_run_loop_forced():
     assert "passed" in r.stdout
 
 
-@pytest.mark.parametrize("variant", ["0", "2", "4"])
-def test_conv133_wgrad_alternative_paths_forced(variant):
-    """The dense weight gradient of large stride-1 planes runs on the bf16 matrix pipe with three-piece fp32 operands
-    (conv133_wgrad_bf3v5_kernel: 32x32x16 MFMA, one wave per SIMD, the staging dealt into the matrix-instruction gaps).
-    E2E_WG_BF3=4 selects the matrix-wave / staging-wave form, 2 the twelve-wave form (all three bit-identical), 0 the fp32-MFMA
-    kernels (v3); they stay in the library for A/B runs.  The knob is read once per process: run the operator cases again in a child process."""
+@pytest.mark.parametrize("env", [{"E2E_WG_H2": "0"}, {"E2E_WG_BF3": "0"}])
+def test_conv133_wgrad_alternative_paths_forced(env):
+    """The dense weight gradient of stride-1 planes at least 16 voxels wide runs on the matrix pipe with split fp32 operands
+    (conv133_wgrad_bf3v5_kernel<G, NPC>): by default on fp16 two-piece operands (three products), scaled from the max |dy| that
+    e2e_in_lrelu_bwd records.  E2E_WG_H2=0 keeps the bf16 three-piece form (six products; also what a caller without the recorded
+    maximum gets), E2E_WG_BF3=0 the fp32-MFMA kernels.  The knobs are read once per process: run the operator cases again in a
+    child process."""
     import subprocess
     import sys
-    env = dict(os.environ, E2E_WG_BF3=variant)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
                         "test_conv133_fwd_bwd", "-p", "no:cacheprovider"],
-                       env=env, capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=900,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "passed" in r.stdout
 
 
-_WG_CHILD = r"""
-import sys, torch
-sys.path.insert(0, %(root)r)
-sys.path.insert(0, %(root)r + "/tools")
-import kbench
-from e2enet_medical_amd._lib import lib
-from e2enet_medical_amd.engine import Act, ConvOp
-torch.manual_seed(0)
-out = {}
-for tag, (B, srcs, cout, dims) in {"ragged": (2, [(33, True), (20, False)], 40, (3, 20, 36)), "whole": (1, [(32, True), (32, False)], 32, (9, 32, 64)),
-                                   "one_tile_runs": (1, [(16, False)], 16, (1, 20, 32))}.items():
-    dev = torch.device("cuda")
-    acts = []
-    for i, (c, normed) in enumerate(srcs):
-        a = Act("s%%d" %% i, (B, c) + dims, normed, dev)
-        a.data.normal_()
-        if normed:
-            a.scale.uniform_(0.5, 1.5); a.shift.normal_()
-        acts.append(a)
-    cin = sum(c for c, _ in srcs)
-    e = kbench.Stub(); e.device = dev
-    e.params = {"b.conv.weight": torch.randn(cout, cin, 1, 3, 3, device=dev), "b.conv.bias": torch.zeros(cout, device=dev),
-                "b.instnorm.weight": torch.ones(cout, device=dev), "b.instnorm.bias": torch.zeros(cout, device=dev)}
-    e.grads = {k: torch.zeros_like(v) for k, v in e.params.items()}
-    op = ConvOp(e, "b", acts, cout, (1, 1, 1))
-    e.wgrad_ws = torch.empty(max(op.wgrad_ws_bytes() // 4, 1), dtype=torch.float32, device=dev)
-    op.out.alloc_grad(); op.plan_backward(); op.out.grad.normal_()
-    lib().conv133_wgrad(op.chans.data_ptr(), op.out.grad.data_ptr(), e.grads["b.conv.weight"].data_ptr(), e.wgrad_ws.data_ptr(), B, cin, cout, *dims, 1, 1, 1, 0)
-    torch.cuda.synchronize()
-    assert (lib().last_kernel() or b"").startswith(b"conv133_wgrad_bf3"), lib().last_kernel()
-    out[tag] = e.grads["b.conv.weight"].cpu()
-torch.save(out, sys.argv[1])
-"""
+def _absmax_word(t):
+    """the device word e2e_in_lrelu_bwd leaves behind: bit pattern of max |t|"""
+    return t.abs().max().reshape(1).contiguous().view(torch.int32)
 
 
-def test_conv133_wgrad_bf3_variants_are_bit_identical(tmp_path):
-    """The three forms of the bf16x3 weight gradient (E2E_WG_BF3 = 5: one wave per SIMD, the default; 4: matrix waves + staging
-    waves; 2: twelve waves) use the same split, the same order per accumulator and the same reduction tree: their results must be
-    EQUAL, bit for bit (ragged channel blocks and tiles, depth shifts, a run of a single tile).  The knob is read once per
-    process: one child per variant."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = {}
-    for v in ("5", "4", "2"):
-        f = str(tmp_path / ("wg_%s.pt" % v))
-        r = subprocess.run([sys.executable, "-c", _WG_CHILD % {"root": root}, f], env=dict(os.environ, E2E_WG_BF3=v),
-                           capture_output=True, text=True, timeout=600, cwd=root)
-        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-        res[v] = torch.load(f)
-    for tag in res["5"]:
-        assert float(res["5"][tag].abs().max()) > 0
-        assert torch.equal(res["5"][tag], res["2"][tag]), "v5 vs v2: %s" % tag
-        assert torch.equal(res["4"][tag], res["2"][tag]), "v4 vs v2: %s" % tag
+def _heavy_tailed(shape, seed, scale):
+    g = torch.Generator().manual_seed(seed)
+    return scale * torch.randn(shape, generator=g) * torch.exp(2.5 * torch.randn(shape, generator=g))
+
+
+@pytest.mark.parametrize("tag,B,src_desc,cout,dims", [
+    ("ragged", 2, [(33, True), (20, False)], 40, (3, 20, 36)),       # ragged channel blocks and tiles, depth shifts
+    ("whole", 1, [(32, True), (32, False)], 32, (9, 32, 64)),
+    ("one_tile_runs", 1, [(16, False)], 16, (1, 20, 32)),
+    ("w16", 1, [(40, True)], 33, (4, 24, 16)),                        # 8 x 16-pixel tiles
+])
+def test_conv133_wgrad_h2_and_bf3_vs_fp64(tag, B, src_desc, cout, dims):
+    """Both operand formats of the matrix-pipe weight gradient against an fp64 evaluation, on a dy of realistic magnitudes
+    (heavy-tailed, 1e-7: below the fp16 range unscaled).  fp16 two-piece (three products, scaled from max |dy|) and bf16
+    three-piece (six products) must both be within 3e-7 of sum |dy x| per entry (measured 0.4-0.8e-7 rms) and the fp16 form no
+    further than 1.5x the bf16 form's rms; and because the scale is an exact power of two taken from the data, the fp16 result of
+    2^-20 dy is 2^-20 times the result of dy, bit for bit."""
+    from e2enet_medical_amd.engine import ConvOp
+    from e2enet_medical_amd._lib import lib
+    srcs = [_make_act((B, c) + dims, normed, 70 + i) for i, (c, normed) in enumerate(src_desc)]
+    cin = sum(c for c, _ in src_desc)
+    params = {"blk.conv.weight": torch.zeros(cout, cin, 1, 3, 3), "blk.conv.bias": torch.zeros(cout),
+              "blk.instnorm.weight": torch.ones(cout), "blk.instnorm.bias": torch.zeros(cout)}
+    e = _eng_stub(params)
+    op = ConvOp(e, "blk", srcs, cout, (1, 1, 1))
+    dy = _heavy_tailed((B, cout) + dims, 7, 1e-7)
+    x = oracle.depth_shift(torch.cat([_act_value(a) for a in srcs], 1)).double()
+    xp = F.pad(x, (1, 1, 1, 1))
+    H, W = dims[1:]
+    ref = torch.zeros(cout, cin, 1, 3, 3, dtype=torch.float64)
+    mag = torch.zeros_like(ref)
+    for kh in range(3):
+        for kw in range(3):
+            win = xp[..., kh:kh + H, kw:kw + W]
+            ref[:, :, 0, kh, kw] = torch.einsum("nodhw,ncdhw->oc", dy.double(), win)
+            mag[:, :, 0, kh, kw] = torch.einsum("nodhw,ncdhw->oc", dy.double().abs(), win.abs())
+    L = lib()
+
+    def run(dyt, with_max):
+        dyd = dyt.cuda()
+        word = _absmax_word(dyd) if with_max else None
+        dw = torch.full((cout, cin, 1, 3, 3), float("nan"), device="cuda")
+        L.conv133_wgrad(op.chans.data_ptr(), dyd.data_ptr(), dw.data_ptr(), e.wgrad_ws.data_ptr(), B, cin, cout, *dims, 1, 1, 1,
+                        word.data_ptr() if with_max else None, 0)
+        torch.cuda.synchronize()
+        return dw.cpu(), (L.last_kernel() or b"").decode()
+    got_h2, k_h2 = run(dy, True)
+    got_b3, k_b3 = run(dy, False)
+    assert k_h2.startswith("conv133_wgrad_h2") and k_b3.startswith("conv133_wgrad_bf3"), (k_h2, k_b3)
+    rms = {}
+    for name, got in (("h2", got_h2), ("bf3", got_b3)):
+        assert torch.isfinite(got).all(), name
+        err = (got.double() - ref) / mag
+        rms[name] = float(err.pow(2).mean().sqrt())
+        assert float(err.abs().max()) < 3e-7, (name, float(err.abs().max()))
+        assert float((got.double() - ref).norm() / ref.norm()) < 2e-6, name
+    assert rms["h2"] <= 1.5 * rms["bf3"] + 1e-9, rms
+    print("wgrad %s: err / sum|dy x| rms h2 %.2e bf3 %.2e" % (tag, rms["h2"], rms["bf3"]))
+    got_small, _ = run(dy * 2.0 ** -20, True)
+    assert torch.equal(got_small, got_h2 * 2.0 ** -20), "power-of-two scale invariance"
+    # a dy of zeros (dead branch) and a dy with one huge entry: finite, exact zero / dominated by that entry
+    z, _ = run(torch.zeros_like(dy), True)
+    assert torch.equal(z, torch.zeros_like(z))
+
+
+@pytest.mark.parametrize("K", [256, 4096, 65536])
+@pytest.mark.parametrize("dist", ["uniform", "act_x_grad", "positive"])
+def test_split_operand_products_vs_fp64(K, dist):
+    """The numerics gate of the matrix-pipe paths (round 5: moved here from tools/scratch/bf3_numerics.hip): a product rebuilt
+    from bf16 three-piece operands (six products) and from fp16 two-piece operands (three products, the gradient-like operand
+    scaled from its max) through the library's own split functions, against fp64, beside the fp32-input MFMA (a plain fp32 FMA
+    chain = what an fp32 kernel computes).  Bars: rms error / sum |a b| no more than 1.5x the fp32 chain's (measured 0.6-1.1x;
+    the accumulation in one fp32 chain dominates all three) and no bias beyond it on one-signed operands."""
+    from e2enet_medical_amd._lib import lib
+    g = torch.Generator().manual_seed(11 + K)
+    if dist == "uniform":
+        a = (torch.rand((32, K), generator=g) * 2 - 1) * torch.randint(1, 8, (32, K), generator=g)
+        b = (torch.rand((32, K), generator=g) * 2 - 1) * torch.randint(1, 8, (32, K), generator=g)
+    elif dist == "act_x_grad":
+        a = F.leaky_relu(torch.randn((32, K), generator=g), 0.01)
+        b = _heavy_tailed((32, K), 12 + K, 1e-7)
+    else:
+        a = torch.randn((32, K), generator=g).abs()
+        b = 1e-3 * torch.randn((32, K), generator=g).abs()
+    ref = a.double() @ b.double().t()
+    mag = a.double().abs() @ b.double().abs().t()
+    ad, bd = a.cuda(), b.cuda()
+    word = _absmax_word(bd)
+    out = {}
+    for mode, name in ((0, "bf16x3"), (1, "fp16x2"), (2, "fp32")):
+        d = torch.empty((32, 32), device="cuda")
+        lib().diag_split_gemm(ad.data_ptr(), bd.data_ptr(), d.data_ptr(), K, mode, word.data_ptr(), 0)
+        err = (d.cpu().double() - ref) / mag
+        out[name] = (float(err.pow(2).mean().sqrt()), float(err.mean()), float(err.abs().max()))
+        assert torch.isfinite(d).all()
+    print("K %d %s: rms / mean / max of err / sum|ab|: %s" % (K, dist, out))
+    for name in ("bf16x3", "fp16x2"):
+        assert out[name][0] <= 1.5 * out["fp32"][0] + 2e-8, (name, out)
+        assert abs(out[name][1]) <= 1.5 * abs(out["fp32"][1]) + 0.5 * out["fp32"][0] + 2e-8, (name, out)
 
 
 @pytest.mark.parametrize("shape", [(2, 1, 16, 32, 32), (1, 1, 40, 56, 40), (2, 2, 7, 9, 13)])

@@ -94,9 +94,11 @@ def conv_case(B, srcs, cout, dims, stride, density, tag):
         L.conv133_dgrad(op.out.grad.data_ptr(), w.data_ptr(), op.live_t.data_ptr() if op.live_t is not None else None,
                         op.outs.data_ptr(), B, cin, cout, di, hi, wi, *stride, 0)
 
+    amax = op.out.grad.abs().max().reshape(1).view(torch.int32)      # what e2e_in_lrelu_bwd records (KB_NO_ABSMAX: bf16x3 operands)
+
     def wgrad():
         L.conv133_wgrad(op.chans.data_ptr(), op.out.grad.data_ptr(), e.grads["b.conv.weight"].data_ptr(), e.wgrad_ws.data_ptr(),
-                        B, cin, cout, di, hi, wi, *stride, 0)
+                        B, cin, cout, di, hi, wi, *stride, None if os.environ.get("KB_NO_ABSMAX") else amax.data_ptr(), 0)
     def fwd_planned():
         sp = op.sp_fwd
         L.conv133_fwd_sparse(sp.table.data_ptr(), cin, sp.wpk.data_ptr(), p["b.conv.bias"].data_ptr(), sp.quads.data_ptr(),

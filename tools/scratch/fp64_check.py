@@ -63,7 +63,7 @@ def wgrad_case():
     xs = oracle.depth_shift(torch.cat([T._act_value(a) for a in srcs], 1))         # fp32 values the kernel consumes
     dy = seeded_input((B, cout) + dims, seed=8)
     dw = torch.zeros_like(w, device="cuda")
-    lib().conv133_wgrad(op.chans.data_ptr(), dy.cuda().data_ptr(), dw.data_ptr(), e.wgrad_ws.data_ptr(), B, cin, cout, *dims, *stride, 0)
+    lib().conv133_wgrad(op.chans.data_ptr(), dy.cuda().data_ptr(), dw.data_ptr(), e.wgrad_ws.data_ptr(), B, cin, cout, *dims, *stride, None, 0)
     torch.cuda.synchronize()
     print("kernel:", lib().last_kernel().decode())
     dw = dw.cpu()

@@ -25,7 +25,7 @@ def run(case):
     dyd = dy.cuda()
     op.out.alloc_grad(); op.plan_backward()
     dw = torch.zeros_like(w, device="cuda")
-    L.conv133_wgrad(op.chans.data_ptr(), dyd.data_ptr(), dw.data_ptr(), e.wgrad_ws.data_ptr(), B, cin, cout, di, hi, wi, *stride, 0)
+    L.conv133_wgrad(op.chans.data_ptr(), dyd.data_ptr(), dw.data_ptr(), e.wgrad_ws.data_ptr(), B, cin, cout, di, hi, wi, *stride, None, 0)
     torch.cuda.synchronize()
     err = (dw.cpu() - wl.grad).abs()
     bad = torch.nonzero(err > 2e-4 * max(1.0, float(wl.grad.abs().max())))

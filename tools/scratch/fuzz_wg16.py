@@ -34,7 +34,7 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
     dyd = dy.cuda()
     op.out.alloc_grad(); op.plan_backward()
     dw = torch.zeros_like(w, device="cuda")
-    L.conv133_wgrad(op.chans.data_ptr(), dyd.data_ptr(), dw.data_ptr(), e.wgrad_ws.data_ptr(), B, cin, cout, di, hi, wi, 1, 1, 1, 0)
+    L.conv133_wgrad(op.chans.data_ptr(), dyd.data_ptr(), dw.data_ptr(), e.wgrad_ws.data_ptr(), B, cin, cout, di, hi, wi, 1, 1, 1, None, 0)
     torch.cuda.synchronize()
     kern = (L.last_kernel() or b"").decode()
     err = float((dw.cpu() - wl.grad).abs().max()); scale = max(1.0, float(wl.grad.abs().max()))
