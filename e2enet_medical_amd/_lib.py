@@ -68,6 +68,9 @@ SIGNATURES = {
     "e2e_conv133_fwd_sparse": (I, [P, I, P, P, P, P, I, P, I, P, P, I, I, I, I, I, P]),
     "e2e_conv133_dgrad_sparse": (I, [P, P, P, P, I, P, P, P, I, I, I, I, I, I, I, P]),
     "e2e_conv133_fwd_dense": (I, [P, I, P, P, P, P, P, I, I, I, I, I, P, LL, P]),
+    "e2e_conv133_mm_ws_bytes": (LL, [I, I, I, I, I, I, I, I, I]),
+    "e2e_conv133_fwd_mm": (I, [P, I, P, P, P, P, P, I, I, I, I, I, P, LL, P]),
+    "e2e_conv133_dgrad_mm": (I, [P, P, P, P, P, I, I, I, I, I, I, P, LL, P]),
     "e2e_conv133_dgrad_dense": (I, [P, P, P, P, I, I, I, I, I, I, P, LL, P]),
     "e2e_conv133_wgrad_ws_bytes": (LL, [I, I, I, I, I, I, I, I, I]),
     "e2e_conv133_wgrad": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, P, P]),
@@ -119,7 +122,7 @@ SIGNATURES = {
     "e2e_aug_finish": (I, [P, P, P, I, I, I, LL, P]),
 }
 
-_NO_STATUS = {"e2e_last_error", "e2e_abi_version", "e2e_last_kernel", "e2e_conv133_num_partials", "e2e_conv133_wgrad_ws_bytes", "e2e_conv133_dense_ws_bytes", "e2e_conv133_sparse_eligible", "e2e_conv133_sparse_wpk_floats", "e2e_maxpool_bwd_num_records", "e2e_conv133_fwd_ws_bytes", "e2e_conv133_dgrad_ws_bytes",
+_NO_STATUS = {"e2e_last_error", "e2e_abi_version", "e2e_last_kernel", "e2e_conv133_num_partials", "e2e_conv133_wgrad_ws_bytes", "e2e_conv133_dense_ws_bytes", "e2e_conv133_mm_ws_bytes", "e2e_conv133_sparse_eligible", "e2e_conv133_sparse_wpk_floats", "e2e_maxpool_bwd_num_records", "e2e_conv133_fwd_ws_bytes", "e2e_conv133_dgrad_ws_bytes",
               "e2e_convT_wgrad_ws_bytes", "e2e_head1x1_wgrad_ws_bytes", "e2e_loss_ws_bytes", "e2e_aug_stats_ws_bytes"}
 
 

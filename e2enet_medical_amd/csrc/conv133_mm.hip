@@ -1,0 +1,783 @@
+// K1m (round 5): the 1x3x3 convolution, forward and stride-1 data gradient, as a GEMM on the fp16 matrix pipe with fp32-exact
+// two-piece operands -- for EVERY stride-1 layer of the 16 x 32 tile class, DSFF-masked or not (gfx950).
+//
+// Reference semantics: as conv133.hip (unetpp_d.py:45-59 depth shift, :453-478 concat, :93/:108 Conv3d k(1,3,3) of a weight whose
+// DSFF-pruned kernels are zero, core_channel.py:427-434; autograd of the same for the data gradient).
+//
+// Why (tools/scratch/h2_numerics.hip, profiles/r05_*): an fp32 product rebuilt from fp16 two-piece operands costs THREE matrix
+// instructions per 16 k-steps (bf16 three-piece: six), with an error at or below an fp32 FMA chain's.  At that price the dense
+// product of a 64 -> 32 layer at 128^3 x 2 is 0.22 ms of matrix-pipe time against 0.78 ms for the sparse vector walk of the same
+// layer at density 0.2 (conv133_sparse.hip; the walk is VALU + LDS bound at 0.2 of the HBM roofline): the mask
+// stops paying on the vector pipe long before it stops paying in FLOPs.  The mask stays structural: pruned kernels are packed as
+// zeros whatever the weight tensor holds.
+//
+// GEMM: M = 32 pixels of a tile row, N = 32 out channels, K = 16 input channels of a chunk, per tap; v_mfma_f32_32x32x16_f16,
+// D[pixel][out channel] (a lane owns one out channel: InstanceNorm sums are register sums).  x = hi + lo (hi = rn16(x),
+// lo = rn16(x - hi), 11 + 11 significant bits), weights likewise, pre-scaled by 2^8 when they are packed (|w| ~ 0.05: the lo
+// piece would be a subnormal fp16 otherwise); product = lo_x hi_w + hi_x lo_w + hi_x hi_w, accumulated in fp32, un-scaled on
+// store.  The data gradient runs the same kernel on dy (pre-scaled by the power of two that puts max |dy|, recorded by
+// e2e_in_lrelu_bwd, in [2^14, 2^15)) with transposed, tap-reversed weights and the scatter epilogue of conv133_kernel.
+//
+// Workgroup = 8 waves = 4 matrix waves + 4 staging waves (two per SIMD; the streams of different waves of a SIMD overlap,
+// tools/scratch/mfma_overlap.hip), PERSISTENT: one workgroup per CU walks the items (16 x 32 tile of one depth slice x 32 out
+// channels) l, l + G, l + 2G, ... as ONE pipeline over (item, 16-channel chunk): while the matrix waves multiply chunk s out of
+// LDS image s & 1, the staging waves convert chunk s + 1 (registers -> normalise-on-load -> split -> image (s + 1) & 1, channel-
+// fastest 32-byte pixel records whose two 16-byte halves are swapped for pixels with bit 3 set: every shifted ds_read_b128
+// fragment is conflict-free), have the loads of chunk s + 2 in flight and fetch the packed weights of chunk s + 1 by LDS-DMA.
+// One barrier per chunk.  Matrix wave r owns tile rows 4r .. 4r+3 (4 x 16 accumulator registers, 108 matrix instructions per
+// chunk); its epilogue (bias, store, InstanceNorm partial record) runs while the staging waves are already a chunk into the
+// next item.
+//
+// Shapes: stride (1,1,1), W % 32 == 0, H % 16 == 0, more than 16 channels on the reduction side, at most CT_MAX.
+#include "e2e_common.h"
+#include <cstdlib>
+#include <type_traits>
+
+// phase stamps (diagnostic build: make DEFS=-DMM_STAMPS, E2E_MM_STAMPS=1): cycles per workgroup pipeline, staging wave 4 and matrix wave 0
+#ifndef MM_DIAG
+#define MM_DIAG 0      // timing-only diagnostic builds (results wrong): 1 no matrix instructions, 2 every plane request reads offset 0 of its plane (cache hits), 4 no conversion arithmetic, 8 no forward stores, 16 no forward statistics
+#endif
+#ifdef MM_STAMPS
+__device__ unsigned long long g_mm_stamps[16];   // staging: [0] dma [1] ctab [2] request [3] commit [4] vmcnt wait [5] barrier; matrix: [8] mma [9] lgkm wait [10] barrier [11] epilogue; [15] chunks
+#define MMT(v) const unsigned long long v = __builtin_readcyclecounter()
+#define MMA(i, a, b) st_acc[i] += (b) - (a)
+#else
+#define MMT(v)
+#define MMA(i, a, b)
+#endif
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef const f32x4_t __attribute__((address_space(1)))* gf4_p;
+
+// Tile geometries (all 512 output pixels per item, so the items of a depth slice and the InstanceNorm partial records of
+// conv133_kernel's 16 x 32 tile class are the same in number):
+//   GEOM 0: 16 x 32 tiles of planes whose width is a multiple of 32; halo columns are loaded (aligned float4 groups w0 - 4 .. w0 + 35)
+//   GEOM 1:  8 x 64 tiles of planes 64 wide       } FULL-WIDTH tiles: the halo columns are the zero padding of the convolution
+//   GEOM 2:  4 x 128 tiles of planes 128 wide     } (written to LDS once), every plane request is whole 128-byte lines.
+//   GEOM 3: 16 x 32 tiles of planes 32 wide       } The memory path of a CU moves ~10 B/clk, in LINES: with 16 x 32 tiles of a 128-wide
+// plane a chunk touches (16 + 2) rows x 3 lines per channel = 54 lines for 16 lines of payload, with 4 x 128 tiles 6 x 4 = 24, and the
+// phase stamps of the first form (profiles/r05_mm_stamps.txt) put the staging waves' request issue -- blocked on that path -- at
+// twice the matrix phase.
+template <int GEOM> struct Geo {
+  static constexpr int TH = GEOM == 1 ? 8 : (GEOM == 2 ? 4 : 16), TW = GEOM == 1 ? 64 : (GEOM == 2 ? 128 : 32);
+  static constexpr bool FULLW = GEOM != 0;
+  static constexpr int XR = TH + 2, XC = TW + 2, NPIX = XR * XC;
+  static constexpr int PSZ = NPIX * 32;            // bytes per piece: 16 channels fp16 per pixel
+  static constexpr int IMG = 2 * PSZ;              // one image (hi, lo)
+  static constexpr int RPW = TH / 4, CB = TW / 32; // tile rows per matrix wave, 32-pixel column blocks: RPW * CB = 4 accumulators
+  static constexpr int NG = FULLW ? TW / 4 : 10;   // 16-byte column groups per staged row
+  static constexpr int SROWS = XR / 2;             // halo'd rows per staging-wave pair
+  static constexpr int SITEMS = SROWS * NG;        // (row, group) items per staging wave: at most two rounds of 64 lanes
+  static constexpr int NF = (RPW + 2) * CB / 2;    // A fragments (row, column block) per half-phase
+  static constexpr int CT_MAX = GEOM == 2 ? 256 : 320;      // reduction-side channels with an entry in the LDS channel table
+  static constexpr int LREC_MAX = GEOM == 2 ? 512 : 1024;   // forward: batch items x padded input channels held in LDS
+  static_assert(RPW * CB == 4 && SITEMS <= 128 && XR % 2 == 0, "geometry");
+  // fragment j of half-phase `half`: halo'd row (relative to the wave's first) and column block
+  static constexpr int frag_ir(int half, int j) { return GEOM == 2 ? j >> 1 : ((RPW + 2) / 2) * half + j / CB; }
+  static constexpr int frag_cb(int half, int j) { return GEOM == 2 ? 2 * half + (j & 1) : j % CB; }
+};
+constexpr int PXB = 32;                          // bytes per pixel and piece
+constexpr int WTAP = 32 * 32;                    // one (tap, piece) block: 32 out channels x 16 ch fp16
+constexpr int WCH = 9 * 2 * WTAP;                // one chunk of packed weights: 18 432 B
+constexpr int WUNITS = WCH / 16;                 // 1152 16-byte units
+constexpr int WSH = 8;                           // weights are packed as w 2^WSH
+template <int GEOM> constexpr int lds_bytes() {
+  return 2 * Geo<GEOM>::IMG + 2 * WCH + 2 * Geo<GEOM>::CT_MAX * 20 + Geo<GEOM>::LREC_MAX * 24 + 2 * 4 * 32 * 2 * 4;
+}
+static_assert(lds_bytes<0>() <= 160 * 1024 && lds_bytes<1>() <= 160 * 1024 && lds_bytes<2>() <= 160 * 1024 && lds_bytes<3>() <= 160 * 1024, "LDS budget");
+
+struct MmParams {
+  const e2e_in_chan_t* chans;     // MODE 0: P input planes
+  const float* xin;               // MODE 1: dy [B, P, D, H, W]
+  const unsigned* x_absmax;       // MODE 1: bit pattern of max |dy| (nullptr: unscaled)
+  const unsigned char* wpk;       // packed weights [qblock][chunk][tap][piece][32 q][16 ch] fp16, pre-scaled, swizzled
+  const struct ChanRec* crec;     // MODE 0: resolved input planes [B][nchunks * 16] (written by the packing launch)
+  const float* bias;
+  float* y;
+  double* part;
+  const e2e_out_chan_t* outs;     // MODE 1: Q destination planes
+  int P, Q, B, D, H, W;
+  int nchunks, qblocks, tiles_x, tiles_y, tiles_per_n, total, grid;
+};
+
+struct ChanRec {                   // 24 bytes: one input plane of one batch item, resolved once per launch
+  unsigned long long ptr;          // plane of depth 0 of (batch item, channel)
+  float a, b, slope;               // normalise-on-load (a = b = 0: channel absent)
+  int dshift;
+};
+
+struct CtEntry {                   // 16 bytes
+  unsigned long long ptr;          // plane of (batch item, shifted depth); always dereferenceable
+  float a, b;                      // normalise-on-load (0, 0: channel absent or depth out of range)
+};
+
+// ---- weights: fp32 [Q][P][9] (strides wq, wp; reversed taps for the data gradient) -> packed two-piece fp16 -----------------------
+// `quads` (null = dense layer): DSFF liveness quad words of this direction, word [q / 4][p / 8], bit (p % 8) * 4 + q % 4
+// (e2e_dsff_expand_quads); a pruned (q, p) kernel is packed as zeros (the mask is structural).
+__global__ __launch_bounds__(256) void pack_weights_h2_kernel(const float* __restrict__ w, const unsigned* __restrict__ quads,
+                                                              unsigned short* __restrict__ wpk, int P, int Q, int wq_stride, int wp_stride,
+                                                              int reverse, int nchunks, int qblocks, const e2e_in_chan_t* __restrict__ chans,
+                                                              ChanRec* __restrict__ crec, int B) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long n = (long long)qblocks * nchunks * 9 * 32 * 16;
+  if (chans != nullptr && idx < (long long)B * nchunks * 16) {
+    // forward: plane pointers and normalise-on-load coefficients of every (batch item, input channel), so that the conv kernel
+    // needs ONE load per channel and item instead of a dependent chain (descriptor -> scale / shift)
+    const int ch = (int)(idx % (nchunks * 16)), nb = (int)(idx / (nchunks * 16));
+    const e2e_in_chan_t cd = chans[ch < P ? ch : 0];
+    ChanRec r;
+    r.ptr = (unsigned long long)(cd.ptr + (long long)nb * cd.nstride);
+    r.a = ch < P ? 1.f : 0.f; r.b = 0.f; r.slope = 1.f;
+    r.dshift = ch < P ? cd.dshift : 0;
+    if (ch < P && cd.scale != nullptr) {
+      r.a = cd.scale[(long long)nb * cd.ab_nstride];
+      r.b = cd.shift[(long long)nb * cd.ab_nstride];
+      r.slope = cd.slope;
+    }
+    crec[idx] = r;
+  }
+  if (idx >= n) return;
+  const int k = (int)(idx % 16), ql = (int)((idx / 16) % 32), tap = (int)((idx / 512) % 9);
+  const int ch = (int)((idx / (512 * 9)) % nchunks), qb = (int)(idx / ((long long)512 * 9 * nchunks));
+  const int q = qb * 32 + ql, pp = ch * 16 + k;
+  float v = 0.f;
+  if (q < Q && pp < P) {
+    const bool alive = quads == nullptr || ((quads[(long long)(q >> 2) * ((P + 7) >> 3) + (pp >> 3)] >> (((pp & 7) << 2) + (q & 3))) & 1u);
+    if (alive) v = w[(long long)q * wq_stride + (long long)pp * wp_stride + (reverse ? 8 - tap : tap)];
+  }
+  v *= (float)(1 << WSH);
+  const _Float16 h = (_Float16)v;
+  const _Float16 l = (_Float16)(v - (float)h);
+  // 32-byte rows; the two 16-byte halves of rows with bit 3 set are swapped (conflict-free ds_read_b128 fragments)
+  const long long base = ((((long long)qb * nchunks + ch) * 9 + tap) * 2) * 512 + ql * 16 + (k ^ (((ql >> 3) & 1) << 3));
+  wpk[base] = __builtin_bit_cast(unsigned short, h);
+  wpk[base + 512] = __builtin_bit_cast(unsigned short, l);
+}
+
+template <int MODE, int GEOM>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv133_mm_kernel(MmParams p) {
+  using GE = Geo<GEOM>;
+  constexpr int TH = GE::TH, TW = GE::TW, XC = GE::XC, PSZ = GE::PSZ, IMG = GE::IMG, RPW = GE::RPW, CB = GE::CB, NF = GE::NF;
+  constexpr int NG = GE::NG, SROWS = GE::SROWS, SITEMS = GE::SITEMS, CT_MAX = GE::CT_MAX, LREC_MAX = GE::LREC_MAX;
+  constexpr bool FULLW = GE::FULLW;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_x[2 * IMG];
+  __shared__ __attribute__((aligned(16))) unsigned char lds_w[2 * WCH];
+  __shared__ __attribute__((aligned(16))) CtEntry ctab[2][CT_MAX];
+  __shared__ float cslope[2][CT_MAX];
+  __shared__ __attribute__((aligned(8))) ChanRec lrec[MODE == 0 ? LREC_MAX : 1];      // the launch's resolved input planes, all batch items
+  __shared__ float red[2][4][32][2];                       // (mean, M2) of 128 values per (item parity, matrix wave, out channel)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef MM_STAMPS
+  unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  const int G = p.grid;
+  const int l0 = e2e::xcd_remap(blockIdx.x, G);
+  if (l0 >= p.total) return;
+  const int nitems = (p.total - l0 + G - 1) / G;
+  const int S = nitems * p.nchunks;                          // chunks of this workgroup's pipeline
+  const int plane = p.H * p.W;                               // (host: H * W < 2^31 / 4)
+
+  struct Item { int n, d, h0, w0, qb, tile_in_n; };
+  auto decode = [&](int k) __attribute__((always_inline)) {
+    Item it;
+    int id = l0 + k * G;
+    it.qb = id % p.qblocks;
+    id /= p.qblocks;
+    it.n = id / p.tiles_per_n;
+    it.tile_in_n = id - it.n * p.tiles_per_n;
+    const int tx = it.tile_in_n % p.tiles_x, t2 = it.tile_in_n / p.tiles_x;
+    const int ty = t2 % p.tiles_y;
+    it.d = t2 / p.tiles_y;
+    it.h0 = ty * TH;
+    it.w0 = tx * TW;
+    return it;
+  };
+
+  // dy scale of the data gradient: 2^k with max |dy| 2^k in [2^14, 2^15) (as conv133_wgrad_bf3.hip)
+  float xsc = 1.f, unsc = __builtin_bit_cast(float, (unsigned)(127 - WSH) << 23);
+  if (MODE == 1 && p.x_absmax != nullptr) {
+    int E = (int)((__builtin_nontemporal_load(p.x_absmax) >> 23) & 0xffu);
+    E = E < 1 ? 1 : E;
+    int k = 141 - E;
+    k = k > 110 ? 110 : (k < -110 ? -110 : k);
+    xsc = __builtin_bit_cast(float, (unsigned)(127 + k) << 23);
+    unsc = __builtin_bit_cast(float, (unsigned)(127 - k - WSH) << 23);
+  }
+
+  // channel table of an item: plane pointer (batch item, shifted depth) and normalise-on-load coefficients per reduction-side
+  // channel, from the records the packing launch resolved (one independent 24-byte load per channel); built by `nthreads`
+  // threads starting at `t0`; NR entries per thread cover up to NR * nthreads channels
+  // forward: the resolved input planes of the whole launch (plane pointer of depth 0, normalise-on-load coefficients, depth shift
+  // per batch item and channel; written by the packing launch) are copied to LDS once per workgroup; the channel table of an item
+  // (plane pointer at the shifted depth, coefficients zeroed where that depth is outside) is then LDS-to-LDS work: no global load
+  // and no wait inside the staging loop
+  if (MODE == 0) {
+    const int nrec = p.B * p.nchunks * 16;
+    for (int i = tid; i < nrec; i += 512) lrec[i] = p.crec[i];
+  }
+  if (FULLW)                                                  // full-width tiles: the halo columns are zero padding, never written again
+    for (int i = tid; i < 2 * IMG / 16; i += 512) reinterpret_cast<u32x4_t*>(lds_x)[i] = u32x4_t{0u, 0u, 0u, 0u};
+  __syncthreads();
+  auto build_ctab = [&](const Item& it, int par, int t0, int nthreads) __attribute__((always_inline)) {
+    CtEntry* tab = ctab[par];
+    float* sl = cslope[par];
+    const int np16 = p.nchunks * 16;
+    for (int ch = t0; ch < np16; ch += nthreads) {
+      CtEntry e;
+      float sv = 1.f;
+      if (MODE == 0) {
+        const ChanRec r = lrec[it.n * np16 + ch];
+        const int din = it.d - r.dshift;
+        const bool valid = (unsigned)din < (unsigned)p.D;
+        e.a = valid ? r.a : 0.f;
+        e.b = valid ? r.b : 0.f;
+        sv = r.slope;
+        e.ptr = r.ptr + (unsigned long long)(valid ? din : 0) * (unsigned long long)plane * 4ull;
+      } else {
+        const bool valid = ch < p.P;
+        e.a = valid ? xsc : 0.f;
+        e.b = 0.f;
+        e.ptr = (unsigned long long)(p.xin + (((long long)it.n * p.P + (valid ? ch : 0)) * p.D + it.d) * plane);
+      }
+      tab[ch] = e;
+      sl[ch] = sv;
+    }
+  };
+
+  build_ctab(decode(0), 0, tid, 512);
+  __syncthreads();                                            // barrier #0
+
+  if (wave >= 4) {
+    // ================================================= staging waves =========================================================
+    // Iteration s runs beside the matrix phase of chunk s: the packed weights of chunk s + 1 are requested (LDS-DMA), the planes
+    // of chunk s + 2 are requested into the register set chunk s left, chunk s + 1 is converted out of the other set into image
+    // (s + 1) & 1.  Straight-line code (no branch around a load: exact vmcnt distances); past the end the last chunk is requested
+    // and staged again into the image nobody reads.
+    const int sw = wave - 4;
+    const int shalf = sw & 1, srh = sw >> 1;                  // channel half of the chunk, row half of the halo'd tile
+    int s_row[2], s_g[2], s_pix0[2], s_loff[2];
+    bool s_act[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int it = r * 64 + lane;
+      s_act[r] = it < SITEMS;
+      const int itc = s_act[r] ? it : 0;
+      s_row[r] = srh * SROWS + itc / NG;
+      s_g[r] = itc % NG;
+      // halo'd pixel index of the group's first column, element offset from the tile origin (h0, w0): general tiles load the aligned
+      // groups w0 - 4 .. w0 + 35 (three columns beyond either halo column are dropped), full-width tiles exactly the plane's rows
+      s_pix0[r] = s_row[r] * XC + (FULLW ? 4 * s_g[r] + 1 : 4 * s_g[r] - 3);
+      s_loff[r] = (s_row[r] - 1) * p.W + (FULLW ? 4 * s_g[r] : 4 * s_g[r] - 4);
+    }
+    struct Cur { int k, c; Item it; };                        // a position in the (item, chunk) sequence; past the end: the last item again
+    auto advance = [&](Cur& q) __attribute__((always_inline)) {
+      if (++q.c == p.nchunks) {                               // (wave-uniform; scalar work only)
+        asm volatile("" ::: "memory");                        // a real branch: the divisions of decode() are not to be speculated into every iteration
+        q.c = 0;
+        ++q.k;
+        q.it = decode(q.k < nitems ? q.k : nitems - 1);
+      }
+    };
+    f32x4_t xv[2][2][8];                                      // [register set][round][channel]
+    bool inside[2][2];
+
+    // plane loads of chunk q -> register set SET: addresses first (channel table entries from LDS), then `issue(i)` requests load
+    // i = 8 round + channel.  The sixteen requests of a chunk are dealt between the conversion steps of the previous chunk
+    // (stage below): all four staging waves of a CU run in step behind the barrier, and sixteen back-to-back requests per wave
+    // saturate the CU's memory path for ~6 k cycles (10 B/clk/CU) and leave it idle while everybody converts (phase stamps,
+    // profiles/r05_mm_stamps.txt): spread out, the path is busy all the time.
+    struct Req { unsigned long long base[8]; unsigned off[2]; };
+    auto prepare = [&](auto SETC, const Cur& q) __attribute__((always_inline)) {
+      constexpr int SET = decltype(SETC)::value;
+      Req rq;
+      const int par = (q.k < nitems ? q.k : nitems - 1) & 1;
+      const CtEntry* tab = ctab[par] + q.c * 16 + shalf * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) rq.base[j] = tab[j].ptr;
+      const int torg = q.it.h0 * p.W + q.it.w0;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int hi = q.it.h0 - 1 + s_row[r], wi = FULLW ? 0 : q.it.w0 - 4 + 4 * s_g[r];
+        inside[SET][r] = s_act[r] & ((unsigned)hi < (unsigned)p.H) & ((unsigned)wi < (unsigned)p.W);
+        rq.off[r] = (inside[SET][r] && !(MM_DIAG & 2)) ? (unsigned)(torg + s_loff[r]) : 0u;
+      }
+      return rq;
+    };
+    auto issue = [&](auto SETC, const Req& rq, int i) __attribute__((always_inline)) {     // i: compile-time after unrolling
+      constexpr int SET = decltype(SETC)::value;
+      xv[SET][i >> 3][i & 7] = *(gf4_p)(rq.base[i & 7] + (unsigned long long)rq.off[i >> 3] * 4ull);
+    };
+    auto request_w = [&](const Cur& q, int buf) __attribute__((always_inline)) {      // packed weights of chunk q -> lds_w[buf] by LDS-DMA
+      const unsigned char* src = p.wpk + ((long long)q.it.qb * p.nchunks + q.c) * WCH;
+      unsigned char* dst = lds_w + buf * WCH;
+#pragma unroll
+      for (int rd = 0; rd < (WUNITS + 255) / 256; ++rd) {
+        const int u0 = rd * 256 + sw * 64;                    // (wave-uniform)
+        if (u0 < WUNITS) {
+          // (inline asm: the compiler waits vmcnt(0) in front of every LDS-DMA builtin and again at the first LDS access that might
+          //  alias it -- that would drain the plane loads in flight; M0 = wave-uniform LDS byte address, written in the same statement)
+          unsigned keep;
+          const unsigned lds_dst = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)(dst + u0 * 16);
+          const unsigned char* gsrc = src + (long long)(u0 + lane) * 16;
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep) : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
+        }
+      }
+    };
+    // register set CUR (chunk qc) -> image buf, with the sixteen plane requests of chunk qn into set NEW dealt two per pixel step
+    auto stage = [&](auto CURC, auto NEWC, const Cur& qc, const Cur& qn, int buf) __attribute__((always_inline)) {
+      constexpr int CUR = decltype(CURC)::value;
+      MMT(u0);
+      const Req rq = prepare(NEWC, qn);
+      unsigned char* img = lds_x + buf * IMG;
+      const int parc = (qc.k < nitems ? qc.k : nitems - 1) & 1;
+      const CtEntry* tab = ctab[parc] + qc.c * 16 + shalf * 8;
+      const float* sl = cslope[parc] + qc.c * 16 + shalf * 8;
+      float ca[8], cb[8], csl[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const CtEntry e = tab[j]; ca[j] = e.a; cb[j] = e.b; csl[j] = sl[j]; }
+      MMT(u1);
+      MMA(6, u0, u1);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        MMT(u2);
+        float ae[8], be[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ae[j] = inside[CUR][r] ? ca[j] : 0.f; be[j] = inside[CUR][r] ? cb[j] : 0.f; }
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+          issue(NEWC, rq, (r * 4 + kx) * 2);
+          issue(NEWC, rq, (r * 4 + kx) * 2 + 1);
+          const int hc = FULLW ? 1 : 4 * s_g[r] - 3 + kx;     // halo column of this pixel (general tiles: may fall outside the halo'd row)
+          float t[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (MM_DIAG & 4) {
+              t[j] = xv[CUR][r][j][kx];
+            } else if (MODE == 0) {
+              const float u = fmaf(xv[CUR][r][j][kx], ae[j], be[j]);
+              t[j] = fmaxf(u, u * csl[j]);                    // LeakyReLU, 0 <= slope <= 1 (the engine's contract); slope 1 = identity
+            } else {
+              t[j] = xv[CUR][r][j][kx] * ae[j];
+            }
+          }
+          u32x4_t hv, lv;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (MM_DIAG & 4) { hv[j] = __builtin_bit_cast(unsigned, t[2 * j]); lv[j] = __builtin_bit_cast(unsigned, t[2 * j + 1]); continue; }
+            // hi = rn16(t) (one v_cvt_pk_f16_f32 per pair), lo = rn16(t - hi) as ONE mixed-precision FMA per value: fma(hi as f16, -1, t)
+            // is exact in fp32 and rounded to fp16 into the low / high half of the destination (3 instead of 7 instructions per pair)
+            const f16x2_t h2 = __builtin_convertvector((f32x2_t{t[2 * j], t[2 * j + 1]}), f16x2_t);
+            hv[j] = __builtin_bit_cast(unsigned, h2);
+            unsigned lw;
+            asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                : "=&v"(lw) : "v"(hv[j]), "v"(t[2 * j]), "v"(t[2 * j + 1]));
+            lv[j] = lw;
+          }
+          if (s_act[r] && hc >= 0 && hc < XC) {
+            const int px = s_pix0[r] + kx;
+            unsigned char* dst = img + px * PXB + ((shalf ^ ((px >> 3) & 1)) << 4);
+            *reinterpret_cast<u32x4_t*>(dst) = hv;
+            *reinterpret_cast<u32x4_t*>(dst + PSZ) = lv;
+          }
+          __builtin_amdgcn_sched_barrier(0);                  // the next two requests stay behind this step
+        }
+        MMT(u3);
+        MMA(7, u2, u3);
+        if (r == 0) MMA(2, u2, u3);
+      }
+    };
+
+    using R0 = std::integral_constant<int, 0>; using R1 = std::integral_constant<int, 1>;
+    // prologue: chunk 0 requested and staged, chunk 1 in flight
+    Cur q1{0, 0, decode(0)};                                  // the chunk being converted (s + 1 inside the loop)
+    Cur q2 = q1;                                              // the chunk being requested (s + 2)
+    request_w(q1, 0);
+    {
+      const Req rq = prepare(R0{}, q1);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) issue(R0{}, rq, i);
+    }
+    advance(q2);                                              // chunk 1 (item 0: nchunks >= 2)
+    if (nitems > 1) build_ctab(decode(1), 1, tid - 256, 256);
+    stage(R0{}, R1{}, q1, q2, 0);                             // chunk 0 -> image 0, chunk 1 -> set 1
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __syncthreads();                                          // barrier #1: image 0 and weights 0 are in LDS
+    auto iteration = [&](auto PARC, int s) __attribute__((always_inline)) {            // PAR = s & 1
+      constexpr int PAR = decltype(PARC)::value;
+      q1 = q2;                                                // chunk s + 1 (requested last iteration into set PAR ^ 1)
+      advance(q2);                                            // chunk s + 2 -> set PAR
+      MMT(t0);
+      request_w(q1, PAR ^ 1);
+      MMT(t1);
+      // table of the item after q1's, written while q1's first chunk is converted: a barrier before its first reader (nchunks >= 2);
+      // LDS-to-LDS (no global load: a branch around a load would cost the exact vmcnt distances of this loop)
+      if (q1.c == 0 && q1.k + 1 < nitems) build_ctab(decode(q1.k + 1), (q1.k + 1) & 1, tid - 256, 256);
+      MMT(t2);
+      stage(std::integral_constant<int, PAR ^ 1>{}, std::integral_constant<int, PAR>{}, q1, q2, PAR ^ 1);
+      MMT(t4);
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // the weight DMA has landed; the 16 plane loads stay in flight
+      MMT(t5);
+      __syncthreads();                                        // barrier #(s + 2)
+      MMT(t6);
+      MMA(0, t0, t1); MMA(1, t1, t2); MMA(3, t2, t4); MMA(4, t4, t5); MMA(5, t5, t6);
+    };
+    for (int s = 0; s < S; s += 2) {
+      iteration(R0{}, s);
+      if (s + 1 < S) iteration(R1{}, s + 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                          // the last item's statistics records
+#ifdef MM_STAMPS
+    if (sw == 0 && lane == 0) { for (int i = 0; i < 8; ++i) atomicAdd(&g_mm_stamps[i], st_acc[i]); atomicAdd(&g_mm_stamps[15], (unsigned long long)S); }
+#endif
+    return;
+  }
+
+  // =================================================== matrix waves ===========================================================
+  const int wr = wave;                                        // tile rows RPW wr .. RPW wr + RPW - 1, all CB column blocks
+  const int fq = lane & 31, fh8 = lane >> 5;
+  const int wfo = fq * 32 + ((fh8 ^ ((fq >> 3) & 1)) << 4);   // weight fragment: out channel fq, channels 8 fh8 .. + 7
+  // A fragment of halo'd row RPW wr + ir, column block cb, tap column kw: pixel (RPW wr + ir) XC + 32 cb + fq + kw; the column block
+  // is an immediate offset (32 pixels leave bit 3 of the pixel index, the half swap, unchanged)
+  int aoff[RPW + 2][3];
+#pragma unroll
+  for (int ir = 0; ir < RPW + 2; ++ir)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int px = (RPW * wr + ir) * XC + kw + fq;
+      aoff[ir][kw] = px * PXB + ((fh8 ^ ((px >> 3) & 1)) << 4);
+    }
+  f32x16 acc[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[r][i] = 0.f;
+
+  auto combine = [&](int k) __attribute__((always_inline)) {                                  // tile record of item k from the four waves' (mean, M2) of 128 values
+    if (MODE != 0 || p.part == nullptr || wr != 0 || lane >= 32) return;
+    const Item it = decode(k);
+    const int q = it.qb * 32 + lane;
+    if (q >= p.Q) return;
+    // Chan combination of four records of 128 values, fp64; the counts are known: bn / tot and cn bn / tot are constants
+    double cm = (double)red[k & 1][0][lane][0], c2 = (double)red[k & 1][0][lane][1];
+    constexpr double wgt[4] = {0.0, 0.5, 1.0 / 3.0, 0.25}, cross[4] = {0.0, 64.0, 256.0 / 3.0, 96.0};
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const double bm = (double)red[k & 1][w][lane][0], b2 = (double)red[k & 1][w][lane][1];
+      const double dl = bm - cm;
+      cm += dl * wgt[w];
+      c2 += b2 + dl * dl * cross[w];
+    }
+    double* pp = p.part + (((long long)it.n * p.Q + q) * p.tiles_per_n + it.tile_in_n) * 3;
+    pp[0] = 512.0; pp[1] = cm; pp[2] = c2;
+  };
+
+  // A chunk is six HALF-PHASES of 18 matrix instructions: kernel column kw = hp / 2 and one half of the wave's (halo'd row, column
+  // block) fragments (Geo::frag_ir / frag_cb).
+  // A fragments (hi and lo piece) are double-buffered in registers by half-phase, B fragments (the three taps of a
+  // kernel column, hi and lo) by kernel column: the ds_read_b128 of the next half-phase are issued in front of the matrix
+  // instructions of the current one.  The workgroup barrier of a chunk sits in front of its LAST half-phase: by then every read of
+  // the chunk's image has been issued and has landed, the staging waves have finished the next image, and the first fragments of
+  // the next chunk are requested right behind it.
+  f16x8 fa[2][NF][2], fb[2][3][2];
+  auto load_a = [&](auto HPC, int s) __attribute__((always_inline)) {                        // A fragments of half-phase HP of chunk s -> set HP & 1
+    constexpr int HP = decltype(HPC)::value, SET = HP & 1, KW = HP >> 1, HALF = HP & 1;
+    const unsigned char* img = lds_x + (s & 1) * IMG;
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+      const unsigned char* ap = img + aoff[GE::frag_ir(HALF, j)][KW] + GE::frag_cb(HALF, j) * 32 * PXB;
+      fa[SET][j][0] = *reinterpret_cast<const f16x8*>(ap);
+      fa[SET][j][1] = *reinterpret_cast<const f16x8*>(ap + PSZ);
+    }
+  };
+  auto load_b = [&](auto SETC, auto KWC, int s) __attribute__((always_inline)) {             // B fragments of kernel column KW of chunk s -> set SET
+    constexpr int SET = decltype(SETC)::value, KW = decltype(KWC)::value;
+    const unsigned char* wl = lds_w + (s & 1) * WCH + wfo;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      fb[SET][kh][0] = *reinterpret_cast<const f16x8*>(wl + ((kh * 3 + KW) * 2) * WTAP);
+      fb[SET][kh][1] = *reinterpret_cast<const f16x8*>(wl + ((kh * 3 + KW) * 2 + 1) * WTAP);
+    }
+  };
+  auto mma = [&](auto HPC, auto BSETC) __attribute__((always_inline)) {
+    constexpr int HP = decltype(HPC)::value, SET = HP & 1, HALF = HP & 1, BS = decltype(BSETC)::value;
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int rr = GE::frag_ir(HALF, j) - kh;             // tile row (of this wave) the fragment feeds through kernel row kh
+        if (rr < 0 || rr >= RPW) continue;
+        const int ai = rr * CB + GE::frag_cb(HALF, j);
+        if (MM_DIAG & 1) { acc[ai][0] += (float)fa[SET][j][0][0] + (float)fb[BS][kh][1][0] + (float)fa[SET][j][1][0] + (float)fb[BS][kh][0][0]; continue; }
+        f32x16 a = acc[ai];                                   // small terms first: lo*hi, hi*lo, then hi*hi
+        a = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][j][1], fb[BS][kh][0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][j][0], fb[BS][kh][1], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][j][0], fb[BS][kh][0], a, 0, 0, 0);
+        acc[ai] = a;
+      }
+  };
+  int pending = -1;                                           // item whose statistics records wait for the next barrier
+  Item itm = decode(0);                                       // the item of the chunk being multiplied
+  int mk = 0, mc = 0;
+  float bq = 0.f;                                             // its bias, requested at the top of every chunk (no branch around the load)
+  auto epilogue = [&](int k) __attribute__((always_inline)) {
+    // ---- epilogue of item k.  D layout of v_mfma_f32_32x32x16: column (out channel) = lane & 31, row (pixel of the tile row) =
+    // (i & 3) + 8 (i >> 2) + 4 (lane >> 5): a lane stores four float4 per tile row
+    const Item it = itm;
+    const int q = it.qb * 32 + fq;
+    if (MODE == 0) {
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          acc[r][i] = fmaf(acc[r][i], unsc, bq);
+          psum += acc[r][i];
+        }
+      if (p.part != nullptr && !(MM_DIAG & 16)) {
+        const float mean = (psum + __shfl_xor(psum, 32, 64)) * (1.f / 128.f);
+        float m2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const float dl = acc[r][i] - mean;
+            m2 = fmaf(dl, dl, m2);
+          }
+        m2 += __shfl_xor(m2, 32, 64);
+        if (fh8 == 0) { red[k & 1][wr][fq][0] = mean; red[k & 1][wr][fq][1] = m2; }
+        pending = k;
+      }
+      if (q < p.Q && !(MM_DIAG & 8)) {
+        float* yp = p.y + (((long long)it.n * p.Q + q) * p.D + it.d) * plane + (long long)(it.h0 + RPW * wr) * p.W + it.w0 + 4 * fh8;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)                           // accumulator r = (tile row r / CB of this wave, column block r % CB)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4_t*>(yp + (r / CB) * p.W + (r % CB) * 32 + 8 * g) = f32x4_t{acc[r][4 * g], acc[r][4 * g + 1], acc[r][4 * g + 2], acc[r][4 * g + 3]};
+      }
+    } else if (q < p.Q) {
+      // data gradient: the gradient of virtual-concat channel q at (shifted) depth d goes to depth d - s(q) of its source; slices
+      // that receive nothing are zero-filled by the workgroups of the out-of-range depths (conv133_kernel's rule)
+      const e2e_out_chan_t oc = p.outs[q];
+      if (oc.ptr != nullptr) {
+        int dd = it.d - oc.dshift;
+        bool zero_fill = false;
+        if (dd < 0) {
+          const int lo = p.D - oc.dshift > 0 ? p.D - oc.dshift : 0;
+          dd = lo + it.d;
+          zero_fill = true;
+        } else if (dd >= p.D) {
+          const int lo = p.D + oc.dshift > 0 ? p.D + oc.dshift : 0;
+          dd = it.d - lo;
+          zero_fill = true;
+        }
+        if (!(zero_fill && oc.accumulate)) {
+          float* xp = oc.ptr + (long long)it.n * oc.nstride + (long long)dd * plane + (long long)(it.h0 + RPW * wr) * p.W + it.w0 + 4 * fh8;
+          const float usc = zero_fill ? 0.f : unsc;
+          if (!zero_fill && oc.accumulate) {                  // all sixteen old values requested before the first one is used
+            f32x4_t old[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+              for (int g = 0; g < 4; ++g) old[r][g] = *reinterpret_cast<const f32x4_t*>(xp + (r / CB) * p.W + (r % CB) * 32 + 8 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+              for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<f32x4_t*>(xp + (r / CB) * p.W + (r % CB) * 32 + 8 * g) =
+                    f32x4_t{acc[r][4 * g], acc[r][4 * g + 1], acc[r][4 * g + 2], acc[r][4 * g + 3]} * usc + old[r][g];
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+              for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<f32x4_t*>(xp + (r / CB) * p.W + (r % CB) * 32 + 8 * g) = f32x4_t{acc[r][4 * g], acc[r][4 * g + 1], acc[r][4 * g + 2], acc[r][4 * g + 3]} * usc;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[r][i] = 0.f;
+  };
+  __syncthreads();                                            // barrier #1
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
+  load_a(I0{}, 0);
+  load_b(I0{}, I0{}, 0);
+  auto chunk = [&](auto PARC, int s) __attribute__((always_inline)) {                        // PAR: the B register set that holds kernel column 0 of chunk s
+    constexpr int PAR = decltype(PARC)::value;
+    using B0 = std::integral_constant<int, PAR>;
+    using B1 = std::integral_constant<int, PAR ^ 1>;
+    if (MODE == 0 && p.bias != nullptr) { const int qq = itm.qb * 32 + fq; bq = p.bias[qq < p.Q ? qq : 0]; }
+    MMT(m0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_a(I1{}, s); load_b(B1{}, I1{}, s);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(I0{}, B0{});
+    __builtin_amdgcn_sched_barrier(0);
+    load_a(I2{}, s);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(I1{}, B0{});
+    __builtin_amdgcn_sched_barrier(0);
+    load_a(I3{}, s); load_b(B0{}, I2{}, s);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(I2{}, B1{});
+    __builtin_amdgcn_sched_barrier(0);
+    load_a(I4{}, s);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(I3{}, B1{});
+    __builtin_amdgcn_sched_barrier(0);
+    load_a(I5{}, s);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(I4{}, B0{});
+    __builtin_amdgcn_sched_barrier(0);
+    MMT(m1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    MMT(m2);
+    __syncthreads();                                          // barrier #(s + 2): image s & 1 is free, image (s + 1) & 1 is complete
+    MMT(m3);
+    if (s + 1 < S) { load_a(I0{}, s + 1); load_b(B1{}, I0{}, s + 1); }
+    __builtin_amdgcn_sched_barrier(0);
+    mma(I5{}, B0{});
+    __builtin_amdgcn_sched_barrier(0);
+    MMT(m4);
+    if (pending >= 0) { combine(pending); pending = -1; }
+    if (++mc == p.nchunks) {
+      asm volatile("" ::: "memory");                          // (a real branch: no speculated divisions)
+      epilogue(mk);
+      mc = 0;
+      ++mk;
+      itm = decode(mk < nitems ? mk : nitems - 1);
+    }
+    MMT(m5);
+    MMA(8, m0, m1); MMA(8, m3, m4); MMA(9, m1, m2); MMA(10, m2, m3); MMA(11, m4, m5);
+  };
+  for (int s = 0; s < S; s += 2) {
+    chunk(std::integral_constant<int, 0>{}, s);
+    if (s + 1 < S) chunk(std::integral_constant<int, 1>{}, s + 1);
+  }
+  __syncthreads();                                            // the last item's statistics records
+  if (pending >= 0) combine(pending);
+#ifdef MM_STAMPS
+  if (wr == 0 && lane == 0) for (int i = 8; i < 15; ++i) atomicAdd(&g_mm_stamps[i], st_acc[i]);
+#endif
+}
+
+inline bool mm_knob() {
+  static const int v = getenv("E2E_CONV_MM") ? atoi(getenv("E2E_CONV_MM")) : 1;
+  return v != 0;
+}
+
+}  // namespace
+
+// tile geometry of a plane width (Geo<>): full-width tiles where the plane is 32, 64 or 128 wide; E2E_MM_GEOM=0 keeps 16 x 32 tiles
+static int mm_geom(int Wi) {
+  static const int knob = getenv("E2E_MM_GEOM") ? atoi(getenv("E2E_MM_GEOM")) : 1;
+  if (!knob) return 0;
+  return Wi == 128 ? 2 : (Wi == 64 ? 1 : (Wi == 32 ? 3 : 0));
+}
+static bool mm_fits(int geom, int B, int Cin, int Cout) {
+  const int ct = geom == 2 ? Geo<2>::CT_MAX : Geo<0>::CT_MAX, lr = geom == 2 ? Geo<2>::LREC_MAX : Geo<0>::LREC_MAX;
+  return Cin <= ct && Cout <= ct && (long long)B * e2e::cdiv(Cin, 16) * 16 <= lr;   // LDS channel table; the forward's LDS copy of the resolved input planes
+}
+
+// shapes the kernel serves; 0 bytes = not eligible
+extern "C" long long e2e_conv133_mm_ws_bytes(int B, int Cin, int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw) {
+  if (!mm_knob()) return 0;
+  if (sd != 1 || sh != 1 || sw != 1) return 0;
+  if (Wi % 32 != 0 || Hi % 16 != 0 || Hi <= 16 || Di < 1) return 0;   // the 16 x 32 tile class of conv133_kernel (the partial records line up)
+  if (Cin <= 16 || Cout <= 16) return 0;                    // at least two 16-channel chunks in both directions (the 4-modal input layer: conv133_kernel)
+  if ((long long)Hi * Wi >= (1ll << 29)) return 0;
+  if (!mm_fits(mm_geom(Wi), B, Cin, Cout) && !mm_fits(0, B, Cin, Cout)) return 0;
+  const long long cmax = Cin > Cout ? Cin : Cout;
+  const long long blocks = e2e::cdiv((int)cmax, 32) * (long long)e2e::cdiv((int)cmax, 16);
+  // packed weights of either direction + the resolved channel records of the forward
+  return ((blocks * WCH + 63) & ~63ll) + (long long)(B > 0 ? B : 1) * e2e::cdiv((int)cmax, 16) * 16 * (long long)sizeof(ChanRec);
+}
+
+static int mm_launch(int mode, const e2e_in_chan_t* chans, const float* xin, const unsigned* x_absmax, const float* w, const unsigned* quads,
+                     const float* bias, float* y, double* part, const e2e_out_chan_t* outs, int B, int P, int Q, int D, int H, int W,
+                     int wq_stride, int wp_stride, void* ws, long long ws_bytes, hipStream_t st) {
+  MmParams p{};
+  p.chans = chans; p.xin = xin; p.x_absmax = x_absmax; p.bias = bias; p.y = y; p.part = part; p.outs = outs;
+  p.P = P; p.Q = Q; p.B = B; p.D = D; p.H = H; p.W = W;
+  p.nchunks = e2e::cdiv(P, 16);
+  p.qblocks = e2e::cdiv(Q, 32);
+  const long long need = (long long)p.qblocks * p.nchunks * WCH;
+  const long long need_all = ((need + 63) & ~63ll) + (long long)B * p.nchunks * 16 * (long long)sizeof(ChanRec);
+  E2E_REQUIRE(ws != nullptr && ws_bytes >= need_all, "conv133 mm: workspace too small (%lld < %lld bytes)", ws_bytes, need_all);
+  p.wpk = reinterpret_cast<const unsigned char*>(ws);
+  int geom = mm_geom(W);
+  const int fwd_cin = mode == 0 ? P : Q, fwd_cout = mode == 0 ? Q : P;
+  if (!mm_fits(geom, B, fwd_cin, fwd_cout)) geom = 0;
+  const int th = geom == 1 ? 8 : (geom == 2 ? 4 : 16), tw = geom == 1 ? 64 : (geom == 2 ? 128 : 32);
+  p.tiles_x = W / tw; p.tiles_y = H / th;
+  p.tiles_per_n = D * p.tiles_y * p.tiles_x;
+  p.total = B * p.tiles_per_n * p.qblocks;
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+    if (ncu <= 0) ncu = 256;
+    ncu &= ~7;
+    if (ncu < 8) ncu = 8;
+  }
+  static const int grid_knob = getenv("E2E_MM_GRID") ? atoi(getenv("E2E_MM_GRID")) : 0;
+  int grid = grid_knob > 0 ? (grid_knob & ~7) : ncu;
+  const int padded = (p.total + 7) & ~7;
+  if (grid > padded) grid = padded;
+  p.grid = grid;
+  long long nel = (long long)p.qblocks * p.nchunks * 9 * 512;
+  ChanRec* crec = reinterpret_cast<ChanRec*>(reinterpret_cast<unsigned char*>(ws) + ((need + 63) & ~63ll));
+  p.crec = crec;
+  if (mode == 0 && nel < (long long)B * p.nchunks * 16) nel = (long long)B * p.nchunks * 16;
+  hipLaunchKernelGGL(pack_weights_h2_kernel, dim3((unsigned)e2e::cdivll(nel, 256)), dim3(256), 0, st, w, quads, reinterpret_cast<unsigned short*>(ws),
+                     P, Q, wq_stride, wp_stride, mode == 1 ? 1 : 0, p.nchunks, p.qblocks, mode == 0 ? chans : nullptr, crec, B);
+  e2e::note_kernel("conv133_mm_h2<mode=%d,tile=%dx%d> wgs=%d items=%d chunks=%d", mode, th, tw, grid, p.total, p.nchunks);
+#define MM_LAUNCH(M, G_) hipLaunchKernelGGL((conv133_mm_kernel<M, G_>), dim3(grid), dim3(512), 0, st, p)
+  if (mode == 0) { if (geom == 0) MM_LAUNCH(0, 0); else if (geom == 1) MM_LAUNCH(0, 1); else if (geom == 2) MM_LAUNCH(0, 2); else MM_LAUNCH(0, 3); }
+  else { if (geom == 0) MM_LAUNCH(1, 0); else if (geom == 1) MM_LAUNCH(1, 1); else if (geom == 2) MM_LAUNCH(1, 2); else MM_LAUNCH(1, 3); }
+#undef MM_LAUNCH
+#ifdef MM_STAMPS
+  if (getenv("E2E_MM_STAMPS")) {
+    (void)hipStreamSynchronize(st);
+    unsigned long long h[16], z[16] = {0};
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_mm_stamps), sizeof(h));
+    const double c = h[15] ? (double)h[15] : 1.0;
+    fprintf(stderr, "[conv133_mm mode %d P %d Q %d] cycles per chunk: staging wave: dma %.0f ctab %.0f stage %.0f (prepare %.0f rounds %.0f, round 0: %.0f) vmcnt %.0f barrier %.0f | matrix wave: mma %.0f lgkm %.0f barrier %.0f epilogue %.0f\n",
+            mode, P, Q, h[0] / c, h[1] / c, h[3] / c, h[6] / c, h[7] / c, h[2] / c, h[4] / c, h[5] / c, h[8] / c, h[9] / c, h[10] / c, h[11] / c);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mm_stamps), z, sizeof(z));
+  }
+#endif
+  return e2e::check_launch("conv133_mm_kernel");
+}
+
+extern "C" int e2e_conv133_fwd_mm(const e2e_in_chan_t* chans, int Cin, const float* w, const float* bias, const unsigned* live, float* y, double* part,
+                                  int B, int Cout, int Di, int Hi, int Wi, void* ws, long long ws_bytes, void* stream) {
+  E2E_REQUIRE(chans && w && y, "conv133_fwd_mm: null pointer");
+  E2E_REQUIRE(e2e_conv133_mm_ws_bytes(B, Cin, Cout, Di, Hi, Wi, 1, 1, 1) > 0, "conv133_fwd_mm: shape not served (stride 1, W %% 32 == 0, H %% 16 == 0, 17..320 channels)");
+  return mm_launch(0, chans, nullptr, nullptr, w, live, bias, y, part, nullptr, B, Cin, Cout, Di, Hi, Wi, Cin * 9, 9, ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int e2e_conv133_dgrad_mm(const float* dy, const unsigned* dy_absmax, const float* w, const unsigned* live_t, const e2e_out_chan_t* outs, int B,
+                                    int Cin, int Cout, int Di, int Hi, int Wi, void* ws, long long ws_bytes, void* stream) {
+  E2E_REQUIRE(dy && w && outs, "conv133_dgrad_mm: null pointer");
+  E2E_REQUIRE(e2e_conv133_mm_ws_bytes(B, Cin, Cout, Di, Hi, Wi, 1, 1, 1) > 0, "conv133_dgrad_mm: shape not served");
+  // the forward kernel with transposed, tap-reversed weights: its "input planes" are dy's Cout channels, its output planes the
+  // Cin virtual-concat channels (weight element [q = c][p = o][tap] = w[o][c][8 - tap])
+  return mm_launch(1, nullptr, dy, dy_absmax, w, live_t, nullptr, nullptr, nullptr, outs, B, Cout, Cin, Di, Hi, Wi, 9, Cin * 9, ws, ws_bytes, (hipStream_t)stream);
+}

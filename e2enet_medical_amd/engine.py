@@ -47,7 +47,10 @@ def _lane_divs(voxels):
 # 2: also the load-balanced conv data gradient (measured: +1.4 ms on those launches against -1.0 ms of in_bwd_reduce: a loss); 0: off
 FUSE_IN_SUMS = int(os.environ.get("E2E_FUSE_IN_SUMS", "1"))
 SPARSE2 = os.environ.get("E2E_CONV_SPARSE2", "1") != "0"         # load-balanced kernel for the DSFF-masked full-resolution layers
-DENSE_ENABLED = True          # tests switch the matrix-core conv path off to compare the sparse walk with itself
+DENSE_ENABLED = True          # tests switch the matrix-core conv paths off to compare the sparse walk with itself
+# fp16 two-piece matrix-pipe conv (conv133_mm.hip, round 5) for every layer it serves whose kernel map is at least this dense
+# (0: all of them -- measured faster than the sparse walk down to density 0.1); E2E_CONV_MM=0 switches the path off in the library
+MM_MIN_DENSITY = float(os.environ.get("E2E_MM_MIN_DENSITY", "0.0"))
 
 
 def shift_amounts(num_channels: int, shift_size: int = 5):
@@ -242,6 +245,8 @@ class ConvOp:
         self.sp_fwd = self.sp_bwd = None
         if km is None or not self.sparse_ok or not SPARSE2:
             return
+        if DENSE_ENABLED and self.mm_ws_bytes > 0 and float(km.float().mean()) >= MM_MIN_DENSITY:
+            return                                          # this layer runs on the matrix pipe (conv133_mm.hip): no walk, no plan
         kh = km.detach().to("cpu", torch.uint8).numpy()
         dev = self.eng.device
         self.sp_fwd = SparsePlan(kh, False, dev)
@@ -285,6 +290,13 @@ class ConvOp:
                 sp.insum = _upload_structs(rows, self.eng.device)
         return sp.table
 
+    def use_mm(self):
+        """fp16 two-piece matrix-pipe kernel (conv133_mm.hip): stride-1 layers of the 16 x 32 tile class with 17..320 channels,
+        DSFF-masked or not (the mask is packed into the weights)."""
+        if not DENSE_ENABLED or self.mm_ws_bytes <= 0 or getattr(self.eng, "fwd_ws", None) is None:
+            return False
+        return self.live is None or self.density >= MM_MIN_DENSITY
+
     def use_dense(self):
         """Dense layers (no DSFF map, or a map too dense for the kernel-granular sparse walk to pay) run on the bf16 matrix
         pipe (conv133_dense.hip: fp32-exact three-piece operands) where the shape is served; E2E_DENSE_MIN_DENSITY moves the
@@ -301,7 +313,11 @@ class ConvOp:
         sd, sh, sw = self.stride
         L = lib()
         ws = getattr(e, "fwd_ws", None)
-        if self.use_dense():
+        if self.use_mm():
+            L.conv133_fwd_mm(self.chans.data_ptr(), self.cin, p[self.w_name].data_ptr(), p[self.prefix + ".conv.bias"].data_ptr(),
+                             _ptr(self.live), self.out.data.data_ptr(), self.part.data_ptr(), b, self.cout, di, hi, wi, ws.data_ptr(),
+                             ws.numel() * 4, _stream())
+        elif self.use_dense():
             L.conv133_fwd_dense(self.chans.data_ptr(), self.cin, p[self.w_name].data_ptr(), p[self.prefix + ".conv.bias"].data_ptr(),
                                 _ptr(self.live), self.out.data.data_ptr(), self.part.data_ptr(), b, self.cout, di, hi, wi, ws.data_ptr(),
                                 ws.numel() * 4, _stream())
@@ -347,7 +363,10 @@ class ConvOp:
             self._wgrad(e, L, g, o, b, di, hi, wi, sd, sh, sw, o.data.numel())
         if self.do_dgrad:
             ws = getattr(e, "fwd_ws", None)
-            if self.use_dense():
+            if self.use_mm():
+                L.conv133_dgrad_mm(o.grad.data_ptr(), self.dy_absmax.data_ptr(), p[self.w_name].data_ptr(), _ptr(self.live_t), self.outs.data_ptr(),
+                                   b, self.cin, self.cout, di, hi, wi, ws.data_ptr(), ws.numel() * 4, _stream())
+            elif self.use_dense():
                 L.conv133_dgrad_dense(o.grad.data_ptr(), p[self.w_name].data_ptr(), _ptr(self.live_t), self.outs.data_ptr(), b, self.cin, self.cout,
                                       di, hi, wi, ws.data_ptr(), ws.numel() * 4, _stream())
             elif self.sp_bwd is not None:
@@ -384,6 +403,13 @@ class ConvOp:
             di, hi, wi = self.in_dims
             self._dense_ws_bytes = int(lib().conv133_dense_ws_bytes(self.out.shape[0], self.cin, self.cout, di, hi, wi, *self.stride))
         return self._dense_ws_bytes
+
+    @property
+    def mm_ws_bytes(self):
+        if not hasattr(self, "_mm_ws_bytes"):
+            di, hi, wi = self.in_dims
+            self._mm_ws_bytes = int(lib().conv133_mm_ws_bytes(self.out.shape[0], self.cin, self.cout, di, hi, wi, *self.stride))
+        return self._mm_ws_bytes
 
     @property
     def dgrad_ws_bytes(self):
@@ -581,7 +607,7 @@ class Engine:
         self.loss_ws = None
         self.loss_val = None
         self.generation = 0                # bumped by every forward(): activations are reused in place
-        fws = max([max(op.fwd_ws_bytes, op.dgrad_ws_bytes if op.do_dgrad else 0, op.dense_ws_bytes) for op in self.conv_ops.values()] + [0])
+        fws = max([max(op.fwd_ws_bytes, op.dgrad_ws_bytes if op.do_dgrad else 0, op.dense_ws_bytes, op.mm_ws_bytes) for op in self.conv_ops.values()] + [0])
         # split-K partial sums (deep levels) / packed weights of the matrix-core conv; one per lane (see _exec)
         self.lane_divs = _lane_divs(batch * self.patch[0] * self.patch[1] * self.patch[2])
         nl = len(self.lane_divs) + 1
@@ -738,7 +764,9 @@ class Engine:
     def _pack_sparse(self):
         """packed weights of the planned convs (one launch): the weights may have moved since the last pass"""
         if self._sparse_jobs is None:
-            jobs = [j for op in self.conv_ops.values() if not op.use_dense() for j in op.sparse_jobs()]
+            # (every op that HAS a plan, whatever kernel it is dispatched to right now: a cached job table must not depend on a
+            #  dispatch decision that tests and knobs can flip afterwards -- its packed weights would silently stay zero)
+            jobs = [j for op in self.conv_ops.values() for j in op.sparse_jobs()]
             self._sparse_jobs = pack_sparse_weights(jobs, self.device) or ()
         if self._sparse_jobs:
             table, n, mx = self._sparse_jobs

@@ -169,6 +169,19 @@ int e2e_conv133_dgrad_sparse(const float* dy, const float* wpk_t, const unsigned
                              const int* pslot_t, const e2e_out_chan_t* outs_plan, const e2e_in_sum_chan_t* insum_plan /* [groups][32] or NULL */,
                              int flush_every, int B, int Cin, int Cout, int Di, int Hi, int Wi, void* stream);
 
+/* ---- K1m (round 5): the same operators as e2e_conv133_fwd / e2e_conv133_dgrad (unetpp_d.py:45-59, :453-478, :93/:108 and their
+ * autograd; DSFF-pruned kernels contribute nothing: they are packed as zeros from `live`, core_channel.py:427-434) as a GEMM on the
+ * fp16 matrix pipe with fp32-exact two-piece operands (three matrix products per fp32 product; conv133_mm.hip) -- every stride-1
+ * layer with Wi % 32 == 0, Hi % 16 == 0, Hi > 16 and 17..320 channels on both sides, masked or not.
+ *   ws          workspace of e2e_conv133_mm_ws_bytes(...) bytes (0: shape not served): the packed weights, rebuilt at every launch
+ *   dy_absmax   NULL, or the word e2e_in_lrelu_bwd(dy_absmax) left behind for this dy: its power-of-two scale (without it dy is
+ *               taken as it is: only for O(1) test data -- full-resolution gradients of 1e-7 are below the fp16 range) */
+long long e2e_conv133_mm_ws_bytes(int B, int Cin, int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw);
+int e2e_conv133_fwd_mm(const e2e_in_chan_t* chans, int Cin, const float* w, const float* bias, const unsigned* live, float* y, double* part,
+                       int B, int Cout, int Di, int Hi, int Wi, void* ws, long long ws_bytes, void* stream);
+int e2e_conv133_dgrad_mm(const float* dy, const unsigned* dy_absmax, const float* w, const unsigned* live_t, const e2e_out_chan_t* outs, int B,
+                         int Cin, int Cout, int Di, int Hi, int Wi, void* ws, long long ws_bytes, void* stream);
+
 /* ---- K6b: 1x3x3 convolution, weight gradient (dense: also for dead kernels, because the
  * reference's clip_grad_norm_ runs over all gradients, nnUNetTrainer_simple.py:573) ----
  *   dw   [Cout,Cin,1,3,3] (overwritten)

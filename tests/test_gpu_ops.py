@@ -83,10 +83,14 @@ CONV_CASES = [
     (2, [(20, True), (13, False)], 34, (3, 9, 20), (1, 1, 1), 1.0),          # ragged tile rows and columns, 33 + 34 channels, depth shifts
     (1, [(40, True)], 33, (2, 16, 16), (1, 1, 1), 0.3),                      # whole tiles, two channel blocks each side
     (1, [(33, True)], 34, (3, 24, 28), (1, 1, 1), 1.0),                      # 28-wide planes: second tile column ragged
-    # dense matrix-core path (conv133_dense.hip: stride 1, W % 32 == 0, H % 16 == 0, >= 16 channels, dense or density >= 0.5)
+    # matrix-pipe paths (conv133_mm.hip: stride 1, W % 32 == 0, H % 16 == 0, 17..320 channels, any density; with E2E_CONV_MM=0
+    # conv133_dense.hip where dense or density >= 0.5)
     (1, [(32, True)], 32, (6, 32, 64), (1, 1, 1), 1.0),
     (2, [(20, True), (28, False)], 40, (3, 32, 32), (1, 1, 1), 1.0),         # ragged channel blocks (48 -> 40), two sources, shift
     (1, [(16, True), (16, False), (8, False)], 64, (7, 48, 96), (1, 1, 1), 0.6),   # DSFF map dense enough for the dense kernel
+    (2, [(40, True), (30, False)], 70, (3, 32, 64), (1, 1, 1), 0.2),         # 70 -> 70: ragged chunks and out-channel blocks both ways, depth shifts, d = 0.2
+    (1, [(100, True), (100, False), (100, False), (20, False)], 33, (2, 32, 32), (1, 1, 1), 0.1),   # 320 -> 33: twenty chunks, one tile per slice
+    (1, [(24, True)], 24, (9, 48, 32), (1, 1, 1), 1.0),                      # more items than a workgroup's first round on a small grid (E2E_MM_GRID)
 ]
 
 
@@ -165,8 +169,8 @@ def test_conv133_fwd_bwd(case):
     e = _eng_stub(params)
     e.batch = B
     op = ConvOp(e, "blk", srcs, cout, stride)
-    if op.dense_ws_bytes > 0:
-        e.fwd_ws = torch.empty(op.dense_ws_bytes // 4, dtype=torch.float32, device=e.device)
+    if max(op.dense_ws_bytes, op.mm_ws_bytes) > 0:
+        e.fwd_ws = torch.empty(max(op.dense_ws_bytes, op.mm_ws_bytes) // 4, dtype=torch.float32, device=e.device)
     if km is not None:
         rows = torch.empty(((cout + 3) // 4) * ((cin + 7) // 8), dtype=torch.int32, device=e.device)
         cols = torch.empty(((cin + 3) // 4) * ((cout + 7) // 8), dtype=torch.int32, device=e.device)
@@ -175,8 +179,10 @@ def test_conv133_fwd_bwd(case):
         op.live, op.live_t = rows, cols
         op.density = float(km.float().mean())
         _plan_and_pack(op, km)                      # load-balanced kernel where the shape is served (conv133_sparse.hip)
-    if dims[2] % 32 == 0 and dims[1] % 16 == 0 and dims[1] > 16 and stride == (1, 1, 1) and cin >= 16 and cout >= 16 and density >= 0.5 \
-            and os.environ.get("E2E_CONV_DENSE", "1") != "0":
+    tile_class = dims[2] % 32 == 0 and dims[1] % 16 == 0 and dims[1] > 16 and stride == (1, 1, 1)
+    if tile_class and cin > 16 and cout > 16 and os.environ.get("E2E_CONV_MM", "1") != "0":
+        assert op.use_mm(), "this case is meant to reach conv133_mm_kernel"
+    elif tile_class and cin >= 16 and cout >= 16 and density >= 0.5 and os.environ.get("E2E_CONV_DENSE", "1") != "0":
         assert op.use_dense(), "this case is meant to reach conv133_dense_kernel"
     op.forward()
     torch.cuda.synchronize()
@@ -503,13 +509,15 @@ def test_conv133_persistent_run_loop_forced():
     assert "passed" in r.stdout
 
 
-@pytest.mark.parametrize("env", [{"E2E_WG_H2": "0"}, {"E2E_WG_BF3": "0"}])
+@pytest.mark.parametrize("env", [{"E2E_WG_H2": "0"}, {"E2E_WG_BF3": "0"}, {"E2E_CONV_MM": "0"}, {"E2E_MM_GRID": "8"}])
 def test_conv133_wgrad_alternative_paths_forced(env):
     """The dense weight gradient of stride-1 planes at least 16 voxels wide runs on the matrix pipe with split fp32 operands
     (conv133_wgrad_bf3v5_kernel<G, NPC>): by default on fp16 two-piece operands (three products), scaled from the max |dy| that
     e2e_in_lrelu_bwd records.  E2E_WG_H2=0 keeps the bf16 three-piece form (six products; also what a caller without the recorded
-    maximum gets), E2E_WG_BF3=0 the fp32-MFMA kernels.  The knobs are read once per process: run the operator cases again in a
-    child process."""
+    maximum gets), E2E_WG_BF3=0 the fp32-MFMA kernels.  E2E_CONV_MM=0: forward / data gradient of the 16 x 32 tile class on the
+    round-4 kernels (sparse plan walk, bf16x3 dense kernel) instead of conv133_mm_kernel; E2E_MM_GRID=8: that kernel as eight
+    persistent workgroups (long item runs per workgroup: every pipeline transition).  The knobs are read once per process: run the
+    operator cases again in a child process."""
     import subprocess
     import sys
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
@@ -539,7 +547,7 @@ def _heavy_tailed(shape, seed, scale):
 def test_conv133_wgrad_h2_and_bf3_vs_fp64(tag, B, src_desc, cout, dims):
     """Both operand formats of the matrix-pipe weight gradient against an fp64 evaluation, on a dy of realistic magnitudes
     (heavy-tailed, 1e-7: below the fp16 range unscaled).  fp16 two-piece (three products, scaled from max |dy|) and bf16
-    three-piece (six products) must both be within 3e-7 of sum |dy x| per entry (measured 0.4-0.8e-7 rms) and the fp16 form no
+    three-piece (six products) must be within 6e-7 / 3e-7 of sum |dy x| per entry (measured 0.4-0.8e-7 rms) and the fp16 form no
     further than 1.5x the bf16 form's rms; and because the scale is an exact power of two taken from the data, the fp16 result of
     2^-20 dy is 2^-20 times the result of dy, bit for bit."""
     from e2enet_medical_amd.engine import ConvOp
@@ -579,7 +587,9 @@ def test_conv133_wgrad_h2_and_bf3_vs_fp64(tag, B, src_desc, cout, dims):
         assert torch.isfinite(got).all(), name
         err = (got.double() - ref) / mag
         rms[name] = float(err.pow(2).mean().sqrt())
-        assert float(err.abs().max()) < 3e-7, (name, float(err.abs().max()))
+        # (an entry dominated by ONE product sees that product's own error: the dropped lo*lo term, <= 2^-22, plus two operand
+        #  roundings of <= 2^-23 each -- 4.8e-7 for the fp16 form; the truncating bf16 splits drop up to 2^-22 as well)
+        assert float(err.abs().max()) < 6e-7, (name, float(err.abs().max()))
         assert float((got.double() - ref).norm() / ref.norm()) < 2e-6, name
     assert rms["h2"] <= 1.5 * rms["bf3"] + 1e-9, rms
     print("wgrad %s: err / sum|dy x| rms h2 %.2e bf3 %.2e" % (tag, rms["h2"], rms["bf3"]))

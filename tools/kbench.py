@@ -76,6 +76,18 @@ def conv_case(B, srcs, cout, dims, stride, density, tag):
     if density < 1.0:
         op.density = float(km.float().mean())
     dense_path = op.use_dense() and os.environ.get("KB_NO_DENSE") is None
+    mm_path = op.mm_ws_bytes > 0 and os.environ.get("KB_NO_MM") is None
+    if mm_path:
+        e.fwd_ws = torch.empty(max(op.mm_ws_bytes, op.dense_ws_bytes) // 4, dtype=torch.float32, device=dev)
+
+    def fwd_mm():
+        L.conv133_fwd_mm(op.chans.data_ptr(), cin, w.data_ptr(), p["b.conv.bias"].data_ptr(),
+                         op.live.data_ptr() if op.live is not None else None, op.out.data.data_ptr(), op.part.data_ptr(),
+                         B, cout, di, hi, wi, e.fwd_ws.data_ptr(), e.fwd_ws.numel() * 4, 0)
+
+    def dgrad_mm():
+        L.conv133_dgrad_mm(op.out.grad.data_ptr(), amax.data_ptr(), w.data_ptr(), op.live_t.data_ptr() if op.live_t is not None else None, op.outs.data_ptr(),
+                           B, cin, cout, di, hi, wi, e.fwd_ws.data_ptr(), e.fwd_ws.numel() * 4, 0)
 
     def fwd_dense():
         L.conv133_fwd_dense(op.chans.data_ptr(), cin, w.data_ptr(), p["b.conv.bias"].data_ptr(),
@@ -110,7 +122,7 @@ def conv_case(B, srcs, cout, dims, stride, density, tag):
                                op._bwd_table().data_ptr(), None, sp.flush_every, B, cin, cout, di, hi, wi, 0)
     dense = 2.0 * 9 * cin * cout * (vout / cout)
     res = {}
-    if density < 1.0 and not dense_path and os.environ.get("KB_OLD") is None:      # load-balanced kernel (conv133_sparse.hip)
+    if density < 1.0 and not dense_path and not mm_path and os.environ.get("KB_OLD") is None:      # load-balanced kernel (conv133_sparse.hip)
         from e2enet_medical_amd.engine import pack_sparse_weights
         op.build_sparse_plans(km)
         jobs = op.sparse_jobs()
@@ -123,6 +135,9 @@ def conv_case(B, srcs, cout, dims, stride, density, tag):
     if dense_path:
         fwd, dgrad = fwd_dense, dgrad_dense
         tag = tag + "[dense]"
+    if mm_path:
+        fwd, dgrad = fwd_mm, dgrad_mm
+        tag = tag.replace("[dense]", "") + "[mm]"
     for name, fn, flops in (("fwd", fwd, dense * density), ("dgrad", dgrad, dense * density), ("wgrad", wgrad, dense)):
         ms = time_ms(fn)
         gbs = (vin + vout) * 4 / ms / 1e6
