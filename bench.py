@@ -507,8 +507,8 @@ def main():
 
     # ---- instrumented steps (outside the timed region): HIP events around the conv entry points --------------------
     # (_splitk: the deep levels' forward / data gradient, same kernel + a sum kernel; _dense: the unmasked layers on the matrix cores)
-    names = ["conv133_fwd", "conv133_fwd_splitk", "conv133_fwd_dense", "conv133_fwd_sparse", "conv133_dgrad", "conv133_dgrad_splitk",
-             "conv133_dgrad_dense", "conv133_dgrad_sparse", "conv133_sparse_pack", "conv133_wgrad"]
+    names = ["conv133_fwd", "conv133_fwd_splitk", "conv133_fwd_dense", "conv133_fwd_sparse", "conv133_fwd_mm", "conv133_dgrad", "conv133_dgrad_splitk",
+             "conv133_dgrad_dense", "conv133_dgrad_sparse", "conv133_dgrad_mm", "conv133_sparse_pack", "conv133_wgrad"]
     if args.op_profile:
         names += ["in_stats_finalize", "in_lrelu_bwd", "convT_fwd", "convT_dgrad", "convT_wgrad", "maxpool_fwd", "maxpool_bwd",
                   "head1x1_fwd", "head1x1_dgrad", "head1x1_wgrad", "dc_ce_reduce", "dc_ce_grad", "grad_sqnorm", "sgd_clip_mask_step"]
@@ -557,7 +557,8 @@ def main():
             out["metric"] = "voxels/sec (inference forward only), 128^3 patch 32ch density=0.2"
         work = conv_work(eng, mask)
         ev = [(e0.elapsed_time(e1), work[a[0]]) for e0, e1, a in timers["conv133_fwd"].events + timers["conv133_fwd_splitk"].events +
-              timers["conv133_fwd_dense"].events + timers["conv133_fwd_sparse"].events]
+              timers["conv133_fwd_dense"].events + timers["conv133_fwd_sparse"].events + timers["conv133_fwd_mm"].events]
+        ev += [(e0.elapsed_time(e1), work[a[4]]) for e0, e1, a in timers["conv133_dgrad_mm"].events]
         ev += [(e0.elapsed_time(e1), work[a[6]]) for e0, e1, a in timers["conv133_dgrad_sparse"].events]
         pack_ms = timers["conv133_sparse_pack"].total_ms()            # weight packing of the planned layers: counted with the family
         ev += [(e0.elapsed_time(e1), work[a[3]]) for e0, e1, a in timers["conv133_dgrad"].events + timers["conv133_dgrad_splitk"].events]
@@ -568,12 +569,13 @@ def main():
             fl = sum(w["flops_live"] for _, w in ev)
             gbs = byt / (ms * 1e-3) / 1e9
             out["roofline"] = {
-                "bound": "hbm", "kernel": "conv133_sparse_kernel + conv133_kernel + conv133_dense_kernel: every launch of e2e_conv133_fwd* and "
-                                          "e2e_conv133_dgrad* (depth shift + concat + 1x3x3 conv, forward and data gradient; DSFF-masked "
-                                          "layers on the sparse VALU walk -- load-balanced plan at full resolution -- incl. their weight "
-                                          "packing launch, unmasked layers on the bf16 matrix pipe with fp32-exact operands)",
+                "bound": "hbm", "kernel": "conv133_mm_kernel + conv133_kernel (+ conv133_sparse_kernel / conv133_dense_kernel where "
+                                          "E2E_CONV_MM=0 or a shape is not served): every launch of e2e_conv133_fwd* and e2e_conv133_dgrad* "
+                                          "(depth shift + concat + 1x3x3 conv, forward and data gradient; stride-1 layers of the 16x32 tile "
+                                          "class, DSFF-masked or not, as a persistent GEMM on the fp16 matrix pipe with fp32-exact two-piece "
+                                          "operands incl. its weight-packing launch; strided convs and planes <= 16 wide on the vector walk)",
                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                "traffic": pmc_traffic("conv133_kernel", "conv133_dense_kernel", "conv133_sparse_kernel"),
+                "traffic": pmc_traffic("conv133_kernel", "conv133_dense_kernel", "conv133_sparse_kernel", "conv133_mm_kernel"),
                 "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" % TRAFFIC_FILE,
                 "algorithmic_bytes_per_launch": byt / len(ev), "launches_per_step": len(ev) // isteps,
                 "avg_ms": ms / len(ev), "ms_per_step": ms / isteps, "share_of_step": (ms / isteps) / ms_step,
@@ -590,12 +592,13 @@ def main():
             fl = sum(work[a[0]]["flops_dense"] for _, _, a in wt.events)
             tf = fl / (ms * 1e-3) / 1e12
             out["roofline_secondary"] = {
-                "bound": "mfma", "kernel": "conv133_wgrad_bf3v5 (bf16 MFMA, six bf16 products per fp32 product) / v2 / s2 / smallc (fp32 MFMA) "
-                                           "+ slab reduce: every launch of e2e_conv133_wgrad (dense weight gradient)",
-                "achieved": tf, "peak": BF16_PEAK_TF / 6.0, "unit": "TFLOP/s", "frac": tf / (BF16_PEAK_TF / 6.0),
-                "note": "fp32-equivalent dense FLOPs / time; peak = the dense bf16 MFMA peak (2500 TFLOP/s) / 6, the rate an fp32 "
-                        "product rebuilt from six bf16 products can reach; against the fp32 MFMA / vector peak (157.3) the fraction "
-                        "is %.3f" % (tf / FP32_PEAK_TF),
+                "bound": "mfma", "kernel": "conv133_wgrad_bf3v5<G, 2> (fp16 MFMA, three fp16 products per fp32 product) / v2 / s2 / smallc "
+                                           "(fp32 MFMA) + slab reduce: every launch of e2e_conv133_wgrad (dense weight gradient)",
+                "achieved": tf, "peak": BF16_PEAK_TF / 3.0, "unit": "TFLOP/s", "frac": tf / (BF16_PEAK_TF / 3.0),
+                "note": "fp32-equivalent dense FLOPs / time; peak = the dense fp16 / bf16 MFMA peak (2500 TFLOP/s) / 3, the rate an fp32 "
+                        "product rebuilt from three fp16 products can reach (rounds 3-4: six bf16 products, peak / 6 = 416.7 -- against "
+                        "that denominator this is %.3f); against the fp32 MFMA / vector peak (157.3) the fraction is %.3f"
+                        % (tf / (BF16_PEAK_TF / 6.0), tf / FP32_PEAK_TF),
                 "traffic": pmc_traffic("conv133_wgrad"),
                 "algorithmic_bytes_per_launch": sum(work[a[0]]["bytes"] for _, _, a in wt.events) / len(wt.events),
                 "launches_per_step": len(wt.events) // isteps,

@@ -245,8 +245,6 @@ class ConvOp:
         self.sp_fwd = self.sp_bwd = None
         if km is None or not self.sparse_ok or not SPARSE2:
             return
-        if DENSE_ENABLED and self.mm_ws_bytes > 0 and float(km.float().mean()) >= MM_MIN_DENSITY:
-            return                                          # this layer runs on the matrix pipe (conv133_mm.hip): no walk, no plan
         kh = km.detach().to("cpu", torch.uint8).numpy()
         dev = self.eng.device
         self.sp_fwd = SparsePlan(kh, False, dev)
@@ -763,13 +761,14 @@ class Engine:
 
     def _pack_sparse(self):
         """packed weights of the planned convs (one launch): the weights may have moved since the last pass"""
-        if self._sparse_jobs is None:
-            # (every op that HAS a plan, whatever kernel it is dispatched to right now: a cached job table must not depend on a
-            #  dispatch decision that tests and knobs can flip afterwards -- its packed weights would silently stay zero)
-            jobs = [j for op in self.conv_ops.values() for j in op.sparse_jobs()]
-            self._sparse_jobs = pack_sparse_weights(jobs, self.device) or ()
-        if self._sparse_jobs:
-            table, n, mx = self._sparse_jobs
+        # the job table is cached under the dispatch decisions it was built for (advisor, round 4: a table built while an op went to a
+        # matrix-pipe kernel left that op's packed weights zero when tests / knobs sent it to the planned walk afterwards)
+        key = tuple(op.use_mm() or op.use_dense() for op in self.conv_ops.values())
+        if self._sparse_jobs is None or self._sparse_jobs[0] != key:
+            jobs = [j for op in self.conv_ops.values() if not (op.use_mm() or op.use_dense()) for j in op.sparse_jobs()]
+            self._sparse_jobs = (key, pack_sparse_weights(jobs, self.device) or ())
+        if self._sparse_jobs[1]:
+            table, n, mx = self._sparse_jobs[1]
             lib().conv133_sparse_pack(table.data_ptr(), n, mx, _stream())
 
     def _forward_ops(self):

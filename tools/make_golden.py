@@ -356,6 +356,44 @@ def gen_net_amos():
     np.savez_compressed(os.path.join(OUT, "net_amos.npz"), **out)
 
 
+def gen_net_w48():
+    """Width 48 -- the width the reference trainer hard-codes (nnUNetTrainer_simple.py:296) -- end to end: 64^3 patch, 4 modalities,
+    4 classes, DSFF density 0.2 (random.seed(0); includes the `shape[0] == 48 => density 0.2` quirk of Masking.init), closed-form
+    weights: forward with deep supervision + loss + backward.  Channel counts 48 / 96 / 192 / 320, concats of 96 / 144 / 240 / 480 ...:
+    ragged 32-blocks in every matrix-pipe kernel."""
+    pools = [[2, 2, 2]] * 5
+    out = {}
+    x = seeded_input((1, 4, 64, 64, 64), seed=241)
+    net = build_ref_net((64, 64, 64), 4, 48, 4, pools)
+    shapes = load_closed_form(net)
+    mask, _ = make_masking(net, density=0.2, seed=0)
+    outs = net(x)
+    targets = [seeded_labels((o.shape[0], 1) + tuple(o.shape[2:]), 4, seed=250 + i) for i, o in enumerate(outs)]
+    loss = _ds_loss()(outs, targets)
+    loss.backward()
+    out["loss"] = np.float64(loss.item())
+    out["out_shapes"] = np.array([list(o.shape) for o in outs])
+    for i, o in enumerate(outs):
+        od = o.detach().double()
+        out["sum%d" % i] = np.float64(od.sum().item())
+        out["abs%d" % i] = np.float64(od.abs().sum().item())
+    out["slice_d31"] = outs[0].detach().numpy()[0, :, 31, ::2, ::2]
+    out["slice_h7"] = outs[0].detach().numpy()[0, :, ::2, 7, ::2]
+    out["logits2"] = outs[2].detach().numpy()
+    out["logits3"] = outs[3].detach().numpy()
+    names = list(shapes.keys())
+    out["names"] = np.array(names)
+    out["grad_l2"] = np.array([net.get_parameter(n).grad.double().norm().item() for n in names])
+    for n in ("conv_blocks_context.0.blocks.0.conv.weight", "loc0.4.1.blocks.0.conv.weight", "loc1.2.0.blocks.0.conv.weight", "up0.4.weight",
+              "up2.0.weight", "seg_outputs.0.weight", "loc2.0.0.blocks.0.instnorm.weight"):
+        g = net.get_parameter(n).grad.numpy()
+        out["grad::" + n] = g[:8] if g.ndim > 1 else g
+    out["mask_names"] = np.array(list(mask.masks.keys()))
+    out["mask_sha"] = np.array([sha_of(pack_kernel_mask(m)) for m in mask.masks.values()])
+    out["mask_nnz"] = np.array([int(m.sum().item()) for m in mask.masks.values()])
+    np.savez_compressed(os.path.join(OUT, "net_w48.npz"), **out)
+
+
 def gen_masks():
     """Initial uniform masks at the BASELINE widths + death-rate schedule + L1 association order."""
     out = {}
@@ -675,7 +713,7 @@ def gen_dataloader():
 
 
 ALL = dict(dataloader=gen_dataloader, export=gen_export, shift=gen_shift, block=gen_block, net=gen_net_tiny, sparse=gen_net_sparse_tiny, net64=gen_net64,
-           hippo=gen_net_hippo, amos=gen_net_amos,
+           hippo=gen_net_hippo, amos=gen_net_amos, w48=gen_net_w48,
            variants=gen_net_variants, nodff=gen_net_nodff, masks=gen_masks, loss=gen_loss, sliding=gen_sliding, dice=gen_dice, init=gen_init)
 
 if __name__ == "__main__":
