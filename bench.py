@@ -365,6 +365,7 @@ def launch_ranks(n, argv):
     reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
     reader.start()
     rc = 0
+    deadline = float("inf")
     alive = set(range(n))
     while alive:
         for r in sorted(alive):
@@ -377,6 +378,13 @@ def launch_ranks(n, argv):
                 sys.stderr.write("bench.py: rank %d exited with code %d, stopping the other ranks\n" % (r, code))
                 for o in alive:
                     procs[o].terminate()
+                deadline = time.time() + 15.0                # a rank stuck inside a collective or a kernel may not honour SIGTERM
+        if rc != 0 and alive and time.time() > deadline:
+            for o in alive:
+                procs[o].kill()
+            for o in alive:
+                procs[o].wait()
+            alive.clear()
         time.sleep(0.05)
     reader.join(timeout=10)
     if chunks and chunks[0]:

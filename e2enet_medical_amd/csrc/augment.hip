@@ -88,7 +88,8 @@ __device__ __forceinline__ double bspline3_at(const float* __restrict__ c, int D
 #define BSPLINE_POLE (-0.26794919243112270647)
 
 // strided axis (D or H): one thread per line, neighbouring threads on neighbouring inner positions (coalesced)
-__global__ __launch_bounds__(256) void bspline_prefilter_strided_kernel(const float* __restrict__ src, float* __restrict__ dst,
+// (src and dst may be the same buffer: the low-resolution path filters in place -- no __restrict__)
+__global__ __launch_bounds__(256) void bspline_prefilter_strided_kernel(const float* src, float* dst,
                                                                         long long n_outer, int len, long long inner) {
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   if (t >= n_outer * inner) return;
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256) void bspline_prefilter_strided_kernel(const fl
 
 // contiguous axis (W): a block stages LPB lines in LDS (coalesced loads), one thread filters one line there, coalesced stores
 template <int LPB>
-__global__ __launch_bounds__(256) void bspline_prefilter_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
+__global__ __launch_bounds__(256) void bspline_prefilter_rows_kernel(const float* src, float* dst,
                                                                      long long n_lines, int len) {
   extern __shared__ float rows[];                       // [LPB][pitch], pitch odd: the LPB serial walkers hit distinct banks
   const int pitch = len | 1;
@@ -507,8 +508,9 @@ extern "C" int e2e_aug_bspline_prefilter_axis(const float* src, float* dst, int 
     if ((long long)64 * pitch * 4 <= 64 * 1024)
       hipLaunchKernelGGL((bspline_prefilter_rows_kernel<64>), dim3((unsigned)e2e::cdivll(lines, 64)), dim3(256), (size_t)64 * pitch * 4, st, src, dst, lines, W);
     else {
-      static bool attr = false;
-      if (!attr) { (void)hipFuncSetAttribute((const void*)bspline_prefilter_rows_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+      // (set before every such launch: a process-wide flag would leave the attribute unset on the other devices of the process)
+      E2E_REQUIRE(hipFuncSetAttribute((const void*)bspline_prefilter_rows_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
+                  "aug_bspline_prefilter_axis: cannot raise the dynamic LDS limit");
       hipLaunchKernelGGL((bspline_prefilter_rows_kernel<16>), dim3((unsigned)e2e::cdivll(lines, 16)), dim3(256), (size_t)16 * pitch * 4, st, src, dst, lines, W);
     }
     return e2e::check_launch("bspline_prefilter_rows_kernel");

@@ -77,7 +77,7 @@ template <int GEOM> struct Geo {
   static constexpr int SITEMS = SROWS * NG;        // (row, group) items per staging wave: at most two rounds of 64 lanes
   static constexpr int NF = (RPW + 2) * CB / 2;    // A fragments (row, column block) per half-phase
   static constexpr int CT_MAX = GEOM == 2 ? 256 : 320;      // reduction-side channels with an entry in the LDS channel table
-  static constexpr int LREC_MAX = GEOM == 2 ? 512 : 1024;   // forward: batch items x padded input channels held in LDS
+  static constexpr int LREC_MAX = GEOM == 2 ? 384 : (GEOM == 1 ? 768 : 1024);   // forward: batch items x padded input channels held in LDS
   static_assert(RPW * CB == 4 && SITEMS <= 128 && XR % 2 == 0, "geometry");
   // fragment j of half-phase `half`: halo'd row (relative to the wave's first) and column block
   static constexpr int frag_ir(int half, int j) { return GEOM == 2 ? j >> 1 : ((RPW + 2) / 2) * half + j / CB; }
@@ -88,8 +88,9 @@ constexpr int WTAP = 32 * 32;                    // one (tap, piece) block: 32 o
 constexpr int WCH = 9 * 2 * WTAP;                // one chunk of packed weights: 18 432 B
 constexpr int WUNITS = WCH / 16;                 // 1152 16-byte units
 constexpr int WSH = 8;                           // weights are packed as w 2^WSH
+constexpr int XSH = 3;                           // forward: activations are staged as x 2^XSH (lo piece normal down to |x| = 2^-6; Inf beyond 8188)
 template <int GEOM> constexpr int lds_bytes() {
-  return 2 * Geo<GEOM>::IMG + 2 * WCH + 2 * Geo<GEOM>::CT_MAX * 20 + Geo<GEOM>::LREC_MAX * 24 + 2 * 4 * 32 * 2 * 4;
+  return 2 * Geo<GEOM>::IMG + 2 * WCH + 2 * Geo<GEOM>::CT_MAX * 20 + Geo<GEOM>::LREC_MAX * 24 + 2 * 4 * 32 * 2 * 4 + 4 * 8 * 36 * 4;
 }
 static_assert(lds_bytes<0>() <= 160 * 1024 && lds_bytes<1>() <= 160 * 1024 && lds_bytes<2>() <= 160 * 1024 && lds_bytes<3>() <= 160 * 1024, "LDS budget");
 
@@ -171,8 +172,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   __shared__ __attribute__((aligned(16))) unsigned char lds_w[2 * WCH];
   __shared__ __attribute__((aligned(16))) CtEntry ctab[2][CT_MAX];
   __shared__ float cslope[2][CT_MAX];
-  __shared__ __attribute__((aligned(8))) ChanRec lrec[MODE == 0 ? LREC_MAX : 1];      // the launch's resolved input planes, all batch items
+  __shared__ __attribute__((aligned(8))) ChanRec lrec[MODE == 0 ? LREC_MAX : CT_MAX]; // forward: the launch's resolved input planes, all batch items;
+  static_assert(sizeof(ChanRec) == sizeof(e2e_out_chan_t), "the data gradient keeps its destination table in the same array");
+  const e2e_out_chan_t* const lout = reinterpret_cast<const e2e_out_chan_t*>(lrec);   // data gradient: the Q destination descriptors
   __shared__ float red[2][4][32][2];                       // (mean, M2) of 128 values per (item parity, matrix wave, out channel)
+  constexpr int TP = 36;                                   // floats per channel row of a transposition buffer: 32 pixels + 4
+  __shared__ __attribute__((aligned(16))) float tbuf[4][8 * TP];      // per matrix wave: one channel octet of one accumulator tile
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   };
 
   // dy scale of the data gradient: 2^k with max |dy| 2^k in [2^14, 2^15) (as conv133_wgrad_bf3.hip)
-  float xsc = 1.f, unsc = __builtin_bit_cast(float, (unsigned)(127 - WSH) << 23);
+  float xsc = 1.f, unsc = __builtin_bit_cast(float, (unsigned)(127 - WSH - (MODE == 0 ? XSH : 0)) << 23);
   if (MODE == 1 && p.x_absmax != nullptr) {
     int E = (int)((__builtin_nontemporal_load(p.x_absmax) >> 23) & 0xffu);
     E = E < 1 ? 1 : E;
@@ -223,6 +228,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (MODE == 0) {
     const int nrec = p.B * p.nchunks * 16;
     for (int i = tid; i < nrec; i += 512) lrec[i] = p.crec[i];
+  } else {
+    for (int i = tid; i < p.Q; i += 512) reinterpret_cast<e2e_out_chan_t*>(lrec)[i] = p.outs[i];
   }
   if (FULLW)                                                  // full-width tiles: the halo columns are zero padding, never written again
     for (int i = tid; i < 2 * IMG / 16; i += 512) reinterpret_cast<u32x4_t*>(lds_x)[i] = u32x4_t{0u, 0u, 0u, 0u};
@@ -238,8 +245,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const ChanRec r = lrec[it.n * np16 + ch];
         const int din = it.d - r.dshift;
         const bool valid = (unsigned)din < (unsigned)p.D;
-        e.a = valid ? r.a : 0.f;
-        e.b = valid ? r.b : 0.f;
+        e.a = valid ? r.a * (float)(1 << XSH) : 0.f;           // (LeakyReLU commutes with the positive pre-scale)
+        e.b = valid ? r.b * (float)(1 << XSH) : 0.f;
         sv = r.slope;
         e.ptr = r.ptr + (unsigned long long)(valid ? din : 0) * (unsigned long long)plane * 4ull;
       } else {
@@ -445,6 +452,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   // =================================================== matrix waves ===========================================================
   const int wr = wave;                                        // tile rows RPW wr .. RPW wr + RPW - 1, all CB column blocks
+  float* const tb = tbuf[wr];
   const int fq = lane & 31, fh8 = lane >> 5;
   const int wfo = fq * 32 + ((fh8 ^ ((fq >> 3) & 1)) << 4);   // weight fragment: out channel fq, channels 8 fh8 .. + 7
   // A fragment of halo'd row RPW wr + ir, column block cb, tap column kw: pixel (RPW wr + ir) XC + 32 cb + fq + kw; the column block
@@ -558,51 +566,96 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (fh8 == 0) { red[k & 1][wr][fq][0] = mean; red[k & 1][wr][fq][1] = m2; }
         pending = k;
       }
-      if (q < p.Q && !(MM_DIAG & 8)) {
-        float* yp = p.y + (((long long)it.n * p.Q + q) * p.D + it.d) * plane + (long long)(it.h0 + RPW * wr) * p.W + it.w0 + 4 * fh8;
+      if (!(MM_DIAG & 8)) {
+        // stores as whole 128-byte lines: in the D layout a lane holds 16-byte pieces of 32 different channel planes, and a store
+        // instruction from it is 32 partial-line write requests (counters: as many write as read requests for a third of the bytes,
+        // the L1 stalled on pending requests 77 % of the time; profiles/r05_mm_pmc.txt).  Per accumulator tile and channel octet the
+        // wave transposes through 1 KB of LDS of its own: lane -> (channel l / 8 of the octet, pixel quad l % 8)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)                           // accumulator r = (tile row r / CB of this wave, column block r % CB)
+        for (int a = 0; a < 4; ++a) {                         // accumulator a = (tile row a / CB of this wave, column block a % CB)
+          float* yrow = p.y + ((long long)it.n * p.Q * p.D + it.d) * plane + (long long)(it.h0 + RPW * wr + a / CB) * p.W + it.w0 + (a % CB) * 32;
 #pragma unroll
-          for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<f32x4_t*>(yp + (r / CB) * p.W + (r % CB) * 32 + 8 * g) = f32x4_t{acc[r][4 * g], acc[r][4 * g + 1], acc[r][4 * g + 2], acc[r][4 * g + 3]};
-      }
-    } else if (q < p.Q) {
-      // data gradient: the gradient of virtual-concat channel q at (shifted) depth d goes to depth d - s(q) of its source; slices
-      // that receive nothing are zero-filled by the workgroups of the out-of-range depths (conv133_kernel's rule)
-      const e2e_out_chan_t oc = p.outs[q];
-      if (oc.ptr != nullptr) {
-        int dd = it.d - oc.dshift;
-        bool zero_fill = false;
-        if (dd < 0) {
-          const int lo = p.D - oc.dshift > 0 ? p.D - oc.dshift : 0;
-          dd = lo + it.d;
-          zero_fill = true;
-        } else if (dd >= p.D) {
-          const int lo = p.D + oc.dshift > 0 ? p.D + oc.dshift : 0;
-          dd = it.d - lo;
-          zero_fill = true;
+          for (int oc8 = 0; oc8 < 4; ++oc8) {
+            if ((fq >> 3) == oc8) {
+#pragma unroll
+              for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<f32x4_t*>(tb + (fq & 7) * TP + 8 * g + 4 * fh8) = f32x4_t{acc[a][4 * g], acc[a][4 * g + 1], acc[a][4 * g + 2], acc[a][4 * g + 3]};
+            }
+            const f32x4_t v = *reinterpret_cast<const f32x4_t*>(tb + (lane >> 3) * TP + (lane & 7) * 4);
+            const int qs = it.qb * 32 + oc8 * 8 + (lane >> 3);
+            if (qs < p.Q) *reinterpret_cast<f32x4_t*>(yrow + (long long)qs * p.D * plane + (lane & 7) * 4) = v;
+          }
         }
-        if (!(zero_fill && oc.accumulate)) {
-          float* xp = oc.ptr + (long long)it.n * oc.nstride + (long long)dd * plane + (long long)(it.h0 + RPW * wr) * p.W + it.w0 + 4 * fh8;
-          const float usc = zero_fill ? 0.f : unsc;
-          if (!zero_fill && oc.accumulate) {                  // all sixteen old values requested before the first one is used
-            f32x4_t old[4][4];
+      }
+    } else {
+      // data gradient: the gradient of virtual-concat channel q at (shifted) depth d goes to depth d - s(q) of its source; slices
+      // that receive nothing are zero-filled by the workgroups of the out-of-range depths (conv133_kernel's rule).  Stores (and the
+      // reads of an accumulating destination) as whole lines through the wave's transposition buffer, as in the forward: a lane
+      // serves channel oc8 * 8 + l / 8 of each octet
+      float* dst[4];
+      float usc4[4];
+      bool accu[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+      for (int oc8 = 0; oc8 < 4; ++oc8) {
+        const int qs = it.qb * 32 + oc8 * 8 + (lane >> 3);
+        dst[oc8] = nullptr; usc4[oc8] = unsc; accu[oc8] = false;
+        if (qs < p.Q) {
+          const e2e_out_chan_t oc = lout[qs];
+          if (oc.ptr != nullptr) {
+            int dd = it.d - oc.dshift;
+            bool zero_fill = false;
+            if (dd < 0) {
+              const int lo = p.D - oc.dshift > 0 ? p.D - oc.dshift : 0;
+              dd = lo + it.d;
+              zero_fill = true;
+            } else if (dd >= p.D) {
+              const int lo = p.D + oc.dshift > 0 ? p.D + oc.dshift : 0;
+              dd = it.d - lo;
+              zero_fill = true;
+            }
+            if (!(zero_fill && oc.accumulate)) {
+              dst[oc8] = oc.ptr + (long long)it.n * oc.nstride + (long long)dd * plane + (long long)(it.h0 + RPW * wr) * p.W + it.w0 + (lane & 7) * 4;
+              usc4[oc8] = zero_fill ? 0.f : unsc;
+              accu[oc8] = !zero_fill && oc.accumulate;
+            }
+          }
+        }
+      }
+      // an accumulating destination: the eight old pieces of two accumulator tiles are requested before the first is used (two memory
+      // round trips per item, not sixteen); lanes whose destination does not accumulate read it too (a valid address) and drop
+      // the value.  The next chunk's fragments are requested BEHIND the epilogue at an item's end (chunk()): those registers are free.
+      const bool any_accu = __builtin_amdgcn_ballot_w64(accu[0] | accu[1] | accu[2] | accu[3]) != 0ull;      // (wave-uniform)
 #pragma unroll
-              for (int g = 0; g < 4; ++g) old[r][g] = *reinterpret_cast<const f32x4_t*>(xp + (r / CB) * p.W + (r % CB) * 32 + 8 * g);
+      for (int ap = 0; ap < 2; ++ap) {
+        f32x4_t old[2][4];
+        if (any_accu) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+          for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+            for (int oc8 = 0; oc8 < 4; ++oc8) {
+              const int a = 2 * ap + a2;
+              const float* src = dst[oc8] != nullptr ? dst[oc8] + (a / CB) * p.W + (a % CB) * 32 : reinterpret_cast<const float*>(p.wpk);
+              old[a2][oc8] = *reinterpret_cast<const f32x4_t*>(src);
+            }
+        }
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+          for (int oc8 = 0; oc8 < 4; ++oc8)
+            if (!any_accu || !accu[oc8]) old[a2][oc8] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2) {
+          const int a = 2 * ap + a2;
+          const int aoffs = (a / CB) * p.W + (a % CB) * 32;
+#pragma unroll
+          for (int oc8 = 0; oc8 < 4; ++oc8) {
+            if ((fq >> 3) == oc8) {
 #pragma unroll
               for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<f32x4_t*>(xp + (r / CB) * p.W + (r % CB) * 32 + 8 * g) =
-                    f32x4_t{acc[r][4 * g], acc[r][4 * g + 1], acc[r][4 * g + 2], acc[r][4 * g + 3]} * usc + old[r][g];
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-              for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<f32x4_t*>(xp + (r / CB) * p.W + (r % CB) * 32 + 8 * g) = f32x4_t{acc[r][4 * g], acc[r][4 * g + 1], acc[r][4 * g + 2], acc[r][4 * g + 3]} * usc;
+                *reinterpret_cast<f32x4_t*>(tb + (fq & 7) * TP + 8 * g + 4 * fh8) = f32x4_t{acc[a][4 * g], acc[a][4 * g + 1], acc[a][4 * g + 2], acc[a][4 * g + 3]};
+            }
+            const f32x4_t v = *reinterpret_cast<const f32x4_t*>(tb + (lane >> 3) * TP + (lane & 7) * 4);
+            if (dst[oc8] != nullptr) *reinterpret_cast<f32x4_t*>(dst[oc8] + aoffs) = v * usc4[oc8] + old[a2][oc8];
           }
         }
       }
@@ -649,7 +702,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     MMT(m2);
     __syncthreads();                                          // barrier #(s + 2): image s & 1 is free, image (s + 1) & 1 is complete
     MMT(m3);
-    if (s + 1 < S) { load_a(I0{}, s + 1); load_b(B1{}, I0{}, s + 1); }
+    const bool item_end = mc + 1 == p.nchunks;                // (wave-uniform)
+    if (!item_end && s + 1 < S) { load_a(I0{}, s + 1); load_b(B1{}, I0{}, s + 1); }
     __builtin_amdgcn_sched_barrier(0);
     mma(I5{}, B0{});
     __builtin_amdgcn_sched_barrier(0);
@@ -661,6 +715,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       mc = 0;
       ++mk;
       itm = decode(mk < nitems ? mk : nitems - 1);
+      if (s + 1 < S) { load_a(I0{}, s + 1); load_b(B1{}, I0{}, s + 1); }      // (behind the epilogue: its registers are the fragments')
     }
     MMT(m5);
     MMA(8, m0, m1); MMA(8, m3, m4); MMA(9, m1, m2); MMA(10, m2, m3); MMA(11, m4, m5);
@@ -690,7 +745,8 @@ static int mm_geom(int Wi) {
   return Wi == 128 ? 2 : (Wi == 64 ? 1 : (Wi == 32 ? 3 : 0));
 }
 static bool mm_fits(int geom, int B, int Cin, int Cout) {
-  const int ct = geom == 2 ? Geo<2>::CT_MAX : Geo<0>::CT_MAX, lr = geom == 2 ? Geo<2>::LREC_MAX : Geo<0>::LREC_MAX;
+  const int ct = geom == 2 ? Geo<2>::CT_MAX : Geo<0>::CT_MAX;
+  const int lr = geom == 2 ? Geo<2>::LREC_MAX : (geom == 1 ? Geo<1>::LREC_MAX : Geo<0>::LREC_MAX);
   return Cin <= ct && Cout <= ct && (long long)B * e2e::cdiv(Cin, 16) * 16 <= lr;   // LDS channel table; the forward's LDS copy of the resolved input planes
 }
 

@@ -627,12 +627,11 @@ int sparse_launch(int mode, SparseParams p, hipStream_t st) {
   size_t dyn = (size_t)2 * p.kmax * WSLOT * 4 + (size_t)p.ppad * sizeof(PlaneDesc);
   static const int pad_kb = getenv("E2E_SPARSE_LDS_PAD_KB") ? atoi(getenv("E2E_SPARSE_LDS_PAD_KB")) : 0;   // occupancy experiment
   dyn += (size_t)pad_kb * 1024;
-  static bool attr_set = false;
-  if (!attr_set) {                                        // static 55 KB + dynamic: beyond the default 64 KB for dense maps / many planes
-    (void)hipFuncSetAttribute((const void*)conv133_sparse_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv133_sparse_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-    attr_set = true;
-  }
+  // static 55 KB + dynamic: beyond the default 64 KB for dense maps / many planes.  Set before every launch of the mode (cheap): a
+  // process-wide "already set" flag is a data race under concurrent callers and leaves other devices of the process without it
+  E2E_REQUIRE(hipFuncSetAttribute(mode == 0 ? (const void*)conv133_sparse_kernel<0> : (const void*)conv133_sparse_kernel<1>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024) == hipSuccess,
+              "conv133_sparse: cannot raise the dynamic LDS limit");
   E2E_REQUIRE(dyn <= 100 * 1024 && p.uw <= 128, "conv133_sparse: %zu bytes of dynamic LDS (kmax %d, %d planes) not served", dyn, p.kmax, p.ppad);
   e2e::note_kernel("conv133_sparse_kernel<mode=%d> wgs=%d groups=%d chunks=%d flush=%d kmax=%d", mode, p.padded_total, p.groups, p.nchunks, p.flush_every, p.kmax);
   if (mode == 0) hipLaunchKernelGGL((conv133_sparse_kernel<0>), dim3(p.padded_total), dim3(NW * 64), dyn, st, p);

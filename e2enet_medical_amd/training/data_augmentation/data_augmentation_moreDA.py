@@ -16,9 +16,13 @@ parameters (tests/test_gpu_augment.py, oracle/augment.py).
 Data interpolation follows the reference's orders: ``order_data=3`` (cubic B-spline, scipy ``map_coordinates`` semantics: mirror
 prefilter + 64-tap gather) in the spatial transform and ``order_upsample=3`` in SimulateLowResolution (scipy ``zoom`` with
 ``grid_mode``, edge pre-padding by 12, clipped to the low-resolution range like skimage's ``resize``); ``order_data=1`` selects
-the linear kernels.  Not built, and rejected when asked for: elastic deformation (switched off by the trainer,
-nnUNetTrainer_simple.py:730), the cascade / pyramid transforms, ``dummy_2D``, region targets, additive brightness, independent
-per-axis scaling, random crops.
+the linear kernels.  ``dummy_2D`` (reference :58-60, :80-81; switched on by the plans of anisotropic patches such as BTCV's
+48 x 192 x 192, nnUNetTrainer_simple.py:701-716): Convert3DTo2DTransform is a reshape of the batch to [B, C * D, H, W], so the
+spatial transform runs on that view as a ONE-slice-deep volume -- one in-plane rotation (``rotation_x``) and scale per sample,
+shared by all slices, 2-D cubic B-spline per slice (prefilter along H and W only) -- through the same kernels; the
+low-resolution simulation then leaves the slice axis alone (``ignore_axes=(0,)``).  Not built, and rejected when asked for:
+elastic deformation (switched off by the trainer, nnUNetTrainer_simple.py:730), the cascade / pyramid transforms, region
+targets, additive brightness, independent per-axis scaling, random crops.
 """
 from typing import Iterable, Optional, Sequence
 
@@ -56,8 +60,9 @@ class DeviceAugmenter:
             p["do_elastic"] = False        # the table default is True; the trainer, the only caller in the reference, switches it off (:730)
         if p.get("do_elastic"):
             raise NotImplementedError("elastic deformation is not built (the trainer switches it off, nnUNetTrainer_simple.py:730)")
-        if p.get("dummy_2D") or p.get("move_last_seg_chanel_to_data"):
-            raise NotImplementedError("dummy_2D / cascade augmentations are outside the 3D shiftConvPP path")
+        if p.get("move_last_seg_chanel_to_data"):
+            raise NotImplementedError("cascade augmentations are outside the 3D shiftConvPP path")
+        self.dummy_2D = bool(p.get("dummy_2D"))
         if p.get("border_mode_data", "constant") != "constant":
             raise NotImplementedError("border_mode_data must be 'constant'")
         if order_seg not in (0, 1):
@@ -83,14 +88,25 @@ class DeviceAugmenter:
              "contrast": np.zeros((B, C)), "zoom": np.zeros((B, C)), "gamma_inv": np.zeros((B, C)), "gamma": np.zeros((B, C)),
              "mirror": np.zeros((B, 3), dtype=bool), "modified": np.zeros(B, dtype=bool)}
         shp = np.array(in_shape, dtype=float)
+        out_patch = np.array(self.patch_size)
+        if self.dummy_2D:                                     # the transform sees [C * D, H, W] images: depth 1 on the device
+            shp = np.array([1.0, in_shape[1], in_shape[2]])
+            in_shape = (1, in_shape[1], in_shape[2])
+            out_patch = np.array([1, self.patch_size[1], self.patch_size[2]])
         for b in range(B):
             # SpatialTransform / augment_spatial: rotation, scaling, then the centre of the loaded patch
             a_mat, modified = np.eye(3), False
             if p.get("do_rotation") and rs.uniform() < p.get("p_rot", 1):
-                ang = []
-                for key in ("rotation_x", "rotation_y", "rotation_z"):
-                    ang.append(rs.uniform(*p[key]) if rs.uniform() <= p.get("rotation_p_per_axis", 1) else 0.0)
-                a_mat = rotation_matrix_3d(*ang).T            # coords^T R  ==  R^T coords
+                if self.dummy_2D:                             # dim == 2: one angle (angle_x), rotate_coords_2d
+                    a = rs.uniform(*p["rotation_x"]) if rs.uniform() <= p.get("rotation_p_per_axis", 1) else 0.0
+                    rot = np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]])
+                    a_mat = np.eye(3)
+                    a_mat[1:, 1:] = rot.T                     # coords^T R  ==  R^T coords
+                else:
+                    ang = []
+                    for key in ("rotation_x", "rotation_y", "rotation_z"):
+                        ang.append(rs.uniform(*p[key]) if rs.uniform() <= p.get("rotation_p_per_axis", 1) else 0.0)
+                    a_mat = rotation_matrix_3d(*ang).T        # coords^T R  ==  R^T coords
                 modified = True
             if p.get("do_scaling") and rs.uniform() < p.get("p_scale", 1):
                 lo, hi = p["scale_range"]
@@ -100,7 +116,11 @@ class DeviceAugmenter:
             if modified:
                 t = shp / 2. - 0.5
             else:                                             # center_crop_aug: integer offsets, an exact copy
-                t = (np.array(self.patch_size) - 1) / 2. + (np.array(in_shape) - np.array(self.patch_size)) // 2
+                t = (out_patch - 1) / 2. + (np.array(in_shape) - out_patch) // 2
+            if self.dummy_2D:                                 # the slice axis is not a spatial axis of the transform
+                a_mat[0, :] = 0.0
+                a_mat[:, 0] = 0.0
+                t[0] = 0.0
             d["mat"][b] = np.concatenate([a_mat, t[:, None]], 1).reshape(-1)
             d["modified"][b] = modified
         for b in range(B):                                    # GaussianNoiseTransform(p_per_sample=0.1), noise_variance (0, 0.1)
@@ -155,9 +175,15 @@ class DeviceAugmenter:
     def apply(self, data: torch.Tensor, seg: Optional[torch.Tensor], draws: dict):
         """Run the chain with the given parameters.  data [B,C,D,H,W], seg [B,CS,D,H,W] float32 on the device."""
         L = lib()
+        B0, C0, D0 = int(data.shape[0]), int(data.shape[1]), int(data.shape[2])
+        if self.dummy_2D:                                     # Convert3DTo2DTransform: [B, C, D, H, W] -> [B, C * D, (1,) H, W]
+            assert D0 == self.patch_size[0], "dummy_2D: the loader's patch keeps the network's depth (basic_generator_patch_size)"
+            data = data.reshape(B0, C0 * D0, 1, data.shape[3], data.shape[4])
+            if seg is not None:
+                seg = seg.reshape(B0, seg.shape[1] * D0, 1, seg.shape[3], seg.shape[4])
         B, C = data.shape[:2]
         Di, Hi, Wi = (int(v) for v in data.shape[2:])
-        Do, Ho, Wo = self.patch_size
+        Do, Ho, Wo = (1, self.patch_size[1], self.patch_size[2]) if self.dummy_2D else self.patch_size
         vol = Do * Ho * Wo
         nbc = B * C
         out = torch.empty((B, C, Do, Ho, Wo), dtype=torch.float32, device=self.device)
@@ -171,7 +197,7 @@ class DeviceAugmenter:
             coef = torch.empty_like(data)
             for b in np.nonzero(mod)[0]:
                 src = data[b]
-                for ax in (0, 1, 2):
+                for ax in ((1, 2) if self.dummy_2D else (0, 1, 2)):       # (a one-slice axis has nothing to filter)
                     L.aug_bspline_prefilter_axis(src.data_ptr(), coef[b].data_ptr(), C, Di, Hi, Wi, ax, _stream())
                     src = coef[b]
             cubic = torch.from_numpy(mod.astype(np.int32)).to(self.device)
@@ -185,6 +211,13 @@ class DeviceAugmenter:
             for b in np.nonzero(~draws["modified"])[0]:
                 lo = [(i - o) // 2 for i, o in zip((Di, Hi, Wi), (Do, Ho, Wo))]
                 oseg[b].copy_(seg[b, :, lo[0]:lo[0] + Do, lo[1]:lo[1] + Ho, lo[2]:lo[2] + Wo])
+        if self.dummy_2D:                                     # Convert2DTo3DTransform: back to [B, C, D, H, W]; the rest of the chain is 3-D
+            out = out.reshape(B0, C0, D0, Ho, Wo)
+            if oseg is not None:
+                oseg = oseg.reshape(B0, oseg.shape[1] // D0, D0, Ho, Wo)
+            B, C, Do = B0, C0, D0
+            vol = Do * Ho * Wo
+            nbc = B * C
         tmp = None
 
         def rows(active, cols):
@@ -227,6 +260,8 @@ class DeviceAugmenter:
             for i, z in enumerate(zoom.reshape(-1)):
                 if z > 0:
                     lo[i] = np.round(np.array([Do, Ho, Wo]) * z).astype(int)
+                    if self.dummy_2D:
+                        lo[i, 0] = Do                         # ignore_axes=(0,): the slice axis keeps its resolution
             if tmp is None:
                 tmp = torch.empty_like(out)
             if self.order_upsample == 3:
@@ -323,8 +358,14 @@ class _DeviceGenerator:
         if self._it is None:
             self._it = iter(self.loader)
         b = next(self._it)
-        # DataLoader3D hands its page-locked staging tensors along: the upload below is then an asynchronous copy
-        return self.fn(b.get("data_pinned", b["data"]), b.get("seg_pinned", b.get("seg")))
+        # DataLoader3D hands its page-locked staging tensors along: the upload below is then an asynchronous copy; the loader is told
+        # when that copy is behind us (an event on this stream) and does not refill the buffer earlier
+        res = self.fn(b.get("data_pinned", b["data"]), b.get("seg_pinned", b.get("seg")))
+        if "data_pinned" in b and hasattr(self.loader, "mark_uploaded") and torch.cuda.is_available():
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.loader.mark_uploaded(ev)
+        return res
 
     next = __next__
 

@@ -78,10 +78,20 @@ def get_patch_size(final_patch_size, rot_x, rot_y, rot_z, scale_range):
     if len(coords) == 3:
         for ang in ((rot_x, 0, 0), (0, rot_y, 0), (0, 0, rot_z)):
             final_shape = np.max(np.vstack((np.abs(coords @ rotation_matrix_3d(*ang)), final_shape)), 0)
+    elif len(coords) == 2:                           # dummy_2D: the in-plane patch of an anisotropic 3D patch (rotate_coords_2d)
+        rot = np.array([[np.cos(rot_x), -np.sin(rot_x)], [np.sin(rot_x), np.cos(rot_x)]])
+        final_shape = np.max(np.vstack((np.abs(coords @ rot), final_shape)), 0)
     else:
-        raise NotImplementedError("2D augmentation is outside the 3D shiftConvPP path")
+        raise NotImplementedError("patch sizes of %d dimensions" % len(coords))
     final_shape /= min(scale_range)
     return final_shape.astype(int)
 
 
 default_2D_augmentation_params = deepcopy(default_3D_augmentation_params)
+default_2D_augmentation_params["elastic_deform_alpha"] = (0., 200.)
+default_2D_augmentation_params["elastic_deform_sigma"] = (9., 13.)
+default_2D_augmentation_params["rotation_x"] = (-180. / 360 * 2. * np.pi, 180. / 360 * 2. * np.pi)
+default_2D_augmentation_params["rotation_y"] = (-0. / 360 * 2. * np.pi, 0. / 360 * 2. * np.pi)
+default_2D_augmentation_params["rotation_z"] = (-0. / 360 * 2. * np.pi, 0. / 360 * 2. * np.pi)
+default_2D_augmentation_params["dummy_2D"] = False
+default_2D_augmentation_params["mirror_axes"] = (0, 1)

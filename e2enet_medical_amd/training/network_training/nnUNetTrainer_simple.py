@@ -146,6 +146,7 @@ class nnUNetTrainer_simple(object):
         self.save_final_checkpoint = True
         # ---- this engine ----
         self.base_num_features_override = None      # reference hard-codes 48 for shiftConvPP (:296)
+        self.synthetic_data = False                 # True: initialize() may install SyntheticGenerator (never silently)
         self.prefetch_batches = True                # fetch + upload batch i+1 under the GPU work of batch i (see run_iteration)
         self._prefetched, self._copy_stream = {}, None
         self._prefetch_error = {}                   # id(generator) -> (generator, exception raised by its one-ahead fetch)
@@ -209,9 +210,34 @@ class nnUNetTrainer_simple(object):
             raise RuntimeError("the MI355X engine implements 3d_fullres plans only")
 
     def setup_DA_params(self):
-        """reference :682-733: deep-supervision target scales from the cumulative pooling."""
+        """reference :682-733: deep-supervision target scales from the cumulative pooling, rotations of +-30 degrees, scale range
+        (0.7, 1.4), no elastic deformation; `do_dummy_2D_data_aug` plans (anisotropic patches) rotate in-plane only, by up to
+        180 degrees, and the loader's patch keeps the network's depth."""
+        from ..data_augmentation.default_data_augmentation import (default_3D_augmentation_params, default_2D_augmentation_params,
+                                                                   get_patch_size)
         self.deep_supervision_scales = [[1, 1, 1]] + list(list(i) for i in 1 / np.cumprod(
             np.vstack(self.net_num_pool_op_kernel_sizes), axis=0))[:-1]
+        p = dict(default_3D_augmentation_params)             # (a copy: the reference mutates the module-level table)
+        ang = (-30. / 360 * 2. * np.pi, 30. / 360 * 2. * np.pi)
+        p['rotation_x'] = p['rotation_y'] = p['rotation_z'] = ang
+        if self.do_dummy_2D_aug:
+            p["dummy_2D"] = True
+            p["elastic_deform_alpha"] = default_2D_augmentation_params["elastic_deform_alpha"]
+            p["elastic_deform_sigma"] = default_2D_augmentation_params["elastic_deform_sigma"]
+            p["rotation_x"] = default_2D_augmentation_params["rotation_x"]
+        p["mask_was_used_for_normalization"] = self.use_mask_for_norm
+        if self.do_dummy_2D_aug:
+            bg = get_patch_size(self.patch_size[1:], p['rotation_x'], p['rotation_y'], p['rotation_z'], p['scale_range'])
+            self.basic_generator_patch_size = np.array([self.patch_size[0]] + list(bg))
+        else:
+            self.basic_generator_patch_size = get_patch_size(self.patch_size, p['rotation_x'], p['rotation_y'], p['rotation_z'],
+                                                             p['scale_range'])
+        p["scale_range"] = (0.7, 1.4)
+        p["do_elastic"] = False
+        p['selected_seg_channels'] = [0]
+        p['patch_size_for_spatialtransform'] = self.patch_size
+        p["num_cached_per_thread"] = 2
+        self.data_aug_params = p
 
     # ------------------------------------------------------------------------------------------ initialize
     def initialize(self, training=True, force_load_plans=False):
@@ -232,11 +258,33 @@ class nnUNetTrainer_simple(object):
             self.initialize_optimizer_and_scheduler()
             if training and self.tr_gen is None:
                 scales = self.deep_supervision_scales[:self._num_ds_outputs()]
-                dev = "cuda" if torch.cuda.is_available() else "cpu"
-                self.tr_gen = SyntheticGenerator(self.batch_size, self.num_input_channels, self.patch_size,
-                                                 self.num_classes, scales, seed=0, device=dev)
-                self.val_gen = SyntheticGenerator(self.batch_size, self.num_input_channels, self.patch_size,
-                                                  self.num_classes, scales, seed=1, device=dev)
+                folder = None
+                if self.dataset_directory is not None and 'data_identifier' in self.plans:
+                    folder = join(self.dataset_directory, self.plans['data_identifier'] + "_stage%d" % self.stage)     # reference :216-217
+                if folder is not None and os.path.isdir(folder):
+                    # reference :218-239: DataLoader3D x 2 over the preprocessed cases + the moreDA chain (here: on the device)
+                    from ..data_augmentation.data_augmentation_moreDA import get_moreDA_augmentation
+                    self.folder_with_preprocessed_data = folder
+                    self.dl_tr, self.dl_val = self.get_basic_generators()
+                    self.tr_gen, self.val_gen = get_moreDA_augmentation(
+                        self.dl_tr, self.dl_val, self.data_aug_params['patch_size_for_spatialtransform'], self.data_aug_params,
+                        deep_supervision_scales=scales, pin_memory=self.pin_memory, use_nondetMultiThreadedAugmenter=False)
+                    self.print_to_log_file("TRAINING KEYS LEN: %s" % (len(self.dataset_tr.keys())), also_print_to_console=False)
+                    self.print_to_log_file("VALIDATION KEYS LEN: %s" % (len(self.dataset_val.keys())), also_print_to_console=False)
+                elif self.synthetic_data:
+                    dev = "cuda" if torch.cuda.is_available() else "cpu"
+                    self.print_to_log_file("WARNING: synthetic_data=True: training on seeded Gaussian noise and random labels "
+                                           "(benchmarks and smoke tests only)")
+                    self.tr_gen = SyntheticGenerator(self.batch_size, self.num_input_channels, self.patch_size,
+                                                     self.num_classes, scales, seed=0, device=dev)
+                    self.val_gen = SyntheticGenerator(self.batch_size, self.num_input_channels, self.patch_size,
+                                                      self.num_classes, scales, seed=1, device=dev)
+                else:
+                    raise FileNotFoundError(
+                        "no preprocessed data under %r (dataset_directory / plans['data_identifier'] + '_stage%s', reference "
+                        "nnUNetTrainer_simple.py:216-217): preprocess the task with the reference package, hand the trainer its own "
+                        "tr_gen / val_gen before initialize(), or set trainer.synthetic_data = True to train on synthetic noise on "
+                        "purpose" % (folder, self.stage))
             assert isinstance(self.network, (SegmentationNetwork, nn.DataParallel))
         self.was_initialized = True
         return self.network, self.optimizer
@@ -631,7 +679,8 @@ class nnUNetTrainer_simple(object):
                     err = e
             dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
             ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=dev)
-            dist.broadcast(ok, src=0, group=group)
+            # (src is a GLOBAL rank: group rank 0 of a sub-group is not global rank 0 in general)
+            dist.broadcast(ok, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
             if err is not None:
                 raise err
             if int(ok.item()) != 1:
@@ -776,9 +825,69 @@ class nnUNetTrainer_simple(object):
                                                     "e2enet/inference/segmentation_export.py)")
 
     def load_dataset(self):
-        """reference :585-586"""
-        _out_of_scope("load_dataset()", "dataset loader (e2enet/training/dataloading/dataset_loading.py)")
+        """reference :585-586 + dataloading/dataset_loading.py:97-118: the preprocessed cases of the stage folder as an ordered dict of
+        file names (the arrays stay on disk: DataLoader3D memory-maps <case>.npy or reads <case>.npz['data'])."""
+        folder = self.folder_with_preprocessed_data
+        ids = sorted({f[:-4] for f in os.listdir(folder) if f.endswith(".npz") or (f.endswith(".npy") and not f.endswith("_segs.npy"))})
+        self.dataset = OrderedDict()
+        for c in ids:
+            e = OrderedDict()
+            e['data_file'] = join(folder, "%s.npz" % c)
+            e['properties_file'] = join(folder, "%s.pkl" % c)
+            if len(ids) <= 1000 and isfile(e['properties_file']):          # (num_cases_properties_loading_threshold)
+                with open(e['properties_file'], 'rb') as f:
+                    e['properties'] = pickle.load(f)
+            self.dataset[c] = e
 
     def do_split(self):
-        """reference :588-651"""
-        _out_of_scope("do_split()", "dataset loader and its KFold split (e2enet/training/dataloading)")
+        """reference :588-651: fold 'all' trains and validates on every case; otherwise splits_final.pkl of the dataset directory
+        (created as a seeded 5-fold split when absent -- sklearn's KFold(5, shuffle=True, random_state=12345), restated with the same
+        RandomState permutation), or a seeded 80:20 split when the fold is not in the file."""
+        if self.fold == "all":
+            tr_keys = val_keys = list(self.dataset.keys())
+        else:
+            splits_file = join(self.dataset_directory, "splits_final.pkl")
+            if not isfile(splits_file):
+                keys = np.sort(list(self.dataset.keys()))
+                # sklearn KFold(n_splits=5, shuffle=True, random_state=12345).split: indices shuffled once by
+                # check_random_state(12345).shuffle, then cut into 5 consecutive folds (the first n % 5 one longer)
+                idx = np.arange(len(keys))
+                np.random.RandomState(12345).shuffle(idx)
+                sizes = np.full(5, len(keys) // 5, dtype=int)
+                sizes[:len(keys) % 5] += 1
+                splits, start = [], 0
+                for sz in sizes:
+                    test = np.sort(idx[start:start + sz])
+                    start += sz
+                    train = np.setdiff1d(np.arange(len(keys)), test)
+                    splits.append(OrderedDict(train=keys[train], val=keys[test]))
+                with open(splits_file, 'wb') as f:
+                    pickle.dump(splits, f)
+            else:
+                with open(splits_file, 'rb') as f:
+                    splits = pickle.load(f)
+            if self.fold < len(splits):
+                tr_keys, val_keys = list(splits[self.fold]['train']), list(splits[self.fold]['val'])
+            else:
+                rnd = np.random.RandomState(seed=12345 + self.fold)
+                keys = np.sort(list(self.dataset.keys()))
+                idx_tr = rnd.choice(len(keys), int(len(keys) * 0.8), replace=False)
+                idx_val = [i for i in range(len(keys)) if i not in idx_tr]
+                tr_keys, val_keys = [keys[i] for i in idx_tr], [keys[i] for i in idx_val]
+        tr_keys.sort()
+        val_keys.sort()
+        self.dataset_tr = OrderedDict((i, self.dataset[i]) for i in tr_keys)
+        self.dataset_val = OrderedDict((i, self.dataset[i]) for i in val_keys)
+
+    def get_basic_generators(self):
+        """reference :735-754 (3D branch)."""
+        from ..dataloading.dataset_loading import DataLoader3D
+        self.load_dataset()
+        self.do_split()
+        dl_tr = DataLoader3D(self.dataset_tr, self.basic_generator_patch_size, self.patch_size, self.batch_size, False,
+                             oversample_foreground_percent=self.oversample_foreground_percent, pad_mode="constant",
+                             pad_sides=self.pad_all_sides, memmap_mode='r')
+        dl_val = DataLoader3D(self.dataset_val, self.patch_size, self.patch_size, self.batch_size, False,
+                              oversample_foreground_percent=self.oversample_foreground_percent, pad_mode="constant",
+                              pad_sides=self.pad_all_sides, memmap_mode='r')
+        return dl_tr, dl_val

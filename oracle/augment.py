@@ -45,6 +45,37 @@ def spatial(data, seg, mats, patch_size, order_seg=1, cval_seg=-1.0, order_data=
     return out, oseg
 
 
+def spatial_dummy_2d(data, seg, mats, patch_size, order_seg=1, cval_seg=-1.0, order_data=3):
+    """The dummy_2D form (data_augmentation_moreDA.py:58-60, :80-81): Convert3DTo2DTransform reshapes [B, C, D, H, W] to
+    [B, C * D, H, W], SpatialTransform interpolates every such image in 2-D with the sample's ONE in-plane affine (`mats` rows in
+    the augmenter's 3 x 4 layout, slice row and column zero), Convert2DTo3DTransform reshapes back.  patch_size: (D, H, W)."""
+    B, C, D = data.shape[:3]
+    ps2 = tuple(patch_size[1:])
+    out = np.zeros((B, C, D) + ps2, np.float32)
+    oseg = None if seg is None else np.zeros((B, seg.shape[1], D) + ps2, np.float32)
+    for b in range(B):
+        m = np.asarray(mats[b], dtype=np.float64).reshape(3, 4)
+        grids = np.meshgrid(*[np.arange(s, dtype=np.float64) - (s - 1) / 2. for s in ps2], indexing="ij")
+        c = np.stack([g.reshape(-1) for g in grids])
+        coords = (m[1:, 1:3] @ c + m[1:, 3:4]).reshape((2,) + ps2)
+        for ch in range(C):
+            for z in range(D):
+                out[b, ch, z] = ndimage.map_coordinates(data[b, ch, z].astype(float), coords, order=order_data, mode='constant', cval=0.0).astype(np.float32)
+        if seg is not None:
+            for ch in range(seg.shape[1]):
+                for z in range(D):
+                    img = seg[b, ch, z]
+                    if order_seg == 0:
+                        oseg[b, ch, z] = ndimage.map_coordinates(img.astype(float), coords, order=0, mode='constant', cval=cval_seg).astype(np.float32)
+                    else:
+                        res = np.zeros(ps2, np.float32)
+                        for lab in np.unique(img):
+                            mm = ndimage.map_coordinates((img == lab).astype(float), coords, order=1, mode='constant', cval=cval_seg)
+                            res[mm >= 0.5] = lab
+                        oseg[b, ch, z] = res
+    return out, oseg
+
+
 def gaussian_blur(x, sigma):
     """augment_gaussian_blur: scipy.ndimage.gaussian_filter(channel, sigma, order=0)"""
     return ndimage.gaussian_filter(x.astype(np.float64), sigma, order=0).astype(np.float32)
@@ -80,12 +111,15 @@ def _resize(img, shape, order):
     return ndimage.zoom(img, np.array(shape, dtype=float) / np.array(img.shape), order=order, mode='nearest', grid_mode=True)
 
 
-def low_resolution(x, zoom, order_upsample=3):
+def low_resolution(x, zoom, order_upsample=3, ignore_axes=None):
     """augment_linear_downsampling_scipy on one channel: nearest down to round(shape * zoom), then up-sampling back with
     skimage resize(order_upsample, mode='edge', anti_aliasing=False) [the reference passes order_upsample=3]; resize's default
-    clip=True clamps the result to the range of its input (a no-op for order <= 1)"""
+    clip=True clamps the result to the range of its input (a no-op for order <= 1); ignore_axes keep their size (dummy_2D: (0,))"""
     shp = np.array(x.shape)
     target = np.round(shp * zoom).astype(int)
+    if ignore_axes is not None:
+        for ax in ignore_axes:
+            target[ax] = shp[ax]
     down = _resize(x.astype(np.float32), target, 0)
     up = _resize(down, shp, order_upsample)
     return np.clip(up, down.min(), down.max()).astype(np.float32)

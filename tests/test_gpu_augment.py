@@ -202,3 +202,61 @@ def test_full_chain_runs_from_a_seed_and_feeds_the_trainer_shapes():
     assert r["data"].shape == (2, 2, 24, 32, 32) and r["data"].is_cuda and torch.isfinite(r["data"]).all()
     assert [tuple(t.shape) for t in r["target"]] == [(2, 1, 24, 32, 32), (2, 1, 12, 16, 16), (2, 1, 6, 8, 8)]
     assert float(r["target"][0].min()) >= 0.0                  # RemoveLabelTransform(-1, 0)
+
+
+@pytest.mark.parametrize("order_seg,order_data", [(1, 3), (0, 1)])
+def test_dummy_2d_spatial_transform_vs_scipy_per_slice(order_seg, order_data):
+    """dummy_2D (reference data_augmentation_moreDA.py:58-60, :80-81; switched on for anisotropic patches such as BTCV's
+    48 x 192 x 192 by nnUNetTrainer_simple.py:701-716): the batch is viewed as [B, C * D, H, W], ONE in-plane rotation + scale per
+    sample, every slice interpolated in 2-D (cubic B-spline with a prefilter along H and W only), the slice axis untouched.
+    Against scipy.ndimage.map_coordinates slice by slice."""
+    patch = (10, 32, 28)
+    a = _aug(patch=patch, order_seg=order_seg, order_data=order_data, params={"dummy_2D": True, "rotation_x": (-np.pi, np.pi)})
+    data, seg = _raw(B=2, C=2, shape=(10, 48, 44), seed=7)
+    d = _blank(a, 2, 2)
+    mats = np.zeros((2, 12))
+    for b, (ang, sc) in enumerate([(0.4, 1.25), (-1.1, 0.8)]):
+        A = np.zeros((3, 3))
+        rot = np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]])
+        A[1:, 1:] = rot.T * sc
+        t = np.array([0.0, data.shape[3] / 2. - 0.5, data.shape[4] / 2. - 0.5])
+        mats[b] = np.concatenate([A, t[:, None]], 1).reshape(-1)
+    d["mat"] = mats
+    out, oseg = a.apply(torch.from_numpy(data).cuda(), torch.from_numpy(seg).cuda(), d)
+    assert tuple(out.shape) == (2, 2) + patch and tuple(oseg.shape) == (2, 1) + patch
+    ref, rseg = oaug.spatial_dummy_2d(data, seg, mats, patch, order_seg, -1.0, order_data)
+    rdat, rseg = oaug.finish(ref, rseg, None)
+    err = np.abs(out.cpu().numpy() - rdat).max()
+    print("[dummy_2D spatial order_data %d] max |device - scipy| = %.3e" % (order_data, err))
+    assert err <= 3e-5
+    assert (oseg.cpu().numpy() != rseg).mean() <= 2e-4
+
+
+def test_dummy_2d_draws_low_resolution_and_full_chain():
+    """dummy_2D end to end: the draws rotate in-plane only (slice row / column of the affine zero), SimulateLowResolution keeps the
+    slice axis (ignore_axes=(0,): against the scipy restatement), and the whole chain runs on the BTCV-like anisotropic shape the
+    reference's planner switches dummy_2D on for (max(patch) / patch[0] > 3)."""
+    patch = (12, 48, 48)
+    scales = [[1, 1, 1], [1, 0.5, 0.5], [0.5, 0.25, 0.25]]
+    a = _aug(patch=patch, deep_supervision_scales=scales, seed=5, params={"dummy_2D": True, "rotation_x": (-np.pi, np.pi)})
+    data, seg = _raw(B=2, C=1, shape=(12, 64, 60), seed=9)
+    seen_mod = False
+    for _ in range(6):
+        r = a(data, seg)
+        m = a.last_draws["mat"].reshape(2, 3, 4)
+        assert np.all(m[:, 0, :] == 0) and np.all(m[:, :, 0] == 0)
+        seen_mod |= bool(a.last_draws["modified"].any())
+        assert r["data"].shape == (2, 1) + patch and torch.isfinite(r["data"]).all()
+        assert [tuple(t.shape) for t in r["target"]] == [(2, 1, 12, 48, 48), (2, 1, 12, 24, 24), (2, 1, 6, 12, 12)]
+    assert seen_mod
+    # low-resolution simulation alone
+    x = np.random.RandomState(3).standard_normal((1, 1) + patch).astype(np.float32)
+    d = _blank(a, 1, 1)
+    ident = np.zeros((3, 4)); ident[1, 1] = ident[2, 2] = 1.0
+    ident[1, 3], ident[2, 3] = (patch[1] - 1) / 2., (patch[2] - 1) / 2.
+    d["mat"] = ident.reshape(1, 12)
+    d["modified"] = np.zeros(1, dtype=bool)
+    d["zoom"] = np.array([[0.6]])
+    out, _ = a.apply(torch.from_numpy(x).cuda(), None, d)
+    ref = oaug.low_resolution(x[0, 0], 0.6, 3, ignore_axes=(0,))
+    assert np.abs(out.cpu().numpy()[0, 0] - ref).max() <= 5e-5

@@ -306,6 +306,7 @@ def test_trainer_surface_runs_iterations():
     tr = nnUNetTrainer_simple(plans, 0, output_folder=None, batch_dice=False, Tconv='shiftConvPP', max_num_epochs=2,
                               num_batches_per_epoch=2)
     tr.base_num_features_override = 8
+    tr.synthetic_data = True
     torch.manual_seed(0)
     net, opt = tr.initialize(True)
 
@@ -350,6 +351,7 @@ def test_checkpoint_with_dsff_state_resumes_bit_exact(tmp_path):
                                   num_batches_per_epoch=2)
         tr.base_num_features_override = 8
         torch.manual_seed(0)
+        tr.synthetic_data = True
         net, opt = tr.initialize(True)
         random.seed(0)
         mask = Masking(opt, death_rate=0.5, death_mode='magnitude', death_rate_decay=CosineDecay(0.5, 8),

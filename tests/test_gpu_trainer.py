@@ -35,6 +35,7 @@ def _trainer(out=None, epochs=2, batch_dice=False, fold=0):
     tr.base_num_features_override = 8
     tr.num_val_batches_per_epoch = 2
     torch.manual_seed(0)
+    tr.synthetic_data = True
     net, opt = tr.initialize(True)
     return tr, net, opt
 
@@ -425,6 +426,7 @@ def test_trainer_builds_and_steps_the_tconv_ablations(tmp_path, tconv, variant, 
     tr = nnUNetTrainer_simple(plans, 0, output_folder=str(tmp_path), Tconv=tconv, max_num_epochs=1, num_batches_per_epoch=1)
     tr.base_num_features_override = 8
     torch.manual_seed(0)
+    tr.synthetic_data = True
     net, opt = tr.initialize(True)
     assert net.conv_variant == variant and net._cfg.shift_size == shift
     pools = [tuple(k) for k in plans['plans_per_stage'][0]['pool_op_kernel_sizes']]
@@ -496,3 +498,62 @@ def test_run_iteration_prefetches_the_next_batch_without_changing_the_sequence(t
     pre, n_pre = run(1)
     assert sync == pre
     assert n_sync == 2 and n_pre == 3
+
+
+def _write_cases(folder, n_cases=6, shape=(20, 44, 40), mods=1):
+    """preprocessed cases in the reference's on-disk form: <case>.npy ([modalities..., seg]) + <case>.pkl (properties with
+    class_locations), closed forms"""
+    import pickle
+    from collections import OrderedDict
+    os.makedirs(folder, exist_ok=True)
+    for ci in range(n_cases):
+        shp = tuple(s + 2 * (ci % 3) for s in shape)
+        j = np.arange(int(np.prod(shp)), dtype=np.float64).reshape(shp)
+        data = [np.sin(0.21 * j + 0.7 * ci + m).astype(np.float32) * (1 + m) for m in range(mods)]
+        zz, yy, xx = np.meshgrid(*[np.arange(s) for s in shp], indexing="ij")
+        seg = (((zz // 3 + yy // 5 + xx // 4 + ci) % 5) < 2).astype(np.float32) + (((zz + yy + xx) % 17) == 0).astype(np.float32)
+        seg = np.minimum(seg, 2.0)
+        seg[:2] = -1                                           # nnU-Net marks voxels outside the nonzero mask with -1
+        np.save(os.path.join(folder, "case_%02d.npy" % ci), np.stack(data + [seg]).astype(np.float32))
+        locs = OrderedDict((c, np.argwhere(seg == c)) for c in (1, 2))
+        with open(os.path.join(folder, "case_%02d.pkl" % ci), "wb") as f:
+            pickle.dump(OrderedDict(class_locations=locs, name="case_%02d" % ci), f)
+
+
+@pytest.mark.parametrize("dummy_2d", [False, True])
+def test_trainer_initialize_feeds_real_cases_through_loader_and_device_augmenter(tmp_path, dummy_2d):
+    """initialize(training=True) as the reference wires it (nnUNetTrainer_simple.py:216-239): load_dataset + do_split over the stage
+    folder, DataLoader3D x 2, get_moreDA_augmentation (here: DeviceAugmenter on the GPU) -- also for a `do_dummy_2D_data_aug` plan,
+    the anisotropic-patch mode BASELINE config 3's shape switches on -- and run_iteration trains on those batches.  Without the
+    folder initialize() raises instead of silently training on noise."""
+    from e2enet_medical_amd.training.network_training.nnUNetTrainer_simple import nnUNetTrainer_simple
+    from e2enet_medical_amd.training.data_augmentation.data_augmentation_moreDA import _DeviceGenerator
+    plans = dict(PLANS, data_identifier="nnUNetData_plans_v2.1")
+    plans['plans_per_stage'] = {0: dict(PLANS['plans_per_stage'][0], do_dummy_2D_data_aug=dummy_2d)}
+    root = tmp_path / "Task998"
+    tr0 = nnUNetTrainer_simple(plans, 0, output_folder=str(tmp_path / "out0"), dataset_directory=str(root), Tconv='shiftConvPP')
+    tr0.base_num_features_override = 8
+    with pytest.raises(FileNotFoundError):
+        tr0.initialize(True)
+    _write_cases(str(root / "nnUNetData_plans_v2.1_stage0"), mods=PLANS['num_modalities'])
+    tr = nnUNetTrainer_simple(plans, 0, output_folder=str(tmp_path / "out"), dataset_directory=str(root), batch_dice=False,
+                              Tconv='shiftConvPP', max_num_epochs=1, num_batches_per_epoch=2)
+    tr.base_num_features_override = 8
+    torch.manual_seed(0)
+    np.random.seed(0)
+    net, opt = tr.initialize(True)
+    assert isinstance(tr.tr_gen, _DeviceGenerator) and isinstance(tr.val_gen, _DeviceGenerator)
+    assert len(tr.dataset_tr) + len(tr.dataset_val) == 6 and len(tr.dataset_val) >= 1
+    assert bool(tr.data_aug_params["dummy_2D"]) == dummy_2d
+    patch = tuple(int(v) for v in tr.patch_size)
+    if dummy_2d:
+        assert int(tr.basic_generator_patch_size[0]) == patch[0]
+    b = next(tr.tr_gen)
+    assert tuple(b["data"].shape) == (tr.batch_size, tr.num_input_channels) + patch and b["data"].is_cuda
+    assert tuple(b["target"][0].shape) == (tr.batch_size, 1) + patch and float(b["target"][0].min()) >= 0
+    assert len(b["target"]) == tr._num_ds_outputs()
+    v = next(tr.val_gen)
+    assert tuple(v["data"].shape) == (tr.batch_size, tr.num_input_channels) + patch
+    losses = [float(tr.run_iteration(tr.tr_gen, True)) for _ in range(3)]
+    assert all(np.isfinite(losses)), losses
+    assert np.isfinite(float(tr.run_iteration(tr.val_gen, False, True)))

@@ -98,6 +98,7 @@ def test_trainer_and_masking_fail_loudly_without_gpu():
              'base_num_features': 32, 'num_modalities': 1, 'num_classes': 2, 'all_classes': [1, 2], 'conv_per_stage': 2}
     tr = nnUNetTrainer_simple(plans, 0, batch_dice=False, Tconv='shiftConvPP')
     tr.base_num_features_override = 8
+    tr.synthetic_data = True
     tr.initialize(True)
     assert tr.ds_loss_weights.tolist() == pytest.approx([8 / 15, 4 / 15, 2 / 15, 1 / 15, 0])
     assert tr.deep_supervision_scales[:3] == [[1, 1, 1], [0.5, 0.5, 0.5], [0.25, 0.25, 0.25]]
@@ -516,3 +517,60 @@ def test_sparse_plan_is_a_valid_balanced_permutation(R, Cc, dens):
             assert np.array_equal(ps[:NC * 8], ps[g * NC * 8:(g + 1) * NC * 8])           # (they share the staged planes through L2)
         if Q % 32 == 0 and dens <= 0.3:
             assert natural / ideal >= 1.3 and (planned / ideal <= 1.2 if G == 1 else planned <= 0.87 * natural), (planned / ideal, natural / ideal)
+
+
+def test_trainer_never_trains_on_noise_by_accident_and_splits_like_sklearn(tmp_path):
+    """initialize(training=True) builds its generators from the preprocessed stage folder (reference nnUNetTrainer_simple.py:216-239);
+    without one it raises unless synthetic_data was set on purpose.  load_dataset / do_split: the reference's file-name dict and
+    its 5-fold split (sklearn KFold(5, shuffle=True, random_state=12345), restated without sklearn: compared with sklearn here)."""
+    import pickle
+    from collections import OrderedDict
+    from e2enet_medical_amd.training.network_training.nnUNetTrainer_simple import nnUNetTrainer_simple
+    plans = {'plans_per_stage': {0: {'batch_size': 1, 'patch_size': [16, 32, 32], 'num_pool_per_axis': [3, 5, 5],
+                                     'pool_op_kernel_sizes': [[2, 2, 2]] * 3 + [[1, 2, 2]] * 2,
+                                     'conv_kernel_sizes': [[3, 3, 3]] * 6, 'do_dummy_2D_data_aug': False}},
+             'base_num_features': 32, 'num_modalities': 1, 'num_classes': 2, 'all_classes': [1, 2], 'conv_per_stage': 2,
+             'data_identifier': 'nnUNetData_plans_v2.1'}
+    tr = nnUNetTrainer_simple(plans, 0, dataset_directory=str(tmp_path), batch_dice=False, Tconv='shiftConvPP')
+    tr.base_num_features_override = 8
+    if not torch.cuda.is_available():
+        with pytest.raises((FileNotFoundError, RuntimeError)):          # (without a GPU the engine itself refuses first)
+            tr.initialize(True)
+    # ---- dataset dict and split (host logic only)
+    folder = tmp_path / "nnUNetData_plans_v2.1_stage0"
+    folder.mkdir()
+    names = ["case_%02d" % i for i in (7, 3, 11, 0, 5, 9, 1, 8, 2, 10, 4, 6, 12)]
+    for n in names:
+        np.save(str(folder / (n + ".npy")), np.zeros((2, 4, 4, 4), np.float32))
+        with open(str(folder / (n + ".pkl")), "wb") as f:
+            pickle.dump(OrderedDict(class_locations={1: np.zeros((0, 3), int)}, name=n), f)
+    tr.folder_with_preprocessed_data = str(folder)
+    tr.load_dataset()
+    assert list(tr.dataset.keys()) == sorted(names)
+    assert tr.dataset["case_03"]["data_file"].endswith("case_03.npz") and tr.dataset["case_03"]["properties"]["name"] == "case_03"
+    from sklearn.model_selection import KFold
+    keys = np.sort(names)
+    want = [(keys[a], keys[b]) for a, b in KFold(n_splits=5, shuffle=True, random_state=12345).split(keys)]
+    for fold in range(5):
+        tr.fold = fold
+        tr.do_split()
+        assert list(tr.dataset_tr.keys()) == sorted(want[fold][0]) and list(tr.dataset_val.keys()) == sorted(want[fold][1])
+    assert (tmp_path / "splits_final.pkl").exists()
+    tr.fold = 7                                                           # not in the file: seeded 80:20 split
+    tr.do_split()
+    assert len(tr.dataset_tr) == int(len(names) * 0.8) and len(tr.dataset_val) == len(names) - int(len(names) * 0.8)
+    tr.fold = "all"
+    tr.do_split()
+    assert list(tr.dataset_tr.keys()) == list(tr.dataset_val.keys()) == sorted(names)
+    # ---- the loader's patch of a dummy_2D plan keeps the depth and grows in-plane only (reference :718-727)
+    plans2 = dict(plans)
+    plans2['plans_per_stage'] = {0: dict(plans['plans_per_stage'][0], patch_size=[16, 64, 64], do_dummy_2D_data_aug=True)}
+    tr2 = nnUNetTrainer_simple(plans2, 0, batch_dice=False, Tconv='shiftConvPP')
+    tr2.load_plans_file()
+    tr2.process_plans(tr2.plans)
+    tr2.setup_DA_params()
+    assert tr2.data_aug_params["dummy_2D"] and tr2.data_aug_params["rotation_x"][1] == pytest.approx(np.pi)
+    assert tr2.basic_generator_patch_size[0] == 16 and tr2.basic_generator_patch_size[1] > 64 and tr2.basic_generator_patch_size[2] > 64
+    tr.process_plans(tr.plans)
+    tr.setup_DA_params()
+    assert not tr.data_aug_params["dummy_2D"] and all(b >= p for b, p in zip(tr.basic_generator_patch_size, tr.patch_size))

@@ -11,6 +11,7 @@ plans = {'plans_per_stage': {0: {'batch_size': 2, 'patch_size': [128, 128, 128],
 tr = nnUNetTrainer_simple(plans, 0, output_folder="/tmp/tb", batch_dice=True, Tconv='shiftConvPP', max_num_epochs=1, num_batches_per_epoch=1)
 tr.base_num_features_override = 32
 torch.manual_seed(0)
+tr.synthetic_data = True
 net, opt = tr.initialize(True)
 class A: adv = False; fix = False; update_frequency = 1200; final_density = 0.05
 random.seed(0)
