@@ -90,7 +90,7 @@ constexpr int WUNITS = WCH / 16;                 // 1152 16-byte units
 constexpr int WSH = 8;                           // weights are packed as w 2^WSH
 constexpr int XSH = 3;                           // forward: activations are staged as x 2^XSH (lo piece normal down to |x| = 2^-6; Inf beyond 8188)
 template <int GEOM> constexpr int lds_bytes() {
-  return 2 * Geo<GEOM>::IMG + 2 * WCH + 2 * Geo<GEOM>::CT_MAX * 20 + Geo<GEOM>::LREC_MAX * 24 + 2 * 4 * 32 * 2 * 4 + 4 * 8 * 36 * 4;
+  return 2 * Geo<GEOM>::IMG + 2 * WCH + 2 * Geo<GEOM>::CT_MAX * 20 + Geo<GEOM>::LREC_MAX * 24 + 2 * 4 * 32 * 2 * 4 + (Geo<GEOM>::CT_MAX + 32) * 4;
 }
 static_assert(lds_bytes<0>() <= 160 * 1024 && lds_bytes<1>() <= 160 * 1024 && lds_bytes<2>() <= 160 * 1024 && lds_bytes<3>() <= 160 * 1024, "LDS budget");
 
@@ -176,8 +176,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   static_assert(sizeof(ChanRec) == sizeof(e2e_out_chan_t), "the data gradient keeps its destination table in the same array");
   const e2e_out_chan_t* const lout = reinterpret_cast<const e2e_out_chan_t*>(lrec);   // data gradient: the Q destination descriptors
   __shared__ float red[2][4][32][2];                       // (mean, M2) of 128 values per (item parity, matrix wave, out channel)
-  constexpr int TP = 36;                                   // floats per channel row of a transposition buffer: 32 pixels + 4
-  __shared__ __attribute__((aligned(16))) float tbuf[4][8 * TP];      // per matrix wave: one channel octet of one accumulator tile
+  struct ODesc { float* dst; float usc; int flags; };      // data gradient: destination of one out channel for one item (flags: 1 store, 2 accumulate)
+  __shared__ __attribute__((aligned(16))) float lbias[MODE == 0 ? CT_MAX + 32 : 4];    // forward: the bias vector (zero padded to whole blocks)
+  __shared__ __attribute__((aligned(16))) ODesc odesc[MODE == 1 ? 2 : 1][32];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -228,6 +229,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (MODE == 0) {
     const int nrec = p.B * p.nchunks * 16;
     for (int i = tid; i < nrec; i += 512) lrec[i] = p.crec[i];
+    for (int i = tid; i < p.qblocks * 32; i += 512) lbias[i] = (p.bias != nullptr && i < p.Q) ? p.bias[i] : 0.f;
   } else {
     for (int i = tid; i < p.Q; i += 512) reinterpret_cast<e2e_out_chan_t*>(lrec)[i] = p.outs[i];
   }
@@ -260,7 +262,40 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   };
 
+  // data gradient: where the 32 out channels of an item go -- the gradient of virtual-concat channel q at (shifted) depth d goes to
+  // depth d - s(q) of its source; slices that receive nothing are zero-filled by the workgroups of the out-of-range depths
+  // (conv133_kernel's rule).  Resolved once per item into LDS by the staging waves (LDS-to-LDS, like the channel table).
+  auto build_odesc = [&](const Item& it, int par, int t) __attribute__((always_inline)) {
+    if (MODE != 1 || t < 0 || t >= 32) return;
+    const int q = it.qb * 32 + t;
+    ODesc od;
+    od.dst = nullptr; od.usc = 0.f; od.flags = 0;
+    if (q < p.Q) {
+      const e2e_out_chan_t oc = lout[q];
+      if (oc.ptr != nullptr) {
+        int dd = it.d - oc.dshift;
+        bool zero_fill = false;
+        if (dd < 0) {
+          const int lo = p.D - oc.dshift > 0 ? p.D - oc.dshift : 0;
+          dd = lo + it.d;
+          zero_fill = true;
+        } else if (dd >= p.D) {
+          const int lo = p.D + oc.dshift > 0 ? p.D + oc.dshift : 0;
+          dd = it.d - lo;
+          zero_fill = true;
+        }
+        if (!(zero_fill && oc.accumulate)) {
+          od.dst = oc.ptr + (long long)it.n * oc.nstride + (long long)dd * plane + (long long)it.h0 * p.W + it.w0;
+          od.usc = zero_fill ? 0.f : unsc;
+          od.flags = 1 | ((!zero_fill && oc.accumulate) ? 2 : 0);
+        }
+      }
+    }
+    odesc[MODE == 1 ? par : 0][t] = od;
+  };
+
   build_ctab(decode(0), 0, tid, 512);
+  build_odesc(decode(0), 0, tid);
   __syncthreads();                                            // barrier #0
 
   if (wave >= 4) {
@@ -415,7 +450,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int i = 0; i < 16; ++i) issue(R0{}, rq, i);
     }
     advance(q2);                                              // chunk 1 (item 0: nchunks >= 2)
-    if (nitems > 1) build_ctab(decode(1), 1, tid - 256, 256);
+    if (nitems > 1) { build_ctab(decode(1), 1, tid - 256, 256); build_odesc(decode(1), 1, tid - 256); }
     stage(R0{}, R1{}, q1, q2, 0);                             // chunk 0 -> image 0, chunk 1 -> set 1
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     __syncthreads();                                          // barrier #1: image 0 and weights 0 are in LDS
@@ -428,7 +463,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       MMT(t1);
       // table of the item after q1's, written while q1's first chunk is converted: a barrier before its first reader (nchunks >= 2);
       // LDS-to-LDS (no global load: a branch around a load would cost the exact vmcnt distances of this loop)
-      if (q1.c == 0 && q1.k + 1 < nitems) build_ctab(decode(q1.k + 1), (q1.k + 1) & 1, tid - 256, 256);
+      if (q1.c == 0 && q1.k + 1 < nitems) {
+        const Item itn = decode(q1.k + 1);
+        build_ctab(itn, (q1.k + 1) & 1, tid - 256, 256);
+        build_odesc(itn, (q1.k + 1) & 1, tid - 256);
+      }
       MMT(t2);
       stage(std::integral_constant<int, PAR ^ 1>{}, std::integral_constant<int, PAR>{}, q1, q2, PAR ^ 1);
       MMT(t4);
@@ -452,7 +491,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   // =================================================== matrix waves ===========================================================
   const int wr = wave;                                        // tile rows RPW wr .. RPW wr + RPW - 1, all CB column blocks
-  float* const tb = tbuf[wr];
   const int fq = lane & 31, fh8 = lane >> 5;
   const int wfo = fq * 32 + ((fh8 ^ ((fq >> 3) & 1)) << 4);   // weight fragment: out channel fq, channels 8 fh8 .. + 7
   // A fragment of halo'd row RPW wr + ir, column block cb, tap column kw: pixel (RPW wr + ir) XC + 32 cb + fq + kw; the column block
@@ -528,134 +566,121 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int ai = rr * CB + GE::frag_cb(HALF, j);
         if (MM_DIAG & 1) { acc[ai][0] += (float)fa[SET][j][0][0] + (float)fb[BS][kh][1][0] + (float)fa[SET][j][1][0] + (float)fb[BS][kh][0][0]; continue; }
         f32x16 a = acc[ai];                                   // small terms first: lo*hi, hi*lo, then hi*hi
-        a = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][j][1], fb[BS][kh][0], a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][j][0], fb[BS][kh][1], a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[SET][j][0], fb[BS][kh][0], a, 0, 0, 0);
+        // D[out channel][pixel]: the weight fragment is the A operand (row = out channel fq), the pixel fragment the B operand
+        // (column = pixel fq): a lane then owns ONE pixel column and 16 out channels, so a store of one accumulator register is two
+        // whole 128-byte lines (lanes 0-31 / 32-63: channels 4 apart) -- with D[pixel][channel] it was 32 partial lines
+        a = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[BS][kh][0], fa[SET][j][1], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[BS][kh][1], fa[SET][j][0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[BS][kh][0], fa[SET][j][0], a, 0, 0, 0);
         acc[ai] = a;
       }
   };
   int pending = -1;                                           // item whose statistics records wait for the next barrier
   Item itm = decode(0);                                       // the item of the chunk being multiplied
   int mk = 0, mc = 0;
-  float bq = 0.f;                                             // its bias, requested at the top of every chunk (no branch around the load)
+  // sum over the 32 lanes of a half wave (the pixels of a tile row): four DPP steps inside the 16-lane rows, then row_bcast:15 adds
+  // the sum of rows 0 / 2 to rows 1 / 3 -- the total is valid in lanes 16-31 and 48-63; no LDS crossbar round trip (32 dependent
+  // ds_bpermute per item were the bulk of the first version of this epilogue)
+  auto half_sum_hi = [&](float v) __attribute__((always_inline)) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
+    return v;
+  };
   auto epilogue = [&](int k) __attribute__((always_inline)) {
-    // ---- epilogue of item k.  D layout of v_mfma_f32_32x32x16: column (out channel) = lane & 31, row (pixel of the tile row) =
-    // (i & 3) + 8 (i >> 2) + 4 (lane >> 5): a lane stores four float4 per tile row
+    // ---- epilogue of item k.  D layout of v_mfma_f32_32x32x16 with the weights as the A operand: column (pixel of the tile row) =
+    // lane & 31, row (out channel of the block) = (i & 3) + 8 (i >> 2) + 4 (lane >> 5): register i of accumulator a is one pixel of
+    // channel ch(i) in tile row a / CB, column block a % CB -- a store of it is two whole lines
     const Item it = itm;
-    const int q = it.qb * 32 + fq;
+    const long long cs = (long long)p.D * plane;              // channel stride of y
     if (MODE == 0) {
-      float psum = 0.f;
+      float bi[16];
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+      for (int j = 0; j < 4; ++j) {
+        const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(lbias + it.qb * 32 + 8 * j + 4 * fh8);
+        bi[4 * j] = b4[0]; bi[4 * j + 1] = b4[1]; bi[4 * j + 2] = b4[2]; bi[4 * j + 3] = b4[3];
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[a][i] = fmaf(acc[a][i], unsc, bi[i]);
+      if (p.part != nullptr && !(MM_DIAG & 16)) {
+        // (count 128, mean, M2) of this wave's 4 x 32 pixels per out channel: per-lane sums over the four accumulators, then over
+        // the 32 lanes of the half; two passes (mean first) like every other kernel of the family
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          acc[r][i] = fmaf(acc[r][i], unsc, bq);
-          psum += acc[r][i];
-        }
-      if (p.part != nullptr && !(MM_DIAG & 16)) {
-        const float mean = (psum + __shfl_xor(psum, 32, 64)) * (1.f / 128.f);
-        float m2 = 0.f;
+          const float tot = half_sum_hi((acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i]));
+          const float t0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), 31));
+          const float t1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), 63));
+          const float mean = (fh8 ? t1 : t0) * (1.f / 128.f);
+          float m2 = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const float dl = acc[r][i] - mean;
+          for (int a = 0; a < 4; ++a) {
+            const float dl = acc[a][i] - mean;
             m2 = fmaf(dl, dl, m2);
           }
-        m2 += __shfl_xor(m2, 32, 64);
-        if (fh8 == 0) { red[k & 1][wr][fq][0] = mean; red[k & 1][wr][fq][1] = m2; }
+          m2 = half_sum_hi(m2);
+          if (fq == 31) {
+            const int ch = (i & 3) + 8 * (i >> 2) + 4 * fh8;
+            red[k & 1][wr][ch][0] = mean; red[k & 1][wr][ch][1] = m2;
+          }
+        }
         pending = k;
       }
       if (!(MM_DIAG & 8)) {
-        // stores as whole 128-byte lines: in the D layout a lane holds 16-byte pieces of 32 different channel planes, and a store
-        // instruction from it is 32 partial-line write requests (counters: as many write as read requests for a third of the bytes,
-        // the L1 stalled on pending requests 77 % of the time; profiles/r05_mm_pmc.txt).  Per accumulator tile and channel octet the
-        // wave transposes through 1 KB of LDS of its own: lane -> (channel l / 8 of the octet, pixel quad l % 8)
+        float* yb = p.y + ((long long)it.n * p.Q + it.qb * 32 + 4 * fh8) * cs + (long long)it.d * plane + (long long)(it.h0 + RPW * wr) * p.W + it.w0 + fq;
+        const int qlim = p.Q - it.qb * 32 - 4 * fh8;          // channels of this lane's half that exist
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {                         // accumulator a = (tile row a / CB of this wave, column block a % CB)
-          float* yrow = p.y + ((long long)it.n * p.Q * p.D + it.d) * plane + (long long)(it.h0 + RPW * wr + a / CB) * p.W + it.w0 + (a % CB) * 32;
+        for (int i = 0; i < 16; ++i) {
+          const int chl = (i & 3) + 8 * (i >> 2);
+          if (chl < qlim) {
 #pragma unroll
-          for (int oc8 = 0; oc8 < 4; ++oc8) {
-            if ((fq >> 3) == oc8) {
-#pragma unroll
-              for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<f32x4_t*>(tb + (fq & 7) * TP + 8 * g + 4 * fh8) = f32x4_t{acc[a][4 * g], acc[a][4 * g + 1], acc[a][4 * g + 2], acc[a][4 * g + 3]};
-            }
-            const f32x4_t v = *reinterpret_cast<const f32x4_t*>(tb + (lane >> 3) * TP + (lane & 7) * 4);
-            const int qs = it.qb * 32 + oc8 * 8 + (lane >> 3);
-            if (qs < p.Q) *reinterpret_cast<f32x4_t*>(yrow + (long long)qs * p.D * plane + (lane & 7) * 4) = v;
+            for (int a = 0; a < 4; ++a) yb[chl * cs + (a / CB) * p.W + (a % CB) * 32] = acc[a][i];
           }
         }
       }
     } else {
-      // data gradient: the gradient of virtual-concat channel q at (shifted) depth d goes to depth d - s(q) of its source; slices
-      // that receive nothing are zero-filled by the workgroups of the out-of-range depths (conv133_kernel's rule).  Stores (and the
-      // reads of an accumulating destination) as whole lines through the wave's transposition buffer, as in the forward: a lane
-      // serves channel oc8 * 8 + l / 8 of each octet
-      float* dst[4];
-      float usc4[4];
-      bool accu[4];
+      // data gradient: destinations from the item's records (odesc), eight out channels of this lane's half at a time: an
+      // accumulating destination's 32 old values are requested before the first is used; the next chunk's fragments are requested
+      // BEHIND the epilogue at an item's end (chunk()), so their registers are free here
+      const int rowoff = RPW * wr * p.W + fq;
 #pragma unroll
-      for (int oc8 = 0; oc8 < 4; ++oc8) {
-        const int qs = it.qb * 32 + oc8 * 8 + (lane >> 3);
-        dst[oc8] = nullptr; usc4[oc8] = unsc; accu[oc8] = false;
-        if (qs < p.Q) {
-          const e2e_out_chan_t oc = lout[qs];
-          if (oc.ptr != nullptr) {
-            int dd = it.d - oc.dshift;
-            bool zero_fill = false;
-            if (dd < 0) {
-              const int lo = p.D - oc.dshift > 0 ? p.D - oc.dshift : 0;
-              dd = lo + it.d;
-              zero_fill = true;
-            } else if (dd >= p.D) {
-              const int lo = p.D + oc.dshift > 0 ? p.D + oc.dshift : 0;
-              dd = it.d - lo;
-              zero_fill = true;
-            }
-            if (!(zero_fill && oc.accumulate)) {
-              dst[oc8] = oc.ptr + (long long)it.n * oc.nstride + (long long)dd * plane + (long long)(it.h0 + RPW * wr) * p.W + it.w0 + (lane & 7) * 4;
-              usc4[oc8] = zero_fill ? 0.f : unsc;
-              accu[oc8] = !zero_fill && oc.accumulate;
-            }
-          }
+      for (int hf = 0; hf < 2; ++hf) {
+        float* dst[8];
+        float usc[8];
+        int flg[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int i = 8 * hf + e;
+          const ODesc od = odesc[k & 1][(i & 3) + 8 * (i >> 2) + 4 * fh8];
+          dst[e] = od.dst; usc[e] = od.usc; flg[e] = od.flags;
         }
-      }
-      // an accumulating destination: the eight old pieces of two accumulator tiles are requested before the first is used (two memory
-      // round trips per item, not sixteen); lanes whose destination does not accumulate read it too (a valid address) and drop
-      // the value.  The next chunk's fragments are requested BEHIND the epilogue at an item's end (chunk()): those registers are free.
-      const bool any_accu = __builtin_amdgcn_ballot_w64(accu[0] | accu[1] | accu[2] | accu[3]) != 0ull;      // (wave-uniform)
+        int anyf = 0;
 #pragma unroll
-      for (int ap = 0; ap < 2; ++ap) {
-        f32x4_t old[2][4];
+        for (int e = 0; e < 8; ++e) anyf |= flg[e];
+        const bool any_accu = __builtin_amdgcn_ballot_w64((anyf & 2) != 0) != 0ull;      // (wave-uniform)
+        float old[8][4];
         if (any_accu) {
 #pragma unroll
-          for (int a2 = 0; a2 < 2; ++a2)
+          for (int e = 0; e < 8; ++e)
 #pragma unroll
-            for (int oc8 = 0; oc8 < 4; ++oc8) {
-              const int a = 2 * ap + a2;
-              const float* src = dst[oc8] != nullptr ? dst[oc8] + (a / CB) * p.W + (a % CB) * 32 : reinterpret_cast<const float*>(p.wpk);
-              old[a2][oc8] = *reinterpret_cast<const f32x4_t*>(src);
+            for (int a = 0; a < 4; ++a) {
+              const float* src = (flg[e] & 1) ? dst[e] + rowoff + (a / CB) * p.W + (a % CB) * 32 : reinterpret_cast<const float*>(p.wpk);
+              old[e][a] = *src;
             }
         }
 #pragma unroll
-        for (int a2 = 0; a2 < 2; ++a2)
+        for (int e = 0; e < 8; ++e)
 #pragma unroll
-          for (int oc8 = 0; oc8 < 4; ++oc8)
-            if (!any_accu || !accu[oc8]) old[a2][oc8] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+          for (int a = 0; a < 4; ++a)
+            if (!any_accu || !(flg[e] & 2)) old[e][a] = 0.f;
 #pragma unroll
-        for (int a2 = 0; a2 < 2; ++a2) {
-          const int a = 2 * ap + a2;
-          const int aoffs = (a / CB) * p.W + (a % CB) * 32;
+        for (int e = 0; e < 8; ++e) {
+          if (flg[e] & 1) {
 #pragma unroll
-          for (int oc8 = 0; oc8 < 4; ++oc8) {
-            if ((fq >> 3) == oc8) {
-#pragma unroll
-              for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<f32x4_t*>(tb + (fq & 7) * TP + 8 * g + 4 * fh8) = f32x4_t{acc[a][4 * g], acc[a][4 * g + 1], acc[a][4 * g + 2], acc[a][4 * g + 3]};
-            }
-            const f32x4_t v = *reinterpret_cast<const f32x4_t*>(tb + (lane >> 3) * TP + (lane & 7) * 4);
-            if (dst[oc8] != nullptr) *reinterpret_cast<f32x4_t*>(dst[oc8] + aoffs) = v * usc4[oc8] + old[a2][oc8];
+            for (int a = 0; a < 4; ++a) dst[e][rowoff + (a / CB) * p.W + (a % CB) * 32] = fmaf(acc[a][8 * hf + e], usc[e], old[e][a]);
           }
         }
       }
@@ -674,7 +699,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int PAR = decltype(PARC)::value;
     using B0 = std::integral_constant<int, PAR>;
     using B1 = std::integral_constant<int, PAR ^ 1>;
-    if (MODE == 0 && p.bias != nullptr) { const int qq = itm.qb * 32 + fq; bq = p.bias[qq < p.Q ? qq : 0]; }
     MMT(m0);
     __builtin_amdgcn_sched_barrier(0);
     load_a(I1{}, s); load_b(B1{}, I1{}, s);
