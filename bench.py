@@ -23,6 +23,9 @@ bucketed RCCL all-reduce of the gradients overlapped with the backward pass.  Pr
   dsff_update            BASELINE config 3: one Masking.truncate_weights() (prune + grow of all 35 masked tensors)
   config3                BASELINE config 3 at its own shape ([2,1,48,192,192], anisotropic pools, 14 classes): ms per training step
                          and the cost of one DSFF update measured inside the running loop
+  width48                the headline configuration at base width 48 (the width the reference trainer hard-codes): ms per step,
+                         whole-step HBM fraction, the conv kernels dispatched
+  config5                BASELINE config 5's per-rank workload (AMOS-shaped, 1 modality, 16 classes) at DSFF density 0.1 and 0.5
   cpu_baseline           the CPU oracle on the same 128^3 patch (B = 1: fwd + loss + bwd), 1 warm-up + up to 3 timed
   parity                 the metric's "Dice vs CPU ref" half: engine vs that oracle on the IDENTICAL patch (the GPU network's
                          weights and masks): Dice of the argmax maps, max |dlogit| per head, loss difference
@@ -51,19 +54,29 @@ BF16_PEAK_TF = 2500.0          # dense bf16 MFMA peak (MI355X_MICROARCH.md; the 
 FWD_BYTES_PER_VOXEL = 5393.0   # BASELINE.md section 3 / SURVEY section 8(d): algorithmic fwd bytes per voxel at 32 ch
 TRAIN_BYTES_PER_VOXEL = 3 * FWD_BYTES_PER_VOXEL
 TRAFFIC_FILE = "r04_pmc_traffic.json"
-# measured outside this process (profiles/r04_pmc_sq_bf3.txt): context for the fractions, not a live number
-CLOCK_NOTE = ("peaks are the 2.4 GHz figures of the guide; SQ busy cycles / kernel time put the shader clock at 1.5-1.6 GHz under "
-              "this kernel family with all 256 CUs busy (2.35 GHz when the same launch is confined to 64 CUs): power-limited")
+NOMINAL_MHZ = 2400.0           # the shader clock the guide's compute peaks are quoted at
+CLOCK_NOTE = ("peaks are the 2.4 GHz figures of the guide; measured_clock_mhz = shader-clock cycles / wall time of workgroup 0 of "
+              "every launch of this family inside the timed steps (s_memtime / s_memrealtime, e2e_diag_kernel_clock); "
+              "frac_at_measured_clock prices the compute peak at that clock (profiles/r05_power_clock.txt: the same launches run at "
+              "~2.35 GHz when confined to 64 CUs -- the chip is power-limited under them)")
 
 
-def build(device, patch=PATCH, cin=CIN, k=K, seed=0, density=DENSITY, pools=None, update_frequency=1200):
+def kernel_clock(libobj, family, reset=True):
+    """(MHz, ms of workgroup-0 time) the launches of a hot-kernel family ran at since the last reset."""
+    import ctypes
+    mhz, ms = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    libobj.diag_kernel_clock(family, ctypes.byref(mhz), ctypes.byref(ms), 1 if reset else 0)
+    return mhz.value, ms.value
+
+
+def build(device, patch=PATCH, cin=CIN, k=K, seed=0, density=DENSITY, pools=None, update_frequency=1200, base=None):
     from torch import nn
     from e2enet_medical_amd.network_architecture.unetpp_d import Generic_UNetPlusPlus
     from e2enet_medical_amd.network_architecture.initialization import InitWeights_He
     from e2enet_medical_amd.training.network_training.sparselearning.core_channel import Masking, CosineDecay
     from e2enet_medical_amd.training.fused_optim import FusedClipSGD
     torch.manual_seed(seed)
-    net = Generic_UNetPlusPlus(patch, cin, BASE, k, 5, 2, 2, nn.Conv3d, nn.InstanceNorm3d, {'eps': 1e-5, 'affine': True},
+    net = Generic_UNetPlusPlus(patch, cin, BASE if base is None else base, k, 5, 2, 2, nn.Conv3d, nn.InstanceNorm3d, {'eps': 1e-5, 'affine': True},
                                nn.Dropout3d, {'p': 0, 'inplace': True}, nn.LeakyReLU,
                                {'negative_slope': 1e-2, 'inplace': True}, True, False, lambda x: x, InitWeights_He(1e-2),
                                pools or POOLS, None, False, True, True).to(device)
@@ -342,6 +355,63 @@ def config3_record(device):
             "amortised_ms_per_step_at_update_frequency_1200": (sum(with_up) / max(1, len(with_up)) - med) / 1200.0}
 
 
+def step_record(device, what, patch, cin, k, base, density, batch, seed, bytes_per_voxel=None):
+    """ms per full training step (forward, loss, backward, clip, SGD, mask step) of another configuration of the same network, and the
+    conv kernels it dispatched to (e2e_last_kernel behind every conv entry point of one step)."""
+    net, opt, mask, fused = build(device, patch, cin=cin, k=k, seed=seed, density=density, base=base)
+    g = torch.Generator().manual_seed(seed + 100)
+    x = torch.randn((batch, cin) + tuple(patch), generator=g).to(device)
+    eng = net.engine(x)
+    outs = eng.forward(x, True)
+    targets = [torch.randint(0, k, (batch, 1) + tuple(o.shape[2:]), generator=g).float().to(device) for o in outs]
+    ds_w = np.array([8, 4, 2, 1, 0], dtype=np.float64) / 15.0
+
+    def one():
+        eng.forward(x, True)
+        eng.loss_backward(targets, ds_w, batch_dice=False)
+        fused.step(eng.grads, mask.masks)
+        mask.step(masks_already_applied=True)
+    from e2enet_medical_amd._lib import lib
+    L = lib()
+    names = ["conv133_fwd", "conv133_fwd_splitk", "conv133_fwd_dense", "conv133_fwd_sparse", "conv133_fwd_mm", "conv133_dgrad",
+             "conv133_dgrad_splitk", "conv133_dgrad_dense", "conv133_dgrad_sparse", "conv133_dgrad_mm", "conv133_wgrad"]
+    seen, orig = {}, {}
+    for nme in names:
+        fn = getattr(L, nme)
+        orig[nme] = fn
+
+        def wrapped(*a, _fn=fn):
+            _fn(*a)
+            kname = (L.last_kernel() or b"").decode().split(" ")[0]
+            seen[kname] = seen.get(kname, 0) + 1
+        setattr(L, nme, wrapped)
+    try:
+        one()                                       # warm-up + kernel census
+    finally:
+        for nme, fn in orig.items():
+            setattr(L, nme, fn)
+    one()
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(6):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        one()
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) * 1e3)
+    med = sorted(times)[len(times) // 2]
+    vox = batch * patch[0] * patch[1] * patch[2]
+    rec = {"workload": what, "ms_per_step": med, "voxels_per_s": vox / (med * 1e-3), "steps_timed": len(times),
+           "conv_kernels_per_step": dict(sorted(seen.items()))}
+    if bytes_per_voxel is not None:
+        rec["hbm_roofline_frac_whole_step"] = vox / (med * 1e-3) * bytes_per_voxel / (HBM_PEAK_GBS * 1e9)
+        rec["bytes_per_voxel"] = bytes_per_voxel
+    del eng
+    net._engines.clear()
+    torch.cuda.empty_cache()
+    return rec
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: this parent has made no GPU call (importing torch initialises nothing);
     it starts N fresh children of this same script, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as
@@ -406,7 +476,8 @@ def dry_rank(args, rank, world, json_fd):
     dist.all_gather(per_rank, torch.tensor([float(rank + 1)], dtype=torch.float64))
     if rank == 0:
         rec = {"metric": "dry run of the launcher (no GPU work)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "rccl": {"backend": "gloo", "world": dist.get_world_size(), "allreduce_of_ones": float(ones.item())},
+               "rccl": {"backend": "gloo", "world": dist.get_world_size(), "allreduce_of_ones": float(ones.item()),
+                        "ms_per_step_without_allreduce": 0.0, "allreduce_exposed_ms": 0.0, "allreduce_bytes_per_step": 0},
                "ms_per_step_per_rank": [float(t.item()) for t in per_rank]}
         os.write(json_fd, (json.dumps(rec) + "\n").encode())
     dist.barrier()
@@ -500,7 +571,9 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    kernel_clock(L, 0), kernel_clock(L, 1)                       # reset: the clocks below are those of the timed steps
     dt = timed(step, args.steps)
+    clk_mm, clk_wg = kernel_clock(L, 0), kernel_clock(L, 1)       # (outside the timed region)
     rccl = per_rank_ms = None
     if use_dist:
         mine = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -512,6 +585,27 @@ def main():
         dist.all_reduce(ones)
         rccl = {"backend": dist.get_backend(), "world": dist.get_world_size(), "allreduce_of_ones": float(ones.item()),
                 "devices": torch.cuda.device_count()}
+        if not args.forward_only:
+            # what the gradient all-reduce costs the step: the same steps with the bucket hook off (every rank trains alone; no
+            # collective inside the step), MAX over ranks like the headline; exposed = step with the overlapped all-reduce - that
+            hook, eng.grad_bucket_hook = eng.grad_bucket_hook, None
+
+            def local_step():
+                eng.forward(x, True)
+                eng.loss_backward(targets, ds_w, batch_dice=False)
+                fused.step(eng.grads, mask.masks)
+                mask.step(masks_already_applied=True)
+            n2 = max(3, min(args.steps, 10))
+            local_step()
+            dt2 = timed(local_step, n2)
+            eng.grad_bucket_hook = hook
+            mine2 = torch.tensor([dt2], dtype=torch.float64, device=device)
+            every2 = torch.zeros(world, dtype=torch.float64, device=device)
+            dist.all_gather_into_tensor(every2, mine2)
+            ms_local = max(float(v) for v in every2.tolist()) / n2 * 1e3
+            rccl["ms_per_step_without_allreduce"] = ms_local
+            rccl["allreduce_exposed_ms"] = dt / args.steps * 1e3 - ms_local
+            rccl["allreduce_bytes_per_step"] = int(eng.grad_flat.numel()) * 4
 
     # ---- instrumented steps (outside the timed region): HIP events around the conv entry points --------------------
     # (_splitk: the deep levels' forward / data gradient, same kernel + a sum kernel; _dense: the unmasked layers on the matrix cores)
@@ -592,8 +686,14 @@ def main():
                           "the serial kernel time with the overlapped step)" % isteps,
                 "fma": {"achieved": fl / (ms * 1e-3) / 1e12, "peak": FP32_PEAK_TF, "unit": "TFLOP/s",
                         "frac": fl / (ms * 1e-3) / 1e12 / FP32_PEAK_TF, "flops": "live (DSFF-masked) FLOPs from the kernel maps"},
+                "measured_clock_mhz": clk_mm[0] or None,
+                # an HBM peak does not move with the shader clock: the same number as frac, kept so that both records carry
+                # the key; the compute sub-record (fma) and roofline_secondary are the ones the clock derates
+                "frac_at_measured_clock": gbs / HBM_PEAK_GBS,
                 "clock_note": CLOCK_NOTE,
             }
+            if clk_mm[0]:
+                out["roofline"]["fma"]["frac_at_measured_clock"] = out["roofline"]["fma"]["frac"] * NOMINAL_MHZ / clk_mm[0]
         wt = timers["conv133_wgrad"]
         if wt.events:
             ms = wt.total_ms()
@@ -611,6 +711,8 @@ def main():
                 "algorithmic_bytes_per_launch": sum(work[a[0]]["bytes"] for _, _, a in wt.events) / len(wt.events),
                 "launches_per_step": len(wt.events) // isteps,
                 "avg_ms": ms / len(wt.events), "ms_per_step": ms / isteps, "share_of_step": (ms / isteps) / ms_step,
+                "measured_clock_mhz": clk_wg[0] or None,
+                "frac_at_measured_clock": (tf / (BF16_PEAK_TF / 3.0) * NOMINAL_MHZ / clk_wg[0]) if clk_wg[0] else None,
                 "clock_note": CLOCK_NOTE}
         if args.op_profile:
             prof = {k: round(t.total_ms() / isteps, 3) for k, t in timers.items() if t.events}
@@ -649,6 +751,15 @@ def main():
             torch.cuda.empty_cache()
             out["sliding_window"] = sliding_window_record(device)
             out["config3"] = config3_record(device)
+            # the width the reference trainer hard-codes (nnUNetTrainer_simple.py:296); algorithmic bytes scale with the channel
+            # counts: 16 179 B/voxel at base 32 -> x 48 / 32 (every term of BASELINE.md section 3 is linear in the width except the
+            # 4-channel input and the K-channel heads, < 1 %)
+            out["width48"] = step_record(device, "BraTS-shaped 4-modal 128^3 patches, shiftConvPP base 48 (the reference trainer's width), "
+                                                 "K=4, DSFF density 0.2, batch 2, full training step", (128, 128, 128), 4, 4, 48, 0.2, 2, 5,
+                                         bytes_per_voxel=TRAIN_BYTES_PER_VOXEL * 48.0 / 32.0)
+            out["config5"] = {"d%s" % dens: step_record(device, "AMOS-shaped 1-modal 128^3 patches, 16 classes, base 32, DSFF density %s, "
+                                                                "batch 2, full training step (per-rank workload of BASELINE config 5)" % dens,
+                                                        (128, 128, 128), 1, 16, 32, dens, 2, 7) for dens in (0.1, 0.5)}
         if sw_multi is not None:
             out["sliding_window"] = sw_multi
         if not args.no_cpu_baseline and world == 1:      # the CPU port is timed on rank 0 of the single-GPU run only

@@ -11,6 +11,31 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # library, still no fallback
 LIB_PATH = os.environ.get("E2E_LIB_PATH") or os.path.join(_HERE, "csrc", "libe2e_hip.so")
 
+# every E2E_* environment variable the package, bench.py and the library read (INTEGRATION.md section 7 says what each does).
+# Anything else spelled E2E_* in the environment is a typo or a knob that no longer exists: refuse it instead of silently
+# running the default configuration under a name that promises something else.
+KNOWN_ENV = frozenset({
+    # library (csrc/*.hip)
+    "E2E_CONV_MM", "E2E_MM_GRID", "E2E_MM_GEOM", "E2E_CONV_DENSE", "E2E_CONV_SPARSE2", "E2E_CONV_PERSIST", "E2E_CONV_WGS",
+    "E2E_CONV_KSPLIT", "E2E_WG_H2", "E2E_WG_BF3", "E2E_CT_BF3",
+    # diagnostic builds of the library only (-DE2E_CONV_DEBUG / -DMM_STAMPS); ignored by the shipped build
+    "E2E_CONV_DBG", "E2E_MM_STAMPS",
+    # host side
+    "E2E_LIB_PATH", "E2E_DENSE_MIN_DENSITY", "E2E_MM_MIN_DENSITY", "E2E_WGRAD_STREAM", "E2E_LANES", "E2E_GRAPHS",
+    "E2E_GRAPH_MAX_VOXELS", "E2E_PLAN_CACHE_GB", "E2E_SW_BLOCKING", "E2E_FORCE_DIST",
+    # bench.py
+    "E2E_CPU_THREADS", "E2E_BENCH_DRY", "E2E_BENCH_DRY_FAIL_RANK", "E2E_BENCH_ALL_LAUNCHES",
+})
+
+
+def check_env(environ=None):
+    """Raise on an E2E_* variable nobody reads (called when the library is loaded)."""
+    environ = os.environ if environ is None else environ
+    unknown = sorted(k for k in environ if k.startswith("E2E_") and k not in KNOWN_ENV)
+    if unknown:
+        raise RuntimeError("unknown E2E_* environment variable(s) %s: not read by this build (known: %s)"
+                           % (", ".join(unknown), ", ".join(sorted(KNOWN_ENV))))
+
 
 class InChan(C.Structure):
     """e2e_in_chan_t"""
@@ -75,6 +100,7 @@ SIGNATURES = {
     "e2e_conv133_wgrad_ws_bytes": (LL, [I, I, I, I, I, I, I, I, I]),
     "e2e_conv133_wgrad": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, P, P]),
     "e2e_diag_split_gemm": (I, [P, P, P, I, I, P, P]),
+    "e2e_diag_kernel_clock": (I, [I, P, P, I]),
     "e2e_in_stats_finalize": (I, [P, I, P, P, F, P, P, P, P, I, I, P]),
     "e2e_in_lrelu_bwd": (I, [P, P, P, P, P, P, F, P, P, P, P, I, I, LL, P, I, P, P]),
     "e2e_convT_fwd": (I, [P, P, P, F, P, P, P, I, I, I, I, I, I, I, I, I, P]),
@@ -161,7 +187,7 @@ class _Lib:
 _lib = None
 
 
-ABI_VERSION = 14          # e2e_abi_version() of the library this binding was written against
+ABI_VERSION = 15          # e2e_abi_version() of the library this binding was written against
 
 
 def lib() -> _Lib:
@@ -171,6 +197,7 @@ def lib() -> _Lib:
         # torch first: libe2e_hip.so must bind to the HIP runtime PyTorch-ROCm has loaded (one runtime per process,
         # so that torch's streams and device pointers are valid in our launches)
         import torch  # noqa: F401
+        check_env()
         handle = _Lib(LIB_PATH)
         got = handle.abi_version()
         if got != ABI_VERSION:           # a stale in-tree .so from another revision: fail loudly, never guess

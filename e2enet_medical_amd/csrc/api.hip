@@ -21,4 +21,14 @@ void note_kernel(const char* fmt, ...) {
 
 extern "C" const char* e2e_last_error(void) { return e2e::g_err; }
 extern "C" const char* e2e_last_kernel(void) { return e2e::g_kernel; }
-extern "C" int e2e_abi_version(void) { return 14; }
+extern "C" int e2e_abi_version(void) { return 15; }
+
+extern "C" int e2e_diag_kernel_clock(int family, double* mhz, double* busy_ms, int reset) {
+  E2E_REQUIRE(mhz != nullptr && (family == 0 || family == 1), "diag_kernel_clock: family 0 (conv133_mm) or 1 (conv133_wgrad v5)");
+  if (hipDeviceSynchronize() != hipSuccess) return e2e::check_launch("diag_kernel_clock");
+  unsigned long long v[2] = {0, 0};
+  if (family == 0) e2e::mm_clock_read(v, reset != 0); else e2e::wgrad_clock_read(v, reset != 0);
+  *mhz = v[1] ? 100.0 * (double)v[0] / (double)v[1] : 0.0;     // s_memrealtime: 100 MHz
+  if (busy_ms) *busy_ms = (double)v[1] / 1e5;
+  return e2e::check_launch("diag_kernel_clock");
+}

@@ -1123,8 +1123,7 @@ int launch_sub(const ConvParams& p, int kind, hipStream_t st);
 
 
 inline int opw8_knob() {
-  static const int v = getenv("E2E_CONV_OPW8") ? atoi(getenv("E2E_CONV_OPW8")) : 0;
-  return v;
+  return 0;
 }
 
 // stride-1 tiles; STG = 1 (aligned float4 staging) needs rows that are multiples of 4 floats

@@ -37,6 +37,7 @@
 #ifndef MM_DIAG
 #define MM_DIAG 0      // timing-only diagnostic builds (results wrong): 1 no matrix instructions, 2 every plane request reads offset 0 of its plane (cache hits), 4 no conversion arithmetic, 8 no forward stores, 16 no forward statistics
 #endif
+__device__ unsigned long long g_mm_clock[2];     // [0] shader-clock cycles, [1] 100 MHz ticks of workgroup 0, summed over launches (e2e_diag_kernel_clock)
 #ifdef MM_STAMPS
 __device__ unsigned long long g_mm_stamps[16];   // staging: [0] dma [1] ctab [2] request [3] commit [4] vmcnt wait [5] barrier; matrix: [8] mma [9] lgkm wait [10] barrier [11] epilogue; [15] chunks
 #define MMT(v) const unsigned long long v = __builtin_readcyclecounter()
@@ -188,6 +189,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int G = p.grid;
   const int l0 = e2e::xcd_remap(blockIdx.x, G);
   if (l0 >= p.total) return;
+  const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_r0 = __builtin_amdgcn_s_memrealtime();
   const int nitems = (p.total - l0 + G - 1) / G;
   const int S = nitems * p.nchunks;                          // chunks of this workgroup's pipeline
   const int plane = p.H * p.W;                               // (host: H * W < 2^31 / 4)
@@ -750,6 +752,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   __syncthreads();                                            // the last item's statistics records
   if (pending >= 0) combine(pending);
+  if (blockIdx.x == 0 && tid == 0) {
+    atomicAdd(&g_mm_clock[0], __builtin_readcyclecounter() - clk_c0);
+    atomicAdd(&g_mm_clock[1], __builtin_amdgcn_s_memrealtime() - clk_r0);
+  }
 #ifdef MM_STAMPS
   if (wr == 0 && lane == 0) for (int i = 8; i < 15; ++i) atomicAdd(&g_mm_stamps[i], st_acc[i]);
 #endif
@@ -761,6 +767,12 @@ inline bool mm_knob() {
 }
 
 }  // namespace
+
+void e2e::mm_clock_read(unsigned long long out[2], bool reset) {
+  const unsigned long long z[2] = {0, 0};
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mm_clock), sizeof(z));
+  if (reset) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mm_clock), z, sizeof(z));
+}
 
 // tile geometry of a plane width (Geo<>): full-width tiles where the plane is 32, 64 or 128 wide; E2E_MM_GEOM=0 keeps 16 x 32 tiles
 static int mm_geom(int Wi) {

@@ -625,8 +625,6 @@ int sparse_launch(int mode, SparseParams p, hipStream_t st) {
 #endif
   p.uw = e2e::cdiv(3 * p.kmax, NW);
   size_t dyn = (size_t)2 * p.kmax * WSLOT * 4 + (size_t)p.ppad * sizeof(PlaneDesc);
-  static const int pad_kb = getenv("E2E_SPARSE_LDS_PAD_KB") ? atoi(getenv("E2E_SPARSE_LDS_PAD_KB")) : 0;   // occupancy experiment
-  dyn += (size_t)pad_kb * 1024;
   // static 55 KB + dynamic: beyond the default 64 KB for dense maps / many planes.  Set before every launch of the mode (cheap): a
   // process-wide "already set" flag is a data race under concurrent callers and leaves other devices of the process without it
   E2E_REQUIRE(hipFuncSetAttribute(mode == 0 ? (const void*)conv133_sparse_kernel<0> : (const void*)conv133_sparse_kernel<1>,

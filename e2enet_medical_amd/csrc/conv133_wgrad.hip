@@ -1092,8 +1092,7 @@ inline int v2_ncb(int Cin, int Ho, int Wo) {      // 8x8 planes: the (4,8,8) til
 
 // v3 (double-buffered 4 x 32 tiles): stride-1 planes at least 32 wide whose rows are multiples of 4 floats
 inline bool use_v3(int Cin, int Hi, int Wi, int sh, int sw) {
-  static const int off = getenv("E2E_WG_NOV3") ? atoi(getenv("E2E_WG_NOV3")) : 0;
-  return !off && sh == 1 && sw == 1 && (Wi % 4) == 0 && Wi >= 32 && Hi > 16;
+  return sh == 1 && sw == 1 && (Wi % 4) == 0 && Wi >= 32 && Hi > 16;
 }
 // block shape of a v3 workgroup: 32 out x 64 in channels, or 64 out x 32 in.  The wide-out shape stages less (the
 // halo'd input tile is the expensive half) and pads fewer input channels (Cin = 160: three 64-blocks waste a sixth of
@@ -1114,7 +1113,7 @@ inline int plan_v3(WgParams& p, int pairs) {
   p.tiles_d = p.Do;
   p.tiles_per_n = p.tiles_d * p.tiles_y * p.tiles_x;
   p.total_tiles = (long long)p.tiles_per_n * p.B;
-  static const int target = getenv("E2E_WG_V3_TARGET") ? atoi(getenv("E2E_WG_V3_TARGET")) : 256;
+  const int target = 256;
   long long want = target / (pairs > 0 ? pairs : 1);        // one workgroup per CU, equal work each; fewer chunks = fewer slabs to reduce
   if (want < p.B) want = p.B;
   int segs = (int)(want / p.B);
@@ -1139,12 +1138,11 @@ inline bool use_bf3(int Cin, int Cout, int Di, int Hi, int Wi, int sd, int sh, i
 inline int wg_h2_env() { static const int v = getenv("E2E_WG_H2") ? atoi(getenv("E2E_WG_H2")) : 1; return v; }
 inline int bf3_pairs(int Cin, int Cout) { return e2e::cdiv(Cin, 32) * e2e::cdiv(Cout, 32); }
 // planes 16..31 voxels wide: the same kernel on 8 x 16-pixel tiles (conv133_wgrad_bf3v5_kernel<1>; round 4, they ran on the fp32
-// MFMA v2 kernel); E2E_WG_W16=0 or E2E_WG_BF3 < 5 keeps v2.  32-bit element offsets inside one batch item (as v5).
+// MFMA v2 kernel); E2E_WG_BF3=0 keeps v2.  32-bit element offsets inside one batch item (as v5).
 inline bool use_bf3_w16(int Cin, int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw) {
   static const int bf3 = getenv("E2E_WG_BF3") ? atoi(getenv("E2E_WG_BF3")) : 1;
-  static const int on = getenv("E2E_WG_W16") ? atoi(getenv("E2E_WG_W16")) : 1;
   const long long Do = (Di - 1) / sd + 1;
-  return bf3 && on && Cin > 4 && sh == 1 && sw == 1 && (Wi % 4) == 0 && Wi >= 16 && Wi < 32 && Hi >= 8 &&
+  return bf3 && Cin > 4 && sh == 1 && sw == 1 && (Wi % 4) == 0 && Wi >= 16 && Wi < 32 && Hi >= 8 &&
          (long long)Di * Hi * Wi < (1ll << 29) && (long long)Cout * Do * Hi * Wi < (1ll << 29);
 }
 inline int plan_w16(WgParams& p, int pairs) {
@@ -1167,8 +1165,7 @@ inline int plan_w16(WgParams& p, int pairs) {
 
 // network input layer (Cin <= 4): stride 1, rows multiples of 4 floats, planes at least one 8 x 32 tile
 inline bool use_smallc(int Cin, int Hi, int Wi, int sh, int sw) {
-  static const int off = getenv("E2E_WG_NOSMALLC") ? atoi(getenv("E2E_WG_NOSMALLC")) : 0;
-  return !off && Cin <= 4 && sh == 1 && sw == 1 && (Wi % 4) == 0 && Wi >= 32 && Hi >= 8;
+  return Cin <= 4 && sh == 1 && sw == 1 && (Wi % 4) == 0 && Wi >= 32 && Hi >= 8;
 }
 inline int plan_smallc(WgParams& p, int pairs) {        // returns the number of workgroup chunks (slabs = 2 x that)
   p.tiles_x = e2e::cdiv(p.Wo, 32);
@@ -1245,8 +1242,7 @@ extern "C" int e2e_conv133_wgrad(const e2e_in_chan_t* chans, const float* dy, fl
   E2E_REQUIRE((sd == 1 || sd == 2) && (sh == 1 || sh == 2) && (sw == 1 || sw == 2), "conv133_wgrad: stride must be 1 or 2");
   hipStream_t st = (hipStream_t)stream;
   WgParams p{};
-  static const int dbg = getenv("E2E_WG_DBG") ? atoi(getenv("E2E_WG_DBG")) : 0;
-  p.dbg = dbg;
+  p.dbg = 0;
   p.chans = chans; p.dy = dy; p.slab = reinterpret_cast<float*>(ws);
   p.B = B; p.Cin = Cin; p.Cout = Cout; p.Di = Di; p.Hi = Hi; p.Wi = Wi; p.sd = sd;
   p.Do = (Di - 1) / sd + 1; p.Ho = (Hi - 1) / sh + 1; p.Wo = (Wi - 1) / sw + 1;

@@ -124,6 +124,7 @@ static_assert(XROWS * XROWB + 16 == CSTR2 && TH * YROWB + 16 == CSTR2 && (CSTR2 
 //        1e-7 gradients, all-positive operands): at or below the bf16x3 form and the fp32 FMA chain in every row; round-to-nearest
 //        splits (truncating ones are biased: 4e-4 of the result at K = 262144 with one-signed operands).
 constexpr int XSH = 3;
+__device__ unsigned long long g_wg_clock[2];     // as g_mm_clock (conv133_mm.hip)
 template <int G, int NPC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv133_wgrad_bf3v5_kernel(e2e::WgBf3Params p) {
   constexpr int XBn = NPC * SSTR2, BUFn = 2 * XBn;          // input image, one (input + dy) image
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   int tile_hi = tile_lo + p.tiles_per_chunk;
   if (tile_hi > p.tiles_per_n) tile_hi = p.tiles_per_n;
   const int ntiles = tile_hi - tile_lo;
+  const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_r0 = __builtin_amdgcn_s_memrealtime();
   f32x16 acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
@@ -477,6 +479,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
     }
   }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+    atomicAdd(&g_wg_clock[0], __builtin_readcyclecounter() - clk_c0);
+    atomicAdd(&g_wg_clock[1], __builtin_amdgcn_s_memrealtime() - clk_r0);
+  }
 }
 
 // ---- diagnostic: one 32 x 32 output block of a GEMM through the SAME split functions and product orders as the kernels above -----
@@ -544,6 +550,12 @@ __global__ __launch_bounds__(64) void diag_split_gemm_kernel(const float* __rest
 }
 
 }  // namespace
+
+void e2e::wgrad_clock_read(unsigned long long out[2], bool reset) {
+  const unsigned long long z[2] = {0, 0};
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_clock), sizeof(z));
+  if (reset) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wg_clock), z, sizeof(z));
+}
 
 extern "C" int e2e_diag_split_gemm(const float* A, const float* Bt, float* D, int K, int mode, const unsigned* absmax_b, void* stream) {
   E2E_REQUIRE(A && Bt && D && K > 0 && K % 16 == 0 && mode >= 0 && mode <= 2, "diag_split_gemm: bad arguments");

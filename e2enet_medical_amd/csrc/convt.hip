@@ -1305,7 +1305,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 inline int wgrad_chunks(long long total_tiles, int pairs, int* tiles_per_chunk, int per_cu = 1) {
   // aim at ~256 workgroups (one 84 KB workgroup per CU, equal work each; per_cu = 2: 512) and keep the slabs few: every chunk is
   // a slab the reduction has to read (1024 chunks cost 14 % more on the 64 -> 32 @64^3 layer); at least 8 tiles per chunk
-  static const int target = getenv("E2E_CT_WG_TARGET") ? atoi(getenv("E2E_CT_WG_TARGET")) : 256;
+  const int target = 256;
   long long want = (long long)target * per_cu / (pairs > 0 ? pairs : 1);
   if (want < 1) want = 1;
   long long tpc = e2e::cdivll(total_tiles, want);
@@ -1378,8 +1378,7 @@ extern "C" int e2e_convT_fwd(const float* x, const float* scale, const float* sh
 }
 
 static int dg_min_tiles() {
-  static const int v = getenv("E2E_CT_DG_MINTILES") ? atoi(getenv("E2E_CT_DG_MINTILES")) : 256;     // 256 tiles (16^3 x 2) still win over the gather kernel, 64 do not
-  return v;
+  return 256;                                               // 256 tiles (16^3 x 2) still win over the gather kernel, 64 do not
 }
 
 extern "C" int e2e_convT_dgrad(const float* dy, const float* w, const unsigned* live_t, float* dx, int accumulate,
@@ -1390,12 +1389,12 @@ extern "C" int e2e_convT_dgrad(const float* dy, const float* w, const unsigned* 
   hipStream_t st = (hipStream_t)stream;
   const long long spatial = (long long)D * H * W;
   // v3 / v4 (dense GEMM on the matrix cores) for the large planes; E2E_CT_BF3=0 keeps the fp32 matrix instructions (v3)
-  static const int no_v3 = getenv("E2E_CT_NOV3") ? atoi(getenv("E2E_CT_NOV3")) : 0;
+  const int no_v3 = 0;
   static const int use_bf3 = getenv("E2E_CT_BF3") ? atoi(getenv("E2E_CT_BF3")) : 1;
   if (!no_v3 && kw == 2 && (kd * kh == 2 || kd * kh == 4) && (W % 2) == 0 && spatial % 4 == 0 && e2e::cdivll(spatial, 32) * B >= dg_min_tiles()) {
     const long long total_tiles = e2e::cdivll(spatial, 32) * B;
     const int cgroups = e2e::cdiv(Cin, 64);
-    static const int target = getenv("E2E_CT_DG_TARGET") ? atoi(getenv("E2E_CT_DG_TARGET")) : 512;   // two 4-wave workgroups fit a CU (186 VGPRs): exactly one round
+    const int target = 512;                                 // two 4-wave workgroups fit a CU (186 VGPRs): exactly one round
     long long wgs = target / cgroups;
     if (wgs < 1) wgs = 1;
     int tpw = (int)e2e::cdivll(total_tiles, wgs);
@@ -1433,14 +1432,9 @@ extern "C" int e2e_convT_dgrad(const float* dy, const float* w, const unsigned* 
   return e2e::check_launch("convT_dgrad_kernel");
 }
 
-// 32-voxel tiles of the bf16x3 weight gradient (two workgroups per CU; kd * kh = 4 only): measured SLOWER than one workgroup
-// per CU with 64-voxel tiles on every level but the 8^3 one (0.215 -> 0.27 ms at 64 -> 32 @64^3, profiles/r04_convt_wgrad_tiles.txt:
-// twice the barriers and slabs per matrix instruction); off unless E2E_CT_TPX32=1
-static bool convT_bf3_tpx32(int kd, int kh) {
-  static const int on = getenv("E2E_CT_TPX32") ? atoi(getenv("E2E_CT_TPX32")) : 0;
-  static const int use_bf3 = getenv("E2E_CT_BF3") ? atoi(getenv("E2E_CT_BF3")) : 1;
-  return on && use_bf3 && kd * kh == 4;
-}
+// (32-voxel tiles of the bf16x3 weight gradient, two workgroups per CU, were measured SLOWER than one workgroup per CU with 64-voxel
+// tiles on every level but the 8^3 one -- 0.215 -> 0.27 ms at 64 -> 32 @64^3, profiles/r04_convt_wgrad_tiles.txt -- and removed in
+// round 5)
 static bool convT_use_v2(int D, int H, int W, int kd, int kh, int kw) {
   return kw == 2 && (kd * kh == 2 || kd * kh == 4) && (W % 2) == 0 && ((long long)D * H * W) % 4 == 0;
 }
@@ -1452,8 +1446,6 @@ extern "C" long long e2e_convT_wgrad_ws_bytes(int B, int Cin, int Cout, int D, i
   int pairs = e2e::cdiv(Cin, 32) * e2e::cdiv(Cout, 32);
   if (convT_use_v2(D, H, W, kd, kh, kw)) pairs = e2e::cdiv(Cin, 32 * convT_v2_ncb(Cin)) * e2e::cdiv(Cout, 32);
   int nchunks = wgrad_chunks(total_tiles, pairs, &tpc);
-  if (convT_use_v2(D, H, W, kd, kh, kw) && convT_bf3_tpx32(kd, kh))
-    nchunks = wgrad_chunks(e2e::cdivll((long long)D * H * W, 32) * B, pairs, &tpc, 2);
   return (long long)nchunks * Cin * Cout * kd * kh * kw * (long long)sizeof(float);
 }
 
@@ -1473,17 +1465,15 @@ extern "C" int e2e_convT_wgrad(const float* x, const float* scale, const float* 
     const int ncb = convT_v2_ncb(Cin);
     const int cgroups = e2e::cdiv(Cin, 32 * ncb);
     const int pairs2 = cgroups * e2e::cdiv(Cout, 32);
-    const bool tpx32 = convT_bf3_tpx32(kd, kh);
-    const int nch = tpx32 ? wgrad_chunks(e2e::cdivll((long long)D * H * W, 32) * B, pairs2, &tpc, 2) : wgrad_chunks(total_tiles, pairs2, &tpc);
+    const int nch = wgrad_chunks(total_tiles, pairs2, &tpc);
     dim3 grid2(nch, pairs2);
     const int kdh = kd * kh;
     static const int use_bf3 = getenv("E2E_CT_BF3") ? atoi(getenv("E2E_CT_BF3")) : 1;
     if (use_bf3) {
-      e2e::note_kernel("convT_wgrad_bf3<%d,%d> chunks=%d pairs=%d%s", kdh, ncb, nch, pairs2, tpx32 ? " tpx=32" : "");
+      e2e::note_kernel("convT_wgrad_bf3<%d,%d> chunks=%d pairs=%d", kdh, ncb, nch, pairs2);
 #define LAUNCH_B3(KDH, NCB, TPX) hipLaunchKernelGGL((convT_wgrad_bf3_kernel<KDH, NCB, TPX>), grid2, dim3(256 * NCB), 0, st, x, scale, shift, \
                                                     slope, dy, slab, B, Cin, Cout, D, H, W, kd, kh, tpc, cgroups)
-      if (kdh == 4 && tpx32) { if (ncb == 2) LAUNCH_B3(4, 2, 32); else LAUNCH_B3(4, 1, 32); }
-      else if (kdh == 4) { if (ncb == 2) LAUNCH_B3(4, 2, 64); else LAUNCH_B3(4, 1, 64); }
+      if (kdh == 4) { if (ncb == 2) LAUNCH_B3(4, 2, 64); else LAUNCH_B3(4, 1, 64); }
       else { if (ncb == 2) LAUNCH_B3(2, 2, 64); else LAUNCH_B3(2, 1, 64); }
 #undef LAUNCH_B3
       hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)e2e::cdivll(numel_all, 64)), dim3(256), 0, st, slab, dw, numel_all, nch);

@@ -13,6 +13,11 @@ void set_error(const char* fmt, ...);
 // dispatch diagnostics: which kernel variant the last entry point on this thread selected (e2e_last_kernel)
 void note_kernel(const char* fmt, ...);
 
+// shader clock the two hot kernel families actually run at (e2e_diag_kernel_clock): workgroup 0 of every launch adds its
+// s_memtime span (shader-clock cycles) and s_memrealtime span (constant 100 MHz) to a device-side pair -- one atomic per launch
+void mm_clock_read(unsigned long long out[2], bool reset);        // conv133_mm.hip
+void wgrad_clock_read(unsigned long long out[2], bool reset);     // conv133_wgrad_bf3.hip
+
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {

@@ -27,15 +27,14 @@ LRELU_SLOPE = 0.01
 IN_EPS = 1e-5
 DENSE_MIN_DENSITY = float(os.environ.get("E2E_DENSE_MIN_DENSITY", "0.5"))
 WGRAD_STREAM = os.environ.get("E2E_WGRAD_STREAM", "1") != "0"      # weight gradients on a second HIP stream
-WGRAD_STREAM_MAX_ELEMS = int(os.environ.get("E2E_WGRAD_STREAM_MAX_ELEMS", "40000000"))   # level 0 of 128^3 stays in line
-WGRAD_LATE = os.environ.get("E2E_WGRAD_LATE", "1") != "0"            # level-0 weight gradients behind their data gradient, on the side stream
+WGRAD_STREAM_MAX_ELEMS = 40000000   # level 0 of 128^3 stays in line
+WGRAD_LATE = True            # level-0 weight gradients behind their data gradient, on the side stream
 LANES = os.environ.get("E2E_LANES", "1") != "0"                    # deep levels on their own HIP stream (Engine._exec)
 # lane of an op = how many of these it passes: output voxels * div <= patch voxels (lane 0 = the caller's stream).  "64" puts
 # levels >= 2 on a second stream; "64,4096" gives levels >= 4 a third one
 # "auto": plans of at most 2^20 voxels (everything latency bound) use three lanes split at 1/8 and 1/512 of the patch
 # (Hippocampus patch fwd+loss+bwd 9.1 -> 7.3 ms), larger plans two lanes split at 1/64 (128^3: a third lane changed nothing)
-LANE_DIVS_ENV = os.environ.get("E2E_LANE_DIVS", "auto")
-LANE_DIVS = None if LANE_DIVS_ENV == "auto" else tuple(int(v) for v in LANE_DIVS_ENV.split(",") if v.strip())
+LANE_DIVS = None              # None = "auto"; a tuple pins the split (tests, tools/scratch)
 
 
 def _lane_divs(voxels):
@@ -45,7 +44,7 @@ def _lane_divs(voxels):
 # fused first pass of the InstanceNorm backward in the LAST writer of a gradient buffer.  1 (default): the pooling backward, which
 # is issued behind the other consumers for that purpose (an HBM-bound kernel that reads y and the final dz anyway: free);
 # 2: also the load-balanced conv data gradient (measured: +1.4 ms on those launches against -1.0 ms of in_bwd_reduce: a loss); 0: off
-FUSE_IN_SUMS = int(os.environ.get("E2E_FUSE_IN_SUMS", "1"))
+FUSE_IN_SUMS = 1
 SPARSE2 = os.environ.get("E2E_CONV_SPARSE2", "1") != "0"         # load-balanced kernel for the DSFF-masked full-resolution layers
 DENSE_ENABLED = True          # tests switch the matrix-core conv paths off to compare the sparse walk with itself
 # fp16 two-piece matrix-pipe conv (conv133_mm.hip, round 5) for every layer it serves whose kernel map is at least this dense
@@ -854,8 +853,7 @@ class Engine:
             return
         main = torch.cuda.current_stream()
         if self._lane_streams is None:
-            prio = int(os.environ.get("E2E_LANE_PRIORITY", "0"))
-            self._lane_streams = [torch.cuda.Stream(device=self.device, priority=prio) for _ in self.lane_divs]
+            self._lane_streams = [torch.cuda.Stream(device=self.device) for _ in self.lane_divs]
         side = self._lane_streams
         streams = [main] + side
 
@@ -1002,7 +1000,7 @@ class Engine:
             # gradient of the same layer (with their own workspace, in issue order among themselves).  Plans replayed as
             # HIP graphs stay single-stream: replaying a two-stream capture faults on ROCm 7.2.
             if self._wg_side is None:
-                self._wg_side = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("E2E_WGRAD_PRIORITY", "0")))
+                self._wg_side = torch.cuda.Stream(device=self.device)
                 self.wgrad_ws_side = torch.empty_like(self._wgrad_ws[0])
             self._wg_active = self._wg_side
         side = self._wg_active

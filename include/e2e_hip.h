@@ -201,6 +201,13 @@ int e2e_conv133_wgrad(const e2e_in_chan_t* chans, const float* dy, float* dw, vo
  * e2e_conv133_wgrad; 2: fp32-input MFMA (an fp32 FMA chain).  K % 16 == 0.  No reference counterpart (torch computes in fp32). */
 int e2e_diag_split_gemm(const float* A, const float* Bt, float* D, int K, int mode, const unsigned* absmax_b, void* stream);
 
+/* Diagnostic: the shader clock the hot kernels ran at.  Workgroup 0 of every launch of family 0 (K1m, conv133_mm) / 1 (the
+ * matrix-pipe K1w, conv133_wgrad v5) adds its s_memtime span (shader-clock cycles) and its s_memrealtime span (100 MHz) to a
+ * device-side pair; this call synchronises the device and returns *mhz = cycles / time over all launches since the last reset
+ * (0 if none) and *busy_ms = that time (may be NULL).  bench.py prices roofline.frac_at_measured_clock with it.  No reference
+ * counterpart. */
+int e2e_diag_kernel_clock(int family, double* mhz, double* busy_ms, int reset);
+
 /* ---- K2: InstanceNorm statistics finalize --------------------------------------------
  * Replaces: nn.InstanceNorm3d(eps, affine, instance statistics) (unetpp_d.py:99,111):
  * combines the per-tile partials (Chan) in fp64 and emits per-(n,c)

@@ -199,7 +199,12 @@ def test_config1_hippocampus_whole_net(B):
     if B == 1:                                      # the reference itself
         for i, o in enumerate(outs):
             od = o.cpu().numpy()
-            assert np.abs((od[:, :, ::2, ::2, ::2] if i == 0 else od) - g["b32_logits%d" % i]).max() <= bars[i].gold
+            # heads 0-2: the north_star's 1e-4 against the reference's own output, outright (measured 6.8-9.3e-5); the 1/8 and 1/16
+            # heads: the CPU path's own noise class (_logit_bars)
+            gold_bar = min(bars[i].gold, 1e-4) if i < 3 else bars[i].gold
+            dg = np.abs((od[:, :, ::2, ::2, ::2] if i == 0 else od) - g["b32_logits%d" % i]).max()
+            print("[golden] head %d: engine-reference max %.3e (bar %.3e)" % (i, dg, gold_bar))
+            assert dg <= gold_bar, "head %d: %.3e from the reference golden > %.3e" % (i, dg, gold_bar)
         assert abs(loss.item() - float(g["loss"])) < 5e-5
         # (the reference's gradients are pinned to the oracle's by tests/test_oracle_golden.py; the engine's are checked
         #  against the oracle below, anchored on fp64)

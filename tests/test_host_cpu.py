@@ -116,6 +116,28 @@ def test_missing_library_is_an_import_error(tmp_path):
     assert "IMPORT_ERROR" in out.stdout, out.stderr
 
 
+def test_every_e2e_knob_read_anywhere_is_listed_and_unknown_ones_are_refused():
+    """INTEGRATION.md section 7 is the one list of knobs: every E2E_* variable the library or the host code reads is in
+    _lib.KNOWN_ENV and in that table, nothing else is, and a variable outside the list stops the library from loading."""
+    import glob
+    from e2enet_medical_amd import _lib
+    read = set()
+    for f in glob.glob(os.path.join(ROOT, "e2enet_medical_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "e2enet_medical_amd", "csrc", "*.h")):
+        read |= set(re.findall(r'getenv\("(E2E_[A-Z0-9_]+)"\)', open(f).read()))
+    for f in glob.glob(os.path.join(ROOT, "e2enet_medical_amd", "**", "*.py"), recursive=True) + [os.path.join(ROOT, "bench.py")]:
+        read |= set(re.findall(r'environ(?:\.get\(|\[)"(E2E_[A-Z0-9_]+)"', open(f).read()))
+    assert read == set(_lib.KNOWN_ENV), read ^ set(_lib.KNOWN_ENV)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    table = set(re.findall(r"^\| `(E2E_[A-Z0-9_]+)`", doc, flags=re.M))
+    assert table == set(_lib.KNOWN_ENV), table ^ set(_lib.KNOWN_ENV)
+    _lib.check_env({"E2E_CONV_MM": "0", "PATH": "/bin"})
+    with pytest.raises(RuntimeError, match="E2E_CT_TPX32"):
+        _lib.check_env({"E2E_CT_TPX32": "1"})
+    code = "import sys; sys.path.insert(0, %r); import e2enet_medical_amd._lib as L; L.lib()" % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, E2E_WG_V3_TARGET="64"))
+    assert out.returncode != 0 and "unknown E2E_* environment variable(s) E2E_WG_V3_TARGET" in out.stderr, out.stderr
+
+
 _WORKER = r'''
 import os, sys
 sys.path.insert(0, %(root)r)
@@ -418,6 +440,7 @@ def test_bench_self_launches_n_ranks_without_torchrun():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 4 and rec["warmup"] == 1
     assert rec["rccl"]["world"] == 2 and rec["rccl"]["allreduce_of_ones"] == 2.0
+    assert {"ms_per_step_without_allreduce", "allreduce_exposed_ms", "allreduce_bytes_per_step"} <= set(rec["rccl"])   # the N > 1 record
     assert rec["ms_per_step_per_rank"] == [1.0, 2.0]                  # rank r contributed r + 1: both ranks were in the group
 
 

@@ -204,6 +204,48 @@ def test_amos_config5_densities_vs_reference(dens):
             assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), key
 
 
+def test_width48_net_vs_reference():
+    """The width the reference trainer hard-codes (nnUNetTrainer_simple.py:296), end to end: 4 x 64^3, K 4, DSFF density 0.2
+    (with the `shape[0] == 48 => 0.2` quirk of Masking.init, core_channel.py:147-151): masks, logits, loss and gradients of the
+    oracle against the reference's (tests/golden/net_w48.npz, tools/make_golden.py gen_net_w48)."""
+    g = golden("net_w48.npz")
+    spec = oracle.make_spec(4, 48, 4)
+    shapes = onet.param_shapes(spec)
+    assert list(shapes.keys()) == [str(s) for s in g["names"]]
+    params = closed_form_params(shapes)
+    names = oracle.masked_names(spec)
+    assert names == [str(s) for s in g["mask_names"]]
+    random.seed(0)
+    masks = oracle.uniform_kernel_masks(shapes, names, 0.2)
+    assert [sha_of(pack_kernel_mask(masks[n])) for n in names] == [str(s) for s in g["mask_sha"]]
+    assert [int(masks[n].sum().item()) for n in names] == g["mask_nnz"].tolist()
+    for n in names:
+        params[n] = params[n] * masks[n]
+    for n in params:
+        params[n] = params[n].detach().requires_grad_(True)
+    x = seeded_input((1, 4, 64, 64, 64), seed=241)
+    outs = oracle.forward(spec, params, x)
+    assert [list(o.shape) for o in outs] == g["out_shapes"].tolist()
+    targets = [seeded_labels((o.shape[0], 1) + tuple(o.shape[2:]), 4, seed=250 + i) for i, o in enumerate(outs)]
+    loss = oracle.deep_supervision_loss(outs, targets, oracle.ds_weights(5))
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 2e-5
+    np.testing.assert_allclose(outs[0].detach().numpy()[0, :, 31, ::2, ::2], g["slice_d31"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(outs[0].detach().numpy()[0, :, ::2, 7, ::2], g["slice_h7"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(outs[2].detach().numpy(), g["logits2"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(outs[3].detach().numpy(), g["logits3"], rtol=0, atol=5e-5)
+    for i, o in enumerate(outs):
+        assert abs(o.detach().double().abs().sum().item() - float(g["abs%d" % i])) <= 1e-5 * float(g["abs%d" % i])
+    l2 = np.array([params[n].grad.double().norm().item() for n in shapes])
+    np.testing.assert_allclose(l2, g["grad_l2"], rtol=2e-3, atol=1e-6)
+    for key in g.files:
+        if key.startswith("grad::"):
+            ref = g[key]
+            got = params[key[6:]].grad.numpy()
+            got = got[:8] if got.ndim > 1 else got
+            assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), key
+
+
 # ------------------------------------------------------------------ a9-a13 DSFF
 @pytest.mark.parametrize("base", [32, 48])
 @pytest.mark.parametrize("dens", [0.1, 0.2, 0.5])

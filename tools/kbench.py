@@ -138,11 +138,18 @@ def conv_case(B, srcs, cout, dims, stride, density, tag):
     if mm_path:
         fwd, dgrad = fwd_mm, dgrad_mm
         tag = tag.replace("[dense]", "") + "[mm]"
+    import ctypes
+    iters = int(os.environ.get("KB_ITERS", "10"))
     for name, fn, flops in (("fwd", fwd, dense * density), ("dgrad", dgrad, dense * density), ("wgrad", wgrad, dense)):
-        ms = time_ms(fn)
+        mhz = ctypes.c_double(0.0)
+        for fam in (0, 1):
+            L.diag_kernel_clock(fam, ctypes.byref(mhz), None, 1)          # reset
+        ms = time_ms(fn, iters=iters)
         gbs = (vin + vout) * 4 / ms / 1e6
         res[name] = ms
-        print("%-26s %-6s %8.3f ms  %7.1f GB/s(alg)  %6.1f TFLOP/s" % (tag, name, ms, gbs, flops / ms / 1e9))
+        L.diag_kernel_clock(1 if name == "wgrad" else 0, ctypes.byref(mhz), None, 1)
+        clk = ("  %4.0f MHz" % mhz.value) if mhz.value else ""       # shader clock of workgroup 0 (matrix-pipe kernels only)
+        print("%-26s %-6s %8.3f ms  %7.1f GB/s(alg)  %6.1f TFLOP/s%s" % (tag, name, ms, gbs, flops / ms / 1e9, clk))
     return res
 
 
