@@ -11,22 +11,29 @@
 // stops paying on the vector pipe long before it stops paying in FLOPs.  The mask stays structural: pruned kernels are packed as
 // zeros whatever the weight tensor holds.
 //
-// GEMM: M = 32 pixels of a tile row, N = 32 out channels, K = 16 input channels of a chunk, per tap; v_mfma_f32_32x32x16_f16,
-// D[pixel][out channel] (a lane owns one out channel: InstanceNorm sums are register sums).  x = hi + lo (hi = rn16(x),
-// lo = rn16(x - hi), 11 + 11 significant bits), weights likewise, pre-scaled by 2^8 when they are packed (|w| ~ 0.05: the lo
-// piece would be a subnormal fp16 otherwise); product = lo_x hi_w + hi_x lo_w + hi_x hi_w, accumulated in fp32, un-scaled on
-// store.  The data gradient runs the same kernel on dy (pre-scaled by the power of two that puts max |dy|, recorded by
-// e2e_in_lrelu_bwd, in [2^14, 2^15)) with transposed, tap-reversed weights and the scatter epilogue of conv133_kernel.
+// GEMM per tap: D[out channel][pixel] += W[out channel][16 in] x X[16 in][pixel] -- the WEIGHTS are the A operand, 32 pixels of a
+// tile row the B operand (v_mfma_f32_32x32x16_f16): an accumulator register of a lane is one out channel at 32 consecutive pixels
+// across the lanes, so the epilogue stores whole 128-byte lines without a transposition and the InstanceNorm sums of an out channel
+// are DPP row reductions (row_bcast:15 + v_readlane).  x = hi + lo (hi = rn16(x), lo = rn16(x - hi), 11 + 11 significant bits),
+// activations pre-scaled by 2^3 and weights by 2^8 when they are split (|w| ~ 0.05, |x| < 0.125: the lo piece would be a subnormal
+// fp16 otherwise); product = lo_w hi_x + hi_w lo_x + hi_w hi_x, accumulated in fp32, un-scaled on store.  The data gradient runs the
+// same kernel on dy (pre-scaled by the power of two that puts max |dy|, recorded by e2e_in_lrelu_bwd, in [2^14, 2^15)) with
+// transposed, tap-reversed weights; its destinations (un-shift on store, accumulate or overwrite) are resolved per item into LDS
+// records by the staging waves.
 //
 // Workgroup = 8 waves = 4 matrix waves + 4 staging waves (two per SIMD; the streams of different waves of a SIMD overlap,
-// tools/scratch/mfma_overlap.hip), PERSISTENT: one workgroup per CU walks the items (16 x 32 tile of one depth slice x 32 out
-// channels) l, l + G, l + 2G, ... as ONE pipeline over (item, 16-channel chunk): while the matrix waves multiply chunk s out of
-// LDS image s & 1, the staging waves convert chunk s + 1 (registers -> normalise-on-load -> split -> image (s + 1) & 1, channel-
-// fastest 32-byte pixel records whose two 16-byte halves are swapped for pixels with bit 3 set: every shifted ds_read_b128
-// fragment is conflict-free), have the loads of chunk s + 2 in flight and fetch the packed weights of chunk s + 1 by LDS-DMA.
-// One barrier per chunk.  Matrix wave r owns tile rows 4r .. 4r+3 (4 x 16 accumulator registers, 108 matrix instructions per
-// chunk); its epilogue (bias, store, InstanceNorm partial record) runs while the staging waves are already a chunk into the
-// next item.
+// tools/scratch/mfma_overlap.hip), PERSISTENT: one workgroup per CU walks the items (a 512-pixel tile of one depth slice x 32 out
+// channels; tile geometries below) l, l + G, l + 2G, ... as ONE pipeline over (item, 16-channel chunk): while the matrix waves
+// multiply chunk s out of LDS image s & 1, the staging waves convert chunk s + 1 (registers -> normalise-on-load -> split -> image
+// (s + 1) & 1, channel-fastest 32-byte pixel records whose two 16-byte halves are swapped for pixels with bit 3 set: every shifted
+// ds_read_b128 fragment is conflict-free), have the loads of chunk s + 2 in flight and fetch the packed weights of chunk s + 1 by
+// LDS-DMA (global_load_lds_dwordx4).  One barrier per chunk.  A matrix wave owns a quarter of the tile's rows (4 x 16 accumulator
+// registers, 108 matrix instructions per chunk in six half-phases with register double-buffered fragments); its epilogue (bias,
+// store, InstanceNorm partial record) runs while the staging waves are already a chunk into the next item.
+//
+// What bounds it (profiles/r05_mm_stamps.txt, r05_mm_pmc.txt): the CU's memory path -- the staging waves' plane
+// requests return at ~10 B/clk/CU (TCP pending-stall 77 % of the cycles), 8.4 k cycles per chunk against 3.5 k of matrix
+// instructions; the matrix pipe is busy a third of the time.
 //
 // Shapes: stride (1,1,1), W % 32 == 0, H % 16 == 0, more than 16 channels on the reduction side, at most CT_MAX.
 #include "e2e_common.h"
@@ -179,7 +186,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   __shared__ float red[2][4][32][2];                       // (mean, M2) of 128 values per (item parity, matrix wave, out channel)
   struct ODesc { float* dst; float usc; int flags; };      // data gradient: destination of one out channel for one item (flags: 1 store, 2 accumulate)
   __shared__ __attribute__((aligned(16))) float lbias[MODE == 0 ? CT_MAX + 32 : 4];    // forward: the bias vector (zero padded to whole blocks)
-  __shared__ __attribute__((aligned(16))) ODesc odesc[MODE == 1 ? 2 : 1][32];
+  __shared__ __attribute__((aligned(16))) ODesc odesc[MODE == 1 ? 3 : 1][32];   // by item % 3: the records of item k + 1 are written while the epilogue of item k - 1 may still read its own
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // data gradient: where the 32 out channels of an item go -- the gradient of virtual-concat channel q at (shifted) depth d goes to
   // depth d - s(q) of its source; slices that receive nothing are zero-filled by the workgroups of the out-of-range depths
   // (conv133_kernel's rule).  Resolved once per item into LDS by the staging waves (LDS-to-LDS, like the channel table).
-  auto build_odesc = [&](const Item& it, int par, int t) __attribute__((always_inline)) {
+  auto build_odesc = [&](const Item& it, int slot, int t) __attribute__((always_inline)) {
     if (MODE != 1 || t < 0 || t >= 32) return;
     const int q = it.qb * 32 + t;
     ODesc od;
@@ -293,7 +300,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
       }
     }
-    odesc[MODE == 1 ? par : 0][t] = od;
+    odesc[MODE == 1 ? slot : 0][t] = od;
   };
 
   build_ctab(decode(0), 0, tid, 512);
@@ -468,7 +475,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (q1.c == 0 && q1.k + 1 < nitems) {
         const Item itn = decode(q1.k + 1);
         build_ctab(itn, (q1.k + 1) & 1, tid - 256, 256);
-        build_odesc(itn, (q1.k + 1) & 1, tid - 256);
+        build_odesc(itn, (q1.k + 1) % 3, tid - 256);
       }
       MMT(t2);
       stage(std::integral_constant<int, PAR ^ 1>{}, std::integral_constant<int, PAR>{}, q1, q2, PAR ^ 1);
@@ -656,7 +663,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int i = 8 * hf + e;
-          const ODesc od = odesc[k & 1][(i & 3) + 8 * (i >> 2) + 4 * fh8];
+          const ODesc od = odesc[k % 3][(i & 3) + 8 * (i >> 2) + 4 * fh8];
           dst[e] = od.dst; usc[e] = od.usc; flg[e] = od.flags;
         }
         int anyf = 0;

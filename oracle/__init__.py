@@ -21,7 +21,7 @@ image (operator semantics identical, last-ulp drift possible).
 """
 from .shift import shift_amounts, depth_shift                      # noqa: F401
 from .network import (NetSpec, make_spec, param_shapes, init_params,  # noqa: F401
-                      forward, conv_block, masked_names)
+                      forward, conv_block, masked_names, Branches)
 from .dsff import (CosineDeathRate, uniform_kernel_masks, kernel_l1,   # noqa: F401
                    kernel_death, kernel_growth, DsffState)
 from .sliding_window import (compute_steps, gaussian_map, pad_to_patch,  # noqa: F401

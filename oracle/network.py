@@ -187,7 +187,33 @@ def init_params(spec: NetSpec, seed: int = 0, dtype=torch.float32) -> "Dict[str,
 
 
 # --------------------------------------------------------------------------- forward
-def conv_block(x, w, b, gamma, beta, stride=(1, 1, 1), shift_size=5):
+class Branches:
+    """Branch decisions of the graph's piecewise-linear operators, taken from ANOTHER evaluation of the same graph (the tests take
+    them from the engine's activations): per conv block the LeakyReLU mask (u > 0, keyed by the block prefix), per pooled node the
+    arg-max index of every window (``F.max_pool3d(return_indices=True)`` layout, keyed by the prefix of the node's last block).
+    ``forward(..., branches=b)`` evaluates the graph WITH these decisions: for fixed decisions the network is a smooth function of
+    weights and input, so two evaluations of its gradient differ by rounding only -- none of the LeakyReLU-kink and pooling-tie
+    flips that make any two fp32 evaluations of the plain graph differ by per cents behind InstanceNorms over few voxels.  No
+    reference counterpart (test infrastructure)."""
+
+    def __init__(self, recording=False):
+        self.lrelu: Dict[str, torch.Tensor] = {}
+        self.pool: Dict[str, torch.Tensor] = {}
+        self.recording = recording          # True: forward() takes its own decisions and writes them down here
+
+
+def _max_pool(x, kernel, branches, key):
+    if branches is not None and branches.recording:
+        out, idx = F.max_pool3d(x, kernel, return_indices=True)
+        branches.pool[key] = idx
+        return out
+    if branches is None or key not in branches.pool:
+        return F.max_pool3d(x, kernel)
+    idx = branches.pool[key]
+    return x.flatten(2).gather(2, idx.flatten(2)).view(idx.shape)
+
+
+def conv_block(x, w, b, gamma, beta, stride=(1, 1, 1), shift_size=5, branches=None, key=None):
     """unetpp_d.py:102-111 for kernel (1,3,3); unetpp_d_313.py / unetpp_d_331.py:101-110 for the other two kernel
     shapes (their shift is switched off in the source: ``if self.conv.kernel_size == (3, 1, 3) and False``)."""
     k = tuple(w.shape[2:])
@@ -195,15 +221,20 @@ def conv_block(x, w, b, gamma, beta, stride=(1, 1, 1), shift_size=5):
         x = depth_shift(x, shift_size)
     y = F.conv3d(x, w, b, stride=stride, padding=tuple(1 if v == 3 else 0 for v in k))
     y = F.instance_norm(y, weight=gamma, bias=beta, eps=1e-5)
+    if branches is not None and branches.recording:
+        branches.lrelu[key] = y.detach() > 0
+    elif branches is not None and key in branches.lrelu:
+        return torch.where(branches.lrelu[key], y, y * 0.01)
     return F.leaky_relu(y, 0.01, inplace=True)      # in place like the reference's nonlin_kwargs (unetpp_d.py:248): same values,
                                                     # one pass and one allocation fewer (14-19 % of the CPU step at 64^3)
 
 
-def _run_blocks(params, prefixes, x, first_stride=(1, 1, 1), shift_size=5):
+def _run_blocks(params, prefixes, x, first_stride=(1, 1, 1), shift_size=5, branches=None):
     for bi, p in enumerate(prefixes):
         x = conv_block(x, params[p + ".conv.weight"], params[p + ".conv.bias"],
                        params[p + ".instnorm.weight"], params[p + ".instnorm.bias"],
-                       stride=first_stride if bi == 0 else (1, 1, 1), shift_size=shift_size)
+                       stride=first_stride if bi == 0 else (1, 1, 1), shift_size=shift_size,
+                       branches=branches, key=p)
     return x
 
 
@@ -227,18 +258,20 @@ def forward_unet(spec: NetSpec, params, x, do_ds=True):
     return outs if do_ds else outs[0]
 
 
-def forward(spec: NetSpec, params, x, do_ds=True, return_nodes=False):
-    """unetpp_d.py:447-488.  Returns [full, 1/2, 1/4, 1/8] logits if do_ds else full only."""
+def forward(spec: NetSpec, params, x, do_ds=True, return_nodes=False, branches=None):
+    """unetpp_d.py:447-488.  Returns [full, 1/2, 1/4, 1/8] logits if do_ds else full only.  ``branches``: see Branches."""
     if spec.graph == "unet":
-        assert not return_nodes
+        assert not return_nodes and branches is None
         return forward_unet(spec, params, x, do_ds)
     P = spec.num_pool
     nodes = {}
+    last = {}                               # node -> prefix of its last conv block (the key of its pooling decisions)
     cur = x
     for st in range(P + 1):
         stride = (1, 1, 1) if st == 0 else spec.pool_kernels[st - 1]
-        cur = _run_blocks(params, encoder_block_prefixes(spec, st), cur, stride, shift_size=spec.shift_size)
+        cur = _run_blocks(params, encoder_block_prefixes(spec, st), cur, stride, shift_size=spec.shift_size, branches=branches)
         nodes[(st, 0)] = cur
+        last[(st, 0)] = encoder_block_prefixes(spec, st)[-1]
         if st == 0:
             continue
         z = P - st
@@ -248,8 +281,10 @@ def forward(spec: NetSpec, params, x, do_ds=True, return_nodes=False):
                      F.conv_transpose3d(nodes[(lvl + 1, j - 1)], params["up%d.%d.weight" % (z, m)],
                                         stride=spec.pool_kernels[lvl])]
             if lvl > 0:
-                parts.append(F.max_pool3d(nodes[(lvl - 1, j - 1)], spec.pool_kernels[lvl - 1]))
-            nodes[(lvl, j)] = _run_blocks(params, loc_block_prefixes(spec, z, m), torch.cat(parts, 1), shift_size=spec.shift_size)
+                parts.append(_max_pool(nodes[(lvl - 1, j - 1)], spec.pool_kernels[lvl - 1], branches, last[(lvl - 1, j - 1)]))
+            nodes[(lvl, j)] = _run_blocks(params, loc_block_prefixes(spec, z, m), torch.cat(parts, 1), shift_size=spec.shift_size,
+                                          branches=branches)
+            last[(lvl, j)] = loc_block_prefixes(spec, z, m)[-1]
     outs = [F.conv3d(nodes[(h, P - h)], params["seg_outputs.%d.weight" % h]) for h in range(4)]
     res = outs if do_ds else outs[0]
     if return_nodes:

@@ -210,9 +210,9 @@ def test_dummy_2d_spatial_transform_vs_scipy_per_slice(order_seg, order_data):
     48 x 192 x 192 by nnUNetTrainer_simple.py:701-716): the batch is viewed as [B, C * D, H, W], ONE in-plane rotation + scale per
     sample, every slice interpolated in 2-D (cubic B-spline with a prefilter along H and W only), the slice axis untouched.
     Against scipy.ndimage.map_coordinates slice by slice."""
-    patch = (10, 32, 28)
+    patch = (12, 32, 28)
     a = _aug(patch=patch, order_seg=order_seg, order_data=order_data, params={"dummy_2D": True, "rotation_x": (-np.pi, np.pi)})
-    data, seg = _raw(B=2, C=2, shape=(10, 48, 44), seed=7)
+    data, seg = _raw(B=2, C=2, shape=(12, 48, 44), seed=7)
     d = _blank(a, 2, 2)
     mats = np.zeros((2, 12))
     for b, (ang, sc) in enumerate([(0.4, 1.25), (-1.1, 0.8)]):

@@ -106,6 +106,48 @@ def test_net_tiny_forward_backward():
     assert abs(full.double().sum().item() - float(g["logits_nods_sum"])) < 1e-2
 
 
+def test_forced_branch_evaluation_removes_the_kink_noise():
+    """oracle.Branches (test infrastructure of the GPU gradient checks): (1) an evaluation that replays its OWN recorded LeakyReLU
+    masks and pooling arg-maxes is the plain evaluation, bit for bit, values and gradients; (2) an fp32 evaluation that replays the
+    fp64 evaluation's decisions has gradients within 1e-4 (relative L2 per tensor; measured 2e-5) of the fp64 ones -- rounding only.
+    (On this tiny net the plain fp32 evaluation happens to take the same decisions; on the 64^3 nets of tests/test_gpu_configs.py it
+    does not, and sits per cents away.)"""
+    spec = tiny_spec()
+    shapes = onet.param_shapes(spec)
+    base = closed_form_params(shapes)
+    x = seeded_input((2, TINY["cin"]) + TINY["patch"], seed=21)
+    w = oracle.ds_weights(5)
+
+    def run(dtype, branches):
+        params = {n: v.detach().to(dtype).clone().requires_grad_(True) for n, v in base.items()}
+        outs = oracle.forward(spec, params, x.to(dtype), branches=branches)
+        targets = [seeded_labels((o.shape[0], 1) + tuple(o.shape[2:]), TINY["k"], seed=30 + i) for i, o in enumerate(outs)]
+        oracle.deep_supervision_loss(outs, targets, w).backward()
+        return outs, params
+
+    rec = oracle.Branches(recording=True)
+    outs_a, par_a = run(torch.float32, rec)
+    assert len(rec.lrelu) == sum(1 for n in shapes if n.endswith(".conv.weight")) and len(rec.pool) > 0
+    rec.recording = False
+    outs_b, par_b = run(torch.float32, rec)
+    outs_c, par_c = run(torch.float32, None)
+    for a_, b_, c_ in zip(outs_a, outs_b, outs_c):
+        assert torch.equal(a_, b_) and torch.equal(a_, c_)
+    for n in shapes:
+        assert torch.equal(par_a[n].grad, par_c[n].grad)
+        assert torch.allclose(par_a[n].grad, par_b[n].grad, rtol=0, atol=1e-6 * max(1.0, par_a[n].grad.abs().max().item()))
+    rec64 = oracle.Branches(recording=True)
+    _, par64 = run(torch.float64, rec64)
+    rec64.recording = False
+    _, par32f = run(torch.float32, rec64)
+
+    def rel(p):
+        return {n: ((p[n].grad.double() - par64[n].grad).norm() / par64[n].grad.norm()).item() for n in shapes if par64[n].grad.norm() > 1e-9}
+    forced, plain = rel(par32f), rel(par_c)
+    print("[branches] worst relative L2 from fp64: forced %.2e plain fp32 %.2e" % (max(forced.values()), max(plain.values())))
+    assert max(forced.values()) <= 1e-4
+
+
 def test_net64_sparse_forward():
     """64^3, base 32, Cin 4, K 4, density 0.2 masks from random.seed(0) (SURVEY golden #4)."""
     g = golden("net64.npz")
