@@ -102,7 +102,7 @@ SIGNATURES = {
     "e2e_diag_split_gemm": (I, [P, P, P, I, I, P, P]),
     "e2e_diag_kernel_clock": (I, [I, P, P, I]),
     "e2e_in_stats_finalize": (I, [P, I, P, P, F, P, P, P, P, I, I, P]),
-    "e2e_in_lrelu_bwd": (I, [P, P, P, P, P, P, F, P, P, P, P, I, I, LL, P, I, P, P]),
+    "e2e_in_lrelu_bwd": (I, [P, P, P, P, P, P, P, F, P, P, P, P, I, I, LL, P, I, P, P]),
     "e2e_convT_fwd": (I, [P, P, P, F, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "e2e_convT_dgrad": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
     "e2e_convT_wgrad_ws_bytes": (LL, [I, I, I, I, I, I, I, I, I]),
@@ -187,7 +187,7 @@ class _Lib:
 _lib = None
 
 
-ABI_VERSION = 15          # e2e_abi_version() of the library this binding was written against
+ABI_VERSION = 16          # e2e_abi_version() of the library this binding was written against
 
 
 def lib() -> _Lib:

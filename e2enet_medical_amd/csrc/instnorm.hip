@@ -66,14 +66,13 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const double* __restri
 __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const float* __restrict__ dz, const float* __restrict__ y,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd,
-                                                            const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, float slope,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, float slope,
                                                             double* __restrict__ sums, int C, long long spatial,
                                                             unsigned* __restrict__ absmax) {
   const int nc = blockIdx.y;
-  const int c = nc % C;
   if (absmax != nullptr && blockIdx.x == 0 && nc == 0 && threadIdx.x == 0) *absmax = 0u;   // the apply pass (next launch) records max |dy|
-  const float mu = mean[nc], rs = rstd[nc], g = gamma[c], b = beta[c];
+  const float mu = mean[nc], rs = rstd[nc], sca = scale[nc], shf = shift[nc];
   const float* dzp = dz + (long long)nc * spatial;
   const float* yp = y + (long long)nc * spatial;
   float s1 = 0.f, s2 = 0.f;
@@ -99,7 +98,7 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const float* __restr
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float xh = (yv[k] - mu) * rs;
-      const float u = fmaf(g, xh, b);
+      const float u = fmaf(yv[k], sca, shf);        // the forward's own u (e2e::in_act): the SAME branch in both directions
       const float du = u > 0.f ? dv[k] : dv[k] * slope;
       s1 += du;
       s2 = fmaf(du, xh, s2);
@@ -127,13 +126,14 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const float* __restr
 __global__ __launch_bounds__(256) void in_bwd_apply_kernel(float* __restrict__ dz, const float* __restrict__ y,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ rstd,
-                                                           const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float slope,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift,
+                                                           const float* __restrict__ gamma, float slope,
                                                            double* __restrict__ sums, int C, long long spatial,
                                                            unsigned* __restrict__ absmax) {
   const int nc = blockIdx.y;
   const int c = nc % C;
-  const float mu = mean[nc], rs = rstd[nc], g = gamma[c], b = beta[c];
+  const float mu = mean[nc], rs = rstd[nc], g = gamma[c], sca = scale[nc], shf = shift[nc];
   const double inv_n = 1.0 / (double)spatial;
   const float m1 = (float)(sums[(long long)nc * 3 + 0] * inv_n);
   const float m2 = (float)(sums[(long long)nc * 3 + 1] * inv_n);
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(float* __restrict__ d
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float xh = (yv[k] - mu) * rs;
-      const float u = fmaf(g, xh, b);
+      const float u = fmaf(yv[k], sca, shf);        // the forward's own u (e2e::in_act)
       const float du = u > 0.f ? dv[k] : dv[k] * slope;
       o[k] = grs * (du - m1 - xh * m2);
       if (vec || i + k < spatial) { part += o[k]; amax = fmaxf(amax, fabsf(o[k])); }
@@ -232,11 +232,11 @@ extern "C" int e2e_in_stats_finalize(const double* part, int np, const float* ga
   return e2e::check_launch("in_finalize_kernel");
 }
 
-extern "C" int e2e_in_lrelu_bwd(float* dz_dy, const float* y, const float* mean, const float* rstd,
-                                const float* gamma, const float* beta, float slope, float* dgamma, float* dbeta,
+extern "C" int e2e_in_lrelu_bwd(float* dz_dy, const float* y, const float* mean, const float* rstd, const float* scale,
+                                const float* shift, const float* gamma, float slope, float* dgamma, float* dbeta,
                                 float* dbias, float* sums, int B, int C, long long spatial, const double* tile_sums, int np,
                                 unsigned* dy_absmax, void* stream) {
-  E2E_REQUIRE(dz_dy && y && mean && rstd && gamma && beta && dgamma && dbeta && sums, "in_lrelu_bwd: null pointer");
+  E2E_REQUIRE(dz_dy && y && mean && rstd && scale && shift && gamma && dgamma && dbeta && sums, "in_lrelu_bwd: null pointer");
   E2E_REQUIRE(B > 0 && C > 0 && spatial > 0, "in_lrelu_bwd: bad dims");
   hipStream_t st = (hipStream_t)stream;
   double* ds = reinterpret_cast<double*>(sums);
@@ -246,13 +246,13 @@ extern "C" int e2e_in_lrelu_bwd(float* dz_dy, const float* y, const float* mean,
   dim3 grid((unsigned)blocks, B * C);
   if (tile_sums == nullptr) {
     e2e::zero_async(ds, (size_t)B * C * 3 * sizeof(double), st);
-    hipLaunchKernelGGL(in_bwd_reduce_kernel, grid, dim3(256), 0, st, dz_dy, y, mean, rstd, gamma, beta, slope, ds, C,
+    hipLaunchKernelGGL(in_bwd_reduce_kernel, grid, dim3(256), 0, st, dz_dy, y, mean, rstd, scale, shift, slope, ds, C,
                        spatial, dy_absmax);
   } else {
     E2E_REQUIRE(np > 0, "in_lrelu_bwd: tile_sums without a record count");
     hipLaunchKernelGGL(in_bwd_tile_sums_kernel, dim3(B * C), dim3(64), 0, st, tile_sums, ds, np, dy_absmax);
   }
-  hipLaunchKernelGGL(in_bwd_apply_kernel, grid, dim3(256), 0, st, dz_dy, y, mean, rstd, gamma, beta, slope, ds, C,
+  hipLaunchKernelGGL(in_bwd_apply_kernel, grid, dim3(256), 0, st, dz_dy, y, mean, rstd, scale, shift, gamma, slope, ds, C,
                      spatial, dy_absmax);
   hipLaunchKernelGGL(in_bwd_params_kernel, dim3(e2e::cdiv(C, 64)), dim3(64), 0, st, ds, dgamma, dbeta, dbias, B, C);
   return e2e::check_launch("in_lrelu_bwd");

@@ -47,6 +47,7 @@ def _lane_divs(voxels):
 FUSE_IN_SUMS = 1
 SPARSE2 = os.environ.get("E2E_CONV_SPARSE2", "1") != "0"         # load-balanced kernel for the DSFF-masked full-resolution layers
 DENSE_ENABLED = True          # tests switch the matrix-core conv paths off to compare the sparse walk with itself
+MM_FORWARD = MM_BACKWARD = True   # tests / diagnostics: K1m in one direction only (the other takes the next kernel in the dispatch order)
 # fp16 two-piece matrix-pipe conv (conv133_mm.hip, round 5) for every layer it serves whose kernel map is at least this dense
 # (0: all of them -- measured faster than the sparse walk down to density 0.1); E2E_CONV_MM=0 switches the path off in the library
 MM_MIN_DENSITY = float(os.environ.get("E2E_MM_MIN_DENSITY", "0.0"))
@@ -310,7 +311,7 @@ class ConvOp:
         sd, sh, sw = self.stride
         L = lib()
         ws = getattr(e, "fwd_ws", None)
-        if self.use_mm():
+        if self.use_mm() and MM_FORWARD:
             L.conv133_fwd_mm(self.chans.data_ptr(), self.cin, p[self.w_name].data_ptr(), p[self.prefix + ".conv.bias"].data_ptr(),
                              _ptr(self.live), self.out.data.data_ptr(), self.part.data_ptr(), b, self.cout, di, hi, wi, ws.data_ptr(),
                              ws.numel() * 4, _stream())
@@ -349,8 +350,8 @@ class ConvOp:
         # instance) has already been done by the last writer of dz where that writer could (conv133_sparse.hip)
         ready = o.sums_ready
         o.sums_ready = False
-        L.in_lrelu_bwd(o.grad.data_ptr(), o.data.data_ptr(), o.mean.data_ptr(), o.rstd.data_ptr(),
-                       p[self.prefix + ".instnorm.weight"].data_ptr(), p[self.prefix + ".instnorm.bias"].data_ptr(),
+        L.in_lrelu_bwd(o.grad.data_ptr(), o.data.data_ptr(), o.mean.data_ptr(), o.rstd.data_ptr(), o.scale.data_ptr(), o.shift.data_ptr(),
+                       p[self.prefix + ".instnorm.weight"].data_ptr(),
                        LRELU_SLOPE, g[self.prefix + ".instnorm.weight"].data_ptr(),
                        g[self.prefix + ".instnorm.bias"].data_ptr(), g[self.prefix + ".conv.bias"].data_ptr(),
                        e.in_sums.data_ptr(), b, self.cout, o.spatial, self.own_sums.data_ptr() if ready else None, self.own_np,
@@ -360,7 +361,7 @@ class ConvOp:
             self._wgrad(e, L, g, o, b, di, hi, wi, sd, sh, sw, o.data.numel())
         if self.do_dgrad:
             ws = getattr(e, "fwd_ws", None)
-            if self.use_mm():
+            if self.use_mm() and MM_BACKWARD:
                 L.conv133_dgrad_mm(o.grad.data_ptr(), self.dy_absmax.data_ptr(), p[self.w_name].data_ptr(), _ptr(self.live_t), self.outs.data_ptr(),
                                    b, self.cin, self.cout, di, hi, wi, ws.data_ptr(), ws.numel() * 4, _stream())
             elif self.use_dense():
@@ -762,9 +763,11 @@ class Engine:
         """packed weights of the planned convs (one launch): the weights may have moved since the last pass"""
         # the job table is cached under the dispatch decisions it was built for (advisor, round 4: a table built while an op went to a
         # matrix-pipe kernel left that op's packed weights zero when tests / knobs sent it to the planned walk afterwards)
-        key = tuple(op.use_mm() or op.use_dense() for op in self.conv_ops.values())
+        def matrix_only(op):
+            return (op.use_mm() and MM_FORWARD and MM_BACKWARD) or op.use_dense()
+        key = tuple(matrix_only(op) for op in self.conv_ops.values())
         if self._sparse_jobs is None or self._sparse_jobs[0] != key:
-            jobs = [j for op in self.conv_ops.values() if not (op.use_mm() or op.use_dense()) for j in op.sparse_jobs()]
+            jobs = [j for op in self.conv_ops.values() if not matrix_only(op) for j in op.sparse_jobs()]
             self._sparse_jobs = (key, pack_sparse_weights(jobs, self.device) or ())
         if self._sparse_jobs[1]:
             table, n, mx = self._sparse_jobs[1]

@@ -223,9 +223,13 @@ int e2e_in_stats_finalize(const double* part, int np, const float* gamma, const 
  *   tile_sums  NULL: the first pass (s1, s2) runs here.  Otherwise the per-tile records [B][C][np][2] that the last writers of
  *              dz have produced (e2e_in_sum_chan_t): they are added up in a fixed order and only the apply pass runs
  *   dy_absmax  NULL, or one device word that receives the bit pattern of max |dy| over the tensor (consumed by e2e_conv133_wgrad)
+ *   scale, shift  the arrays e2e_in_stats_finalize produced for this tensor: the LeakyReLU branch of an element is decided from
+ *              u = fma(y, scale, shift) -- bit for bit the value every forward consumer formed (normalise-on-load), so the backward
+ *              differentiates exactly the function the forward evaluated (until round 5 it was re-derived as gamma * xhat + beta,
+ *              whose sign differs for |u| ~ 1e-7: found by the same-branch gradient check of tests/test_gpu_configs.py)
  */
-int e2e_in_lrelu_bwd(float* dz_dy, const float* y, const float* mean, const float* rstd, const float* gamma,
-                     const float* beta, float slope, float* dgamma, float* dbeta, float* dbias, float* sums,
+int e2e_in_lrelu_bwd(float* dz_dy, const float* y, const float* mean, const float* rstd, const float* scale, const float* shift,
+                     const float* gamma, float slope, float* dgamma, float* dbeta, float* dbias, float* sums,
                      int B, int C, long long spatial, const double* tile_sums, int np, unsigned* dy_absmax, void* stream);
 
 /* ---- K3: transposed convolution, kernel == stride in {1,2}^3, no bias ------------------

@@ -200,6 +200,8 @@ class Branches:
         self.lrelu: Dict[str, torch.Tensor] = {}
         self.pool: Dict[str, torch.Tensor] = {}
         self.recording = recording          # True: forward() takes its own decisions and writes them down here
+        self.taps = None                    # a dict: forward() keeps every block's pre-norm conv output in it with retain_grad()
+                                            # (diagnostics: d loss / d y per block against the engine's dy buffers)
 
 
 def _max_pool(x, kernel, branches, key):
@@ -220,6 +222,9 @@ def conv_block(x, w, b, gamma, beta, stride=(1, 1, 1), shift_size=5, branches=No
     if k == (1, 3, 3):
         x = depth_shift(x, shift_size)
     y = F.conv3d(x, w, b, stride=stride, padding=tuple(1 if v == 3 else 0 for v in k))
+    if branches is not None and branches.taps is not None:
+        y.retain_grad()
+        branches.taps[key] = y
     y = F.instance_norm(y, weight=gamma, bias=beta, eps=1e-5)
     if branches is not None and branches.recording:
         branches.lrelu[key] = y.detach() > 0

@@ -90,3 +90,68 @@ def synthetic_cases(folder):
         dataset[name] = OrderedDict(data_file=os.path.join(folder, name + ".npz"),
                                     properties=OrderedDict(class_locations=locs, name=name))
     return dataset
+
+
+# ---------------------------------------------------------------------------------- gradients under the engine's own branch decisions
+def engine_branches(eng):
+    """The LeakyReLU masks and pooling arg-maxes the ENGINE took in its last forward, as oracle.Branches: every consumer forms
+    u = fma(y, scale, shift) from the stored pre-norm output (e2e::in_act), whose sign the fp64 product-and-sum has exactly; the
+    pooling kernel keeps the first maximum in (d, h, w) order like ATen."""
+    import oracle
+    import torch.nn.functional as F
+    from e2enet_medical_amd.engine import ConvOp, PoolOp
+    br = oracle.Branches()
+
+    def pre(a):
+        B, C = a.shape[:2]
+        return a.data.double() * a.scale.double().view(B, C, 1, 1, 1) + a.shift.double().view(B, C, 1, 1, 1)
+    for op in eng.ops:
+        if isinstance(op, ConvOp):
+            br.lrelu[op.prefix] = (pre(op.out) > 0).cpu()
+        elif isinstance(op, PoolOp) and op.src.normed:
+            u = pre(op.src).float()
+            v = torch.where(u > 0, u, u * 0.01)
+            br.pool[op.src.name] = F.max_pool3d(v, op.kernel, return_indices=True)[1].cpu()
+    return br
+
+
+def check_grads_same_branches(eng, spec, params, x, targets, w, shapes, tol_global=1e-4, tol_tensor=3e-4):
+    """The sharp gradient check: the fp64 oracle evaluated WITH the engine's own LeakyReLU / pooling decisions is a smooth function
+    the engine's backward pass differentiates too, so the two gradients differ by rounding only -- against the per cents any two
+    plain evaluations differ by (_check_all_grads).  The fp32 CPU oracle is put through the same decisions as the yardstick of
+    what fp32 rounding costs on this graph (InstanceNorms over 8 voxels at the deep levels amplify it): the engine must stay within
+    3x of it or within the absolute bars (1e-4 global, 3e-4 per tensor), per tensor (relative L2) and over all gradients together.
+    Measured (round 5): 64^3 nets (config 5 at both densities, width 48) engine 3.2-4.3e-5 global against 3.6-7.7e-5 for the CPU
+    path; config 1 (5 x 7 planes at the deep levels) 4.8-6.2e-4 against 2.7-2.8e-4.  This check found the one place where the
+    engine's backward re-derived a branch decision instead of repeating the forward's (e2e_in_lrelu_bwd, ABI 16).  Tensors whose exact gradient
+    is zero (conv biases in front of an InstanceNorm): max norm against the scale of the other gradients, as _check_all_grads."""
+    import oracle
+    br = engine_branches(eng)
+
+    def forced(dtype):
+        leaves = {n: p.detach().to(dtype).clone().requires_grad_(True) for n, p in params.items()}
+        ref = oracle.forward(spec, leaves, x.to(dtype), branches=br)
+        oracle.deep_supervision_loss(ref, targets, w, False).backward()
+        return {n: leaves[n].grad.double() for n in shapes}
+    g64, g32 = forced(torch.float64), forced(torch.float32)
+    worst = {"engine": (0.0, None), "cpu32": (0.0, None)}
+    num = {"engine": 0.0, "cpu32": 0.0}
+    den = 0.0
+    for n in shapes:
+        r = g64[n]
+        den += r.pow(2).sum().item()
+        for who, got in (("engine", eng.grads[n].cpu().double()), ("cpu32", g32[n])):
+            d = got - r
+            num[who] += d.pow(2).sum().item()
+            if r.norm().item() > 1e-6:
+                e = d.norm().item() / r.norm().item()
+                if e > worst[who][0]:
+                    worst[who] = (e, n)
+            elif who == "engine":
+                assert d.abs().max().item() <= 2e-3, (n, "zero-gradient tensor", d.abs().max().item())
+    glob = {k: (v / den) ** 0.5 for k, v in num.items()}
+    print("[grad, same branches] vs fp64: engine global rel-L2 %.3e worst tensor %.3e (%s) | cpu32 global %.3e worst %.3e (%s)"
+          % (glob["engine"], worst["engine"][0], worst["engine"][1], glob["cpu32"], worst["cpu32"][0], worst["cpu32"][1]))
+    assert glob["engine"] <= max(tol_global, 3.0 * glob["cpu32"]), ("global", glob)
+    assert worst["engine"][0] <= max(tol_tensor, 3.0 * worst["cpu32"][0]), ("worst tensor", worst)
+    return glob, worst

@@ -19,7 +19,7 @@ import torch.nn.functional as F
 
 import oracle
 from oracle import network as onet
-from tests.helpers import golden, closed_form_params, seeded_input, seeded_labels, pack_kernel_mask, sha_of
+from tests.helpers import golden, closed_form_params, seeded_input, seeded_labels, pack_kernel_mask, sha_of, check_grads_same_branches
 from tests import test_gpu_ops as ops
 from tests.test_gpu_net import build_net, load_closed_form, HIPPO
 
@@ -156,7 +156,7 @@ def _check_all_grads(eng, shapes, leaves, tol=2e-4, leaves64=None):
     #  convs: x0.83 / x3.50 / x1.96 of the CPU's on config 5 d = 0.1 / d = 0.5 / width 48, x1.87 / x1.20 with the round-4 kernels;
     #  hence also admitted: twice the CPU path's worst single tensor, the size of one such event in this configuration)
     #  Round 5, final kernels: x4.2 on width 48 with the MEDIAN tensor at x0.5 -- the figure is chance, which is why the sharp check
-    #  is _check_grads_same_branches (same decisions => rounding only) and the bars here are those of the noise class itself:
+    #  is helpers.check_grads_same_branches (same decisions => rounding only) and the bars here are those of the noise class itself:
     #  the reference's own fp32 gradients sit up to 17 % (per tensor) from fp64 on config 1.
     assert glob_g <= max(tol, 3.0 * glob_c, 2.0 * worst_c, 0.05), ("global relative L2", glob_g, glob_c, worst_c)
     assert med_g <= max(tol, 3.0 * med_c), ("median relative L2", med_g, med_c)
@@ -166,50 +166,6 @@ def _check_all_grads(eng, shapes, leaves, tol=2e-4, leaves64=None):
     for n in shapes:
         assert mx_gpu[n] <= max(tol, 10.0 * worst_cpu), (n, "max norm", mx_gpu[n], worst_cpu)
     return l2_gpu[n_worst], n_worst
-
-
-def _engine_branches(eng):
-    """The LeakyReLU masks and pooling arg-maxes the ENGINE took in its last forward, as oracle.Branches: every consumer forms
-    u = fma(y, scale, shift) from the stored pre-norm output (e2e::in_act), whose sign the fp64 product-and-sum has exactly; the
-    pooling kernel keeps the first maximum in (d, h, w) order like ATen."""
-    from e2enet_medical_amd.engine import ConvOp, PoolOp
-    br = oracle.Branches()
-
-    def pre(a):
-        B, C = a.shape[:2]
-        return a.data.double() * a.scale.double().view(B, C, 1, 1, 1) + a.shift.double().view(B, C, 1, 1, 1)
-    for op in eng.ops:
-        if isinstance(op, ConvOp):
-            br.lrelu[op.prefix] = (pre(op.out) > 0).cpu()
-        elif isinstance(op, PoolOp) and op.src.normed:
-            u = pre(op.src).float()
-            v = torch.where(u > 0, u, u * 0.01)
-            br.pool[op.src.name] = F.max_pool3d(v, op.kernel, return_indices=True)[1].cpu()
-    return br
-
-
-def _check_grads_same_branches(eng, spec, params, x, targets, w, shapes, tol=1e-4):
-    """The sharp gradient check: the fp64 oracle evaluated WITH the engine's own LeakyReLU / pooling decisions is a smooth function
-    the engine's backward pass differentiates too, so the two gradients differ by rounding only -- every tensor within `tol`
-    relative L2 (measured: printed), against the per cents any two plain evaluations differ by (_check_all_grads)."""
-    br = _engine_branches(eng)
-    leaves = {n: p.detach().double().clone().requires_grad_(True) for n, p in params.items()}
-    ref = oracle.forward(spec, leaves, x.double(), branches=br)
-    oracle.deep_supervision_loss(ref, targets, w, False).backward()
-    worst, worst_n, num, den = 0.0, None, 0.0, 0.0
-    for n in shapes:
-        r = leaves[n].grad
-        d = eng.grads[n].cpu().double() - r
-        num, den = num + d.pow(2).sum().item(), den + r.pow(2).sum().item()
-        if r.norm().item() > 1e-6:
-            e = d.norm().item() / r.norm().item()
-            if e > worst:
-                worst, worst_n = e, n
-        else:
-            assert d.abs().max().item() <= 1e-5, (n, "zero-gradient tensor", d.abs().max().item())
-    print("[grad, same branches] engine vs fp64: global rel-L2 %.3e, worst tensor %.3e (%s)" % ((num / den) ** 0.5, worst, worst_n))
-    assert worst <= tol, (worst_n, worst)
-    return (num / den) ** 0.5, worst
 
 
 def _oracle_grads(spec, params, x, targets, w, dtype):
@@ -258,7 +214,7 @@ def test_config1_hippocampus_whole_net(B):
     leaves, ref_loss = _oracle_grads(spec, params, x, targets, w, torch.float32)
     leaves64, _ = _oracle_grads(spec, params, x, targets, w, torch.float64)
     assert abs(loss.item() - ref_loss.item()) < 5e-5
-    _check_grads_same_branches(eng, spec, params, x, targets, w, shapes)
+    check_grads_same_branches(eng, spec, params, x, targets, w, shapes)
     _check_all_grads(eng, shapes, leaves, tol=2e-3, leaves64=leaves64)
 
 
@@ -334,7 +290,7 @@ def test_config5_amos_density_whole_net(dens):
     leaves, ref_loss = _oracle_grads(spec, masked_params, x, targets, w, torch.float32)
     leaves64, _ = _oracle_grads(spec, masked_params, x, targets, w, torch.float64)
     assert abs(loss.item() - ref_loss.item()) < 5e-5
-    _check_grads_same_branches(eng, spec, masked_params, x, targets, w, shapes)
+    check_grads_same_branches(eng, spec, masked_params, x, targets, w, shapes)
     _check_all_grads(eng, shapes, leaves, tol=2e-3, leaves64=leaves64)
     # (the reference's own gradients are pinned to the oracle's by tests/test_oracle_golden.py)
 
@@ -398,7 +354,7 @@ def test_width48_whole_net_vs_reference_golden_and_oracle():
     leaves, ref_loss = _oracle_grads(spec, masked_params, x, targets, w, torch.float32)
     leaves64, _ = _oracle_grads(spec, masked_params, x, targets, w, torch.float64)
     assert abs(loss.item() - ref_loss.item()) < 5e-5
-    _check_grads_same_branches(eng, spec, masked_params, x, targets, w, shapes)
+    check_grads_same_branches(eng, spec, masked_params, x, targets, w, shapes)
     _check_all_grads(eng, shapes, leaves, tol=2e-3, leaves64=leaves64)
     # --- and the reference's gradients where the golden keeps them
     names = [str(s) for s in g["names"]]

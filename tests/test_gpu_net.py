@@ -738,7 +738,8 @@ def test_whole_net_128_vs_oracle():
     """BASELINE config 2 at the benchmarked size against the CPU oracle (reference: unetpp_d.py:447-488 at 128^3): B = 1,
     the benchmark's network (He init under torch.manual_seed(0), DSFF masks at density 0.2 under random.seed(0)), its input
     and targets: all four logit heads within 1e-4 of the fp32 oracle, loss within 5e-5, Dice of the argmax maps >= 1 - 1e-3
-    (metrics.py:106-121).  One oracle forward + loss at this size takes ~10-20 s on the host."""
+    (metrics.py:106-121); then EVERY parameter gradient against the fp64 oracle under the engine's own branch decisions.  One oracle
+    forward + loss at this size takes ~10-20 s on the host, the two forced-branch passes ~2 min."""
     import bench
     net, opt, mask, fused = bench.build(torch.device("cuda"))
     x, targets = bench.synthetic_batch(torch.device("cuda"), bench.PATCH, 1, seed=100)
@@ -761,6 +762,11 @@ def test_whole_net_128_vs_oracle():
     seg, rseg = outs[0].argmax(1).cpu().numpy(), ref[0].argmax(1).numpy()
     for label in range(1, bench.K):
         assert oracle.hard_dice(seg, rseg, label) >= 1 - 1e-3
+    # gradients at the benchmarked size: every parameter gradient against the fp64 oracle evaluated with the engine's own LeakyReLU /
+    # pooling decisions (tests/helpers.py: rounding only, no kink noise) -- two more oracle passes of 128^3 on the host (~2 min)
+    from tests.helpers import check_grads_same_branches
+    shapes = {n: tuple(p.shape) for n, p in net.named_parameters()}
+    check_grads_same_branches(eng, spec, params, x.cpu(), [t.cpu() for t in targets], w, shapes)
 
 
 @pytest.mark.parametrize("mode", ["explicit", "loss"])
