@@ -3,7 +3,7 @@
 head the largest and the RMS |dlogit| of the engine against (a) the reference's own golden logits, (b) an fp64 evaluation
 of the same graph, next to the fp32 CPU oracle's own distance from fp64; loss difference; per-tensor gradient noise.
 
-    python tools/parity_report.py [--out profiles/r04_parity.json] [--tag default] [--net128]
+    python tools/parity_report.py [--out profiles/r05_parity.json] [--tag default] [--net128]
 
 Test infrastructure: imports `oracle` (checker).  Run once per library build (E2E_LIB_PATH selects a diagnostic build);
 records are merged into the output file under their tag."""
@@ -20,7 +20,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import oracle                                                     # noqa: E402
-from tests.helpers import golden, seeded_input, seeded_labels    # noqa: E402
+from tests.helpers import golden, seeded_input, seeded_labels, check_grads_same_branches    # noqa: E402
 from tests.test_gpu_net import build_net, load_closed_form, HIPPO  # noqa: E402
 
 
@@ -63,6 +63,13 @@ def grad_stats(eng, shapes, leaves32, leaves64):
             "tensors_engine_above_3x_cpu_worst": sum(1 for n in names if l2g[n] > 3 * l2c[wc])}
 
 
+def same_branch_stats(eng, spec, params, x, targets, w, shapes):
+    """gradients under the engine's own LeakyReLU / pooling decisions (tests/helpers.py): engine and fp32 CPU oracle vs fp64"""
+    glob, worst = check_grads_same_branches(eng, spec, params, x, targets, w, shapes, tol_global=1.0, tol_tensor=1.0)
+    return {"global_rel_l2_engine": glob["engine"], "global_rel_l2_cpu32": glob["cpu32"],
+            "worst_tensor_engine": [worst["engine"][1], worst["engine"][0]], "worst_tensor_cpu32": [worst["cpu32"][1], worst["cpu32"][0]]}
+
+
 def oracle_grads(spec, params, x, targets, w, dtype):
     leaves = {n: p.detach().to(dtype).clone().requires_grad_(True) for n, p in params.items()}
     ref = oracle.forward(spec, leaves, x.to(dtype))
@@ -92,7 +99,8 @@ def config1(B=1):
     if B == 1:
         gold = [((lambda a: a[:, :, ::2, ::2, ::2]) if i == 0 else (lambda a: a), g["b32_logits%d" % i]) for i in range(len(outs))]
     rec = {"heads": head_stats(outs, ref32, ref64, gold), "loss_engine": loss.item(), "loss_cpu32": loss32.item(),
-           "loss_fp64": loss64.item(), "grads": grad_stats(eng, shapes, l32, l64)}
+           "loss_fp64": loss64.item(), "grads": grad_stats(eng, shapes, l32, l64),
+           "grads_same_branches": same_branch_stats(eng, spec, params, x, targets, w, shapes)}
     if B == 1:
         rec["loss_golden"] = float(g["loss"])
     return rec
@@ -127,7 +135,41 @@ def config5(dens):
     l64, loss64, ref64 = oracle_grads(spec, mp, x, targets, w, torch.float64)
     gold = [((lambda a: a[0, :, 31, ::2, ::2]), g[tag + "_slice_d31"]), None, None, ((lambda a: a), g[tag + "_logits3"])]
     return {"heads": head_stats(outs, ref32, ref64, gold), "loss_engine": loss.item(), "loss_cpu32": loss32.item(),
-            "loss_fp64": loss64.item(), "loss_golden": float(g[tag + "_loss"]), "grads": grad_stats(eng, shapes, l32, l64)}
+            "loss_fp64": loss64.item(), "loss_golden": float(g[tag + "_loss"]), "grads": grad_stats(eng, shapes, l32, l64),
+            "grads_same_branches": same_branch_stats(eng, spec, mp, x, targets, w, shapes)}
+
+
+def width48():
+    """the reference trainer's width at 64^3 (tests/test_gpu_configs.py::test_width48_whole_net_vs_reference_golden_and_oracle)"""
+    from e2enet_medical_amd.training.network_training.sparselearning.core_channel import Masking, CosineDecay
+    g = golden("net_w48.npz")
+    net = build_net((64, 64, 64), 4, 48, 4, [(2, 2, 2)] * 5)
+    shapes, params = load_closed_form(net)
+    opt = torch.optim.SGD(net.parameters(), 1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)
+
+    class A:
+        adv = False
+        fix = False
+        update_frequency = 1200
+        final_density = 0.05
+    random.seed(0)
+    mask = Masking(opt, death_rate=0.5, death_mode='magnitude', death_rate_decay=CosineDecay(0.5, 10), growth_mode='random',
+                   redistribution_mode='none', args=A())
+    mask.add_module(net, sparse_init='uniform', density=0.2)
+    x = seeded_input((1, 4, 64, 64, 64), seed=241)
+    eng = net.engine(x.cuda())
+    outs = eng.forward(x.cuda(), True)
+    targets = [seeded_labels((o.shape[0], 1) + tuple(o.shape[2:]), 4, seed=250 + i) for i, o in enumerate(outs)]
+    w = oracle.ds_weights(5)
+    loss = eng.loss_backward([t.cuda() for t in targets], w, batch_dice=False)
+    spec = oracle.make_spec(4, 48, 4)
+    mp = {n: p.detach().cpu().clone() for n, p in net.named_parameters()}
+    l32, loss32, ref32 = oracle_grads(spec, mp, x, targets, w, torch.float32)
+    l64, loss64, ref64 = oracle_grads(spec, mp, x, targets, w, torch.float64)
+    gold = [((lambda a: a[0, :, 31, ::2, ::2]), g["slice_d31"]), None, ((lambda a: a), g["logits2"]), ((lambda a: a), g["logits3"])]
+    return {"heads": head_stats(outs, ref32, ref64, gold), "loss_engine": loss.item(), "loss_cpu32": loss32.item(),
+            "loss_fp64": loss64.item(), "loss_golden": float(g["loss"]), "grads": grad_stats(eng, shapes, l32, l64),
+            "grads_same_branches": same_branch_stats(eng, spec, mp, x, targets, w, shapes)}
 
 
 def net128():
@@ -148,12 +190,14 @@ def net128():
         ref32 = oracle.forward(spec, params, x.cpu())
         loss32 = oracle.deep_supervision_loss(ref32, [t.cpu() for t in targets], w, False)
         ref64 = oracle.forward(spec, {n: p.double() for n, p in params.items()}, x.cpu().double())
-    return {"heads": head_stats(outs, ref32, ref64), "loss_engine": loss.item(), "loss_cpu32": loss32.item()}
+    shapes = {n: tuple(p.shape) for n, p in net.named_parameters()}
+    return {"heads": head_stats(outs, ref32, ref64), "loss_engine": loss.item(), "loss_cpu32": loss32.item(),
+            "grads_same_branches": same_branch_stats(eng, spec, params, x.cpu(), [t.cpu() for t in targets], w, shapes)}
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04_parity.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r05_parity.json"))
     ap.add_argument("--tag", default="default")
     ap.add_argument("--net128", action="store_true")
     args = ap.parse_args()
@@ -164,6 +208,7 @@ def main():
     rec["config1_B2"] = config1(2)
     rec["config5_d0.1"] = config5(0.1)
     rec["config5_d0.5"] = config5(0.5)
+    rec["width48"] = width48()
     if args.net128:
         rec["config2_net128_B1"] = net128()
     allrec = {}
@@ -184,6 +229,11 @@ def main():
             print("%-18s grads: global %.4f (cpu %.4f) median %.4f (cpu %.4f) worst %s %.4f (cpu worst %.4f)" % (
                 k, gr["global_rel_l2_engine"], gr["global_rel_l2_cpu32"], gr["median_rel_l2_engine"], gr["median_rel_l2_cpu32"],
                 gr["worst_tensor_engine"][0], gr["worst_tensor_engine"][1], gr["worst_tensor_cpu32"][1]))
+        if "grads_same_branches" in v:
+            gr = v["grads_same_branches"]
+            print("%-18s grads under the engine's branch decisions, vs fp64: engine global %.3e worst %.3e (%s) | cpu32 global %.3e worst %.3e" % (
+                k, gr["global_rel_l2_engine"], gr["worst_tensor_engine"][1], gr["worst_tensor_engine"][0], gr["global_rel_l2_cpu32"],
+                gr["worst_tensor_cpu32"][1]))
 
 
 if __name__ == "__main__":
