@@ -53,7 +53,7 @@ FP32_PEAK_TF = 157.3           # fp32 vector FMA peak = fp32-input MFMA peak (MI
 BF16_PEAK_TF = 2500.0          # dense bf16 MFMA peak (MI355X_MICROARCH.md; the 5 PF headline figure includes 2:1 sparsity)
 FWD_BYTES_PER_VOXEL = 5393.0   # BASELINE.md section 3 / SURVEY section 8(d): algorithmic fwd bytes per voxel at 32 ch
 TRAIN_BYTES_PER_VOXEL = 3 * FWD_BYTES_PER_VOXEL
-TRAFFIC_FILE = "r04_pmc_traffic.json"
+TRAFFIC_FILE = "r05_pmc_traffic.json"
 NOMINAL_MHZ = 2400.0           # the shader clock the guide's compute peaks are quoted at
 CLOCK_NOTE = ("peaks are the 2.4 GHz figures of the guide; measured_clock_mhz = shader-clock cycles / wall time of workgroup 0 of "
               "every launch of this family inside the timed steps (s_memtime / s_memrealtime, e2e_diag_kernel_clock); "
