@@ -41,6 +41,9 @@
 #include <type_traits>
 
 // phase stamps (diagnostic build: make DEFS=-DMM_STAMPS, E2E_MM_STAMPS=1): cycles per workgroup pipeline, staging wave 4 and matrix wave 0
+#ifndef MM_ATOMIC_ACC
+#define MM_ATOMIC_ACC 1  // data gradient: accumulating destinations by global_atomic_add_f32 (0: load / add / store)
+#endif
 #ifndef MM_DIAG
 #define MM_DIAG 0      // timing-only diagnostic builds (results wrong): 1 no matrix instructions, 2 every plane request reads offset 0 of its plane (cache hits), 4 no conversion arithmetic, 8 no forward stores, 16 no forward statistics
 #endif
@@ -666,6 +669,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           const ODesc od = odesc[k % 3][(i & 3) + 8 * (i >> 2) + 4 * fh8];
           dst[e] = od.dst; usc[e] = od.usc; flg[e] = od.flags;
         }
+#if MM_ATOMIC_ACC
+        // accumulating destinations: one no-return global_atomic_add_f32 per element instead of a load / add / store round trip.
+        // Every element is touched by exactly one lane of one workgroup per launch and launches are stream-ordered, so the sum is
+        // the same number as the read-modify-write's (the scale is a power of two: RN(old + acc * usc) either way) and
+        // deterministic; the adder sits in L2, the old values never travel to the CU.
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (flg[e] & 1) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+              float* q = dst[e] + rowoff + (a / CB) * p.W + (a % CB) * 32;
+              const float v = acc[a][8 * hf + e] * usc[e];
+              if (flg[e] & 2) asm volatile("global_atomic_add_f32 %0, %1, off" :: "v"(q), "v"(v) : "memory");
+              else *q = v;
+            }
+          }
+        }
+#else
         int anyf = 0;
 #pragma unroll
         for (int e = 0; e < 8; ++e) anyf |= flg[e];
@@ -692,6 +713,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int a = 0; a < 4; ++a) dst[e][rowoff + (a / CB) * p.W + (a % CB) * 32] = fmaf(acc[a][8 * hf + e], usc[e], old[e][a]);
           }
         }
+#endif
       }
     }
 #pragma unroll
