@@ -37,11 +37,21 @@ __global__ __launch_bounds__(1024) void k(const float* __restrict__ x, float* __
         for (int d = 0; d < DEPTH; ++d) acc += v[d];
       }
     }
-    if (store) {                                     // 32 out planes x 4 rows x 512 B
+    if (store == 1) {                                // 32 out planes x 4 rows x 512 B, 16 bytes per lane
       for (int r = threadIdx.x; r < 32 * 4 * 32; r += blockDim.x) {
         const int ch = r / 128, q = r % 128;
         float* p = y + (long long)ch * chan_stride + (long long)s * plane_elems + (4 * t + q / 32) * 128 + (q % 32) * 4;
         *reinterpret_cast<f4*>(p) = acc;
+      }
+    } else if (store >= 2 && wave < 4) {             // as K1m's epilogue: the first four waves only, 4 bytes per lane, 32 consecutive pixels of two
+      const int fq = lane & 31, fh = lane >> 5;      // channels per instruction; wave w owns tile row w (store == 3: the same through atomics)
+      for (int i = 0; i < 16; ++i) {
+        const int ch = (i & 3) + 8 * (i >> 2) + 4 * fh;
+        for (int a = 0; a < 4; ++a) {
+          float* p = y + (long long)ch * chan_stride + (long long)s * plane_elems + (4 * t + wave) * 128 + a * 32 + fq;
+          if (store == 3) asm volatile("global_atomic_add_f32 %0, %1, off" :: "v"(p), "v"(acc[0]) : "memory");
+          else *p = acc[a];
+        }
       }
     }
   }
@@ -57,10 +67,10 @@ int main() {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int slices = 128, tiles = 32, items = slices * tiles;   // one batch item of a 128^3 plane set
   printf("%-8s %-6s %-6s %-5s %-6s %10s %12s %12s\n", "waves", "depth", "rows", "store", "chunks", "ms", "read TB/s", "payload TB/s");
-  for (int store : {0, 1})
-    for (int rows : {6, 4})
-      for (int nw : {4, 8, 16})
-        for (int depth : {4, 8, 16}) {
+  for (int store : {0, 1, 2, 3})
+    for (int rows : {6})
+      for (int nw : {8})
+        for (int depth : {8, 16}) {
           const int nchunks = 4;
           auto launch = [&]() {
             if (depth == 4) hipLaunchKernelGGL(k<4>, dim3(256), dim3(64 * nw), 0, 0, x, y, sink, planes, rows, tiles, items, nchunks, store, 256);
@@ -72,7 +82,7 @@ int main() {
           for (int i = 0; i < 5; ++i) launch();
           hipEventRecord(e1); hipEventSynchronize(e1);
           float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
-          const double rd = (double)items * nchunks * 16 * rows * 512.0, payload = (double)items * nchunks * 16 * 4 * 512.0 + (store ? (double)items * 32 * 4 * 512.0 : 0.0);
+          const double rd = (double)items * nchunks * 16 * rows * 512.0, payload = (double)items * nchunks * 16 * 4 * 512.0 + (store ? (double)items * 32 * 4 * 512.0 : 0.0);   // (store 2 / 3: four loader + four storing waves of the eight)
           printf("%-8d %-6d %-6d %-5d %-6d %10.3f %12.2f %12.2f\n", nw, depth, rows, store, nchunks, ms, rd / ms / 1e9, payload / ms / 1e9);
         }
   return 0;
