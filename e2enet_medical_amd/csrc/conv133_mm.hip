@@ -41,9 +41,6 @@
 #include <type_traits>
 
 // phase stamps (diagnostic build: make DEFS=-DMM_STAMPS, E2E_MM_STAMPS=1): cycles per workgroup pipeline, staging wave 4 and matrix wave 0
-#ifndef MM_ATOMIC_ACC
-#define MM_ATOMIC_ACC 1  // data gradient: accumulating destinations by global_atomic_add_f32 (0: load / add / store)
-#endif
 #ifndef MM_DIAG
 #define MM_DIAG 0      // timing-only diagnostic builds (results wrong): 1 no matrix instructions, 2 every plane request reads offset 0 of its plane (cache hits), 4 no conversion arithmetic, 8 no forward stores, 16 no forward statistics
 #endif
@@ -601,6 +598,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
     return v;
   };
+  // 4 x 4 transpose across the lanes of a quad: before, register r of lane l holds (channel c0 + r, pixel 4 q + l); after, register r
+  // holds (channel c0 + l, pixel 4 q + r) -- four consecutive pixels of one channel per lane, i.e. ONE 16-byte store per lane and
+  // block instead of four 4-byte ones, and ONE destination record per lane and block instead of four (data gradient).  Measured
+  // on one box against 4-byte stores (profiles/r05_store_ab.txt): data gradient -3 ... -4 %, forward +2 ... +3 % (kept there as it
+  // was): the width of the stores is not what the ~9 k cycles per item of the epilogue wait for.
+  const bool q_hi2 = (lane & 2) != 0, q_hi1 = (lane & 1) != 0;
+  auto quad_transpose = [&](float r0, float r1, float r2, float r3) __attribute__((always_inline)) {
+    auto x2 = [](float v) __attribute__((always_inline)) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false)); };   // quad_perm [2,3,0,1]
+    auto x1 = [](float v) __attribute__((always_inline)) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false)); };   // quad_perm [1,0,3,2]
+    const float t0 = x2(r0), t1 = x2(r1), t2 = x2(r2), t3 = x2(r3);
+    const float a0 = q_hi2 ? t2 : r0, a1 = q_hi2 ? t3 : r1, a2 = q_hi2 ? r2 : t0, a3 = q_hi2 ? r3 : t1;
+    const float u0 = x1(a0), u1 = x1(a1), u2 = x1(a2), u3 = x1(a3);
+    return f32x4_t{q_hi1 ? u1 : a0, q_hi1 ? a1 : u0, q_hi1 ? u3 : a2, q_hi1 ? a3 : u2};
+  };
   auto epilogue = [&](int k) __attribute__((always_inline)) {
     // ---- epilogue of item k.  D layout of v_mfma_f32_32x32x16 with the weights as the A operand: column (pixel of the tile row) =
     // lane & 31, row (out channel of the block) = (i & 3) + 8 (i >> 2) + 4 (lane >> 5): register i of accumulator a is one pixel of
@@ -642,6 +653,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         pending = k;
       }
       if (!(MM_DIAG & 8)) {
+        // (4-byte stores, two whole lines per instruction; the quad-transposed 16-byte form of the data gradient below was measured
+        //  2-3 % SLOWER here on one box, profiles/r05_store_ab.txt: the transposition costs more than the narrower stores)
         float* yb = p.y + ((long long)it.n * p.Q + it.qb * 32 + 4 * fh8) * cs + (long long)it.d * plane + (long long)(it.h0 + RPW * wr) * p.W + it.w0 + fq;
         const int qlim = p.Q - it.qb * 32 - 4 * fh8;          // channels of this lane's half that exist
 #pragma unroll
@@ -654,66 +667,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
       }
     } else {
-      // data gradient: destinations from the item's records (odesc), eight out channels of this lane's half at a time: an
-      // accumulating destination's 32 old values are requested before the first is used; the next chunk's fragments are requested
-      // BEHIND the epilogue at an item's end (chunk()), so their registers are free here
-      const int rowoff = RPW * wr * p.W + fq;
+      // data gradient: destinations from the item's records (odesc).  After the quad transpose a lane owns ONE out channel per
+      // block j -- 8 j + 4 fh8 + (lane & 3) -- and four consecutive pixels of it: one 16-byte store, or four no-return
+      // global_atomic_add_f32 where the destination accumulates (one lane of one workgroup per element and launch, launches
+      // stream-ordered: RN(old + acc * usc), the same number as a load / add / store, deterministic; the adder sits in L2)
+      const int rowoff = RPW * wr * p.W + (fq & ~3);
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        float* dst[8];
-        float usc[8];
-        int flg[8];
+      for (int j = 0; j < 4; ++j) {
+        const ODesc od = odesc[k % 3][8 * j + 4 * fh8 + (lane & 3)];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int i = 8 * hf + e;
-          const ODesc od = odesc[k % 3][(i & 3) + 8 * (i >> 2) + 4 * fh8];
-          dst[e] = od.dst; usc[e] = od.usc; flg[e] = od.flags;
-        }
-#if MM_ATOMIC_ACC
-        // accumulating destinations: one no-return global_atomic_add_f32 per element instead of a load / add / store round trip.
-        // Every element is touched by exactly one lane of one workgroup per launch and launches are stream-ordered, so the sum is
-        // the same number as the read-modify-write's (the scale is a power of two: RN(old + acc * usc) either way) and
-        // deterministic; the adder sits in L2, the old values never travel to the CU.
+        for (int a = 0; a < 4; ++a) {
+          const f32x4_t v = quad_transpose(acc[a][4 * j], acc[a][4 * j + 1], acc[a][4 * j + 2], acc[a][4 * j + 3]) * od.usc;
+          if (od.flags & 1) {
+            float* q = od.dst + rowoff + (a / CB) * p.W + (a % CB) * 32;
+            if (od.flags & 2) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          if (flg[e] & 1) {
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-              float* q = dst[e] + rowoff + (a / CB) * p.W + (a % CB) * 32;
-              const float v = acc[a][8 * hf + e] * usc[e];
-              if (flg[e] & 2) asm volatile("global_atomic_add_f32 %0, %1, off" :: "v"(q), "v"(v) : "memory");
-              else *q = v;
+              for (int e = 0; e < 4; ++e) asm volatile("global_atomic_add_f32 %0, %1, off" :: "v"(q + e), "v"(v[e]) : "memory");
+            } else {
+              *(__attribute__((address_space(1))) f32x4_t*)(q) = v;      // (a global store: the pointer came out of LDS as a generic one)
             }
           }
         }
-#else
-        int anyf = 0;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) anyf |= flg[e];
-        const bool any_accu = __builtin_amdgcn_ballot_w64((anyf & 2) != 0) != 0ull;      // (wave-uniform)
-        float old[8][4];
-        if (any_accu) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-              const float* src = (flg[e] & 1) ? dst[e] + rowoff + (a / CB) * p.W + (a % CB) * 32 : reinterpret_cast<const float*>(p.wpk);
-              old[e][a] = *src;
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-#pragma unroll
-          for (int a = 0; a < 4; ++a)
-            if (!any_accu || !(flg[e] & 2)) old[e][a] = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          if (flg[e] & 1) {
-#pragma unroll
-            for (int a = 0; a < 4; ++a) dst[e][rowoff + (a / CB) * p.W + (a % CB) * 32] = fmaf(acc[a][8 * hf + e], usc[e], old[e][a]);
-          }
-        }
-#endif
       }
     }
 #pragma unroll
