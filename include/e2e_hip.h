@@ -175,7 +175,10 @@ int e2e_conv133_dgrad_sparse(const float* dy, const float* wpk_t, const unsigned
  * layer with Wi % 32 == 0, Hi % 16 == 0, Hi > 16 and 17..320 channels on both sides, masked or not.
  *   ws          workspace of e2e_conv133_mm_ws_bytes(...) bytes (0: shape not served): the packed weights, rebuilt at every launch
  *   dy_absmax   NULL, or the word e2e_in_lrelu_bwd(dy_absmax) left behind for this dy: its power-of-two scale (without it dy is
- *               taken as it is: only for O(1) test data -- full-resolution gradients of 1e-7 are below the fp16 range) */
+ *               taken as it is: only for O(1) test data -- full-resolution gradients of 1e-7 are below the fp16 range)
+ *   outs        as e2e_conv133_dgrad; destinations with `accumulate` set are updated by no-return global_atomic_add_f32 -- every element
+ *               by exactly one lane per launch, launches stream-ordered: the same value as a load / add / store and deterministic;
+ *               the buffers must be device (coarse-grained) memory */
 long long e2e_conv133_mm_ws_bytes(int B, int Cin, int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw);
 int e2e_conv133_fwd_mm(const e2e_in_chan_t* chans, int Cin, const float* w, const float* bias, const unsigned* live, float* y, double* part,
                        int B, int Cout, int Di, int Hi, int Wi, void* ws, long long ws_bytes, void* stream);
