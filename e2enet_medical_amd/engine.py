@@ -600,6 +600,7 @@ class Engine:
             self._build_unetpp(cfg)
         self.grads: Dict[str, torch.Tensor] = {}
         self.grad_bucket_hook = None       # callable(lo, hi): flat gradient slice [lo, hi) is final (data-parallel overlap)
+        self._comm_stream = None           # the stream the bucket hook is called on (backward)
         self.batch_dice_hook = None        # callable(fp64 tensor [K*3]): all-reduce of the folded tp/fp/fn (data-parallel batch dice)
         self._backward_ready = False
         self.loss_ws = None
@@ -846,15 +847,16 @@ class Engine:
         return LANES and any(self._lane_of) and not self._graph_ok() and not torch.cuda.is_current_stream_capturing()
 
     def _exec(self, order, deps, events, action, checkpoint=None):
-        """Issue action(op) for the ops in `order`; `checkpoint(op)` (data-parallel bucket hook) runs on the caller's stream
-        after both lanes have been joined."""
+        """Issue action(op) for the ops in `order`; `checkpoint(op, wait_all)` (data-parallel bucket hook) runs after op was issued:
+        wait_all(stream) makes `stream` wait for everything issued so far on the caller's stream and on the lanes, without
+        holding any of THEM up."""
+        main = torch.cuda.current_stream()
         if not self._lanes_on():
             for i in order:
                 action(self.ops[i])
                 if checkpoint is not None:
-                    checkpoint(self.ops[i], lambda: None)
+                    checkpoint(self.ops[i], lambda st: st.wait_stream(main))
             return
-        main = torch.cuda.current_stream()
         if self._lane_streams is None:
             self._lane_streams = [torch.cuda.Stream(device=self.device) for _ in self.lane_divs]
         side = self._lane_streams
@@ -863,6 +865,10 @@ class Engine:
         def join():
             for st in side:
                 main.wait_stream(st)
+
+        def wait_all(st):
+            for s_ in streams:
+                st.wait_stream(s_)
         for st in side:
             st.wait_stream(main)
         try:
@@ -882,7 +888,7 @@ class Engine:
                         events[i] = torch.cuda.Event()
                     events[i].record(streams[ln])
                 if checkpoint is not None:
-                    checkpoint(self.ops[i], join)
+                    checkpoint(self.ops[i], wait_all)
         finally:
             self._lane = 0
             join()
@@ -1017,12 +1023,20 @@ class Engine:
             else:
                 op.backward()
 
-        def checkpoint(op, join_lanes):
+        def checkpoint(op, wait_all):
             if hook is not None and id(op) in self._bucket_after_op:
-                join_lanes()
+                # gradients in flat[lo:hi] are final once everything issued so far has run.  The collective is issued from a stream
+                # of its own that waits for the caller's stream, the lanes and the weight-gradient stream -- none of THEM waits: until
+                # round 5 the caller's stream joined all the others here, four times per pass, which cost 1.2 ms of lost overlap per
+                # step even with one rank (bench rccl.allreduce_exposed_ms)
+                if self._comm_stream is None:
+                    self._comm_stream = torch.cuda.Stream(device=self.device)
+                comm = self._comm_stream
+                wait_all(comm)
                 if side is not None:
-                    main.wait_stream(side)
-                hook(*self._bucket_after_op[id(op)])           # gradients in flat[lo:hi] are final
+                    comm.wait_stream(side)
+                with torch.cuda.stream(comm):
+                    hook(*self._bucket_after_op[id(op)])
         try:
             self._exec(self._bwd_order, self._deps_bwd, self._ev_bwd, act, checkpoint)
         finally:
