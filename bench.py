@@ -132,6 +132,10 @@ def pmc_traffic(*prefixes):
     if not os.path.exists(path):
         return None
     d = json.load(open(path))
+    meta = d.pop("_meta", None)
+    from e2enet_medical_amd._lib import ABI_VERSION
+    if meta is None or meta.get("abi_version") != ABI_VERSION:
+        return None                          # collected from another revision of the library: stale, not reported
     sel = {k: v for k, v in d.items() if any(k.startswith(pf) for pf in prefixes)}
     n = sum(v["launches"] for v in sel.values())
     if not n:
@@ -678,7 +682,8 @@ def main():
                                           "operands incl. its weight-packing launch; strided convs and planes <= 16 wide on the vector walk)",
                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                 "traffic": pmc_traffic("conv133_kernel", "conv133_dense_kernel", "conv133_sparse_kernel", "conv133_mm_kernel"),
-                "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" % TRAFFIC_FILE,
+                "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch; null when the summary was "
+                                  "collected from another ABI version of the library)" % TRAFFIC_FILE,
                 "algorithmic_bytes_per_launch": byt / len(ev), "launches_per_step": len(ev) // isteps,
                 "avg_ms": ms / len(ev), "ms_per_step": ms / isteps, "share_of_step": (ms / isteps) / ms_step,
                 "timing": "HIP events around each launch in %d instrumented steps issued on ONE stream; the timed steps run the "

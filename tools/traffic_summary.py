@@ -31,7 +31,16 @@ for name, v in tot.items():
     out[name] = {"launches": v["n_fetch"], "fetch_bytes_per_launch_corrected": fetch, "write_bytes_per_launch": write,
                  "hbm_bytes_per_launch": fetch + write}
 rows = sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])
-json.dump(dict(rows), open(os.path.join(root, "traffic.json"), "w"), indent=1)
+doc = dict(rows)
+# which library the counters were collected from: bench.py refuses a summary whose ABI version is not the loaded library's
+# (kernels changed since: the numbers would be stale)
+try:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from e2enet_medical_amd._lib import ABI_VERSION
+    doc["_meta"] = {"abi_version": ABI_VERSION}
+except Exception:
+    pass
+json.dump(doc, open(os.path.join(root, "traffic.json"), "w"), indent=1)
 for name, v in rows[:14]:
     print("%-72s n=%-4d fetch=%8.1f MB write=%8.1f MB" % (name, v["launches"], v["fetch_bytes_per_launch_corrected"] / 1e6,
                                                           v["write_bytes_per_launch"] / 1e6))
