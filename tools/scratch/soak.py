@@ -1,0 +1,59 @@
+#!/usr/bin/env python
+"""Round 5 soak: the benchmark's network (128^3, B = 2, base 32, d = 0.2) trained for a few hundred iterations on a LEARNABLE
+synthetic task (labels = quantiles of a smoothed input channel), with DSFF prune / grow every 50 iterations, lr 1e-2 -- watching
+what the fp16 two-piece kernels depend on: the range of the normalised activations (Inf beyond 8 188), the recorded max |dy| of
+every conv block (the power-of-two scale), finiteness of loss / gradients, and that the loss goes down.
+   python tools/scratch/soak.py [iters] [patch]"""
+import os, sys, struct
+import numpy as np
+import torch
+import torch.nn.functional as F
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import bench   # noqa: E402
+from e2enet_medical_amd.engine import ConvOp   # noqa: E402
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+ps = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+dev = torch.device("cuda")
+patch = (ps,) * 3
+net, opt, mask, fused = bench.build(dev, patch, update_frequency=50)
+g = torch.Generator().manual_seed(7)
+batches = []
+for b in range(4):
+    x = torch.randn((2, bench.CIN) + patch, generator=g)
+    sm = F.avg_pool3d(x[:, :1], 5, 1, 2)
+    q = torch.quantile(sm.flatten()[::97], torch.tensor([0.25, 0.5, 0.75]))
+    full = torch.bucketize(sm, q).float()
+    batches.append((x.to(dev), [full[:, :, ::s, ::s, ::s].contiguous().to(dev) for s in (1, 2, 4, 8)]))
+eng = net.engine(batches[0][0])
+ds_w = np.array([8, 4, 2, 1, 0], dtype=np.float64) / 15.0
+losses = []
+emin, emax, amax = 255, 0, 0.0
+for it in range(iters):
+    x, targets = batches[it % len(batches)]
+    eng.forward(x, True)
+    loss = eng.loss_backward(targets, ds_w, batch_dice=False)
+    fused.step(eng.grads, mask.masks)
+    mask.step(masks_already_applied=True)
+    if it % 20 == 0 or it == iters - 1:
+        lv = float(loss.item())
+        losses.append(lv)
+        words = [int(op.dy_absmax.item()) & 0xffffffff for op in eng.ops if isinstance(op, ConvOp)]
+        ex = [(w >> 23) & 0xff for w in words]
+        emin, emax = min(emin, min(ex)), max(emax, max(ex))
+        mx = 0.0
+        for op in eng.ops:
+            if isinstance(op, ConvOp):
+                a = op.out
+                B, C = a.shape[:2]
+                u = a.data * a.scale.view(B, C, 1, 1, 1) + a.shift.view(B, C, 1, 1, 1)
+                mx = max(mx, float(u.abs().max().item()))
+        amax = max(amax, mx)
+        gn = float(torch.sqrt(sum((gr.double() ** 2).sum() for gr in eng.grads.values())).item())
+        print("iter %4d  loss %.5f  |grad| %.4e  max |normalised activation| %.2f  max|dy| words: 2^%d .. 2^%d  finite=%s"
+              % (it, lv, gn, mx, min(ex) - 127, max(ex) - 127, np.isfinite(lv) and np.isfinite(gn)), flush=True)
+        assert np.isfinite(lv) and np.isfinite(gn)
+print("loss %.4f -> %.4f (min %.4f); normalised activations up to %.1f (fp16 two-piece forward: Inf beyond 8188); max |dy| between 2^%d and 2^%d"
+      % (losses[0], losses[-1], min(losses), amax, emin - 127, emax - 127))
+assert losses[-1] < losses[0] - 0.1
