@@ -54,6 +54,8 @@ BF16_PEAK_TF = 2500.0          # dense bf16 MFMA peak (MI355X_MICROARCH.md; the 
 FWD_BYTES_PER_VOXEL = 5393.0   # BASELINE.md section 3 / SURVEY section 8(d): algorithmic fwd bytes per voxel at 32 ch
 TRAIN_BYTES_PER_VOXEL = 3 * FWD_BYTES_PER_VOXEL
 TRAFFIC_FILE = "r05_pmc_traffic.json"
+DTYPE_NOTE = "f32 (fp16x2 split products, f32 accumulate)"   # inputs, outputs, statistics fp32 / fp64; conv products = three fp16 MFMAs on 11+11-bit pieces
+PURE_FP32_ENV = {"E2E_CONV_MM": "0", "E2E_CONV_DENSE": "0", "E2E_WG_BF3": "0", "E2E_CT_BF3": "0"}   # every product an fp32 FMA / fp32-input MFMA
 NOMINAL_MHZ = 2400.0           # the shader clock the guide's compute peaks are quoted at
 CLOCK_NOTE = ("peaks are the 2.4 GHz figures of the guide; measured_clock_mhz = shader-clock cycles / wall time of workgroup 0 of "
               "every launch of this family inside the timed steps (s_memtime / s_memrealtime, e2e_diag_kernel_clock); "
@@ -264,6 +266,67 @@ def cpu_baseline(sample, patch_edge=128, budget_s=150.0):
     return base, parity
 
 
+def pure_fp32_record(steps=6, warmup=2):
+    """The same step with every split-operand path switched off (library knobs, read once per process: a child process): the vector
+    walk for the convs, the fp32-input MFMA kernels for the weight gradients and the transposed convs.  Reported beside the headline so
+    that what the fp16 two-piece products buy -- and that they are what the headline runs on -- is always visible."""
+    import subprocess
+    env = dict(os.environ, **PURE_FP32_ENV)
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warmup), "--no-extras", "--no-cpu-baseline"]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+        d = json.loads(line)
+        return {"env": PURE_FP32_ENV, "ms_per_step": d["ms_per_step"], "voxels_per_s": d["value"],
+                "roofline_frac": d.get("roofline", {}).get("frac"), "roofline_ms_per_step": d.get("roofline", {}).get("ms_per_step"),
+                "wgrad_ms_per_step": d.get("roofline_secondary", {}).get("ms_per_step"), "steps": steps,
+                "what": "the headline workload with E2E_CONV_MM=0 E2E_CONV_DENSE=0 (convs on the fp32 vector walk), E2E_WG_BF3=0 "
+                        "(weight gradients on fp32-input MFMA), E2E_CT_BF3=0 (transposed convs on the fp32 kernels), child process"}
+    except Exception as e:                               # noqa: BLE001 -- a sub-record must not take the headline down
+        return {"env": PURE_FP32_ENV, "error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+
+
+def config1_parity_record(device):
+    """BASELINE config 1 (Hippocampus-shaped plumbing case: [1,1,40,56,40], pools [[2,2,2]]*3+[[1,1,1]]*2, K 3, density 1.0, base 32):
+    engine vs the fp32 CPU oracle vs an fp64 evaluation of the same graph, max |dlogit| per head.  Stated plainly in the record: on
+    this configuration the engine is NOT within the literal 1e-4 of the CPU path on every head -- nor is the CPU path within 1e-4 of
+    exact arithmetic (InstanceNorms over 8..175 voxels at the deep levels): the tests assert the triangle bound instead."""
+    import oracle
+    from torch import nn
+    from e2enet_medical_amd.network_architecture.unetpp_d import Generic_UNetPlusPlus
+    from e2enet_medical_amd.network_architecture.initialization import InitWeights_He
+    pools = [(2, 2, 2)] * 3 + [(1, 1, 1)] * 2
+    patch, cin, k = (40, 56, 40), 1, 3
+    torch.manual_seed(11)
+    net = Generic_UNetPlusPlus(patch, cin, BASE, k, 5, 2, 2, nn.Conv3d, nn.InstanceNorm3d, {'eps': 1e-5, 'affine': True}, nn.Dropout3d,
+                               {'p': 0, 'inplace': True}, nn.LeakyReLU, {'negative_slope': 1e-2, 'inplace': True}, True, False,
+                               lambda x: x, InitWeights_He(1e-2), pools, None, False, True, True).to(device)
+    x = torch.randn((1, cin) + patch, generator=torch.Generator().manual_seed(12))
+    with torch.no_grad():
+        outs = [o.cpu() for o in net(x.to(device))]
+    spec = oracle.make_spec(cin, BASE, k, pools)
+    params = {n: p.detach().cpu().clone() for n, p in net.named_parameters()}
+    with torch.no_grad():
+        r32 = oracle.forward(spec, params, x)
+        r64 = oracle.forward(spec, {n: p.double() for n, p in params.items()}, x.double())
+    rec = {"what": "config 1 (Hippocampus-shaped, density 1.0, B=1, He init): max |dlogit| per head [full, 1/2, 1/4, 1/8]",
+           "engine_vs_cpu32": [float((a - b).abs().max()) for a, b in zip(outs, r32)],
+           "engine_vs_fp64": [float((a.double() - b).abs().max()) for a, b in zip(outs, r64)],
+           "cpu32_vs_fp64": [float((a.double() - b).abs().max()) for a, b in zip(r32, r64)]}
+    worst = max(rec["engine_vs_cpu32"])
+    rec["config1_engine_vs_cpu"] = worst
+    rec["note"] = ("engine vs the reference CPU path on config 1: %.2e max |dlogit| -- %s the literal 1e-4 bar of the north_star; the fp32 "
+                   "CPU path itself is %.2e from an fp64 evaluation of the same graph here and the engine %.2e (two fp32 evaluations of "
+                   "InstanceNorms over 8..175 voxels cannot agree to 1e-4); tests assert engine <= 1e-4 + the CPU path's own distance "
+                   "from fp64 (tests/test_gpu_configs.py:_logit_bars).  The headline configuration (config 2) meets the literal bar: "
+                   "see max_abs_dlogit above." % (worst, "EXCEEDS" if worst > 1e-4 else "within", max(rec["cpu32_vs_fp64"]),
+                                                 max(rec["engine_vs_fp64"])))
+    del net
+    torch.cuda.empty_cache()
+    return rec
+
+
 def sliding_window_record(device, rank=0, world=1):
     """BASELINE config 4 shape: AMOS-like volume [1,220,400,400], 16 classes, base 32, patch 128^3,
     step 0.5, 8 mirrors.  Wall time of predict_3D with the volume already on the host as float32 (the call uploads it
@@ -286,39 +349,59 @@ def sliding_window_record(device, rank=0, world=1):
     steps = net._compute_steps_for_sliding_window(PATCH, vol.shape[1:], 0.5)
     tiles = len(steps[0]) * len(steps[1]) * len(steps[2])
     net.predict_3D(vol[:, :128, :160, :160], **kw)          # warm-up: plan allocation for the 8-mirror batch (and RCCL channels)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    seg, probs = net.predict_3D(vol, **kw)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    sharded = world > 1 or os.environ.get("E2E_FORCE_DIST") == "1"
+
+    def timed_predict():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        seg, probs = net.predict_3D(vol, **kw)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, seg, probs
+    dt, seg, probs = timed_predict()
     vox = float(np.prod(vol.shape[1:]))
     rec = {"workload": "predict_3D [1,220,400,400] N(0,1), K=16, base 32, density 0.2, patch 128^3, step 0.5, 8 mirrors "
                        "(%d tiles x 8 forwards, mirrors of a tile as one batch-8 forward)" % tiles,
            "seconds": dt, "volume_voxels_per_s": vox / dt, "patch_voxels_per_s": tiles * 8 * 128 ** 3 / dt,
            "includes": "host->device upload of the volume, device->host copy of seg + probs (1.4 GB)", "n_gpus": world}
     st = getattr(net, "last_shard_stats", None)
-    if st:
+    if st and sharded:
         rec["sharding"] = dict(st)
-        if world > 1 or os.environ.get("E2E_FORCE_DIST") == "1":
-            # calibration: the same all-gather (one group: `world` patches of [16,128^3] fp32), blocking, 5 times
-            mine = torch.zeros((16,) + PATCH, dtype=torch.float32, device=device)
-            outb = torch.empty((world, 16) + PATCH, dtype=torch.float32, device=device)
+        rec["sharding"]["mode"] = st.get("mode", "allgather_patches")
+        counts = torch.zeros(world, dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(counts, torch.tensor([st["tiles_local"]], dtype=torch.int64, device=device))
+        rec["sharding"]["tiles_per_rank"] = [int(v) for v in counts.tolist()]
+        assert sum(rec["sharding"]["tiles_per_rank"]) == tiles, (rec["sharding"]["tiles_per_rank"], tiles)
+        # calibration: the same all-gather (one group: `world` patches of [16,128^3] fp32), blocking, 5 times
+        mine = torch.zeros((16,) + PATCH, dtype=torch.float32, device=device)
+        outb = torch.empty((world, 16) + PATCH, dtype=torch.float32, device=device)
+        dist.all_gather_into_tensor(outb.view(-1), mine.view(-1))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
             dist.all_gather_into_tensor(outb.view(-1), mine.view(-1))
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(5):
-                dist.all_gather_into_tensor(outb.view(-1), mine.view(-1))
-            torch.cuda.synchronize()
-            rec["sharding"]["allgather_ms_per_group_blocking"] = (time.perf_counter() - t1) / 5 * 1e3
-            rec["sharding"]["allgather_bytes_per_group_per_rank_inbound"] = (world - 1) * mine.numel() * 4
+        torch.cuda.synchronize()
+        rec["sharding"]["allgather_ms_per_group_blocking"] = (time.perf_counter() - t1) / 5 * 1e3
+        rec["sharding"]["allgather_bytes_per_group_per_rank_inbound"] = (world - 1) * mine.numel() * 4
+        del mine, outb
+        # the other exchange of SURVEY section 8e, beside it: partial volumes, ONE all-reduce at the end (fewer bytes, not
+        # overlappable, <= 1e-6 from the all-gather form, which is bit-identical to one GPU)
+        net.shard_tiles(rank, world, None, force=world == 1, exchange="allreduce")
+        dt2, seg2, probs2 = timed_predict()
+        st2 = dict(getattr(net, "last_shard_stats", {}))
+        st2.pop("force", None)
+        st2.update(seconds=dt2, volume_voxels_per_s=vox / dt2, max_abs_dprob_vs_allgather=float(np.abs(probs2 - probs).max()),
+                   argmax_mismatch_voxels_vs_allgather=int((seg2 != seg).sum()))
+        rec["sharding_allreduce"] = st2
+        net.shard_tiles(rank, world, None, force=world == 1, exchange="allgather")
     return rec
 
 
@@ -478,9 +561,11 @@ def dry_rank(args, rank, world, json_fd):
     dist.all_reduce(ones)
     per_rank = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
     dist.all_gather(per_rank, torch.tensor([float(rank + 1)], dtype=torch.float64))
+    assert float(ones.item()) == float(world), "all-reduce of ones gave %r on %d ranks" % (float(ones.item()), world)
     if rank == 0:
         rec = {"metric": "dry run of the launcher (no GPU work)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "rccl": {"backend": "gloo", "world": dist.get_world_size(), "allreduce_of_ones": float(ones.item()),
+                        "device_per_rank": list(range(world)),
                         "ms_per_step_without_allreduce": 0.0, "allreduce_exposed_ms": 0.0, "allreduce_bytes_per_step": 0},
                "ms_per_step_per_rank": [float(t.item()) for t in per_rank]}
         os.write(json_fd, (json.dumps(rec) + "\n").encode())
@@ -587,8 +672,14 @@ def main():
         dt = max(float(v) for v in every.tolist())               # MAX over ranks
         ones = torch.ones(1, dtype=torch.float32, device=device)
         dist.all_reduce(ones)
+        devs = torch.zeros(world, dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(devs, torch.tensor([torch.cuda.current_device()], dtype=torch.int64, device=device))
         rccl = {"backend": dist.get_backend(), "world": dist.get_world_size(), "allreduce_of_ones": float(ones.item()),
-                "devices": torch.cuda.device_count()}
+                "devices": torch.cuda.device_count(), "device_per_rank": [int(v) for v in devs.tolist()]}
+        # the first multi-GPU run must not be a debugging session: a wrong world size or two ranks on one GPU stop the run here
+        assert rccl["allreduce_of_ones"] == float(world), "RCCL all-reduce of ones gave %r on %d ranks" % (rccl["allreduce_of_ones"], world)
+        if torch.cuda.device_count() >= world:
+            assert len(set(rccl["device_per_rank"])) == world, "ranks share a GPU: %r" % (rccl["device_per_rank"],)
         if not args.forward_only:
             # what the gradient all-reduce costs the step: the same steps with the bucket hook off (every rank trains alone; no
             # collective inside the step), MAX over ranks like the headline; exposed = step with the overlapped all-reduce - that
@@ -648,7 +739,7 @@ def main():
             "metric": "voxels/sec (train step fwd+bwd+update), 128^3 patch 32ch density=0.2",
             "value": value, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": DTYPE_NOTE, "data": "synthetic",
             "config": {"workload": "BraTS-shaped 4-modal %d^3 patches, shiftConvPP base 32, K=4, DSFF density 0.2, "
                                    "batch %d per GPU, %s" % (patch[0], args.batch, "inference forward (deep supervision heads off)"
                                                              if args.forward_only else
@@ -771,6 +862,11 @@ def main():
             if sample is None:
                 sample = parity_sample(net, device, patch, ds_w)
             out["cpu_baseline"], out["parity"] = cpu_baseline(sample, args.patch)
+            if not args.no_extras:
+                out["parity"]["config1"] = config1_parity_record(device)
+                out["parity"]["config1_engine_vs_cpu"] = out["parity"]["config1"]["config1_engine_vs_cpu"]
+        if world == 1 and not args.no_extras and not args.forward_only and not any(os.environ.get(k) == v for k, v in PURE_FP32_ENV.items()):
+            out["pure_fp32"] = pure_fp32_record()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()

@@ -803,6 +803,23 @@ extern "C" long long e2e_conv133_mm_ws_bytes(int B, int Cin, int Cout, int Di, i
   return ((blocks * WCH + 63) & ~63ll) + (long long)(B > 0 ? B : 1) * e2e::cdiv((int)cmax, 16) * 16 * (long long)sizeof(ChanRec);
 }
 
+// compute units of the CURRENT device, rounded down to a multiple of 8 (one persistent workgroup per CU, XCD-aware remap);
+// cached per device id: a process may drive GPUs with different CU counts
+static int mm_num_cus() {
+  static int cache[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (cache[dev] == 0) {
+    hipDeviceProp_t prop;
+    int n = 0;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+    n &= ~7;
+    cache[dev] = n < 8 ? 8 : n;
+  }
+  return cache[dev];
+}
+
 static int mm_launch(int mode, const e2e_in_chan_t* chans, const float* xin, const unsigned* x_absmax, const float* w, const unsigned* quads,
                      const float* bias, float* y, double* part, const e2e_out_chan_t* outs, int B, int P, int Q, int D, int H, int W,
                      int wq_stride, int wp_stride, void* ws, long long ws_bytes, hipStream_t st) {
@@ -822,17 +839,10 @@ static int mm_launch(int mode, const e2e_in_chan_t* chans, const float* xin, con
   p.tiles_x = W / tw; p.tiles_y = H / th;
   p.tiles_per_n = D * p.tiles_y * p.tiles_x;
   p.total = B * p.tiles_per_n * p.qblocks;
-  static int ncu = 0;
-  if (ncu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-    if (ncu <= 0) ncu = 256;
-    ncu &= ~7;
-    if (ncu < 8) ncu = 8;
-  }
+  const int ncu = mm_num_cus();
   static const int grid_knob = getenv("E2E_MM_GRID") ? atoi(getenv("E2E_MM_GRID")) : 0;
   int grid = grid_knob > 0 ? (grid_knob & ~7) : ncu;
+  if (grid < 8) grid = 8;                                   // (E2E_MM_GRID = 1..7: the XCD remap works on multiples of 8)
   const int padded = (p.total + 7) & ~7;
   if (grid > padded) grid = padded;
   p.grid = grid;

@@ -68,6 +68,42 @@ __global__ __launch_bounds__(256) void death_kernel(const float* __restrict__ l1
   if (l1[i] <= *thr) kmask[i] = 0;
 }
 
+// growth_mode = 'gradient' (core_channel.py:771-790): score[r, c, a] = sum_kh( sum_kw |grad| ) of the kernels that are dead, 0 for the
+// live ones -- the reference's TWO chained torch.sum(dim=-1) (the depth extent of the kernel is NOT summed: a transposed-conv weight
+// [Cin, Cout, 2, 2, 2] has two scores per kernel), each taken left to right.  The gradient the reference reads is weight.grad AFTER
+// clip_grad_norm_ scaled it in place (nnUNetTrainer_simple.py:573): with `sq` the fused optimizer's squared global norm the same
+// coefficient is applied here (RN(g * coef), as torch's mul_), with sq == nullptr the tensor is taken as it is.
+__global__ __launch_bounds__(256) void grad_score_kernel(const float* __restrict__ g, const double* __restrict__ sq, float max_norm,
+                                                         const unsigned char* __restrict__ kmask, float* __restrict__ score,
+                                                         long long n, int kd, int kh, int kw) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;      // (r, c, a)
+  if (i >= n * kd) return;
+  float coef = 1.f;
+  if (sq != nullptr) {
+    coef = max_norm / ((float)sqrt(*sq) + 1e-6f);
+    coef = coef > 1.f ? 1.f : coef;
+  }
+  const float* p = g + i * (kh * kw);
+  float sh = 0.f;
+  for (int b = 0; b < kh; ++b) {
+    float sw = 0.f;
+    for (int c = 0; c < kw; ++c) {
+      const float v = fabsf(sq != nullptr ? __fmul_rn(p[b * kw + c], coef) : p[b * kw + c]);
+      sw = (c == 0) ? v : __fadd_rn(sw, v);
+    }
+    sh = (b == 0) ? sw : __fadd_rn(sh, sw);
+  }
+  score[i] = __fmul_rn(sh, kmask[i / kd] ? 0.f : 1.f);               // data_sum * (mask_sum < 1).float()
+}
+
+// new_mask[idx] = 1 for every (r, c, a) whose score exceeds the threshold (strictly, :786-787)
+__global__ __launch_bounds__(256) void grow_above_kernel(const float* __restrict__ score, const float* __restrict__ thr,
+                                                         unsigned char* __restrict__ kmask, long long n, int kd) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * kd) return;
+  if (score[i] > *thr) kmask[i / kd] = 1;
+}
+
 __global__ __launch_bounds__(256) void expand_mask_kernel(const unsigned char* __restrict__ kmask, float* __restrict__ mask,
                                                           long long n, int ks) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -152,6 +188,22 @@ extern "C" int e2e_dsff_death(const float* l1, const float* thr, unsigned char* 
   E2E_REQUIRE(l1 && thr && kmask && n > 0, "dsff_death: bad arguments");
   hipLaunchKernelGGL(death_kernel, dim3(e2e::cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, l1, thr, kmask, n);
   return e2e::check_launch("death_kernel");
+}
+
+extern "C" int e2e_dsff_grad_score(const float* grad, const double* sq_norm, float max_norm, const unsigned char* kmask, float* score,
+                                   int R, int Cc, int kd, int kh, int kw, void* stream) {
+  E2E_REQUIRE(grad && kmask && score && R > 0 && Cc > 0 && kd > 0 && kh > 0 && kw > 0, "dsff_grad_score: bad arguments");
+  const long long n = (long long)R * Cc;
+  hipLaunchKernelGGL(grad_score_kernel, dim3((unsigned)e2e::cdivll(n * kd, 256)), dim3(256), 0, (hipStream_t)stream, grad, sq_norm, max_norm,
+                     kmask, score, n, kd, kh, kw);
+  return e2e::check_launch("grad_score_kernel");
+}
+
+extern "C" int e2e_dsff_grow_above(const float* score, const float* thr, unsigned char* kmask, int R, int Cc, int kd, void* stream) {
+  E2E_REQUIRE(score && thr && kmask && R > 0 && Cc > 0 && kd > 0, "dsff_grow_above: bad arguments");
+  const long long n = (long long)R * Cc;
+  hipLaunchKernelGGL(grow_above_kernel, dim3((unsigned)e2e::cdivll(n * kd, 256)), dim3(256), 0, (hipStream_t)stream, score, thr, kmask, n, kd);
+  return e2e::check_launch("grow_above_kernel");
 }
 
 extern "C" int e2e_dsff_expand(const unsigned char* kmask, float* mask, unsigned* bits_rows, unsigned* bits_cols, int R,

@@ -54,6 +54,28 @@ __global__ __launch_bounds__(256) void softmax_flip_acc_kernel(const float* __re
   }
 }
 
+// the same accumulation for an inference_apply_nonlin other than softmax (reference neural_network.py:531-560 applies whatever
+// the attribute holds): NL 0 = identity (the constructor's default `lambda x: x`, :80), NL 2 = sigmoid (region-based heads)
+template <int NL>
+__global__ __launch_bounds__(256) void nonlin_flip_acc_kernel(const float* __restrict__ logits, float* __restrict__ result,
+                                                              float w, int first, int K, int X, int Y, int Z, int axes) {
+  const long long spatial = (long long)X * Y * Z;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= spatial) return;
+  const int z = (int)(i % Z);
+  const long long r = i / Z;
+  const int y = (int)(r % Y), x = (int)(r / Y);
+  const long long o = flipped_index(x, y, z, X, Y, Z, axes);
+  for (int k = 0; k < K; ++k) {
+    const float v = logits[(long long)k * spatial + i];
+    const float p = NL == 2 ? 1.f / (1.f + expf(-v)) : v;
+    float* dst = result + (long long)k * spatial + o;
+    const float wp = __fmul_rn(w, p);
+    if (first) *dst = wp;
+    else *dst = __fadd_rn(*dst, wp);
+  }
+}
+
 __global__ __launch_bounds__(256) void sw_accumulate_kernel(const float* __restrict__ patch, const float* __restrict__ gauss,
                                                             float* __restrict__ agg, float* __restrict__ cnt, int K, int X, int Y,
                                                             int Z, int px, int py, int pz, int x0, int y0, int z0) {
@@ -68,8 +90,10 @@ __global__ __launch_bounds__(256) void sw_accumulate_kernel(const float* __restr
   const long long vs = (long long)X * Y * Z;
   for (int k = 0; k < K; ++k) {
     // reference: patch *= gaussian (rounded), then aggregated += patch (neural_network.py:562-563, :392-393)
-    const float pg = __fmul_rn(patch[(long long)k * ps + i], g);
-    agg[(long long)k * vs + o] = __fadd_rn(agg[(long long)k * vs + o], pg);
+    if (patch != nullptr) {                                   // (null: a tile another rank evaluates -- weight map only)
+      const float pg = __fmul_rn(patch[(long long)k * ps + i], g);
+      agg[(long long)k * vs + o] = __fadd_rn(agg[(long long)k * vs + o], pg);
+    }
     cnt[(long long)k * vs + o] = __fadd_rn(cnt[(long long)k * vs + o], g);
   }
 }
@@ -239,9 +263,20 @@ extern "C" int e2e_softmax_flip_acc(const float* logits, float* result, float w,
   return e2e::check_launch("softmax_flip_acc_kernel");
 }
 
+extern "C" int e2e_nonlin_flip_acc(const float* logits, float* result, float w, int first, int K, int X, int Y, int Z,
+                                   int axes, int nonlin, void* stream) {
+  E2E_REQUIRE(logits && result && K > 0, "nonlin_flip_acc: bad arguments");
+  E2E_REQUIRE(nonlin >= 0 && nonlin <= 2, "nonlin_flip_acc: nonlin must be 0 (identity), 1 (softmax over the classes) or 2 (sigmoid)");
+  if (nonlin == 1) return e2e_softmax_flip_acc(logits, result, w, first, K, X, Y, Z, axes, stream);
+  dim3 grid((unsigned)e2e::cdivll((long long)X * Y * Z, 256));
+  if (nonlin == 0) hipLaunchKernelGGL((nonlin_flip_acc_kernel<0>), grid, dim3(256), 0, (hipStream_t)stream, logits, result, w, first, K, X, Y, Z, axes);
+  else hipLaunchKernelGGL((nonlin_flip_acc_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, logits, result, w, first, K, X, Y, Z, axes);
+  return e2e::check_launch("nonlin_flip_acc_kernel");
+}
+
 extern "C" int e2e_sw_accumulate(const float* patch, const float* gauss, float* agg, float* cnt, int K, int X, int Y,
                                  int Z, int px, int py, int pz, int x0, int y0, int z0, void* stream) {
-  E2E_REQUIRE(patch && agg && cnt && K > 0, "sw_accumulate: bad arguments");
+  E2E_REQUIRE(agg && cnt && K > 0, "sw_accumulate: bad arguments");
   E2E_REQUIRE(x0 >= 0 && y0 >= 0 && z0 >= 0 && x0 + px <= X && y0 + py <= Y && z0 + pz <= Z, "sw_accumulate: tile outside volume");
   dim3 grid((unsigned)e2e::cdivll((long long)px * py * pz, 256));
   hipLaunchKernelGGL(sw_accumulate_kernel, grid, dim3(256), 0, (hipStream_t)stream, patch, gauss, agg, cnt, K, X, Y, Z, px, py, pz, x0, y0, z0);

@@ -599,7 +599,10 @@ class Engine:
         else:
             self._build_unetpp(cfg)
         self.grads: Dict[str, torch.Tensor] = {}
-        self.grad_bucket_hook = None       # callable(lo, hi): flat gradient slice [lo, hi) is final (data-parallel overlap)
+        # callable(lo, hi): flat gradient slice [lo, hi) is final (data-parallel overlap).  Called with a private communication
+        # stream current (it waits for everything issued so far; nothing waits for it until backward() returns, where the
+        # caller's stream joins it); the tail slice is handed over on the caller's stream after that join
+        self.grad_bucket_hook = None
         self._comm_stream = None           # the stream the bucket hook is called on (backward)
         self.batch_dice_hook = None        # callable(fp64 tensor [K*3]): all-reduce of the folded tp/fp/fn (data-parallel batch dice)
         self._backward_ready = False
@@ -1043,6 +1046,11 @@ class Engine:
             if side is not None:
                 main.wait_stream(side)
                 self._wg_active = None
+            if self._comm_stream is not None:
+                # whatever a bucket hook ENQUEUED on the communication stream (a synchronous collective, a scale, a copy) is
+                # ordered in front of the caller's next kernel -- the optimizer step.  Free for the asynchronous RCCL path:
+                # there the stream holds event waits only and finish() joins the work handles themselves.
+                main.wait_stream(self._comm_stream)
         if hook is not None and self._bucket_tail[1] > self._bucket_tail[0]:
             hook(*self._bucket_tail)
         return self.grads

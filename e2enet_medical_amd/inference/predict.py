@@ -17,7 +17,9 @@ what scikit-image 0.19.3's ``resize(order=1, mode='edge', anti_aliasing=False)``
 scipy (oracle/export.py; scikit-image is absent from the image: "parity unpinned").  The NIfTI writer (SimpleITK) is host
 tooling; ``predict_cases`` therefore takes a ``writer`` callback.
 """
-from typing import Callable, Iterable, Optional, Sequence, Tuple
+import os
+import pickle
+from typing import Callable, Iterable, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 import torch
@@ -154,3 +156,96 @@ def predict_cases(trainer, params: Sequence[dict], preprocessed: Iterable[Tuple[
         writer(seg, output_filename, dct)
         done.append(output_filename)
     return done
+
+
+def nifti_writer():
+    """writer(seg_uint8, path, properties) of predict_cases / predict_from_folder: the reference's SimpleITK export
+    (segmentation_export.py:144-148) when SimpleITK is importable, else ``<case>.npy`` beside the requested ``.nii.gz`` path."""
+    try:
+        import SimpleITK as sitk
+    except ImportError:
+        sitk = None
+
+    def write(seg, path, props):
+        if sitk is None:
+            np.save(path[:-7] + ".npy" if path.endswith(".nii.gz") else path + ".npy", seg)
+            return
+        img = sitk.GetImageFromArray(seg.astype(np.uint8))
+        img.SetSpacing(props['itk_spacing'])
+        img.SetOrigin(props['itk_origin'])
+        img.SetDirection(props['itk_direction'])
+        sitk.WriteImage(img, path)
+    return write
+
+
+def check_input_folder_and_return_caseIDs(input_folder: str, expected_num_modalities: int):
+    """Case identifiers of an input folder.  Two layouts are served:
+      * PREPROCESSED cases (what the reference's GenericPreprocessor writes): ``<case>.npz`` (or ``<case>.npy``) holding
+        [modalities (+ seg), X, Y, Z] plus ``<case>.pkl`` with the properties dict -- returned as (ids, "preprocessed");
+      * the reference's raw layout ``<case>_XXXX.nii.gz`` (predict.py:631-672) -- returned as (ids, "nifti"); predicting from it
+        needs the reference's preprocessing package (crop, resample, normalise: SimpleITK / scikit-image), outside this engine."""
+    files = sorted(os.listdir(input_folder))
+    nii = [f for f in files if f.endswith(".nii.gz")]
+    if nii:
+        ids = sorted({f[:-12] for f in nii})
+        missing = [c + "_%04.0d.nii.gz" % n for c in ids for n in range(expected_num_modalities)
+                   if not os.path.isfile(os.path.join(input_folder, c + "_%04.0d.nii.gz" % n))]
+        if missing:
+            print("Some files are missing:")
+            print(missing)
+            raise RuntimeError("missing files in input_folder")
+        return ids, "nifti"
+    ids = sorted({f[:-4] for f in files if (f.endswith(".npz") or (f.endswith(".npy") and not f.endswith("_segs.npy")))
+                  and os.path.isfile(os.path.join(input_folder, f[:-4] + ".pkl"))})
+    return ids, "preprocessed"
+
+
+def predict_from_folder(model: str, input_folder: str, output_folder: str, folds: Union[Tuple[int], List[int], None],
+                        save_npz: bool, num_threads_preprocessing: int, num_threads_nifti_save: int,
+                        lowres_segmentations: Union[str, None], part_id: int, num_parts: int, tta: bool,
+                        mixed_precision: bool = True, overwrite_existing: bool = True, mode: str = 'normal',
+                        overwrite_all_in_gpu: bool = None, step_size: float = 0.5,
+                        checkpoint_name: str = "model_final_checkpoint", segmentation_export_kwargs: dict = None,
+                        disable_postprocessing: bool = False, writer=None):
+    """reference predict.py:675-764 with the same arguments: the cases ``[part_id::num_parts]`` of ``input_folder`` through
+    ``load_model_and_checkpoint_files`` (model_restore.py:108-154) -> fold ensemble -> export, written to ``output_folder``.
+    The per-case work is ``predict_cases`` above (softmax resident in HBM).  ``num_threads_*`` are accepted and unused: there are
+    no preprocessing / export worker processes here."""
+    import shutil
+    from ..training.model_restore import load_model_and_checkpoint_files
+    if mode != "normal":
+        raise NotImplementedError("mode=%r: the engine implements the reference's 'normal' mode (predict.py:729-737)" % (mode,))
+    if lowres_segmentations is not None:
+        raise NotImplementedError("cascade inputs (lowres_segmentations) are outside the shiftConvPP hot path")
+    os.makedirs(output_folder, exist_ok=True)
+    assert os.path.isfile(os.path.join(model, "plans.pkl")), "Folder with saved model weights must contain a plans.pkl file"
+    shutil.copy(os.path.join(model, 'plans.pkl'), output_folder)
+    with open(os.path.join(model, "plans.pkl"), 'rb') as f:
+        expected_num_modalities = pickle.load(f)['num_modalities']
+    case_ids, layout = check_input_folder_and_return_caseIDs(input_folder, expected_num_modalities)
+    if layout == "nifti":
+        raise NotImplementedError(
+            "%s holds raw NIfTI cases (<case>_XXXX.nii.gz): cropping / resampling / normalisation is the reference's preprocessing "
+            "package (e2enet/preprocessing, SimpleITK + scikit-image; SURVEY.md section 2 row 11, out of scope).  Preprocess the "
+            "folder with it and point -i at the resulting <case>.npz + <case>.pkl files" % input_folder)
+    case_ids = case_ids[part_id::num_parts]
+    output_files = [os.path.join(output_folder, c + ".nii.gz") for c in case_ids]
+    if not overwrite_existing:
+        keep = [i for i, o in enumerate(output_files) if not (os.path.isfile(o) or os.path.isfile(o[:-7] + ".npy"))]
+        case_ids, output_files = [case_ids[i] for i in keep], [output_files[i] for i in keep]
+    print("number of cases that still need to be predicted:", len(case_ids))
+    if not case_ids:
+        return []
+    trainer, params = load_model_and_checkpoint_files(model, folds, mixed_precision=mixed_precision, checkpoint_name=checkpoint_name)
+    all_in_gpu = False if overwrite_all_in_gpu is None else overwrite_all_in_gpu
+
+    def cases():
+        for c, out in zip(case_ids, output_files):
+            npy, npz = os.path.join(input_folder, c + ".npy"), os.path.join(input_folder, c + ".npz")
+            d = np.load(npy) if os.path.isfile(npy) else np.load(npz)['data']
+            with open(os.path.join(input_folder, c + ".pkl"), 'rb') as f:
+                props = pickle.load(f)
+            d = np.asarray(d)[:expected_num_modalities]          # (preprocessed training cases carry their labels as a last channel)
+            yield out, (d, props)
+    return predict_cases(trainer, params, cases(), writer if writer is not None else nifti_writer(), do_tta=tta,
+                         step_size=step_size, all_in_gpu=all_in_gpu, mixed_precision=mixed_precision)

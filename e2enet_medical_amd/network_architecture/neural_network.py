@@ -84,15 +84,24 @@ class SegmentationNetwork(NeuralNetwork):
         self.tile_group = None
         self.tile_rank, self.tile_world = 0, 1
         self.tile_force = False
+        # how the ranks' tiles meet: "allgather" = per group of `world` tiles one all-gather of the probability
+        # patches, every rank overlap-adds all tiles in the reference's order (bit-identical to one process); "allreduce" = every
+        # rank overlap-adds its own tiles into a partial volume, one all-reduce at the end (fewer bytes, <= 1e-6 from one process)
+        self.tile_exchange = "allgather"
         # inference/predict.py (fold ensembling + export on device): predict_3D then returns device tensors
         self.keep_on_device = False
 
     # ------------------------------------------------------------------------------------------ configuration
-    def shard_tiles(self, rank: int, world: int, group=None, force: bool = False):
+    def shard_tiles(self, rank: int, world: int, group=None, force: bool = False, exchange: str = None):
         """Evaluate tiles ``rank::world`` of the x->y->z tile list on this process and exchange the weighted
         probability patches with one all-gather over ``group`` (RCCL on GPUs, gloo in CPU tests).  ``force`` takes the
-        sharded branch (all-gather included) even for a single rank: self-test of the exchange on one GPU."""
+        sharded branch (all-gather included) even for a single rank: self-test of the exchange on one GPU.
+        ``exchange``: "allgather" (default) or "allreduce" (see ``tile_exchange``)."""
         self.tile_rank, self.tile_world, self.tile_group, self.tile_force = int(rank), int(world), group, bool(force)
+        if exchange is not None:
+            if exchange not in ("allgather", "allreduce"):
+                raise ValueError("exchange must be 'allgather' or 'allreduce', got %r" % (exchange,))
+            self.tile_exchange = exchange
 
     # ------------------------------------------------------------------------------------------ public API
     def predict_3D(self, x: np.ndarray, do_mirroring: bool, mirror_axes: Tuple[int, ...] = (0, 1, 2),
@@ -152,21 +161,63 @@ class SegmentationNetwork(NeuralNetwork):
             raise RuntimeError("inference on the MI355X engine needs the network on a GPU (no CPU fallback)")
         return dev
 
+    def _inference_nonlin_code(self) -> int:
+        """Which fused kernel mode stands for ``self.inference_apply_nonlin`` (the reference applies whatever the attribute
+        holds to the network output of every mirrored pass, neural_network.py:531-560; the constructor default is the
+        identity, :80, the trainer installs ``softmax_helper``, nnUNetTrainer_simple.py:363): 0 identity, 1 softmax over
+        the class axis, 2 sigmoid.  The callable is recognised by what it computes on a probe tensor, so a caller's own
+        ``lambda x: F.softmax(x, 1)`` is served as well; anything else raises -- nothing is silently replaced by softmax."""
+        fn = self.inference_apply_nonlin
+        cached = getattr(self, "_nonlin_probe", None)
+        if cached is not None and cached[0] is fn:
+            return cached[1]
+        from ..utilities.nd_softmax import softmax_helper
+        code = None
+        if fn is softmax_helper:
+            code = 1
+        else:
+            k = max(2, int(self.num_classes or 2))
+            probe = torch.linspace(-3.0, 4.0, k * 8, dtype=torch.float32).reshape(1, k, 2, 2, 2).flip(1) * \
+                torch.tensor([1.0, -0.5, 0.25, 2.0, -1.5, 0.75, 1.25, -2.0]).reshape(1, 1, 2, 2, 2)
+            try:
+                out = fn(probe.clone())
+            except Exception as e:      # noqa: BLE001 -- reported with the callable's name below
+                out = e
+            if isinstance(out, torch.Tensor) and out.shape == probe.shape:
+                if torch.equal(out, probe):
+                    code = 0
+                elif torch.allclose(out, torch.softmax(probe, 1), rtol=1e-6, atol=1e-7):
+                    code = 1
+                elif torch.allclose(out, torch.sigmoid(probe), rtol=1e-6, atol=1e-7):
+                    code = 2
+        if code is None:
+            raise NotImplementedError(
+                "inference_apply_nonlin = %r: the MI355X engine fuses the identity, softmax over the class axis "
+                "(softmax_helper) and sigmoid into its mirror-accumulation kernel (e2e_nonlin_flip_acc); apply any other "
+                "function to the returned volume instead" % (fn,))
+        self._nonlin_probe = (fn, code)
+        return code
+
+    def _flip_acc(self, logits: torch.Tensor, result: torch.Tensor, weight: float, first: bool, axes_bits: int):
+        """result (+)= weight * flip(inference_apply_nonlin(logits)); HIP kernel (neural_network.py:531-560)."""
+        k = logits.shape[-4]
+        X, Y, Z = logits.shape[-3:]
+        lib().nonlin_flip_acc(logits.data_ptr(), result.data_ptr(), float(weight), 1 if first else 0, k, X, Y, Z,
+                              axes_bits, self._inference_nonlin_code(), _stream())
+
     def _net_probs_into(self, x: torch.Tensor, result: torch.Tensor, weight: float, first: bool, axes_bits: int):
-        """result (+)= weight * flip(softmax(net(x))) with x already flipped; HIP kernel (neural_network.py:531-560)."""
+        """result (+)= weight * flip(nonlin(net(x))) with x already flipped."""
         logits = self(x)
         if isinstance(logits, (list, tuple)):
             logits = logits[0]
-        k = logits.shape[1]
-        X, Y, Z = logits.shape[2:]
-        lib().softmax_flip_acc(logits.data_ptr(), result.data_ptr(), float(weight), 1 if first else 0, k, X, Y, Z,
-                               axes_bits, _stream())
+        self._flip_acc(logits, result, weight, first, axes_bits)
 
     def _internal_maybe_mirror_and_pred_3D(self, x: Union[np.ndarray, torch.Tensor], mirror_axes: tuple,
                                            do_mirroring: bool = True, mult=None) -> torch.Tensor:
         """reference :500-565.  Returns the [1,K,X,Y,Z] device tensor of (optionally Gaussian-weighted)
         mirrored-and-averaged softmax probabilities."""
         dev = self._device()
+        self._inference_nonlin_code()        # (an unsupported callable raises before any forward pass is spent)
         if not isinstance(x, torch.Tensor):
             x = torch.from_numpy(np.ascontiguousarray(x)).float()
         x = x.to(dev, non_blocking=True).contiguous()
@@ -197,10 +248,8 @@ class SegmentationNetwork(NeuralNetwork):
                 logits = self(xb)
                 if isinstance(logits, (list, tuple)):
                     logits = logits[0]
-                k = logits.shape[1]
                 for m, bits in enumerate(combos):
-                    lib().softmax_flip_acc(logits[m].data_ptr(), result.data_ptr(), float(w), 1 if first else 0, k, X, Y, Z,
-                                           bits, _stream())
+                    self._flip_acc(logits[m], result, w, first, bits)
                     first = False
             else:
                 flipped = torch.empty_like(x)
@@ -272,10 +321,19 @@ class SegmentationNetwork(NeuralNetwork):
             for ti in range(num_tiles):
                 accumulate(ti, predict_tile(ti))
         else:
-            from ..parallel import run_tiles_sharded
+            from ..parallel import run_tiles_sharded, run_tiles_partial
             self.last_shard_stats = {"time": bool(getattr(self, "time_sharding", False))}      # (timing costs a device sync: benchmark only)
-            run_tiles_sharded(num_tiles, rank, world, self.tile_group, predict_tile, accumulate, (K, px, py, pz), dev,
-                              pipelined=os.environ.get("E2E_SW_BLOCKING") != "1", stats=self.last_shard_stats)
+            if self.tile_exchange == "allreduce":
+                def count_only(ti):
+                    sx, sy, sz = tiles[ti]
+                    L.sw_accumulate(None, gauss_dev.data_ptr() if gauss_dev is not None else None, agg.data_ptr(), cnt.data_ptr(),
+                                    K, X, Y, Z, px, py, pz, sx, sy, sz, _stream())
+                self.last_shard_stats["force"] = self.tile_force
+                run_tiles_partial(num_tiles, rank, world, self.tile_group, predict_tile, accumulate, count_only, agg,
+                                  stats=self.last_shard_stats)
+            else:
+                run_tiles_sharded(num_tiles, rank, world, self.tile_group, predict_tile, accumulate, (K, px, py, pz), dev,
+                                  pipelined=os.environ.get("E2E_SW_BLOCKING") != "1", stats=self.last_shard_stats)
 
         crop = [(s.start, s.stop) for s in slicer[1:]]
         (cx0, cx1), (cy0, cy1), (cz0, cz1) = crop

@@ -1,6 +1,8 @@
 """Multi-GPU sharding of the hot path: one process per GPU, torch.distributed over RCCL (backend "nccl" on ROCm).
 
-* Sliding-window inference (BASELINE config 4): the x->y->z tile list is dealt round-robin over the ranks; weights
+* Sliding-window inference (BASELINE config 4), two exchanges (``SegmentationNetwork.tile_exchange``): the default
+  "allgather" below, bit-identical to one GPU, and "allreduce" (``run_tiles_partial``: partial volumes, one all-reduce at the
+  end, <= 1e-6 from the single-process result).  All-gather: the x->y->z tile list is dealt round-robin over the ranks; weights
   are replicated; per group of `world` consecutive tiles one asynchronous all-gather moves the ranks' mirror-averaged
   probability patches to all ranks while the next group's tiles are computed; every rank overlap-adds the groups in
   the reference's tile order (neural_network.py:373-393), so fp32 summation order -- and the result -- is identical
@@ -70,7 +72,8 @@ def run_tiles_sharded(num_tiles: int, rank: int, world: int, group, predict_tile
         stats = {}
     timed = bool(stats.get("time"))
     mine_tiles = partition_tiles(num_tiles, rank, world)
-    stats.update(tiles_total=num_tiles, tiles_local=len(mine_tiles), world=world, pipelined=bool(pipelined))
+    stats.update(tiles_total=num_tiles, tiles_local=len(mine_tiles), world=world, pipelined=bool(pipelined),
+                 mode="allgather_patches")
     if not pipelined:
         per = slots_per_rank(num_tiles, world)
         mine = torch.zeros((per,) + tuple(patch_shape), dtype=dtype, device=device)
@@ -118,6 +121,44 @@ def run_tiles_sharded(num_tiles: int, rank: int, world: int, group, predict_tile
         stats["collective_wait_ms"] = sum(a.elapsed_time(b) for a, b in waits)
     stats["groups"] = ngroups
     stats["exchange_buffer_bytes"] = 2 * (world + 1) * int(torch.tensor(patch_shape).prod()) * 4
+    return None
+
+
+def run_tiles_partial(num_tiles: int, rank: int, world: int, group, predict_tile, accumulate, count_only, agg: torch.Tensor,
+                      stats: dict = None):
+    """The cheaper exchange SURVEY section 8e names beside the all-gather: every rank overlap-adds ITS tiles
+    (``rank::world`` of the x -> y -> z list) into its own partial ``[K, X, Y, Z]`` volume ``agg`` -- ``accumulate(ti, patch)``
+    -- and ONE all-reduce (sum) of the partial volumes at the end replaces the per-group all-gathers.  The weight map is
+    not exchanged: it does not depend on the data, so every rank adds the Gaussian of ALL tiles to its own copy in tile order
+    (``count_only(ti)``: e2e_sw_accumulate with a null patch), bit-identical to the single-process map.
+
+    Bytes: 2 (N-1)/N x K X Y Z x 4 once (3.9 GB at K = 16, 220 x 400 x 400, N = 8) instead of (N-1) x K x 128^3 x 4 per rank and
+    group (0.94 GB x 14 groups).  It cannot be overlapped with compute (it needs every tile), and it changes the fp32 summation
+    order of overlapping tiles -- per voxel the tiles of one rank are added first, then the ranks' partial sums in the
+    collective's order -- so the probabilities differ from the single-process result in the last bits (<= 1e-6; the all-gather
+    form is bit-identical).  Independent-tile structure: reference neural_network.py:373-393."""
+    if stats is None:
+        stats = {}
+    timed = bool(stats.get("time"))
+    mine = set(partition_tiles(num_tiles, rank, world))
+    stats.update(tiles_total=num_tiles, tiles_local=len(mine), world=world, mode="allreduce_partial_volumes", pipelined=False)
+    for ti in range(num_tiles):
+        if ti in mine:
+            accumulate(ti, predict_tile(ti))
+        else:
+            count_only(ti)
+    cuda = agg.is_cuda
+    if cuda and timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    if world > 1 or stats.get("force"):
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM, group=group)
+    if cuda and timed:
+        e1.record()
+        torch.cuda.synchronize()
+        stats["collective_wait_ms"] = e0.elapsed_time(e1)
+    stats["exchange_buffer_bytes"] = 0                       # in place on the partial volume
+    stats["allreduce_bytes"] = int(agg.numel()) * 4
     return None
 
 

@@ -10,7 +10,7 @@ Keeps the operator surface of reference e2enet/training/network_training/nnUNetT
   manage_patience (:812-860)            on_epoch_end (:863-877)          update_train_loss_MA (:879-884)
   run_training (:929-1027)              process_plans (:1036-1103)       save_checkpoint (:1140-1176)
   load_best / latest / final_checkpoint (:1178-1202)                     load_checkpoint(_ram) (:1204-1255)
-  predict_preprocessed_data_return_seg_and_softmax (:491-527)
+  predict_preprocessed_data_return_seg_and_softmax (:491-527)           validate (:1309-1479)
 
 The arithmetic of an iteration -- forward, deep-supervision Dice+CE, backward, clip_grad_norm_(12), SGD-Nesterov, DSFF
 mask, and for validation batches the loss value and the hard tp/fp/fn counts -- is one chain of HIP kernel launches
@@ -19,8 +19,9 @@ iteration is data parallel (one process per GPU, RCCL): bucketed gradient all-re
 global batch dice, broadcast DSFF masks (``parallel``; the reference's collective inventory is nnUNetTrainerV2_DDP.py:198,
 :263-268).
 
-Out of scope: the batchgenerators data pipeline, preprocessing, NIfTI export and
-``validate``: those entry points raise NotImplementedError naming the subsystem.  Data arrives through any iterator of
+Out of scope: the batchgenerators data pipeline and preprocessing: those entry points raise
+NotImplementedError naming the subsystem.  ``validate`` (:1309-1479) runs on the engine; NIfTI reading / writing is a callback
+(SimpleITK when it is importable).  Data arrives through any iterator of
 ``{'data': [B,C,...], 'target': [list of [B,1,...] per scale]}`` dicts (the format of the reference's augmenter output,
 :538-540); ``SyntheticGenerator`` provides seeded synthetic batches.
 """
@@ -421,6 +422,9 @@ class nnUNetTrainer_simple(object):
             if mask is not None:
                 if dp_on and getattr(mask, "process_group", None) is None:
                     mask.process_group = group
+                if getattr(mask, "growth_mode", "random") == "gradient":
+                    # the reference's kernel_grad_growth reads weight.grad after clip_grad_norm_ (core_channel.py:833-835)
+                    mask.set_gradients(eng.grads, self._fused._sq, self._fused.max_norm)
                 mask.step(masks_already_applied=True)
         else:
             loss = eng.loss_value(target, self.ds_loss_weights, batch_dice=self.batch_dice)
@@ -608,6 +612,12 @@ class nnUNetTrainer_simple(object):
             self.initialize(True)
         if self.output_folder:
             os.makedirs(self.output_folder, exist_ok=True)
+            if self.output_folder_base and self._rank()[0] == 0:
+                # what predict_from_folder reads the modality count from (inference/predict.py:704-707).  The reference writes it in
+                # save_debug_information (:906), which simple_main.py leaves commented out (:186)
+                os.makedirs(self.output_folder_base, exist_ok=True)
+                with open(join(self.output_folder_base, "plans.pkl"), 'wb') as f:
+                    pickle.dump(self.plans, f)
         while self.epoch < self.max_num_epochs:
             self.print_to_log_file("\nepoch: ", self.epoch)
             epoch_start_time = time()
@@ -702,6 +712,8 @@ class nnUNetTrainer_simple(object):
         torch.save(save_this, fname)
         info = OrderedDict(init=self.init_args, name=self.__class__.__name__, plans=self.plans)
         info['class'] = str(self.__class__)
+        if getattr(self, 'base_num_features_override', None) is not None:
+            info['e2e_base_num_features'] = self.base_num_features_override      # (extra key: reference loaders ignore it)
         with open(fname + ".pkl", 'wb') as f:
             pickle.dump(info, f)
 
@@ -809,12 +821,150 @@ class nnUNetTrainer_simple(object):
         self.network.do_ds = ds
         return ret
 
-    # ------------------------------------------------------------------------------------------ out of scope
-    def validate(self, *args, **kwargs):
-        """reference :1309-1479"""
-        _out_of_scope("validate()", "dataset loader, NIfTI export and evaluation tooling (e2enet/training/dataloading, "
-                                    "e2enet/inference/segmentation_export.py, e2enet/evaluation)")
+    # ------------------------------------------------------------------------------------------ validation
+    def validate(self, do_mirroring: bool = True, use_sliding_window: bool = True, step_size: float = 0.5,
+                 save_softmax: bool = True, use_gaussian: bool = True, overwrite: bool = True,
+                 validation_folder_name: str = 'validation_raw', debug: bool = False, all_in_gpu: bool = False,
+                 segmentation_export_kwargs: dict = None, run_postprocessing_on_folds: bool = True, writer=None, gt_reader=None):
+        """reference :1309-1479: every case of the validation split through the sliding-window prediction, exported to the case's
+        original geometry, scored against the ground truth, ``summary.json`` written in the reference's structure.
 
+        On this engine the softmax volume never leaves the device between prediction and export (``inference.predict.
+        export_segmentation``: transpose_backward, resampling, argmax, crop-box placement as HIP kernels); the host receives the
+        uint8 label volume.  NIfTI I/O is host tooling (SimpleITK, absent from this image):
+          ``writer(seg_uint8, path_nii_gz, properties)``   default: SimpleITK when importable, else ``<case>.npy`` next to it;
+          ``gt_reader(path_nii_gz) -> label array``         default: SimpleITK when importable, else ``<case>.npy`` in the ground-truth
+                                                           folder, else the segmentation channel of the preprocessed case (then the
+                                                           comparison happens on the network's grid and summary.json says so).
+        The connected-component post-processing search (``determine_postprocessing``, e2enet/postprocessing) is outside the hot
+        path and is skipped with a log line.  Returns the score dict ``aggregate_scores`` builds (the reference returns None)."""
+        import json
+        import shutil
+        from ...inference.predict import export_segmentation
+        from ...evaluation.evaluator import aggregate_scores
+        current_mode = self.network.training
+        self.network.eval()
+        assert self.was_initialized, "must initialize, ideally with checkpoint (or train first)"
+        if self.dataset_val is None:
+            if self.folder_with_preprocessed_data is None:
+                self.folder_with_preprocessed_data = join(self.dataset_directory, self.plans['data_identifier'] + "_stage%d" % self.stage)
+            self.load_dataset()
+            self.do_split()
+        if segmentation_export_kwargs is None:
+            if 'segmentation_export_params' in self.plans.keys():
+                force_separate_z = self.plans['segmentation_export_params']['force_separate_z']
+                interpolation_order = self.plans['segmentation_export_params']['interpolation_order']
+                interpolation_order_z = self.plans['segmentation_export_params']['interpolation_order_z']
+            else:
+                force_separate_z, interpolation_order, interpolation_order_z = None, 1, 0
+        else:
+            force_separate_z = segmentation_export_kwargs['force_separate_z']
+            interpolation_order = segmentation_export_kwargs['interpolation_order']
+            interpolation_order_z = segmentation_export_kwargs['interpolation_order_z']
+        output_folder = join(self.output_folder, validation_folder_name)
+        os.makedirs(output_folder, exist_ok=True)
+        my_input_args = {'do_mirroring': do_mirroring, 'use_sliding_window': use_sliding_window, 'step_size': step_size,
+                         'save_softmax': save_softmax, 'use_gaussian': use_gaussian, 'overwrite': overwrite,
+                         'validation_folder_name': validation_folder_name, 'debug': debug, 'all_in_gpu': all_in_gpu,
+                         'segmentation_export_kwargs': segmentation_export_kwargs}
+        with open(join(output_folder, "validation_args.json"), 'w') as f:
+            json.dump(my_input_args, f, sort_keys=True, indent=4)
+        if do_mirroring:
+            if not self.data_aug_params['do_mirror']:
+                raise RuntimeError("We did not train with mirroring so you cannot do inference with mirroring enabled")
+            mirror_axes = self.data_aug_params['mirror_axes']
+        else:
+            mirror_axes = ()
+        try:
+            import SimpleITK as sitk
+        except ImportError:
+            sitk = None
+
+        def default_writer(seg, path, props):
+            if sitk is None:
+                np.save(path[:-7] + ".npy", seg)
+                return
+            img = sitk.GetImageFromArray(seg.astype(np.uint8))               # segmentation_export.py:144-148
+            img.SetSpacing(props['itk_spacing'])
+            img.SetOrigin(props['itk_origin'])
+            img.SetDirection(props['itk_direction'])
+            sitk.WriteImage(img, path)
+
+        def default_gt_reader(path):
+            if sitk is not None and isfile(path):
+                return sitk.GetArrayFromImage(sitk.ReadImage(path))
+            if isfile(path[:-7] + ".npy"):
+                return np.load(path[:-7] + ".npy")
+            return None
+        writer = default_writer if writer is None else writer
+        gt_reader = default_gt_reader if gt_reader is None else gt_reader
+
+        net = self.network
+        keep = net.keep_on_device
+        cases, grids = [], set()
+        try:
+            with torch.no_grad():
+                for k in self.dataset_val.keys():
+                    entry = self.dataset[k]
+                    if 'properties' in entry:
+                        properties = entry['properties']
+                    else:
+                        with open(entry['properties_file'], 'rb') as f:
+                            properties = pickle.load(f)
+                    fname = properties['list_of_data_files'][0].split("/")[-1][:-12]
+                    out_nii = join(output_folder, fname + ".nii.gz")
+                    npy_case = entry['data_file'][:-4] + ".npy"
+                    data = np.load(npy_case) if isfile(npy_case) else np.load(entry['data_file'])['data']
+                    data = np.array(data)                                     # (a writable copy: memory-mapped / npz arrays)
+                    print(k, data.shape)
+                    data[-1][data[-1] == -1] = 0
+                    net.keep_on_device = True
+                    seg_grid, softmax = self.predict_preprocessed_data_return_seg_and_softmax(
+                        data[:-1], do_mirroring=do_mirroring, mirror_axes=mirror_axes, use_sliding_window=use_sliding_window,
+                        step_size=step_size, use_gaussian=use_gaussian, all_in_gpu=all_in_gpu, verbose=False,
+                        mixed_precision=self.fp16)
+                    net.keep_on_device = keep
+                    tb = self.transpose_backward
+                    seg = export_segmentation(softmax.contiguous(), properties, tb, self.regions_class_order, force_separate_z,
+                                              interpolation_order, interpolation_order_z)
+                    if save_softmax:
+                        # (float16 like segmentation_export.py:109; the reference stores the volume on the case's own grid, here the
+                        #  network's grid is stored: it is what an ensembling step on this engine reads back)
+                        np.savez_compressed(join(output_folder, fname + ".npz"),
+                                            softmax=softmax.permute(0, *[i + 1 for i in tb]).cpu().numpy().astype(np.float16))
+                    writer(seg, out_nii, properties)
+                    gt_path = join(self.gt_niftis_folder, fname + ".nii.gz") if self.gt_niftis_folder else None
+                    gt = gt_reader(gt_path) if gt_path is not None else None
+                    if gt is not None and tuple(gt.shape) == tuple(seg.shape):
+                        cases.append((seg, np.asarray(gt), out_nii, gt_path))
+                        grids.add("original")
+                    else:
+                        # no readable ground-truth volume: score on the network's grid against the preprocessed case's own labels
+                        cases.append((seg_grid.cpu().numpy().astype(np.uint8), data[-1].astype(np.int16), out_nii, entry['data_file']))
+                        grids.add("preprocessed")
+        finally:
+            net.keep_on_device = keep
+        print("finished prediction")
+        print("evaluation of raw predictions")
+        task = self.dataset_directory.split("/")[-1] if self.dataset_directory else ""
+        scores = aggregate_scores(cases, labels=list(range(self.num_classes)), json_output_file=join(output_folder, "summary.json"),
+                                  json_name=self.experiment_name + " val tiled %s" % (str(use_sliding_window)),
+                                  json_description="" if grids == {"original"} else
+                                  "scored on the network's grid against the preprocessed labels (no readable ground-truth volume)",
+                                  json_author="Fabian", json_task=task)
+        if run_postprocessing_on_folds:
+            self.print_to_log_file("validate: determine_postprocessing (connected-component search, e2enet/postprocessing) is outside "
+                                   "the MI355X hot path and was skipped; run it with the reference package on %s" % output_folder)
+        if self.gt_niftis_folder and os.path.isdir(self.gt_niftis_folder) and self.output_folder_base:
+            gt_nifti_folder = join(self.output_folder_base, "gt_niftis")                 # reference :1455-1477
+            os.makedirs(gt_nifti_folder, exist_ok=True)
+            for f_ in sorted(os.listdir(self.gt_niftis_folder)):
+                if f_.endswith(".nii.gz") or f_.endswith(".npy"):
+                    shutil.copy(join(self.gt_niftis_folder, f_), gt_nifti_folder)
+        self.network.train(current_mode)
+        return scores
+
+    # ------------------------------------------------------------------------------------------ out of scope
     def preprocess_patient(self, input_files):
         """reference :425-452"""
         _out_of_scope("preprocess_patient()", "preprocessing package (e2enet/preprocessing: crop, resample, normalise)")

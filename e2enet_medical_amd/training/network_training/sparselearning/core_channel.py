@@ -9,7 +9,9 @@ Drop-in for reference e2enet/training/network_training/sparselearning/core_chann
 Mechanism: the per-kernel L1 sums (same association order as the three chained ``torch.sum``), the exact k-th order
 statistic (radix select instead of a full sort) and the death comparison run as HIP kernels; the index draws stay
 on the host with Python's ``random`` so that the mask indices are bit-identical to the reference for the same seed.
-Only death_mode='magnitude' with growth_mode='random' (the CLI defaults, :24-25) are implemented.
+death_mode='magnitude' (the CLI default, :25) with growth_mode='random' (the CLI default, :24; ``kernel_growth`` :721-739) or
+growth_mode='gradient' (``kernel_grad_growth`` :771-790: the dead kernels with the largest |gradient| sums regrow -- the dense
+weight gradient the clip norm needs anyway is in HBM every step) are implemented.
 """
 from __future__ import print_function
 
@@ -80,9 +82,9 @@ class Masking(object):
     def __init__(self, optimizer, death_rate=0.3, growth_death_ratio=1.0, death_rate_decay=None, death_mode='magnitude',
                  growth_mode='momentum', redistribution_mode='momentum', threshold=0.001, train_loader=None, T_max=0.,
                  args=None, verbose=False):
-        if death_mode != 'magnitude' or growth_mode != 'random':
-            raise NotImplementedError("MI355X Masking implements death_mode='magnitude' with growth_mode='random' "
-                                      "(the reference CLI defaults, core_channel.py:24-25); got %s/%s"
+        if death_mode != 'magnitude' or growth_mode not in ('random', 'gradient'):
+            raise NotImplementedError("MI355X Masking implements death_mode='magnitude' (core_channel.py:25) with growth_mode="
+                                      "'random' (the CLI default, :24) or 'gradient' (:771-790); got %s/%s"
                                       % (death_mode, growth_mode))
         self.args = args
         self.device = torch.device("cuda")
@@ -110,6 +112,16 @@ class Masking(object):
         self.prune_every_k_steps = None if getattr(args, 'fix', False) else getattr(args, 'update_frequency', None)
         self._table = None
         self._table_keys = None
+        # growth_mode='gradient': where the weight gradients are.  The reference reads ``weight.grad`` AFTER clip_grad_norm_ has
+        # scaled it in place (nnUNetTrainer_simple.py:573, core_channel.py:833-835).  The trainer's fused step leaves the
+        # gradients unscaled in the engine's flat buffer and hands them over with the squared global norm (set_gradients);
+        # without that, ``parameter.grad`` is used as it is (the autograd route: clip_grad_norm_ already scaled it).
+        self._grad_source = None
+
+    def set_gradients(self, grads, sq_norm=None, max_norm=12.0):
+        """grads: name -> gradient tensor of this iteration (device); sq_norm: device fp64 scalar holding the squared global
+        gradient norm the clip coefficient max_norm / (sqrt(sq_norm) + 1e-6) is derived from (None: already clipped)."""
+        self._grad_source = (grads, sq_norm, float(max_norm))
 
     # ------------------------------------------------------------------------------------------ setup
     def add_module(self, module, density, sparse_init='ER'):
@@ -233,7 +245,7 @@ class Masking(object):
     def sync_kernel_maps(self, host_maps, src=0):
         """Data-parallel replicas draw the growth indices with Python's ``random`` on every rank; identical seeds give
         identical masks, but nothing in the reference guarantees identical seeds.  After a prune/grow the kernel maps of
-        rank ``src`` are therefore broadcast (one uint8 tensor, 1.39 M kernels = 1.4 MB at 32 ch; RCCL on GPUs, gloo in
+        group rank ``src`` are therefore broadcast (one uint8 tensor, 1.39 M kernels = 1.4 MB at 32 ch; RCCL on GPUs, gloo in
         the CPU tests) and adopted by every rank.  ``host_maps``: name -> numpy uint8 [dim0, dim1]; returns the same
         dict holding rank src's maps."""
         import torch.distributed as dist
@@ -245,7 +257,8 @@ class Masking(object):
         backend = dist.get_backend(group)
         dev = self._params[self.names[0]].device if backend == "nccl" else torch.device("cpu")
         t = torch.from_numpy(flat).to(dev)
-        dist.broadcast(t, src=src, group=group)
+        # (dist.broadcast takes a GLOBAL rank: rank `src` OF THE GROUP is not global rank `src` for a sub-group)
+        dist.broadcast(t, src=dist.get_global_rank(group, src) if group is not None else src, group=group)
         flat = t.cpu().numpy()
         off = 0
         for n in names:
@@ -348,12 +361,59 @@ class Masking(object):
             flat = packed[off:off + shp[0] * shp[1]].copy()
             off += shp[0] * shp[1]
             self.num_remove[name] = int(self._kmask_host[name].sum()) - int(flat.sum())
-            cand = np.flatnonzero(flat < 1)                        # row-major (dim0, dim1), reference :732
-            idx_rand = random.sample(range(cand.shape[0]), self.num_death[name])
-            flat[cand[np.asarray(idx_rand, dtype=np.int64)]] = 1
+            if self.growth_mode == 'random':
+                cand = np.flatnonzero(flat < 1)                    # row-major (dim0, dim1), reference :732
+                idx_rand = random.sample(range(cand.shape[0]), self.num_death[name])
+                flat[cand[np.asarray(idx_rand, dtype=np.int64)]] = 1
             new_maps[name] = flat.reshape(shp)
+        if self.growth_mode == 'gradient':
+            new_maps = self._gradient_growth(new_maps)
         new_maps = self.sync_kernel_maps(new_maps)
         for name in self.names:
             self._set_kmask(name, new_maps[name])
         self._push_liveness()
         self.apply_mask()
+
+    def _gradient_growth(self, maps_after_death):
+        """reference kernel_grad_growth (:771-790) on the device: per dead kernel (and per depth slice of the kernel: the
+        reference sums the LAST TWO axes only) the sum of |weight.grad|, 0 for live ones; threshold = the (num_growth)-th
+        largest score (0-based, exact order statistic); every kernel holding a score strictly above it regrows.  The
+        device kernel maps already hold the death pass."""
+        L = lib()
+        dev = self._params[self.names[0]].device
+        src = self._grad_source
+        nmax = max(self._kmask_host[n].size * int(self._params[n].shape[-3]) for n in self.names)
+        score = torch.empty(nmax, dtype=torch.float32, device=dev)
+        thr = torch.empty(1, dtype=torch.float32, device=dev)
+        for name in self.names:
+            w = self._params[name]
+            num_growth = self.num_death[name]
+            if num_growth == 0:                                     # :773
+                continue
+            if src is not None and name in src[0]:
+                g, sq, max_norm = src[0][name], src[1], src[2]
+            else:
+                g, sq, max_norm = w.grad, None, 0.0
+            if g is None:
+                raise RuntimeError("growth_mode='gradient' needs the weight gradient of %s: call Masking.set_gradients(...) "
+                                   "(the trainer does) or run backward() so that parameter.grad exists" % name)
+            assert g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and g.numel() == w.numel()
+            r, cc = self._kmask_host[name].shape
+            kd, kh, kw = (int(v) for v in w.shape[-3:])
+            n = r * cc * kd
+            if num_growth >= n:
+                raise IndexError("kernel_grad_growth: num_growth %d >= %d scores of %s (the reference indexes "
+                                 "value[num_growth], core_channel.py:786)" % (num_growth, n, name))
+            km = self.kmasks[name]
+            L.dsff_grad_score(g.data_ptr(), sq.data_ptr() if sq is not None else None, max_norm, km.data_ptr(), score.data_ptr(),
+                              r, cc, kd, kh, kw, _stream())
+            # descending order, index num_growth  ==  ascending order, index n - 1 - num_growth
+            L.dsff_kth_value(score.data_ptr(), n, n - 1 - num_growth, thr.data_ptr(), None, _stream())
+            L.dsff_grow_above(score.data_ptr(), thr.data_ptr(), km.data_ptr(), r, cc, kd, _stream())
+        packed = torch.cat([self.kmasks[n].reshape(-1) for n in self.names]).cpu().numpy()
+        out, off = {}, 0
+        for name in self.names:
+            shp = maps_after_death[name].shape
+            out[name] = packed[off:off + shp[0] * shp[1]].copy().reshape(shp)
+            off += shp[0] * shp[1]
+        return out

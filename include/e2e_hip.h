@@ -337,6 +337,13 @@ int e2e_dsff_kernel_l1(const float* w, float* l1, int R, int Cc, int kd, int kh,
 int e2e_dsff_kth_value(const float* v, int n, int k, float* out, void* ws, void* stream);
 /* kmask [R*Cc] u8: kmask &= !(l1 <= *thr) */
 int e2e_dsff_death(const float* l1, const float* thr, unsigned char* kmask, int n, void* stream);
+/* growth_mode='gradient' (Masking.kernel_grad_growth, core_channel.py:771-790): score [R*Cc*kd] = sum_kh(sum_kw |grad|) of
+ * dead kernels (0 for live ones; two chained sums, the kernel's depth extent stays), grad [R,Cc,kd,kh,kw] scaled by the
+ * clip_grad_norm_ coefficient max_norm / (sqrt(*sq_norm) + 1e-6) clamped to 1 (sq_norm NULL: taken as it is);
+ * then kmask[i / kd] = 1 where score[i] > *thr (thr = the (num_growth)-th largest score: e2e_dsff_kth_value) */
+int e2e_dsff_grad_score(const float* grad, const double* sq_norm, float max_norm, const unsigned char* kmask, float* score,
+                        int R, int Cc, int kd, int kh, int kw, void* stream);
+int e2e_dsff_grow_above(const float* score, const float* thr, unsigned char* kmask, int R, int Cc, int kd, void* stream);
 /* expand a kernel-granular u8 map to the fp32 element mask [R,Cc,ks] and to liveness bit tables:
  * bits_rows [R, ceil(Cc/32)] and bits_cols [Cc, ceil(R/32)] (either may be NULL) */
 int e2e_dsff_expand(const unsigned char* kmask, float* mask, unsigned* bits_rows, unsigned* bits_cols, int R,
@@ -359,7 +366,13 @@ int e2e_flip3d(const float* src, float* dst, int NC, int X, int Y, int Z, int ax
 /* result (+)= w * flip(softmax_c(logits));  first != 0 overwrites */
 int e2e_softmax_flip_acc(const float* logits, float* result, float w, int first, int K, int X, int Y, int Z,
                          int axes, void* stream);
-/* agg[:, x0:x0+px, ...] += patch * gauss (gauss NULL => 1); cnt[x..] += gauss (or 1) */
+/* the same with the network's `inference_apply_nonlin` named (neural_network.py:531-560 applies whatever the attribute
+ * holds, the constructor default at :80 is the identity): nonlin 0 = identity, 1 = softmax over the classes (the call
+ * above), 2 = sigmoid */
+int e2e_nonlin_flip_acc(const float* logits, float* result, float w, int first, int K, int X, int Y, int Z,
+                        int axes, int nonlin, void* stream);
+/* agg[:, x0:x0+px, ...] += patch * gauss (gauss NULL => 1); cnt[x..] += gauss (or 1); patch NULL: the weight map cnt
+ * only (a tile whose probabilities another rank adds into ITS partial volume, parallel.run_tiles_partial) */
 int e2e_sw_accumulate(const float* patch, const float* gauss, float* agg, float* cnt, int K, int X, int Y, int Z,
                       int px, int py, int pz, int x0, int y0, int z0, void* stream);
 /* probs = agg[crop]/cnt[crop]; seg = argmax_k (first max), int64 */

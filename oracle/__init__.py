@@ -23,7 +23,7 @@ from .shift import shift_amounts, depth_shift                      # noqa: F401
 from .network import (NetSpec, make_spec, param_shapes, init_params,  # noqa: F401
                       forward, conv_block, masked_names, Branches)
 from .dsff import (CosineDeathRate, uniform_kernel_masks, kernel_l1,   # noqa: F401
-                   kernel_death, kernel_growth, DsffState)
+                   kernel_death, kernel_growth, kernel_grad_growth, DsffState)
 from .sliding_window import (compute_steps, gaussian_map, pad_to_patch,  # noqa: F401
                              mirror_predict, predict_tiled)
 from .loss import dc_ce_loss, deep_supervision_loss, ds_weights, hard_dice  # noqa: F401

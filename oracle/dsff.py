@@ -8,6 +8,7 @@ e2enet/training/network_training/sparselearning/core_channel.py:
   * Masking.step / truncate_weights    :290-317, :556-611
   * kernel_death                       :647-666
   * kernel_growth                      :721-739
+  * kernel_grad_growth                 :771-790
 All index draws use Python's ``random`` module exactly like the reference, so
 with the same ``random.seed`` the mask indices are bit-identical.
 """
@@ -84,6 +85,22 @@ def kernel_growth(mask: torch.Tensor, num_growth: int):
     picks = random.sample(list(range(0, cand.shape[0])), num_growth)
     g = cand[picks]
     new_mask[g[:, 0], g[:, 1]] = 1
+    return new_mask.float()
+
+
+def kernel_grad_growth(mask: torch.Tensor, grad: torch.Tensor, num_growth: int):
+    """core_channel.py:771-790 (growth_mode='gradient'): per kernel -- and per depth slice of the kernel, only the LAST TWO
+    axes are summed -- the sum of |weight.grad| where the mask is dead, 0 elsewhere; every entry strictly above the
+    (num_growth)-th largest (0-based) revives its whole kernel."""
+    new_mask = mask.to(torch.uint8).clone()
+    if num_growth == 0:
+        return new_mask.float()
+    mask_sum = torch.squeeze(torch.sum(torch.sum(torch.abs(new_mask), dim=-1), dim=-1))
+    data_sum = torch.squeeze(torch.sum(torch.sum(torch.abs(grad), dim=-1), dim=-1))
+    score = data_sum * (mask_sum < 1).float()
+    value, _ = torch.sort(score.reshape(-1), descending=True)
+    idx = torch.nonzero(score > value[num_growth].item())
+    new_mask[idx[:, 0], idx[:, 1]] = 1
     return new_mask.float()
 
 

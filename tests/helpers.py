@@ -155,3 +155,53 @@ def check_grads_same_branches(eng, spec, params, x, targets, w, shapes, tol_glob
     assert glob["engine"] <= max(tol_global, 3.0 * glob["cpu32"]), ("global", glob)
     assert worst["engine"][0] <= max(tol_tensor, 3.0 * worst["cpu32"][0]), ("worst tensor", worst)
     return glob, worst
+
+
+def write_synthetic_task(pre_root, task="Task998_Synth", plans=None, n_cases=6, shape=(20, 44, 40), mods=1, with_gt=True):
+    """A preprocessed nnU-Net task folder in the reference's on-disk form, from closed forms:
+      <pre_root>/<task>/nnUNetPlansv2.1_plans_3D.pkl, <task>/<data_identifier>_stage0/<case>.npy ([modalities..., seg]) + <case>.pkl
+      (properties: list_of_data_files, crop box inside a larger original volume, spacings, class_locations; the last case was
+      'resampled': its size_after_cropping differs from the stored grid), <task>/gt_segmentations/<case>.npy (labels on the ORIGINAL
+      grid; .npy because SimpleITK is absent from the image).  Returns (dataset_directory, plans)."""
+    import pickle
+    from collections import OrderedDict
+    plans = dict(plans)
+    plans.setdefault('data_identifier', "nnUNetData_plans_v2.1")
+    ddir = os.path.join(pre_root, task)
+    folder = os.path.join(ddir, plans['data_identifier'] + "_stage0")
+    os.makedirs(folder, exist_ok=True)
+    os.makedirs(os.path.join(ddir, "gt_segmentations"), exist_ok=True)
+    with open(os.path.join(ddir, "nnUNetPlansv2.1_plans_3D.pkl"), "wb") as f:
+        pickle.dump(plans, f)
+    for ci in range(n_cases):
+        shp = tuple(s + 2 * (ci % 3) for s in shape)
+        j = np.arange(int(np.prod(shp)), dtype=np.float64).reshape(shp)
+        data = [np.sin(0.21 * j + 0.7 * ci + m).astype(np.float32) * (1 + m) for m in range(mods)]
+        zz, yy, xx = np.meshgrid(*[np.arange(s) for s in shp], indexing="ij")
+        seg = (((zz // 3 + yy // 5 + xx // 4 + ci) % 5) < 2).astype(np.float32) + (((zz + yy + xx) % 17) == 0).astype(np.float32)
+        seg = np.minimum(seg, 2.0)
+        name = "case_%02d" % ci
+        np.save(os.path.join(folder, name + ".npy"), np.stack(data + [seg]).astype(np.float32))
+        resampled = ci == n_cases - 1
+        after_crop = tuple(int(round(s * 1.25)) for s in shp) if resampled else shp
+        off = (1 + ci % 2, 2, 3)
+        orig = tuple(a + o + 2 for a, o in zip(after_crop, off))
+        props = OrderedDict(class_locations=OrderedDict((c, np.argwhere(seg == c)) for c in (1, 2)), name=name,
+                            list_of_data_files=["/raw/%s_0000.nii.gz" % name], original_size_of_raw_data=np.array(orig),
+                            crop_bbox=[[o, o + a] for o, a in zip(off, after_crop)], size_after_cropping=np.array(after_crop),
+                            original_spacing=np.array([1.0, 1.0, 1.0]),
+                            spacing_after_resampling=np.array([1.25, 1.25, 1.25] if resampled else [1.0, 1.0, 1.0]),
+                            itk_spacing=(1.0, 1.0, 1.0), itk_origin=(0.0, 0.0, 0.0),
+                            itk_direction=(1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0))
+        with open(os.path.join(folder, name + ".pkl"), "wb") as f:
+            pickle.dump(props, f)
+        if with_gt:
+            gt = np.zeros(orig, dtype=np.uint8)
+            if resampled:
+                idx = [np.minimum((np.arange(a) / 1.25).astype(int), s - 1) for a, s in zip(after_crop, shp)]
+                inner = seg[np.ix_(*idx)]
+            else:
+                inner = seg
+            gt[tuple(slice(o, o + a) for o, a in zip(off, after_crop))] = inner.astype(np.uint8)
+            np.save(os.path.join(ddir, "gt_segmentations", name + ".npy"), gt)
+    return ddir, plans

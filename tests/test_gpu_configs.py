@@ -596,6 +596,8 @@ def test_conv_variant_engine_fastpath_and_predict_vs_oracle(var):
     # inference: 24 x 24 x 96 volume, patch = the network's, step 0.5, all 8 mirrors, Gaussian weighting
     vol = seeded_input((V["cin"], 24, 24, 96), seed=160).numpy()
     net.eval()
+    from e2enet_medical_amd.utilities.nd_softmax import softmax_helper
+    net.inference_apply_nonlin = softmax_helper        # what the trainer installs (nnUNetTrainer_simple.py:363); the default is the identity
     seg, probs = net.predict_3D(vol, True, (0, 1, 2), True, 0.5, V["patch"], None, True, "constant", {'constant_values': 0},
                                 False, False)
     with torch.no_grad():
@@ -772,29 +774,26 @@ def test_config3_btcv_full_shape_vs_oracle_and_dsff_update_replay():
         assert o.shape == r.shape and err <= 1e-4, "head %d: max|dlogit| %.3e" % (i, err)
     assert abs(loss.item() - ref_loss.item()) <= 5e-5
     del ref
-    # gradients on the first sample alone (the oracle's autograd graph of the full batch would hold ~30 GB on the host): every
-    # tensor in the fp32 noise class of a network this deep (relative L2; a wrong tap, shift, stride or mask is O(1)); the
-    # full-resolution and head tensors, whose sums run over millions of voxels, tightly
+    # gradients on the first sample alone (the oracle's autograd graph of the full batch would hold ~30 GB on the host).  Every
+    # tensor by the sharp rule used everywhere else (round 6; until round 5 this leg admitted 10 % per tensor): the fp64 oracle
+    # evaluated with the engine's own LeakyReLU / pooling decisions, engine within 3 x the fp32 CPU path's distance under the same
+    # decisions or 1e-4 global / 3e-4 per tensor; and the full-resolution and head tensors, whose sums run over millions of
+    # voxels, also against the plain fp32 evaluation
     x1, t1 = x[:1].contiguous(), [t[:1].contiguous() for t in targets]
     eng1 = net.engine(x1)
     eng1.forward(x1, True)
     loss1 = eng1.loss_backward([t.cuda() for t in t1], w, batch_dice=False)
+    shapes = {n: tuple(p.shape) for n, p in params.items()}
+    check_grads_same_branches(eng1, spec, params, x1.cpu(), t1, w, shapes)
     leaves = {n: p.clone().requires_grad_(True) for n, p in params.items()}
     ref_loss1 = oracle.deep_supervision_loss(oracle.forward(spec, leaves, x1.cpu()), t1, w, False)
     assert abs(loss1.item() - ref_loss1.item()) <= 5e-5
     ref_loss1.backward()
-    worst = (0.0, None)
     for n in params:
-        rg = leaves[n].grad
-        nrm = rg.norm().item()
-        if nrm <= 1e-6 or n.endswith(".conv.bias"):      # a conv bias in front of an InstanceNorm has an exactly-zero gradient: both sides hold noise
-            continue
-        rel = (eng1.grads[n].cpu() - rg).norm().item() / nrm
-        if rel > worst[0]:
-            worst = (rel, n)
-        tight = n.startswith("seg_outputs") or n.startswith("loc0.4") or n == "up0.4.weight"
-        assert rel <= (2e-3 if tight else 1e-1), (n, rel)
-    print("[config 3] worst gradient tensor rel-L2 vs cpu32 (B = 1): %.3e (%s)" % worst)
+        if n.startswith("seg_outputs") or n.startswith("loc0.4") or n == "up0.4.weight":
+            rg = leaves[n].grad
+            rel = (eng1.grads[n].cpu() - rg).norm().item() / rg.norm().item()
+            assert rel <= 2e-3, (n, rel)
     del leaves
     # ---- one optimizer step, then the DSFF update on the device, replayed by the oracle's rule on the same weights and draws
     fused.step(eng.grads, mask.masks)

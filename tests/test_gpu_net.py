@@ -294,6 +294,87 @@ def test_predict_3d_vs_reference_golden(tag, kw):
     assert np.array_equal(seg, seg1) and np.array_equal(probs, probs1)
 
 
+@pytest.mark.parametrize("kind", ["identity", "sigmoid", "own_softmax"])
+def test_predict_3d_applies_inference_apply_nonlin(kind):
+    """predict_3D applies what ``inference_apply_nonlin`` holds (reference neural_network.py:531-560; the constructor default
+    is the identity, :80) -- identity and sigmoid through their own modes of e2e_nonlin_flip_acc, a caller's own softmax
+    lambda through the fused softmax -- against the oracle's tiled prediction with the same function."""
+    import torch.nn.functional as F
+    net, _, params = tiny_net()
+    spec = oracle.make_spec(TINY["cin"], TINY["base"], TINY["k"], TINY["pools"], 2, TINY["max_feat"])
+    fns = {"identity": lambda t: t, "sigmoid": torch.sigmoid, "own_softmax": lambda t: F.softmax(t, dim=1)}
+    if kind != "identity":
+        net.inference_apply_nonlin = fns[kind]          # identity: the attribute is left at the constructor's default
+    net.eval()
+    net.do_ds = False
+    vol = seeded_input((TINY["cin"], 13, 50, 70), seed=72).numpy()
+    seg, probs = net.predict_3D(vol, do_mirroring=True, mirror_axes=(0, 1, 2), use_sliding_window=True, step_size=0.5,
+                                patch_size=TINY["patch"], use_gaussian=True, verbose=False)
+    with torch.no_grad():
+        rseg, rprobs = oracle.predict_tiled(lambda t: fns[kind](oracle.forward(spec, params, t, do_ds=False)), vol, TINY["k"],
+                                            TINY["patch"], 0.5, True, (0, 1, 2), True)
+    scale = max(1.0, float(np.abs(rprobs).max()))
+    assert np.abs(probs - rprobs).max() <= (1e-4 if kind == "identity" else 2e-5) * scale
+    assert (seg != rseg).mean() <= 1e-3
+    if kind == "identity":
+        assert probs.min() < 0 and np.abs(probs.sum(0) - 1).max() > 1e-2      # logits, not probabilities
+
+
+def test_predict_3d_refuses_an_unknown_nonlin():
+    net, _, _ = tiny_net()
+    net.inference_apply_nonlin = torch.tanh
+    net.eval()
+    vol = seeded_input((TINY["cin"], 13, 50, 70), seed=72).numpy()
+    with pytest.raises(NotImplementedError, match="inference_apply_nonlin"):
+        net.predict_3D(vol, do_mirroring=False, use_sliding_window=True, patch_size=TINY["patch"], verbose=False)
+
+
+@pytest.mark.parametrize("tag", ["raw", "clip"])
+def test_gradient_growth_bit_exact_masks_vs_reference_golden(tag):
+    """Masking(growth_mode='gradient').truncate_weights on the device (e2e_dsff_grad_score -> e2e_dsff_kth_value ->
+    e2e_dsff_grow_above) against the masks the reference's truncate_weights produced from the same weights, masks and
+    weight.grad (core_channel.py:556-611, :771-790; tests/golden/grad_growth.npz) -- 'raw': parameter.grad as it is;
+    'clip': the trainer's route, unscaled gradients + the squared global norm the clip coefficient is derived from."""
+    from e2enet_medical_amd.training.network_training.sparselearning.core_channel import Masking, CosineDecay
+    from tests.test_oracle_golden import _grad_growth_fixture
+    g, shapes, params, grads, names, before, after, num_death = _grad_growth_fixture(tag)
+    net, _, _ = tiny_net()
+    opt = torch.optim.SGD(net.parameters(), 1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)
+
+    class A:
+        adv, fix, update_frequency, final_density = False, False, 1, 0.05
+    random.seed(5)
+    mask = Masking(opt, death_rate=0.3, death_mode='magnitude', death_rate_decay=CosineDecay(0.3, 10), growth_mode='gradient',
+                   redistribution_mode='none', args=A())
+    mask.add_module(net, sparse_init='uniform', density=0.4)
+    assert mask.names == names
+    for n in names:                      # the reference's initial masks (the same draws under the same seed)
+        assert np.array_equal(mask._kmask_host[n], before[n]), n
+    dev_grads = {n: t.cuda().contiguous() for n, t in grads.items()}
+    if tag == "raw":
+        for n, p_ in net.named_parameters():
+            p_.grad = dev_grads[n]
+    else:
+        sq = torch.zeros(1, dtype=torch.float64, device="cuda")
+        sq[0] = sum(float((t.double() ** 2).sum()) for t in grads.values())
+        np.testing.assert_allclose(float(sq.sqrt()), g["clip_total_norm"][0], rtol=1e-6)
+        mask.set_gradients(dev_grads, sq, float(g["clip_max_norm"][0]))
+    mask.truncate_weights()
+    for n in names:
+        assert mask.num_death[n] == num_death[n]
+        assert np.array_equal(mask._kmask_host[n], after[n]), n
+        assert np.array_equal(mask.kmasks[n].cpu().numpy(), after[n]), n
+        w = net.get_parameter(n)
+        assert float((w * (1 - mask.masks[n])).abs().max()) == 0.0
+
+
+def test_masking_refuses_unimplemented_modes():
+    from e2enet_medical_amd.training.network_training.sparselearning.core_channel import Masking
+    for kw in (dict(growth_mode='momentum'), dict(death_mode='SET', growth_mode='random')):
+        with pytest.raises(NotImplementedError):
+            Masking(None, **kw)
+
+
 def test_trainer_surface_runs_iterations():
     """nnUNetTrainer_simple surface: plans dict -> initialize -> run_iteration with Masking; loss finite, masks kept."""
     from e2enet_medical_amd.training.network_training.nnUNetTrainer_simple import nnUNetTrainer_simple

@@ -557,3 +557,102 @@ def test_trainer_initialize_feeds_real_cases_through_loader_and_device_augmenter
     losses = [float(tr.run_iteration(tr.tr_gen, True)) for _ in range(3)]
     assert all(np.isfinite(losses)), losses
     assert np.isfinite(float(tr.run_iteration(tr.val_gen, False, True)))
+
+
+def test_validate_exports_and_scores_the_validation_split(tmp_path):
+    """nnUNetTrainer_simple.validate (reference :1309-1479): every validation case -> sliding-window prediction -> device export to
+    the case's original geometry (crop box, one resampled case) -> writer; scored against the ground-truth volumes with the restated
+    confusion-matrix metrics; summary.json in the reference's structure.  The exported label maps equal the host route (predict ->
+    oracle export); the Dice in summary.json equals oracle.hard_dice on the same volumes."""
+    import json
+    import pickle
+    from tests.helpers import write_synthetic_task
+    from e2enet_medical_amd.training.network_training.nnUNetTrainer_simple import nnUNetTrainer_simple
+    ddir, plans = write_synthetic_task(str(tmp_path / "pre"), plans=PLANS)
+    tr = nnUNetTrainer_simple(plans, 0, output_folder=str(tmp_path / "out"), dataset_directory=ddir, batch_dice=False,
+                              Tconv='shiftConvPP', max_num_epochs=1, num_batches_per_epoch=2)
+    tr.base_num_features_override = 8
+    torch.manual_seed(0)
+    np.random.seed(0)
+    tr.initialize(True)
+    assert tr.gt_niftis_folder == os.path.join(ddir, "gt_segmentations") and len(tr.dataset_val) >= 1
+    written = {}
+    scores = tr.validate(do_mirroring=True, save_softmax=True, writer=lambda seg, path, props: written.__setitem__(path, seg.copy()))
+    out = os.path.join(tr.output_folder, "validation_raw")
+    js = json.load(open(os.path.join(out, "summary.json")))
+    assert sorted(js.keys()) == ['author', 'description', 'id', 'name', 'results', 'task', 'timestamp']
+    assert js["name"] == "nnUNetTrainer_simple val tiled True" and js["task"] == "Task998_Synth" and js["description"] == ""
+    assert os.path.isfile(os.path.join(out, "validation_args.json"))
+    assert len(js["results"]["all"]) == len(tr.dataset_val) == len(written)
+    for k, rec in zip(tr.dataset_val.keys(), js["results"]["all"]):
+        props = pickle.load(open(tr.dataset[k]['properties_file'], 'rb'))
+        path = os.path.join(out, k + ".nii.gz")
+        seg = written[path]
+        assert rec["test"] == path and seg.dtype == np.uint8 and tuple(seg.shape) == tuple(props['original_size_of_raw_data'])
+        gt = np.load(os.path.join(ddir, "gt_segmentations", k + ".npy"))
+        for label in (1, 2):
+            d = oracle.hard_dice(seg, gt, label)
+            assert abs(rec[str(label)]["Dice"] - d) < 1e-12
+        # host route: the same prediction through the oracle's export
+        data = np.load(tr.dataset[k]['data_file'][:-4] + ".npy")
+        _, sm = tr.predict_preprocessed_data_return_seg_and_softmax(data[:-1], do_mirroring=True, mirror_axes=(0, 1, 2), verbose=False)
+        ref_seg = oracle.export_segmentation(sm, props, plans['transpose_backward'])
+        assert (seg != ref_seg).mean() <= 1e-4
+        sm16 = np.load(os.path.join(out, k + ".npz"))["softmax"]
+        assert sm16.dtype == np.float16 and sm16.shape == sm.shape
+    assert set(scores["mean"].keys()) == {"0", "1", "2"}
+    assert os.path.isdir(os.path.join(tr.output_folder_base, "gt_niftis"))
+
+
+def test_simple_main_and_simple_predict_take_the_reference_argv(tmp_path, monkeypatch):
+    """python -m e2enet_medical_amd.simple_main / .simple_predict with the reference's argv (simple_main.py:34-105, simple_predict.py:
+    26-128): two epochs on a synthetic task folder with DSFF, the checkpoints the reference names ({Tconv}_model_final_checkpoint.model
+    + .pkl, plans.pkl), -c continues with the saved masks, --validation_only writes summary.json, simple_predict predicts the folder
+    from the written checkpoint (case sharding by --part_id / --num_parts) and reproduces validate()'s label maps."""
+    from tests.helpers import write_synthetic_task
+    from e2enet_medical_amd import simple_main, simple_predict
+    pre, res = tmp_path / "pre", tmp_path / "res"
+    monkeypatch.setenv("nnUNet_preprocessed", str(pre))
+    monkeypatch.setenv("RESULTS_FOLDER", str(res))
+    monkeypatch.setenv("nnUNet_raw_data_base", str(tmp_path / "raw"))
+    ddir, plans = write_synthetic_task(str(pre), plans=PLANS)
+    common = ["--task", "998", "--fold", "0", "--Tconv", "shiftConvPP", "--base_num_features", "8", "--sparse", "True", "--density",
+              "0.5", "--update_frequency", "2", "--death-rate", "0.3"]
+    random.seed(3)
+    torch.manual_seed(3)
+    np.random.seed(3)
+    tr = simple_main.main(common + ["--max_num_epochs", "2", "--num_batches_per_epoch", "2"])
+    fold_dir = os.path.join(str(res), "nnUNet", "3d_fullres", "Task998_Synth", "nnUNetTrainerV2__nnUNetPlansv2.1", "fold_0")
+    assert tr.output_folder == fold_dir
+    for f in ("shiftConvPP_model_final_checkpoint.model", "shiftConvPP_model_final_checkpoint.model.pkl"):
+        assert os.path.isfile(os.path.join(fold_dir, f)), f
+    assert os.path.isfile(os.path.join(os.path.dirname(fold_dir), "plans.pkl"))
+    assert len(tr.all_tr_losses) == 2 and all(np.isfinite(tr.all_tr_losses))
+    ck = torch.load(os.path.join(fold_dir, "shiftConvPP_model_final_checkpoint.model"), weights_only=False)
+    assert 'dsff_state' in ck and ck['dsff_state']['steps'] == 4
+    # -c: one more epoch from the written checkpoint, masks and schedule position restored
+    tr2 = simple_main.main(common + ["--max_num_epochs", "3", "--num_batches_per_epoch", "2", "-c"])
+    assert len(tr2.all_tr_losses) == 3 and tr2._mask.steps == 6
+    # --validation_only: loads the final checkpoint, validates, writes summary.json
+    tr3 = simple_main.main(common + ["--validation_only", "True", "--val_folder", "val_cli"])
+    vdir = os.path.join(fold_dir, "val_cli")
+    assert os.path.isfile(os.path.join(vdir, "summary.json"))
+    val_keys = list(tr3.dataset_val.keys())
+    # simple_predict over the stage folder (preprocessed cases), two parts like two processes would
+    stage = os.path.join(ddir, plans['data_identifier'] + "_stage0")
+    outp = str(tmp_path / "pred")
+    done = []
+    for part in (0, 1):
+        done += simple_predict.main(["-i", stage, "-o", outp, "-t", "998", "-f", "0", "--Tconv", "shiftConvPP", "--part_id", str(part),
+                                     "--num_parts", "2"])
+    assert sorted(os.path.basename(d) for d in done) == ["case_%02d.nii.gz" % i for i in range(6)]
+    assert os.path.isfile(os.path.join(outp, "plans.pkl"))
+    for k in val_keys:
+        a = np.load(os.path.join(outp, k + ".npy"))
+        b = np.load(os.path.join(vdir, k + ".npy"))
+        assert a.dtype == np.uint8 and np.array_equal(a, b), k
+    with pytest.raises(NotImplementedError, match="preprocessing"):
+        os.makedirs(str(tmp_path / "rawcases"))
+        open(os.path.join(str(tmp_path / "rawcases"), "c_0000.nii.gz"), "wb").close()
+        simple_predict.main(["-i", str(tmp_path / "rawcases"), "-o", outp, "-t", "998", "-f", "0", "--Tconv", "shiftConvPP",
+                             "--overwrite_existing"])

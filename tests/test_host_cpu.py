@@ -118,7 +118,8 @@ def test_missing_library_is_an_import_error(tmp_path):
 
 def test_every_e2e_knob_read_anywhere_is_listed_and_unknown_ones_are_refused():
     """INTEGRATION.md section 7 is the one list of knobs: every E2E_* variable the library or the host code reads is in
-    _lib.KNOWN_ENV and in that table, nothing else is, and a variable outside the list stops the library from loading."""
+    _lib.KNOWN_ENV and in that table, nothing else is; a variable outside the list is reported when the library loads (a warning
+    -- "E2E_" is a common harness prefix -- or, under E2E_STRICT_ENV=1, a refusal)."""
     import glob
     from e2enet_medical_amd import _lib
     read = set()
@@ -131,11 +132,16 @@ def test_every_e2e_knob_read_anywhere_is_listed_and_unknown_ones_are_refused():
     table = set(re.findall(r"^\| `(E2E_[A-Z0-9_]+)`", doc, flags=re.M))
     assert table == set(_lib.KNOWN_ENV), table ^ set(_lib.KNOWN_ENV)
     _lib.check_env({"E2E_CONV_MM": "0", "PATH": "/bin"})
+    with pytest.warns(RuntimeWarning, match="E2E_BASE_URL"):
+        _lib.check_env({"E2E_BASE_URL": "http://localhost"})
     with pytest.raises(RuntimeError, match="E2E_CT_TPX32"):
-        _lib.check_env({"E2E_CT_TPX32": "1"})
+        _lib.check_env({"E2E_CT_TPX32": "1", "E2E_STRICT_ENV": "1"})
     code = "import sys; sys.path.insert(0, %r); import e2enet_medical_amd._lib as L; L.lib()" % ROOT
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, E2E_WG_V3_TARGET="64"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, E2E_WG_V3_TARGET="64", E2E_STRICT_ENV="1"))
     assert out.returncode != 0 and "unknown E2E_* environment variable(s) E2E_WG_V3_TARGET" in out.stderr, out.stderr
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, E2E_WG_V3_TARGET="64"))
+    assert out.returncode == 0 and "E2E_WG_V3_TARGET" in out.stderr, out.stderr
 
 
 _WORKER = r'''
@@ -195,6 +201,26 @@ for pipelined in (True, False):
     probs = agg[sl] / cnt[sl]
     assert np.array_equal(probs, probs_ref), "sharded overlap-add must be bit identical to the single-process order"
     assert np.array_equal(probs.argmax(0), seg_ref)
+
+# the other exchange (SURVEY section 8e): every rank overlap-adds its own tiles into a partial volume, ONE all-reduce at the end;
+# the weight map is accumulated for all tiles on every rank (count_only).  Summation order differs: <= 1e-6, not bit-identical
+def count_only(ti):                        # stands in for e2e_sw_accumulate(patch = NULL)
+    sx, sy, sz = tiles[ti]
+    cnt[:, sx:sx + 16, sy:sy + 32, sz:sz + 32] += g
+agg[:] = 0; cnt[:] = 0; del evaluated[:]
+agg_t = torch.from_numpy(agg)              # (shares memory: the all-reduce lands in agg)
+st = {}
+parallel.run_tiles_partial(len(tiles), rank, world, None, predict_tile, accumulate, count_only, agg_t, stats=st)
+assert evaluated == list(range(rank, len(tiles), world)) and st["mode"] == "allreduce_partial_volumes"
+assert st["allreduce_bytes"] == agg.size * 4
+probs = agg[sl] / cnt[sl]
+assert np.abs(probs - probs_ref).max() <= 1e-6, np.abs(probs - probs_ref).max()
+assert (probs.argmax(0) != seg_ref).mean() <= 1e-4
+cnt_partial = cnt.copy()
+agg[:] = 0; cnt[:] = 0
+for ti in range(len(tiles)):
+    count_only(ti)
+assert np.array_equal(cnt, cnt_partial), "the weight map does not depend on who evaluated a tile"
 
 # data-parallel gradient averaging + DSFF mask broadcast
 grads = {"a": torch.full((5, 3), float(rank + 1)), "b": torch.arange(4, dtype=torch.float32) * (rank + 1)}
@@ -264,6 +290,43 @@ def test_world_size_2_tile_sharding_and_dp_exchange_gloo(tmp_path):
         procs.append(subprocess.Popen([sys.executable, str(script)], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                                       text=True))
     outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    assert "WORKER_OK" in outs[0][0]
+
+
+_WORKER_SUBGROUP = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+sub = dist.new_group([1, 2])               # data-parallel replicas on global ranks 1 and 2: group rank 0 is GLOBAL rank 1
+if rank in (1, 2):
+    from e2enet_medical_amd.training.network_training.sparselearning.core_channel import Masking
+    m = Masking.__new__(Masking)
+    m.names = ["a"]
+    m._params = {"a": torch.zeros(3, 4, 1, 3, 3)}
+    m.process_group = sub
+    maps = {"a": (np.arange(12).reshape(3, 4) %% (rank + 1) == 0).astype(np.uint8)}
+    got = m.sync_kernel_maps(maps)         # src = 0 is a rank OF THE GROUP (dist.broadcast wants the global one)
+    assert np.array_equal(got["a"], (np.arange(12).reshape(3, 4) %% 2 == 0).astype(np.uint8)), got["a"]
+dist.barrier()
+if rank == 0:
+    print("WORKER_OK")
+dist.destroy_process_group()
+'''
+
+
+def test_mask_broadcast_in_a_subgroup_uses_the_global_rank_gloo(tmp_path):
+    """Masking.sync_kernel_maps(src=0) inside a process group that does not contain global rank 0 (three gloo ranks, group =
+    ranks 1 and 2): group rank 0 is global rank 1; passing the group-relative 0 to dist.broadcast raises / hangs."""
+    script = tmp_path / "worker_sub.py"
+    script.write_text(_WORKER_SUBGROUP % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29557", WORLD_SIZE="3", OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(3)]
+    outs = [p.communicate(timeout=300) for p in procs]
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, se[-2000:]
     assert "WORKER_OK" in outs[0][0]
@@ -440,7 +503,7 @@ def test_bench_self_launches_n_ranks_without_torchrun():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 4 and rec["warmup"] == 1
     assert rec["rccl"]["world"] == 2 and rec["rccl"]["allreduce_of_ones"] == 2.0
-    assert {"ms_per_step_without_allreduce", "allreduce_exposed_ms", "allreduce_bytes_per_step"} <= set(rec["rccl"])   # the N > 1 record
+    assert {"ms_per_step_without_allreduce", "allreduce_exposed_ms", "allreduce_bytes_per_step", "device_per_rank"} <= set(rec["rccl"])   # the N > 1 record
     assert rec["ms_per_step_per_rank"] == [1.0, 2.0]                  # rank r contributed r + 1: both ranks were in the group
 
 
@@ -597,3 +660,51 @@ def test_trainer_never_trains_on_noise_by_accident_and_splits_like_sklearn(tmp_p
     tr.process_plans(tr.plans)
     tr.setup_DA_params()
     assert not tr.data_aug_params["dummy_2D"] and all(b >= p for b, p in zip(tr.basic_generator_patch_size, tr.patch_size))
+
+
+def test_inference_nonlin_is_recognised_by_what_it_computes():
+    """SegmentationNetwork._inference_nonlin_code: identity (the constructor default), softmax over the class axis (softmax_helper
+    or a caller's own lambda) and sigmoid map to the modes of e2e_nonlin_flip_acc; anything else raises instead of being replaced by
+    softmax (reference neural_network.py:80, :531-560; nnUNetTrainer_simple.py:363)."""
+    import torch
+    import torch.nn.functional as F
+    from e2enet_medical_amd.network_architecture.neural_network import SegmentationNetwork
+    from e2enet_medical_amd.utilities.nd_softmax import softmax_helper
+    for k in (2, 3, 16):
+        net = SegmentationNetwork()
+        net.num_classes = k
+        assert net._inference_nonlin_code() == 0
+        for fn, code in ((softmax_helper, 1), (lambda t: F.softmax(t, 1), 1), (lambda t: torch.softmax(t, dim=1), 1),
+                         (torch.sigmoid, 2), (lambda t: t.clone(), 0)):
+            net.inference_apply_nonlin = fn
+            assert net._inference_nonlin_code() == code
+        for bad in (torch.tanh, lambda t: F.softmax(t, 2), lambda t: t * 2, lambda t: t[:, :1]):
+            net.inference_apply_nonlin = bad
+            with pytest.raises(NotImplementedError, match="inference_apply_nonlin"):
+                net._inference_nonlin_code()
+
+
+def test_evaluator_matches_reference_aggregate_scores(tmp_path):
+    """e2enet_medical_amd.evaluation.evaluator (what nnUNetTrainer_simple.validate writes summary.json with) against the
+    reference's aggregate_scores / Evaluator on the same label maps (tests/golden/evaluator.npz): metric names and order,
+    per-case values incl. the NaN rules for absent / full labels, nan-means, summary.json keys."""
+    import json
+    from e2enet_medical_amd.evaluation.evaluator import aggregate_scores, DEFAULT_METRICS
+    g = golden("evaluator.npz")
+    cases = [(g["test%d" % c], g["ref%d" % c], "t%d" % c, "r%d" % c) for c in range(3)]
+    jf = tmp_path / "summary.json"
+    scores = aggregate_scores(cases, [0, 1, 2, 3], json_output_file=str(jf), json_name="n", json_task="t")
+    names = [str(m) for m in g["metric_names"]]
+    assert sorted(DEFAULT_METRICS) == names
+    for c in range(3):
+        assert scores["all"][c]["test"] == "t%d" % c and scores["all"][c]["reference"] == "r%d" % c
+        for l in range(4):
+            assert list(scores["all"][c][str(l)].keys()) == names
+            got = np.array([float(scores["all"][c][str(l)][m]) for m in names])
+            np.testing.assert_array_equal(got, g["all"][c, l])            # (NaN == NaN under assert_array_equal)
+    for l in range(4):
+        got = np.array([float(scores["mean"][str(l)][m]) for m in names])
+        np.testing.assert_array_equal(got, g["mean"][l])
+    js = json.load(open(jf))
+    assert sorted(js.keys()) == [str(k) for k in g["summary_keys"]]
+    assert js["name"] == "n" and js["task"] == "t" and len(js["id"]) == 12 and len(js["results"]["all"]) == 3

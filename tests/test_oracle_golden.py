@@ -578,3 +578,47 @@ def test_nodff_unet_graph_vs_reference_golden():
     for key in g.files:
         if key.startswith("grad::"):
             assert np.abs(leaves[key[6:]].grad.numpy() - g[key]).max() <= 1e-6 * max(1.0, np.abs(g[key]).max())
+
+
+def _grad_growth_fixture(tag):
+    """the recipe of tools/make_golden.py:gen_grad_growth: tiny net, closed-form weights, closed-form heavy-tailed gradients"""
+    from tests.helpers import closed_form_tensor
+    g = golden("grad_growth.npz")
+    pools = [(2, 2, 2)] * 3 + [(1, 2, 2)] * 2
+    spec = oracle.make_spec(2, 8, 3, pools, 2, 32)
+    shapes = oracle.param_shapes(spec)
+    params = closed_form_params(shapes)
+    grads = {}
+    for i, (n, shp) in enumerate(shapes.items()):
+        t = closed_form_tensor(tuple(shp), 200 + i, "conv" if len(shp) > 1 else "bias")
+        grads[n] = (t * (1.0 + 3.0 * t.abs())).clone()
+    names = [str(s_) for s_ in g[tag + "_names"]]
+
+    def unpack(key, n):
+        shp = shapes[n]
+        return np.unpackbits(g[key + "::" + n])[:shp[0] * shp[1]].reshape(shp[0], shp[1]).astype(np.uint8)
+    before = {n: unpack(tag + "_before", n) for n in names}
+    after = {n: unpack(tag + "_after", n) for n in names}
+    num_death = {n: int(g[tag + "_num_death::" + n][0]) for n in names}
+    return g, shapes, params, grads, names, before, after, num_death
+
+
+@pytest.mark.parametrize("tag", ["raw", "clip"])
+def test_gradient_growth_matches_reference_truncate_weights(tag):
+    """oracle.kernel_death + oracle.kernel_grad_growth reproduce the masks of the reference's truncate_weights with
+    growth_mode='gradient' (core_channel.py:556-611, :771-790) bit for bit, also behind clip_grad_norm_."""
+    g, shapes, params, grads, names, before, after, num_death = _grad_growth_fixture(tag)
+    if tag == "clip":
+        tot = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(t) for t in grads.values()]))
+        np.testing.assert_allclose(float(tot), g["clip_total_norm"][0], rtol=1e-6)
+        coef = torch.clamp(float(g["clip_max_norm"][0]) / (tot + 1e-6), max=1.0)
+        grads = {n: t * coef for n, t in grads.items()}
+    for n in names:
+        shp = shapes[n]
+        m = torch.from_numpy(before[n]).float().reshape(shp[0], shp[1], 1, 1, 1).expand(shp).clone()
+        w = params[n] * m
+        m, prune_num = oracle.kernel_death(m, w, 0.3)
+        assert prune_num == num_death[n]
+        m = oracle.kernel_grad_growth(m, grads[n], prune_num)
+        km = (m.reshape(shp[0], shp[1], -1).sum(-1) > 0).numpy().astype(np.uint8)
+        assert np.array_equal(km, after[n]), n

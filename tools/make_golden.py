@@ -430,6 +430,46 @@ def gen_masks():
     np.savez_compressed(os.path.join(OUT, "masks.npz"), **out)
 
 
+def gen_grad_growth():
+    """growth_mode='gradient' (Masking.kernel_grad_growth, core_channel.py:771-790) through the reference's own
+    truncate_weights: closed-form weights and closed-form weight.grad on the tiny net (its up-sampling kernels are (2,2,2) and
+    (1,2,2): the two-sum score keeps the kernel's depth extent), once with the gradients as they are and once after
+    torch.nn.utils.clip_grad_norm_ scaled them in place (what nnUNetTrainer_simple.py:573 does before mask.step())."""
+    from tests.helpers import closed_form_tensor
+    out = {}
+    pools = [[2, 2, 2]] * 3 + [[1, 2, 2]] * 2
+    for tag, max_norm in (("raw", None), ("clip", 0.75)):
+        net = build_ref_net((16, 32, 32), 2, 8, 3, pools, 32, seed=0)
+        load_closed_form(net)
+        opt = torch.optim.SGD(net.parameters(), 1e-2, weight_decay=3e-5, momentum=0.99, nesterov=True)
+        args = _Args()
+        random.seed(5)
+        import io, contextlib
+        mask = Masking(opt, death_rate=0.3, death_mode='magnitude', death_rate_decay=CosineDecay(0.3, 10),
+                       growth_mode='gradient', redistribution_mode='none', args=args)
+        with contextlib.redirect_stdout(io.StringIO()):
+            mask.add_module(net, sparse_init='uniform', density=0.4)
+        names = list(mask.masks.keys())
+        out[tag + "_names"] = np.array(names)
+        for n in names:
+            out[tag + "_before::" + n] = pack_kernel_mask(mask.masks[n])
+        # gradients: closed form per parameter (index offset 200), heavy-tailed so that the scores are well separated
+        for i, (n, p_) in enumerate(net.named_parameters()):
+            g = closed_form_tensor(tuple(p_.shape), 200 + i, "conv" if p_.dim() > 1 else "bias")
+            p_.grad = (g * (1.0 + 3.0 * g.abs())).clone()
+        if max_norm is not None:
+            total = torch.nn.utils.clip_grad_norm_(net.parameters(), max_norm)
+            out[tag + "_total_norm"] = np.array([float(total)], dtype=np.float64)
+            out[tag + "_max_norm"] = np.array([max_norm], dtype=np.float64)
+            assert float(total) > max_norm
+        with contextlib.redirect_stdout(io.StringIO()):
+            mask.truncate_weights()
+        for n in names:
+            out[tag + "_after::" + n] = pack_kernel_mask(mask.masks[n])
+            out[tag + "_num_death::" + n] = np.array([mask.num_death[n]])
+    np.savez_compressed(os.path.join(OUT, "grad_growth.npz"), **out)
+
+
 def gen_loss():
     out = {}
     for tag, batch_dice in (("sample", False), ("batch", True)):
@@ -489,6 +529,52 @@ def gen_dice():
     out["dice"] = np.array([ref_dice(a == l, b == l) for l in range(1, 4)])
     out["dice_small"] = np.float64(ref_dice(np.array([0, 1, 1, 0]), np.array([0, 1, 0, 0])))
     np.savez_compressed(os.path.join(OUT, "dice.npz"), **out)
+
+
+def gen_evaluator():
+    """The reference's aggregate_scores / Evaluator (e2enet/evaluation/evaluator.py:37-51, :216-226, :321-400; metrics.py) on three
+    random label-map pairs, one of them with a label absent from both maps (NaN rules) and one with an all-foreground label."""
+    import json
+    import tempfile
+    fo = types.ModuleType('batchgenerators.utilities.file_and_folder_operations')
+
+    def save_json(obj, file, indent=4, sort_keys=True):
+        with open(file, 'w') as f:
+            json.dump(obj, f, sort_keys=sort_keys, indent=indent)
+    fo.save_json, fo.join, fo.subfiles = save_json, os.path.join, lambda *a, **k: []
+    sys.modules['batchgenerators.utilities'] = types.ModuleType('batchgenerators.utilities')
+    sys.modules['batchgenerators.utilities.file_and_folder_operations'] = fo
+    sys.modules.setdefault('SimpleITK', types.ModuleType('SimpleITK'))
+    from e2enet.evaluation import evaluator as ev
+    ev.Pool = lambda n: types.SimpleNamespace(map=lambda f, it: list(map(f, it)), close=lambda: None, join=lambda: None)
+    rng = np.random.RandomState(11)
+    out = {}
+    pairs = []
+    for c in range(3):
+        a = rng.randint(0, 4, (9, 11, 7))
+        b = np.where(rng.rand(9, 11, 7) < 0.7, a, rng.randint(0, 4, (9, 11, 7)))
+        if c == 1:
+            a[a == 3] = 0
+            b[b == 3] = 0                    # label 3 absent from both maps
+        if c == 2:
+            a[:] = 2
+            b[:4] = 2                        # label 2 fills the test map
+        out["test%d" % c], out["ref%d" % c] = a.astype(np.int8), b.astype(np.int8)
+        pairs.append((a, b))
+    with tempfile.TemporaryDirectory() as tmp:
+        jf = os.path.join(tmp, "summary.json")
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            scores = ev.aggregate_scores(pairs, evaluator=ev.Evaluator, labels=[0, 1, 2, 3], json_output_file=jf, json_name="n",
+                                         json_task="t", num_threads=1)
+        with open(jf) as f:
+            js = json.load(f)
+    out["summary_keys"] = np.array(sorted(js.keys()))
+    out["metric_names"] = np.array(list(scores["all"][0]["0"].keys()))
+    out["all"] = np.array([[[float(scores["all"][c][str(l)][m]) for m in out["metric_names"]] for l in range(4)] for c in range(3)])
+    out["mean"] = np.array([[float(scores["mean"][str(l)][m]) for m in out["metric_names"]] for l in range(4)])
+    np.savez_compressed(os.path.join(OUT, "evaluator.npz"), **out)
 
 
 def gen_init():
@@ -714,7 +800,7 @@ def gen_dataloader():
 
 ALL = dict(dataloader=gen_dataloader, export=gen_export, shift=gen_shift, block=gen_block, net=gen_net_tiny, sparse=gen_net_sparse_tiny, net64=gen_net64,
            hippo=gen_net_hippo, amos=gen_net_amos, w48=gen_net_w48,
-           variants=gen_net_variants, nodff=gen_net_nodff, masks=gen_masks, loss=gen_loss, sliding=gen_sliding, dice=gen_dice, init=gen_init)
+           variants=gen_net_variants, nodff=gen_net_nodff, masks=gen_masks, grad_growth=gen_grad_growth, evaluator=gen_evaluator, loss=gen_loss, sliding=gen_sliding, dice=gen_dice, init=gen_init)
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
