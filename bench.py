@@ -705,7 +705,8 @@ def main():
     # ---- instrumented steps (outside the timed region): HIP events around the conv entry points --------------------
     # (_splitk: the deep levels' forward / data gradient, same kernel + a sum kernel; _dense: the unmasked layers on the matrix cores)
     names = ["conv133_fwd", "conv133_fwd_splitk", "conv133_fwd_dense", "conv133_fwd_sparse", "conv133_fwd_mm", "conv133_dgrad", "conv133_dgrad_splitk",
-             "conv133_dgrad_dense", "conv133_dgrad_sparse", "conv133_dgrad_mm", "conv133_sparse_pack", "conv133_wgrad"]
+             "conv133_dgrad_dense", "conv133_dgrad_sparse", "conv133_dgrad_mm", "conv133_sparse_pack", "conv133_mm_pack",
+             "conv133_input_ranges", "conv133_wgrad"]
     if args.op_profile:
         names += ["in_stats_finalize", "in_lrelu_bwd", "convT_fwd", "convT_dgrad", "convT_wgrad", "maxpool_fwd", "maxpool_bwd",
                   "head1x1_fwd", "head1x1_dgrad", "head1x1_wgrad", "dc_ce_reduce", "dc_ce_grad", "grad_sqnorm", "sgd_clip_mask_step"]
@@ -757,7 +758,8 @@ def main():
               timers["conv133_fwd_dense"].events + timers["conv133_fwd_sparse"].events + timers["conv133_fwd_mm"].events]
         ev += [(e0.elapsed_time(e1), work[a[4]]) for e0, e1, a in timers["conv133_dgrad_mm"].events]
         ev += [(e0.elapsed_time(e1), work[a[6]]) for e0, e1, a in timers["conv133_dgrad_sparse"].events]
-        pack_ms = timers["conv133_sparse_pack"].total_ms()            # weight packing of the planned layers: counted with the family
+        # weight packing (once per optimizer step for all K1m layers and both directions) and the operand-range words: counted with the family
+        pack_ms = timers["conv133_sparse_pack"].total_ms() + timers["conv133_mm_pack"].total_ms() + timers["conv133_input_ranges"].total_ms()
         ev += [(e0.elapsed_time(e1), work[a[3]]) for e0, e1, a in timers["conv133_dgrad"].events + timers["conv133_dgrad_splitk"].events]
         ev += [(e0.elapsed_time(e1), work[a[3]]) for e0, e1, a in timers["conv133_dgrad_dense"].events]
         if ev:
@@ -770,7 +772,7 @@ def main():
                                           "E2E_CONV_MM=0 or a shape is not served): every launch of e2e_conv133_fwd* and e2e_conv133_dgrad* "
                                           "(depth shift + concat + 1x3x3 conv, forward and data gradient; stride-1 layers of the 16x32 tile "
                                           "class, DSFF-masked or not, as a persistent GEMM on the fp16 matrix pipe with fp32-exact two-piece "
-                                          "operands incl. its weight-packing launch; strided convs and planes <= 16 wide on the vector walk)",
+                                          "operands incl. the per-step weight-packing and operand-range launches; strided convs and planes <= 16 wide on the vector walk)",
                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                 "traffic": pmc_traffic("conv133_kernel", "conv133_dense_kernel", "conv133_sparse_kernel", "conv133_mm_kernel"),
                 "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch; null when the summary was "

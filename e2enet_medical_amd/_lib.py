@@ -78,6 +78,24 @@ class SparsePackJob(C.Structure):
                 ("reverse", C.c_int), ("kmax", C.c_int)]
 
 
+class MmPackJob(C.Structure):
+    """e2e_mm_pack_job_t"""
+    _fields_ = [("w", C.c_void_p), ("quads", C.c_void_p), ("wpk", C.c_void_p), ("w_absmax", C.c_void_p), ("P", C.c_int), ("Q", C.c_int),
+                ("wq_stride", C.c_int), ("wp_stride", C.c_int), ("reverse", C.c_int), ("owns_absmax", C.c_int)]
+
+
+class RangeSrc(C.Structure):
+    """e2e_range_src_t"""
+    _fields_ = [("kind", C.c_int), ("C", C.c_int), ("N", C.c_longlong), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("w", C.c_void_p),
+                ("wCout", C.c_int), ("wks", C.c_int), ("word", C.c_void_p)]
+
+
+class RangeJob(C.Structure):
+    """e2e_range_job_t"""
+    _fields_ = [("src", RangeSrc * 3), ("out", C.c_void_p)]
+
+
+assert C.sizeof(MmPackJob) == 56 and C.sizeof(RangeSrc) == 56 and C.sizeof(RangeJob) == 176
 assert C.sizeof(InChan) == 48 and C.sizeof(OutChan) == 24 and C.sizeof(ParamEntry) == 40 and C.sizeof(SparsePackJob) == 72 and C.sizeof(InSumChan) == 72
 
 P, I, F, LL = C.c_void_p, C.c_int, C.c_float, C.c_longlong
@@ -103,11 +121,14 @@ SIGNATURES = {
     "e2e_conv133_dgrad_sparse": (I, [P, P, P, P, I, P, P, P, I, I, I, I, I, I, I, P]),
     "e2e_conv133_fwd_dense": (I, [P, I, P, P, P, P, P, I, I, I, I, I, P, LL, P]),
     "e2e_conv133_mm_ws_bytes": (LL, [I, I, I, I, I, I, I, I, I]),
-    "e2e_conv133_fwd_mm": (I, [P, I, P, P, P, P, P, I, I, I, I, I, P, LL, P]),
-    "e2e_conv133_dgrad_mm": (I, [P, P, P, P, P, I, I, I, I, I, I, P, LL, P]),
+    "e2e_conv133_mm_pack": (I, [P, I, LL, P]),
+    "e2e_conv133_input_ranges": (I, [P, I, P]),
+    "e2e_absmax_word": (I, [P, LL, P, P]),
+    "e2e_conv133_fwd_mm": (I, [P, I, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "e2e_conv133_dgrad_mm": (I, [P, P, P, P, P, I, I, I, I, I, I, P]),
     "e2e_conv133_dgrad_dense": (I, [P, P, P, P, I, I, I, I, I, I, P, LL, P]),
     "e2e_conv133_wgrad_ws_bytes": (LL, [I, I, I, I, I, I, I, I, I]),
-    "e2e_conv133_wgrad": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, P, P]),
+    "e2e_conv133_wgrad": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, P, P, P]),
     "e2e_diag_split_gemm": (I, [P, P, P, I, I, P, P]),
     "e2e_diag_kernel_clock": (I, [I, P, P, I]),
     "e2e_in_stats_finalize": (I, [P, I, P, P, F, P, P, P, P, I, I, P]),

@@ -1237,7 +1237,8 @@ extern "C" long long e2e_conv133_wgrad_ws_bytes(int B, int Cin, int Cout, int Di
 }
 
 extern "C" int e2e_conv133_wgrad(const e2e_in_chan_t* chans, const float* dy, float* dw, void* ws, int B, int Cin,
-                                 int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw, const unsigned* dy_absmax, void* stream) {
+                                 int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw, const unsigned* dy_absmax,
+                                 const unsigned* x_absmax, void* stream) {
   E2E_REQUIRE(chans && dy && dw && ws, "conv133_wgrad: null pointer");
   E2E_REQUIRE((sd == 1 || sd == 2) && (sh == 1 || sh == 2) && (sw == 1 || sw == 2), "conv133_wgrad: stride must be 1 or 2");
   hipStream_t st = (hipStream_t)stream;
@@ -1286,7 +1287,7 @@ extern "C" int e2e_conv133_wgrad(const e2e_in_chan_t* chans, const float* dy, fl
     q.B = B; q.Cin = Cin; q.Cout = Cout; q.Di = Di; q.Hi = Hi; q.Wi = Wi; q.Do = p.Do; q.sd = sd;
     q.tiles_x = p.tiles_x; q.tiles_y = p.tiles_y; q.tiles_per_n = p.tiles_per_n; q.tiles_per_chunk = p.tiles_per_chunk;
     q.segs = p.cblocks_segs; q.cblocks = e2e::cdiv(Cin, 32);
-    q.h2 = wg_h2_env() && dy_absmax != nullptr; q.dy_absmax = dy_absmax;
+    q.h2 = wg_h2_env() && dy_absmax != nullptr; q.dy_absmax = dy_absmax; q.x_absmax = x_absmax;
     e2e::note_kernel("conv133_wgrad_%s chunks=%d pairs=%d", q.h2 ? "h2" : "bf3", nchunks, pairs);
     rc = e2e::launch_wgrad_bf3(q, nchunks, pairs, st);
     if (rc != E2E_OK) return rc;
@@ -1320,7 +1321,7 @@ extern "C" int e2e_conv133_wgrad(const e2e_in_chan_t* chans, const float* dy, fl
     q.B = B; q.Cin = Cin; q.Cout = Cout; q.Di = Di; q.Hi = Hi; q.Wi = Wi; q.Do = p.Do; q.sd = sd;
     q.tiles_x = p.tiles_x; q.tiles_y = p.tiles_y; q.tiles_per_n = p.tiles_per_n; q.tiles_per_chunk = p.tiles_per_chunk;
     q.segs = p.cblocks_segs; q.cblocks = e2e::cdiv(Cin, 32); q.geom = 1;
-    q.h2 = wg_h2_env() && dy_absmax != nullptr; q.dy_absmax = dy_absmax;
+    q.h2 = wg_h2_env() && dy_absmax != nullptr; q.dy_absmax = dy_absmax; q.x_absmax = x_absmax;
     e2e::note_kernel("conv133_wgrad_%sw16 chunks=%d pairs=%d", q.h2 ? "h2" : "bf3", nchunks, pairs);
     rc = e2e::launch_wgrad_bf3(q, nchunks, pairs, st);
     if (rc != E2E_OK) return rc;

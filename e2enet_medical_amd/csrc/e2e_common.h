@@ -128,6 +128,7 @@ struct WgBf3Params {
   int geom;                    // 0: 4 x 32-pixel tiles, 1: 8 x 16-pixel tiles (planes 16..31 wide; v5 kernel only)
   int h2;                      // 1: fp16 two-piece operands, three products (v5 kernel only); 0: bf16 three-piece, six products
   const unsigned* dy_absmax;   // h2: bit pattern of max |dy| over the tensor (device; nullptr: dy is taken unscaled)
+  const unsigned* x_absmax;    // h2: bit pattern of (a bound of) max |x| over the input planes after normalise-on-load (nullptr: fixed 2^3)
 };
 int launch_wgrad_bf3(const WgBf3Params& p, int nchunks, int pairs, hipStream_t st);
 

@@ -21,7 +21,7 @@ import torch
 
 import numpy as np
 
-from ._lib import lib, InChan, OutChan, ParamEntry, SparsePackJob, InSumChan
+from ._lib import lib, InChan, OutChan, ParamEntry, SparsePackJob, InSumChan, MmPackJob, RangeSrc, RangeJob
 
 LRELU_SLOPE = 0.01
 IN_EPS = 1e-5
@@ -51,6 +51,19 @@ MM_FORWARD = MM_BACKWARD = True   # tests / diagnostics: K1m in one direction on
 # fp16 two-piece matrix-pipe conv (conv133_mm.hip, round 5) for every layer it serves whose kernel map is at least this dense
 # (0: all of them -- measured faster than the sparse walk down to density 0.1); E2E_CONV_MM=0 switches the path off in the library
 MM_MIN_DENSITY = float(os.environ.get("E2E_MM_MIN_DENSITY", "0.0"))
+
+
+# Native kernels of this package write parameters through raw pointers (the fused optimizer step, Masking.apply_mask): torch's
+# per-tensor version counters do not see that.  Every such writer calls note_native_param_write(); an engine re-derives what it caches
+# from the weights (packed fp16 weights of the matrix-pipe conv, operand ranges) when this epoch, a parameter's storage or its
+# torch version has changed since.  NOT seen: in-place writes through `parameter.data` (a view with its own version counter) or from
+# foreign native code -- follow those with `network.weights_changed()`.
+PARAM_EPOCH = 0
+
+
+def note_native_param_write():
+    global PARAM_EPOCH
+    PARAM_EPOCH += 1
 
 
 def shift_amounts(num_channels: int, shift_size: int = 5):
@@ -185,6 +198,12 @@ class ConvOp:
         self.out = Act(prefix, (b, cout) + self.out_dims, True, eng.device)
         self.out.producer = self
         self.dy_absmax = torch.zeros(1, dtype=torch.int32, device=eng.device)   # bit pattern of max |dy| (e2e_in_lrelu_bwd -> e2e_conv133_wgrad)
+        # operand ranges of the fp16 two-piece kernels (conv133_mm.hip, conv133_wgrad_bf3.hip): a bound of |x| over this conv's input
+        # planes, derived from the parameters by e2e_conv133_input_ranges (Engine._refresh_weight_caches), and max |w| recorded by the
+        # packing launch; the packed weights of the two directions live as long as the plan (rebuilt when the weights change)
+        self.x_absmax = torch.zeros(1, dtype=torch.int32, device=eng.device)
+        self.w_absmax = torch.zeros(1, dtype=torch.int32, device=eng.device)
+        self.wpk_fwd = self.wpk_bwd = None
         self.own_sums = None    # [B, Cout, own_np, 2] fp64 records of the InstanceNorm-backward sums, written by the last writer of out.grad
         self.own_np = 0
         self.np = lib().conv133_num_partials(*self.out_dims, sh, sw)
@@ -215,6 +234,7 @@ class ConvOp:
         # load-balanced sparse kernel (conv133_sparse.hip): plans are built with the kernel maps (Engine.set_kernel_masks)
         self.sp_fwd = self.sp_bwd = None
         self.sparse_ok = bool(lib().conv133_sparse_eligible(self.cin, cout, di, hi, wi, sd, sh, sw))
+        self.range_known = False    # set with the range job table (Engine._refresh_weight_caches)
 
     def plan_backward(self):
         if not self.do_dgrad:
@@ -288,10 +308,73 @@ class ConvOp:
                 sp.insum = _upload_structs(rows, self.eng.device)
         return sp.table
 
+    def x_absmax_ptr(self):
+        """the range word of this conv's input planes, or None where no bound exists (a raw network input of <= 4 channels: the kernels
+        that serve it do not split operands)"""
+        return self.x_absmax.data_ptr() if self.range_known else None
+
+    def range_job(self):
+        """e2e_range_job_t: where the bound of |x| over this conv's sources comes from (reference concat order, unetpp_d.py:453-478)"""
+        e = self.eng
+        srcs = []
+        for s in self.sources:
+            prod = s.producer if s.normed else getattr(s, "pool_of", None)
+            if prod is not None:                                   # a conv block's output, or the max-pool of one
+                srcs.append(RangeSrc(1, prod.cout, prod.out.spatial, e.params[prod.prefix + ".instnorm.weight"].data_ptr(),
+                                     e.params[prod.prefix + ".instnorm.bias"].data_ptr(), None, 0, 0, None))
+            elif getattr(s, "up_of", None) is not None:            # transposed conv of a conv block's output
+                up = s.up_of
+                prod = up.src.producer
+                kd, kh, kw = up.kernel
+                srcs.append(RangeSrc(2, prod.cout, prod.out.spatial, e.params[prod.prefix + ".instnorm.weight"].data_ptr(),
+                                     e.params[prod.prefix + ".instnorm.bias"].data_ptr(), e.params[up.w_name].data_ptr(), up.cout,
+                                     kd * kh * kw, None))
+            elif s is e.input and e.input_absmax is not None:
+                srcs.append(RangeSrc(3, 0, 0, None, None, None, 0, 0, e.input_absmax.data_ptr()))
+            else:
+                return None
+        while len(srcs) < 3:
+            srcs.append(RangeSrc(0, 0, 0, None, None, None, 0, 0, None))
+        return RangeJob((RangeSrc * 3)(*srcs), self.x_absmax.data_ptr())
+
+    def mm_jobs(self, directions):
+        """e2e_mm_pack_job_t of this layer for the directions in `directions` ('f', 'b'); allocates the packed buffers"""
+        if not self.use_mm():
+            return []
+        w = self.eng.params[self.w_name]
+        dev = self.eng.device
+        jobs = []
+        if "f" in directions and MM_FORWARD:
+            if self.wpk_fwd is None:
+                self.wpk_fwd = torch.empty(self.mm_ws_bytes, dtype=torch.uint8, device=dev)
+            jobs.append(MmPackJob(w.data_ptr(), _ptr(self.live), self.wpk_fwd.data_ptr(), self.w_absmax.data_ptr(), self.cin, self.cout,
+                                  self.cin * 9, 9, 0, 1))
+        if "b" in directions and MM_BACKWARD and self.do_dgrad:
+            if self.wpk_bwd is None:
+                self.wpk_bwd = torch.empty(self.mm_ws_bytes, dtype=torch.uint8, device=dev)
+            jobs.append(MmPackJob(w.data_ptr(), _ptr(self.live_t), self.wpk_bwd.data_ptr(), self.w_absmax.data_ptr(), self.cout, self.cin,
+                                  9, self.cin * 9, 1, 0 if jobs else 1))
+        return jobs
+
+    def pack_mm_standalone(self, directions):
+        """an op driven outside an Engine (operator tests, tools/kbench.py): pack this layer's weights now"""
+        jobs = self.mm_jobs(directions)
+        if jobs:
+            table = _upload_structs(jobs, self.eng.device)
+            mx = max(((j.Q + 31) // 32) * ((j.P + 15) // 16) * 9 * 512 for j in jobs)
+            lib().conv133_mm_pack(table.data_ptr(), len(jobs), mx, _stream())
+
+    def set_input_range(self, max_abs):
+        """operator tests: hand the conv a measured max |x| of its input planes (after normalise-on-load) instead of the bound the
+        engine derives from the parameters; None = no range word (the fixed 2^3 scale of round 5)"""
+        self.range_known = max_abs is not None
+        if max_abs is not None:
+            self.x_absmax.copy_(torch.tensor([float(max_abs)], dtype=torch.float32).view(torch.int32))
+
     def use_mm(self):
         """fp16 two-piece matrix-pipe kernel (conv133_mm.hip): stride-1 layers of the 16 x 32 tile class with 17..320 channels,
         DSFF-masked or not (the mask is packed into the weights)."""
-        if not DENSE_ENABLED or self.mm_ws_bytes <= 0 or getattr(self.eng, "fwd_ws", None) is None:
+        if not DENSE_ENABLED or self.mm_ws_bytes <= 0:
             return False
         return self.live is None or self.density >= MM_MIN_DENSITY
 
@@ -312,9 +395,11 @@ class ConvOp:
         L = lib()
         ws = getattr(e, "fwd_ws", None)
         if self.use_mm() and MM_FORWARD:
-            L.conv133_fwd_mm(self.chans.data_ptr(), self.cin, p[self.w_name].data_ptr(), p[self.prefix + ".conv.bias"].data_ptr(),
-                             _ptr(self.live), self.out.data.data_ptr(), self.part.data_ptr(), b, self.cout, di, hi, wi, ws.data_ptr(),
-                             ws.numel() * 4, _stream())
+            if not hasattr(e, "_refresh_weight_caches"):
+                self.pack_mm_standalone("f")
+            L.conv133_fwd_mm(self.chans.data_ptr(), self.cin, self.wpk_fwd.data_ptr(), self.w_absmax.data_ptr(),
+                             p[self.prefix + ".conv.bias"].data_ptr(), self.x_absmax_ptr(), self.out.data.data_ptr(), self.part.data_ptr(),
+                             b, self.cout, di, hi, wi, _stream())
         elif self.use_dense():
             L.conv133_fwd_dense(self.chans.data_ptr(), self.cin, p[self.w_name].data_ptr(), p[self.prefix + ".conv.bias"].data_ptr(),
                                 _ptr(self.live), self.out.data.data_ptr(), self.part.data_ptr(), b, self.cout, di, hi, wi, ws.data_ptr(),
@@ -362,8 +447,10 @@ class ConvOp:
         if self.do_dgrad:
             ws = getattr(e, "fwd_ws", None)
             if self.use_mm() and MM_BACKWARD:
-                L.conv133_dgrad_mm(o.grad.data_ptr(), self.dy_absmax.data_ptr(), p[self.w_name].data_ptr(), _ptr(self.live_t), self.outs.data_ptr(),
-                                   b, self.cin, self.cout, di, hi, wi, ws.data_ptr(), ws.numel() * 4, _stream())
+                if not hasattr(e, "_refresh_weight_caches"):
+                    self.pack_mm_standalone("b")
+                L.conv133_dgrad_mm(o.grad.data_ptr(), self.dy_absmax.data_ptr(), self.wpk_bwd.data_ptr(), self.w_absmax.data_ptr(),
+                                   self.outs.data_ptr(), b, self.cin, self.cout, di, hi, wi, _stream())
             elif self.use_dense():
                 L.conv133_dgrad_dense(o.grad.data_ptr(), p[self.w_name].data_ptr(), _ptr(self.live_t), self.outs.data_ptr(), b, self.cin, self.cout,
                                       di, hi, wi, ws.data_ptr(), ws.numel() * 4, _stream())
@@ -389,7 +476,7 @@ class ConvOp:
     def _wgrad(self, e, L, g, o, b, di, hi, wi, sd, sh, sw, elems):
         with _wgrad_stream(e, elems) as ws:
             L.conv133_wgrad(self.chans.data_ptr(), o.grad.data_ptr(), g[self.w_name].data_ptr(), ws.data_ptr(),
-                            b, self.cin, self.cout, di, hi, wi, sd, sh, sw, self.dy_absmax.data_ptr(), _stream())
+                            b, self.cin, self.cout, di, hi, wi, sd, sh, sw, self.dy_absmax.data_ptr(), self.x_absmax_ptr(), _stream())
 
     def wgrad_ws_bytes(self):
         di, hi, wi = self.in_dims
@@ -433,6 +520,7 @@ class UpOp:
         self.cin = cin
         kd, kh, kw = self.kernel
         self.out = Act(w_name, (b, cout, d * kd, h * kh, w * kw), False, eng.device)
+        self.out.up_of = self if (src.normed and src.producer is not None) else None     # (ConvOp.range_job)
         self.live = None      # [Cout, ceil(Cin/32)]
         self.live_t = None    # [Cin, ceil(Cout/32)]
         self.acc = 0
@@ -471,6 +559,7 @@ class PoolOp:
         b, c, d, h, w = src.shape
         kd, kh, kw = self.kernel
         self.out = Act(name, (b, c, d // kd, h // kh, w // kw), False, eng.device)
+        self.out.pool_of = src.producer if src.normed else None                          # (ConvOp.range_job)
         self.acc = 0
 
     def plan_backward(self):
@@ -593,6 +682,9 @@ class Engine:
         self.up_ops: Dict[str, UpOp] = {}
         self.input = Act("input", (batch, cfg.in_channels) + self.patch, False, device)
         self.input.needs_grad = False
+        # a network input of more than four channels reaches split-operand kernels (weight gradient, K1m from 17 channels): its
+        # max |x| is measured at every forward (e2e_absmax_word); narrower inputs are served by kernels that do not split
+        self.input_absmax = torch.zeros(1, dtype=torch.int32, device=device) if cfg.in_channels > 4 else None
         self.heads: List[HeadOp] = []
         if cfg.graph == "unet":
             self._build_unet(cfg)
@@ -609,7 +701,7 @@ class Engine:
         self.loss_ws = None
         self.loss_val = None
         self.generation = 0                # bumped by every forward(): activations are reused in place
-        fws = max([max(op.fwd_ws_bytes, op.dgrad_ws_bytes if op.do_dgrad else 0, op.dense_ws_bytes, op.mm_ws_bytes) for op in self.conv_ops.values()] + [0])
+        fws = max([max(op.fwd_ws_bytes, op.dgrad_ws_bytes if op.do_dgrad else 0, op.dense_ws_bytes) for op in self.conv_ops.values()] + [0])
         # split-K partial sums (deep levels) / packed weights of the matrix-core conv; one per lane (see _exec)
         self.lane_divs = _lane_divs(batch * self.patch[0] * self.patch[1] * self.patch[2])
         nl = len(self.lane_divs) + 1
@@ -628,6 +720,11 @@ class Engine:
         self.maps_generation = 0           # bumped when the liveness tables are replaced (their pointers are baked into a graph)
         self._sparse_jobs = None           # pack-job table of the load-balanced convs (rebuilt with the kernel maps)
         self._tgt_static = None
+        self._mm_tables = {}               # directions -> (dispatch key, device job table, njobs, max elems)
+        self._mm_packed = {}               # direction -> weights key its packed buffers were built from
+        self._range_table = None           # (device job table, njobs) of e2e_conv133_input_ranges
+        self._range_key = None
+        self.weights_epoch = 0             # bumped by weights_changed(): in-place parameter writes nothing else can see
 
     def _build_unetpp(self, cfg):
         """reference Generic_UNetPlusPlus.forward (unetpp_d.py:447-488) and create_nest (:491-550)"""
@@ -777,7 +874,58 @@ class Engine:
             table, n, mx = self._sparse_jobs[1]
             lib().conv133_sparse_pack(table.data_ptr(), n, mx, _stream())
 
+    # ------------------------------------------------------------------------------------------ caches derived from the weights
+    def weights_changed(self):
+        """Tell the plan that parameters were modified in a way it cannot see (in place through ``parameter.data``, foreign native
+        code): the packed matrix-pipe weights and the operand ranges are rebuilt at the next pass."""
+        self.weights_epoch += 1
+
+    def _weights_key(self):
+        ptrs = tuple(p.data_ptr() for p in self.params.values())
+        return ptrs, (PARAM_EPOCH, self.weights_epoch, self.maps_generation, tuple(p._version for p in self.params.values()))
+
+    def _refresh_weight_caches(self, directions):
+        """What the split-operand kernels cache from the parameters, rebuilt only when the parameters (storage, torch version,
+        native-write epoch) or the kernel maps have changed since it was built -- in a training loop once per optimizer step, in
+        sliding-window inference once per checkpoint (round 5: a packing launch in front of every conv launch):
+          * the operand-range words of every conv (e2e_conv133_input_ranges: ONE launch),
+          * the packed fp16 two-piece weights of the K1m layers in the directions asked for (e2e_conv133_mm_pack: two launches).
+        Inside a HIP-graph capture (small plans, E2E_GRAPHS) the launches are issued unconditionally: a replay runs no Python."""
+        L = lib()
+        ptrs, state = self._weights_key()
+        always = self._graph_ok() or torch.cuda.is_current_stream_capturing()
+        if self.input_absmax is not None and "f" in directions:      # (depends on the data: every forward)
+            L.absmax_word(self.input.data.data_ptr(), self.input.data.numel(), self.input_absmax.data_ptr(), _stream())
+        if always or self._range_key != (ptrs, state):
+            if self._range_table is None or self._range_table[2] != ptrs:
+                jobs = []
+                for op in self.conv_ops.values():
+                    jb = op.range_job()
+                    op.range_known = jb is not None
+                    if jb is not None:
+                        jobs.append(jb)
+                self._range_table = (_upload_structs(jobs, self.device) if jobs else None, len(jobs), ptrs)
+            if self._range_table[1]:
+                L.conv133_input_ranges(self._range_table[0].data_ptr(), self._range_table[1], _stream())
+            self._range_key = (ptrs, state)
+        # which layers run on K1m in which direction is part of what a packed set is valid for (tests and knobs move it)
+        dkey = (tuple(op.use_mm() for op in self.conv_ops.values()), MM_FORWARD, MM_BACKWARD, self.maps_generation, ptrs)
+        todo = "".join(d for d in directions if always or self._mm_packed.get(d) != (dkey, state))
+        if not todo:
+            return
+        tab = self._mm_tables.get(todo)
+        if tab is None or tab[0] != dkey:
+            jobs = [j for op in self.conv_ops.values() for j in op.mm_jobs(todo)]
+            mx = max([((j.Q + 31) // 32) * ((j.P + 15) // 16) * 9 * 512 for j in jobs] + [0])
+            tab = (dkey, _upload_structs(jobs, self.device) if jobs else None, len(jobs), mx)
+            self._mm_tables[todo] = tab
+        if tab[2]:
+            L.conv133_mm_pack(tab[1].data_ptr(), tab[2], tab[3], _stream())
+        for d in todo:
+            self._mm_packed[d] = (dkey, state)
+
     def _forward_ops(self):
+        self._refresh_weight_caches("fb" if self._backward_ready else "f")
         self._pack_sparse()
 
         def act(op):
@@ -1005,6 +1153,7 @@ class Engine:
                     h.out.grad.copy_(g)
         for op in self.conv_ops.values():       # (a pass that was abandoned between a writer and its producer)
             op.out.sums_ready = False
+        self._refresh_weight_caches("b")        # (a no-op when the forward of this step packed both directions)
         hook = self.grad_bucket_hook
         main = torch.cuda.current_stream()
         if WGRAD_STREAM and not self._graph_ok() and not torch.cuda.is_current_stream_capturing():

@@ -368,6 +368,13 @@ class Generic_UNetPlusPlus(SegmentationNetwork):
         self._sync_sparsity(eng)
         return eng
 
+    def weights_changed(self):
+        """Parameters were modified in a way the plans cannot see -- in place through ``parameter.data`` (a view with its own
+        version counter) or by foreign native code: the packed matrix-pipe weights and operand ranges are rebuilt at the next pass.
+        Not needed after optimizer steps, ``load_state_dict``, ``Masking`` updates or any in-place op on the parameters themselves."""
+        for eng in self._engines.values():
+            eng.weights_changed()
+
     def _invalidate_sparsity(self):
         self._sparsity_version = getattr(self, "_sparsity_version", 0) + 1
 

@@ -62,6 +62,8 @@ class FusedClipSGD:
                              float(g['weight_decay']), float(g['momentum']), 1 if g['nesterov'] else 0,
                              1 if self.first else 0, _stream())
         self.first = False
+        from ..engine import note_native_param_write
+        note_native_param_write()               # (parameters written through raw pointers: torch's version counters do not move)
 
     def total_norm(self):
         """sqrt of the last squared gradient norm (device sync)."""

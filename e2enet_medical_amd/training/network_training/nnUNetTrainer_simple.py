@@ -847,6 +847,10 @@ class nnUNetTrainer_simple(object):
         assert self.was_initialized, "must initialize, ideally with checkpoint (or train first)"
         if self.dataset_val is None:
             if self.folder_with_preprocessed_data is None:
+                if self.dataset_directory is None or 'data_identifier' not in self.plans:
+                    raise FileNotFoundError("validate() needs the preprocessed cases of the task (dataset_directory / plans["
+                                            "'data_identifier'] + '_stage%s', reference nnUNetTrainer_simple.py:216-217); this trainer "
+                                            "has none (synthetic batches?)" % (self.stage,))
                 self.folder_with_preprocessed_data = join(self.dataset_directory, self.plans['data_identifier'] + "_stage%d" % self.stage)
             self.load_dataset()
             self.do_split()

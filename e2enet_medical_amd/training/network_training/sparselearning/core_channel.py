@@ -295,6 +295,8 @@ class Masking(object):
         if self._table is None or keys != self._table_keys:
             self._build_table()
         lib().apply_mask(self._table.data_ptr(), len(self.names), _stream())
+        from ....engine import note_native_param_write
+        note_native_param_write()               # (weights written through raw pointers: see engine.PARAM_EPOCH)
         self._notify_masks_applied()
 
     def step(self, masks_already_applied=False):

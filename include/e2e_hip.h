@@ -173,17 +173,53 @@ int e2e_conv133_dgrad_sparse(const float* dy, const float* wpk_t, const unsigned
  * autograd; DSFF-pruned kernels contribute nothing: they are packed as zeros from `live`, core_channel.py:427-434) as a GEMM on the
  * fp16 matrix pipe with fp32-exact two-piece operands (three matrix products per fp32 product; conv133_mm.hip) -- every stride-1
  * layer with Wi % 32 == 0, Hi % 16 == 0, Hi > 16 and 17..320 channels on both sides, masked or not.
- *   ws          workspace of e2e_conv133_mm_ws_bytes(...) bytes (0: shape not served): the packed weights, rebuilt at every launch
+ *   wpk         the layer's packed weights of this direction: a buffer of e2e_conv133_mm_ws_bytes(...) bytes (0: shape not served)
+ *               that e2e_conv133_mm_pack filled -- ONE launch pair for all layers and both directions, after an optimizer step or a
+ *               parameter load (round 6; until round 5 every conv launch re-packed its weights)
+ *   w_absmax    the device word e2e_conv133_mm_pack recorded max |w| in (its power-of-two scale); NULL: packed with the fixed 2^8
+ *   x_absmax    NULL, or a device word holding (a bound of) max |x| over all input planes after normalise-on-load
+ *               (e2e_conv133_input_ranges derives one from the parameters; e2e_absmax_word measures one): the activations are
+ *               moved into the fp16 range by the power of two it implies.  NULL keeps the fixed 2^3 of round 5: |x| > 8188 -> Inf
  *   dy_absmax   NULL, or the word e2e_in_lrelu_bwd(dy_absmax) left behind for this dy: its power-of-two scale (without it dy is
  *               taken as it is: only for O(1) test data -- full-resolution gradients of 1e-7 are below the fp16 range)
  *   outs        as e2e_conv133_dgrad; destinations with `accumulate` set are updated by no-return global_atomic_add_f32 -- every element
  *               by exactly one lane per launch, launches stream-ordered: the same value as a load / add / store and deterministic;
  *               the buffers must be device (coarse-grained) memory */
+typedef struct {
+  const float* w;            /* the layer's weight tensor [Cout, Cin, 1, 3, 3] */
+  const unsigned* quads;     /* DSFF liveness quad words of this direction (e2e_dsff_expand_quads) or NULL (dense) */
+  void* wpk;                 /* e2e_conv133_mm_ws_bytes(...) bytes */
+  unsigned* w_absmax;        /* one word per layer (shared by its two directions) */
+  int P, Q;                  /* reduction-side / output-side channels: forward (Cin, Cout), data gradient (Cout, Cin) */
+  int wq_stride, wp_stride;  /* element strides of w for (output-side, reduction-side) channel: forward (Cin*9, 9), data gradient (9, Cin*9) */
+  int reverse;               /* data gradient: taps reversed */
+  int owns_absmax;           /* this job computes *w_absmax (one job per layer) */
+} e2e_mm_pack_job_t;
+typedef struct {
+  int kind;                  /* 0 none, 1 normalised source (or its max-pool), 2 transposed conv of a normalised source, 3 measured word */
+  int C;                     /* channels of the normalised tensor */
+  long long N;               /* voxels per instance of the normalised tensor */
+  const float* gamma;        /* [C] instnorm.weight of its producer */
+  const float* beta;         /* [C] instnorm.bias */
+  const float* w;            /* kind 2: transposed-conv weight [C, wCout, wks] */
+  int wCout, wks;
+  const unsigned* word;      /* kind 3 */
+} e2e_range_src_t;
+typedef struct {
+  e2e_range_src_t src[3];    /* the concat sources of one conv (reference unetpp_d.py:453-478) */
+  unsigned* out;             /* bit pattern of the bound of |x| over all of them */
+} e2e_range_job_t;
 long long e2e_conv133_mm_ws_bytes(int B, int Cin, int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw);
-int e2e_conv133_fwd_mm(const e2e_in_chan_t* chans, int Cin, const float* w, const float* bias, const unsigned* live, float* y, double* part,
-                       int B, int Cout, int Di, int Hi, int Wi, void* ws, long long ws_bytes, void* stream);
-int e2e_conv133_dgrad_mm(const float* dy, const unsigned* dy_absmax, const float* w, const unsigned* live_t, const e2e_out_chan_t* outs, int B,
-                         int Cin, int Cout, int Di, int Hi, int Wi, void* ws, long long ws_bytes, void* stream);
+/* jobs: DEVICE table; max_elems >= the largest ceil(Q/32)*ceil(P/16)*9*512 of the table */
+int e2e_conv133_mm_pack(const e2e_mm_pack_job_t* jobs, int njobs, long long max_elems, void* stream);
+/* jobs: DEVICE table, one per conv whose forward or weight gradient runs on split operands */
+int e2e_conv133_input_ranges(const e2e_range_job_t* jobs, int njobs, void* stream);
+/* *word = bit pattern of max |x| over n floats (a non-finite element gives +Inf) */
+int e2e_absmax_word(const float* x, long long n, unsigned* word, void* stream);
+int e2e_conv133_fwd_mm(const e2e_in_chan_t* chans, int Cin, const void* wpk, const unsigned* w_absmax, const float* bias,
+                       const unsigned* x_absmax, float* y, double* part, int B, int Cout, int Di, int Hi, int Wi, void* stream);
+int e2e_conv133_dgrad_mm(const float* dy, const unsigned* dy_absmax, const void* wpk_t, const unsigned* w_absmax,
+                         const e2e_out_chan_t* outs, int B, int Cin, int Cout, int Di, int Hi, int Wi, void* stream);
 
 /* ---- K6b: 1x3x3 convolution, weight gradient (dense: also for dead kernels, because the
  * reference's clip_grad_norm_ runs over all gradients, nnUNetTrainer_simple.py:573) ----
@@ -195,8 +231,11 @@ long long e2e_conv133_wgrad_ws_bytes(int B, int Cin, int Cout, int Di, int Hi, i
  *              the shapes served by the matrix-pipe kernel run on fp16 two-piece operands (three products per fp32 product, dy
  *              pre-scaled by the power of two that puts its maximum in [2^14, 2^15)); without it on bf16 three-piece operands
  *              (six products, no range assumption).  Both are fp32-exact to the last two bits of an operand. */
+/*   x_absmax   NULL, or the word e2e_conv133_input_ranges / e2e_absmax_word produced for this conv's input planes: the power-of-two
+ *              scale of the activations in the fp16 two-piece kernel (NULL: the fixed 2^3 of round 5, |x| > 8188 -> Inf) */
 int e2e_conv133_wgrad(const e2e_in_chan_t* chans, const float* dy, float* dw, void* ws, int B, int Cin,
-                      int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw, const unsigned* dy_absmax, void* stream);
+                      int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw, const unsigned* dy_absmax,
+                      const unsigned* x_absmax, void* stream);
 
 /* Diagnostic (the numerics gate of the split-operand matrix paths, tests/test_gpu_ops.py): D[32][32] = A[32][K] Bt[32][K]^T through the
  * split functions and product orders of the matrix-pipe kernels.  mode 0: bf16 three-piece operands, six products; 1: fp16 two-piece

@@ -247,6 +247,63 @@ def test_config1_hippocampus_width48_forward_and_predict():
     assert (seg != rseg).mean() <= 1e-3
 
 
+@pytest.mark.parametrize("what", ["gamma50", "up1e3", "in1e6"])
+def test_whole_net_with_large_activations_stays_finite_and_on_the_matrix_pipe(what):
+    """Round 6 (verdict r05 weak 2): a whole network (base 32 at 32 x 64 x 64: the 64 -> 32 and 160 -> 64 layers run on
+    conv133_mm_h2, their weight gradients on conv133_wgrad_h2) whose activations leave the range round 5's fixed 2^3 scale could
+    hold -- every InstanceNorm weight 50 ('gamma50'), transposed-conv weights x 1e3 on top of that ('up1e3': un-normalised concat
+    sources of ~1e5), the input x 1e6 ('in1e6') -- against the fp32 CPU oracle at RELATIVE bars: logits 1e-4 of max |logit|, loss
+    1e-4 relative, gradients by the same-branch rule.  The engine derives each conv's operand range from the parameters
+    (e2e_conv133_input_ranges); nothing is Inf or NaN, and the split-operand kernels are the ones that ran."""
+    patch, cin, base, k = (32, 64, 64), 2, 32, 3
+    pools = [(2, 2, 2)] * 4 + [(1, 2, 2)]
+    net = build_net(patch, cin, base, k, pools)
+    shapes, params = load_closed_form(net)
+    with torch.no_grad():
+        for n in shapes:
+            if what in ("gamma50", "up1e3") and n.endswith("instnorm.weight"):
+                params[n] = params[n] * 50.0
+            if what == "up1e3" and n.startswith("up") and n.endswith(".weight"):
+                params[n] = params[n] * 1e3
+            net.get_parameter(n).copy_(params[n])
+    spec = oracle.make_spec(cin, base, k, pools)
+    x = seeded_input((1, cin) + patch, seed=901) * (1e6 if what == "in1e6" else 1.0)
+    eng = net.engine(x.cuda())
+    with KernelLog(CONV_ENTRIES) as kl:
+        outs = eng.forward(x.cuda(), True)
+        targets = [seeded_labels((o.shape[0], 1) + tuple(o.shape[2:]), k, seed=910 + i) for i, o in enumerate(outs)]
+        w = oracle.ds_weights(5)
+        loss = eng.loss_backward([t.cuda() for t in targets], w, batch_dice=False)
+        torch.cuda.synchronize()
+    fams = [kk.split(" ")[0] for _, kk in kl.log]
+    assert sum(f.startswith("conv133_mm_h2<mode=0") for f in fams) >= 6 and sum(f.startswith("conv133_mm_h2<mode=1") for f in fams) >= 6, fams
+    assert sum(f.startswith("conv133_wgrad_h2") for f in fams) >= 6, fams
+    assert all(torch.isfinite(o).all() for o in outs) and math.isfinite(loss.item())
+    assert all(torch.isfinite(g_).all() for g_ in eng.grads.values()), [n for n, g_ in eng.grads.items() if not torch.isfinite(g_).all()]
+    # the range words the engine derived are bounds of what the convs actually read
+    for op in eng.conv_ops.values():
+        if op.range_known:
+            bound = float(op.x_absmax.view(torch.float32).item())
+            seen = 0.0
+            for s_ in op.sources:
+                v = s_.data
+                if s_.normed:
+                    B_, C_ = v.shape[:2]
+                    v = torch.nn.functional.leaky_relu(v * s_.scale.view(B_, C_, 1, 1, 1) + s_.shift.view(B_, C_, 1, 1, 1), 0.01)
+                seen = max(seen, float(v.abs().max()))
+            assert seen <= bound, (op.prefix, seen, bound)
+    leaves = {n: p.clone().requires_grad_(True) for n, p in params.items()}
+    ref = oracle.forward(spec, leaves, x)
+    ref_loss = oracle.deep_supervision_loss(ref, targets, w, False)
+    for i, (o, r) in enumerate(zip(outs, ref)):
+        sc = max(1.0, float(r.detach().abs().max()))
+        err = float((o.cpu() - r.detach()).abs().max())
+        print("[%s] head %d: max |logit| %.3e, max |dlogit| %.3e" % (what, i, sc, err))
+        assert err <= 1e-4 * sc, (i, err, sc)
+    assert abs(loss.item() - ref_loss.item()) <= 1e-4 * max(1.0, abs(ref_loss.item()))
+    check_grads_same_branches(eng, spec, params, x, targets, w, shapes)
+
+
 # ------------------------------------------------------------------------------------------------ config 5
 @pytest.mark.parametrize("dens", [0.1, 0.5])
 def test_config5_amos_density_whole_net(dens):
@@ -790,8 +847,8 @@ def test_config3_btcv_full_shape_vs_oracle_and_dsff_update_replay():
     assert abs(loss1.item() - ref_loss1.item()) <= 5e-5
     ref_loss1.backward()
     for n in params:
-        if n.startswith("seg_outputs") or n.startswith("loc0.4") or n == "up0.4.weight":
-            rg = leaves[n].grad
+        if (n.startswith("seg_outputs") or n.startswith("loc0.4") or n == "up0.4.weight") and not n.endswith(".conv.bias"):
+            rg = leaves[n].grad              # (a conv bias in front of an InstanceNorm has an exactly-zero gradient: both sides hold noise)
             rel = (eng1.grads[n].cpu() - rg).norm().item() / rg.norm().item()
             assert rel <= 2e-3, (n, rel)
     del leaves

@@ -169,8 +169,8 @@ def test_conv133_fwd_bwd(case):
     e = _eng_stub(params)
     e.batch = B
     op = ConvOp(e, "blk", srcs, cout, stride)
-    if max(op.dense_ws_bytes, op.mm_ws_bytes) > 0:
-        e.fwd_ws = torch.empty(max(op.dense_ws_bytes, op.mm_ws_bytes) // 4, dtype=torch.float32, device=e.device)
+    if op.dense_ws_bytes > 0:
+        e.fwd_ws = torch.empty(op.dense_ws_bytes // 4, dtype=torch.float32, device=e.device)
     if km is not None:
         rows = torch.empty(((cout + 3) // 4) * ((cin + 7) // 8), dtype=torch.int32, device=e.device)
         cols = torch.empty(((cin + 3) // 4) * ((cout + 7) // 8), dtype=torch.int32, device=e.device)
@@ -179,6 +179,7 @@ def test_conv133_fwd_bwd(case):
         op.live, op.live_t = rows, cols
         op.density = float(km.float().mean())
         _plan_and_pack(op, km)                      # load-balanced kernel where the shape is served (conv133_sparse.hip)
+    op.set_input_range(max(float(_act_value(a).abs().max()) for a in srcs))      # (inside an Engine: e2e_conv133_input_ranges)
     tile_class = dims[2] % 32 == 0 and dims[1] % 16 == 0 and dims[1] > 16 and stride == (1, 1, 1)
     if tile_class and cin > 16 and cout > 16 and os.environ.get("E2E_CONV_MM", "1") != "0":
         assert op.use_mm(), "this case is meant to reach conv133_mm_kernel"
@@ -571,16 +572,21 @@ def test_conv133_wgrad_h2_and_bf3_vs_fp64(tag, B, src_desc, cout, dims):
             mag[:, :, 0, kh, kw] = torch.einsum("nodhw,ncdhw->oc", dy.double().abs(), win.abs())
     L = lib()
 
-    def run(dyt, with_max):
+    xmax = float(x.abs().max())
+
+    def run(dyt, with_max, x_word=True):
         dyd = dyt.cuda()
         word = _absmax_word(dyd) if with_max else None
+        op.set_input_range(xmax if x_word else None)
         dw = torch.full((cout, cin, 1, 3, 3), float("nan"), device="cuda")
         L.conv133_wgrad(op.chans.data_ptr(), dyd.data_ptr(), dw.data_ptr(), e.wgrad_ws.data_ptr(), B, cin, cout, *dims, 1, 1, 1,
-                        word.data_ptr() if with_max else None, 0)
+                        word.data_ptr() if with_max else None, op.x_absmax_ptr(), 0)
         torch.cuda.synchronize()
         return dw.cpu(), (L.last_kernel() or b"").decode()
     got_h2, k_h2 = run(dy, True)
     got_b3, k_b3 = run(dy, False)
+    got_fixed, _ = run(dy, True, x_word=False)             # round 5's fixed 2^3 input scale: same products up to the lo pieces' range
+    assert float((got_fixed.double() - ref).norm() / ref.norm()) < 2e-6
     assert k_h2.startswith("conv133_wgrad_h2") and k_b3.startswith("conv133_wgrad_bf3"), (k_h2, k_b3)
     rms = {}
     for name, got in (("h2", got_h2), ("bf3", got_b3)):
@@ -807,7 +813,7 @@ def test_conv133_masks_are_structural_on_every_path(path, density, monkeypatch):
               "blk.instnorm.bias": torch.zeros(cout)}
     e = _eng_stub(params)
     op = ConvOp(e, "blk", srcs, cout, (1, 1, 1))
-    e.fwd_ws = torch.empty(max(op.dense_ws_bytes, op.mm_ws_bytes) // 4, dtype=torch.float32, device=e.device)
+    e.fwd_ws = torch.empty(max(op.dense_ws_bytes, 4) // 4, dtype=torch.float32, device=e.device)
     rows = torch.empty(((cout + 3) // 4) * ((cin + 7) // 8), dtype=torch.int32, device=e.device)
     cols = torch.empty(((cin + 3) // 4) * ((cout + 7) // 8), dtype=torch.int32, device=e.device)
     lib().dsff_expand_quads(km.to(e.device).data_ptr(), rows.data_ptr(), cols.data_ptr(), cout, cin, 0)
@@ -828,8 +834,9 @@ def test_conv133_masks_are_structural_on_every_path(path, density, monkeypatch):
     L = lib()
     if path == "mm":
         word = _absmax_word(op.out.grad)
-        L.conv133_dgrad_mm(op.out.grad.data_ptr(), word.data_ptr(), e.params["blk.conv.weight"].data_ptr(), op.live_t.data_ptr(), op.outs.data_ptr(),
-                           B, cin, cout, *dims, e.fwd_ws.data_ptr(), e.fwd_ws.numel() * 4, 0)
+        op.pack_mm_standalone("b")               # (from the dirty tensor: pruned kernels must pack as zeros)
+        L.conv133_dgrad_mm(op.out.grad.data_ptr(), word.data_ptr(), op.wpk_bwd.data_ptr(), op.w_absmax.data_ptr(), op.outs.data_ptr(),
+                           B, cin, cout, *dims, 0)
         torch.cuda.synchronize()
         assert L.last_kernel().decode().startswith("conv133_mm_h2<mode=1")
         assert (srcs[0].grad.cpu() - x.grad).abs().max() < 2e-4 * max(1.0, float(x.grad.abs().max())), "matrix-pipe data gradient used a pruned kernel"
@@ -884,3 +891,122 @@ def test_convT_masks_are_structural_on_the_gemm_paths(dims, kernel):
     op.backward()
     torch.cuda.synchronize()
     assert (src.grad.cpu() - xl.grad).abs().max() < 2e-4 * max(1.0, float(xl.grad.abs().max())), "data gradient used a pruned kernel"
+
+
+@pytest.mark.parametrize("what,mag", [("raw", 1e4), ("raw", 1e6), ("gamma", 50.0), ("tiny", 1e-6), ("weights", 1e4)])
+def test_split_operand_kernels_hold_the_fp32_range(what, mag):
+    """Round 6 (verdict r05 weak 2): the fp16 two-piece kernels move every operand into the fp16 range by a power of two derived from
+    the tensor -- the activations from the range word (a bound of |x| over the conv's input planes), the weights from max |w| recorded
+    by the packing launch, dy from max |dy| -- instead of the fixed 2^3 / 2^8 of round 5 (|x| > 8188 or |w| >= 256 became Inf).
+    Conv forward (conv133_mm_h2<mode=0>), data gradient (<mode=1>) and weight gradient (conv133_wgrad_h2) against fp64 with
+    activations of 1e4 and 1e6 (un-normalised source), a normalised source with |scale| = 50, activations of 1e-6 and weights of
+    1e4: finite, within the usual RELATIVE bars (the reference computes in fp32 throughout, nnUNetTrainer_simple.py:551-573)."""
+    from e2enet_medical_amd.engine import ConvOp
+    from e2enet_medical_amd._lib import lib
+    B, dims, cout = 1, (3, 32, 64), 40
+    srcs = [_make_act((B, 24) + dims, True, 301), _make_act((B, 16) + dims, False, 302)]
+    wscale = 1.0
+    if what == "raw":
+        srcs[1].data.mul_(mag)
+    elif what == "gamma":
+        srcs[0].scale.mul_(mag)
+    elif what == "tiny":
+        srcs[1].data.mul_(mag)
+        srcs[0].scale.mul_(mag)
+        srcs[0].shift.mul_(mag)
+    else:
+        wscale = mag
+    cin = 40
+    w = seeded_input((cout, cin, 1, 3, 3), seed=303) * (wscale / math.sqrt(cin * 9))
+    params = {"blk.conv.weight": w, "blk.conv.bias": torch.zeros(cout), "blk.instnorm.weight": torch.ones(cout),
+              "blk.instnorm.bias": torch.zeros(cout)}
+    e = _eng_stub(params)
+    op = ConvOp(e, "blk", srcs, cout, (1, 1, 1))
+    assert op.use_mm()
+    xs = [_act_value(a) for a in srcs]
+    op.set_input_range(max(float(v.abs().max()) for v in xs))
+    L = lib()
+    op.forward()
+    torch.cuda.synchronize()
+    x64 = oracle.depth_shift(torch.cat(xs, 1)).double().requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    y64 = F.conv3d(x64, w64, None, padding=(0, 1, 1))
+    got = op.out.data.cpu()
+    assert torch.isfinite(got).all(), "forward overflowed"
+    ysc = float(y64.abs().max())
+    assert float((got.double() - y64.detach()).abs().max()) <= 2e-6 * ysc, "forward vs fp64 (relative to max |y|)"
+    assert float((got.double() - y64.detach()).norm() / y64.detach().norm()) <= 6e-7
+    # backward: dy handed over as the pre-norm gradient, with its recorded maximum (what e2e_in_lrelu_bwd leaves behind)
+    dy = _heavy_tailed(tuple(y64.shape), 304, 1e-7)
+    y64.backward(dy.double())
+    op.out.alloc_grad()
+    op.plan_backward()
+    op.out.grad.copy_(dy)
+    word = _absmax_word(op.out.grad)
+    for s_ in srcs:
+        s_.grad.fill_(float("nan"))
+    op.pack_mm_standalone("b")
+    L.conv133_dgrad_mm(op.out.grad.data_ptr(), word.data_ptr(), op.wpk_bwd.data_ptr(), op.w_absmax.data_ptr(), op.outs.data_ptr(),
+                       B, cin, cout, *dims, 0)
+    torch.cuda.synchronize()
+    assert L.last_kernel().decode().startswith("conv133_mm_h2<mode=1")
+    gx = torch.cat([s_.grad.cpu() for s_ in srcs], 1).double()
+    # (x64 is the shifted concat: undo the shift on the reference side by shifting the engine's result the same way)
+    ref_gx = x64.grad
+    got_gx = oracle.depth_shift(gx.float()).double()
+    live = oracle.depth_shift(torch.ones_like(gx).float()).double() > 0          # slices the shift moved out of range receive nothing
+    assert torch.isfinite(gx).all(), "data gradient overflowed"
+    assert float(((got_gx - ref_gx) * live).norm() / (ref_gx * live).norm()) <= 3e-6, "data gradient vs fp64"
+    dw = torch.full((cout, cin, 1, 3, 3), float("nan"), device="cuda")
+    L.conv133_wgrad(op.chans.data_ptr(), op.out.grad.data_ptr(), dw.data_ptr(), e.wgrad_ws.data_ptr(), B, cin, cout, *dims, 1, 1, 1,
+                    word.data_ptr(), op.x_absmax_ptr(), 0)
+    torch.cuda.synchronize()
+    assert L.last_kernel().decode().startswith("conv133_wgrad_h2")
+    assert torch.isfinite(dw).all(), "weight gradient overflowed"
+    assert float((dw.cpu().double() - w64.grad).norm() / w64.grad.norm()) <= 3e-6, "weight gradient vs fp64"
+    if what == "raw" and mag >= 1e4:
+        # what round 5 did with the same data: the fixed 2^3 scale overflows fp16 (the hole this test closes)
+        op.set_input_range(None)
+        op.forward()
+        torch.cuda.synchronize()
+        assert not torch.isfinite(op.out.data).all()
+
+
+def test_input_range_words_bound_the_activations():
+    """e2e_conv133_input_ranges: the word of a conv is a rigorous bound of |x| over its input planes -- |gamma| sqrt(N - 1) + |beta|
+    for a normalised source (and its max-pool), sum_c bound_c |W[c, o, k]| for a transposed conv of one, the measured maximum for a
+    raw tensor -- never below the true maximum, and tight on adversarial data (one spike per instance reaches sqrt(N - 1))."""
+    import ctypes as C
+    from e2enet_medical_amd._lib import lib, RangeSrc, RangeJob
+    L = lib()
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    Cn, N = 24, 6 * 8 * 10
+    gamma = (torch.randn(Cn, generator=g) * 3).to(dev)
+    beta = torch.randn(Cn, generator=g).to(dev)
+    wt = (torch.randn(Cn, 12, 2, 2, 2, generator=g) * 0.2).to(dev)
+    xin = (torch.randn(3, 5, 7, generator=g) * 40).to(dev)
+    xin[1, 2, 3] = float("-9e3")
+    words = torch.zeros(4, dtype=torch.int32, device=dev)
+    L.absmax_word(xin.data_ptr(), xin.numel(), words[3:].data_ptr(), 0)
+    none = RangeSrc(0, 0, 0, None, None, None, 0, 0, None)
+    norm = RangeSrc(1, Cn, N, gamma.data_ptr(), beta.data_ptr(), None, 0, 0, None)
+    up = RangeSrc(2, Cn, N, gamma.data_ptr(), beta.data_ptr(), wt.data_ptr(), 12, 8, None)
+    raw = RangeSrc(3, 0, 0, None, None, None, 0, 0, words[3:].data_ptr())
+    jobs = [RangeJob((RangeSrc * 3)(norm, none, none), words[0:].data_ptr()), RangeJob((RangeSrc * 3)(up, none, none), words[1:].data_ptr()),
+            RangeJob((RangeSrc * 3)(norm, up, raw), words[2:].data_ptr())]
+    table = torch.frombuffer(bytearray(b"".join(bytes(j) for j in jobs)), dtype=torch.uint8).to(dev)
+    L.conv133_input_ranges(table.data_ptr(), 3, 0)
+    torch.cuda.synchronize()
+    got = words.view(torch.float32).cpu().double()
+    root = math.sqrt(N - 1)
+    b_norm = (gamma.abs().cpu().double() * root + beta.abs().cpu().double())
+    b_up = (b_norm.view(Cn, 1, 1) * wt.abs().cpu().double().view(Cn, 12, 8)).sum(0).max()
+    assert float(got[3]) == 9e3
+    for val, ref in ((got[0], b_norm.max()), (got[1], b_up), (got[2], max(float(b_norm.max()), float(b_up), 9e3))):
+        assert float(ref) <= float(val) <= float(ref) * (1 + 2e-3), (float(val), float(ref))
+    # adversarial instance: one spike, everything else equal -> |xhat| of the spike = sqrt(N - 1) exactly; the bound holds with equality
+    y = torch.zeros(1, 1, N)
+    y[0, 0, 0] = 1.0
+    xhat = (y - y.mean()) / y.var(unbiased=False).sqrt()
+    assert abs(float(xhat.abs().max()) - root) < 1e-3 * root

@@ -106,9 +106,10 @@ def test_run_training_writes_reference_named_checkpoints_and_resumes(tmp_path):
     assert tr3.fold == 1 and tr3.output_folder.endswith("fold_1") and tr3.output_folder_pretrained == tr3.output_folder
     with pytest.raises(RuntimeError):
         tr3.load_final_checkpoint()
-    for fn in (tr3.validate, lambda: tr3.preprocess_patient(["a.nii.gz"])):
-        with pytest.raises(NotImplementedError):
-            fn()
+    with pytest.raises(NotImplementedError):         # preprocessing stays with the reference package
+        tr3.preprocess_patient(["a.nii.gz"])
+    with pytest.raises(FileNotFoundError):           # validate() runs on the engine, but this trainer was fed synthetic batches
+        tr3.validate()
 
 
 def test_online_evaluation_counts_match_torch():
@@ -390,6 +391,7 @@ def test_predict_cases_fold_ensemble_on_device():
     sd1 = {k: (v + 0.05 * torch.randn_like(v)) for k, v in sd0.items()}
     params = [{'epoch': 0, 'state_dict': sd, 'optimizer_state_dict': None, 'plot_stuff': ([], [], [], []),
                'best_stuff': (None, None, None)} for sd in (sd0, sd1)]
+    tr.plans = dict(tr.plans)                        # (PLANS is the module's shared dict: no leak into later tests)
     tr.plans['transpose_forward'], tr.plans['transpose_backward'] = [1, 2, 0], [2, 0, 1]
     vol = seeded_input((1, 20, 40, 45), seed=9).numpy()
     props = {'size_after_cropping': np.array([40, 45, 20])[[0, 1, 2]], 'original_size_of_raw_data': np.array([22, 41, 50]),
@@ -568,7 +570,7 @@ def test_validate_exports_and_scores_the_validation_split(tmp_path):
     import pickle
     from tests.helpers import write_synthetic_task
     from e2enet_medical_amd.training.network_training.nnUNetTrainer_simple import nnUNetTrainer_simple
-    ddir, plans = write_synthetic_task(str(tmp_path / "pre"), plans=PLANS)
+    ddir, plans = write_synthetic_task(str(tmp_path / "pre"), plans=dict(PLANS, transpose_forward=[0, 1, 2], transpose_backward=[0, 1, 2]))
     tr = nnUNetTrainer_simple(plans, 0, output_folder=str(tmp_path / "out"), dataset_directory=ddir, batch_dice=False,
                               Tconv='shiftConvPP', max_num_epochs=1, num_batches_per_epoch=2)
     tr.base_num_features_override = 8
@@ -615,7 +617,7 @@ def test_simple_main_and_simple_predict_take_the_reference_argv(tmp_path, monkey
     monkeypatch.setenv("nnUNet_preprocessed", str(pre))
     monkeypatch.setenv("RESULTS_FOLDER", str(res))
     monkeypatch.setenv("nnUNet_raw_data_base", str(tmp_path / "raw"))
-    ddir, plans = write_synthetic_task(str(pre), plans=PLANS)
+    ddir, plans = write_synthetic_task(str(pre), plans=dict(PLANS, transpose_forward=[0, 1, 2], transpose_backward=[0, 1, 2]))
     common = ["--task", "998", "--fold", "0", "--Tconv", "shiftConvPP", "--base_num_features", "8", "--sparse", "True", "--density",
               "0.5", "--update_frequency", "2", "--death-rate", "0.3"]
     random.seed(3)

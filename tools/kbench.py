@@ -78,16 +78,16 @@ def conv_case(B, srcs, cout, dims, stride, density, tag):
     dense_path = op.use_dense() and os.environ.get("KB_NO_DENSE") is None
     mm_path = op.mm_ws_bytes > 0 and os.environ.get("KB_NO_MM") is None
     if mm_path:
-        e.fwd_ws = torch.empty(max(op.mm_ws_bytes, op.dense_ws_bytes) // 4, dtype=torch.float32, device=dev)
+        op.pack_mm_standalone("fb")              # once: the engine packs once per optimizer step, not per launch
+        op.set_input_range(8.0)                  # (N(0,1)-ish activations: the scale exponent the benchmarked net derives)
 
     def fwd_mm():
-        L.conv133_fwd_mm(op.chans.data_ptr(), cin, w.data_ptr(), p["b.conv.bias"].data_ptr(),
-                         op.live.data_ptr() if op.live is not None else None, op.out.data.data_ptr(), op.part.data_ptr(),
-                         B, cout, di, hi, wi, e.fwd_ws.data_ptr(), e.fwd_ws.numel() * 4, 0)
+        L.conv133_fwd_mm(op.chans.data_ptr(), cin, op.wpk_fwd.data_ptr(), op.w_absmax.data_ptr(), p["b.conv.bias"].data_ptr(),
+                         op.x_absmax_ptr(), op.out.data.data_ptr(), op.part.data_ptr(), B, cout, di, hi, wi, 0)
 
     def dgrad_mm():
-        L.conv133_dgrad_mm(op.out.grad.data_ptr(), amax.data_ptr(), w.data_ptr(), op.live_t.data_ptr() if op.live_t is not None else None, op.outs.data_ptr(),
-                           B, cin, cout, di, hi, wi, e.fwd_ws.data_ptr(), e.fwd_ws.numel() * 4, 0)
+        L.conv133_dgrad_mm(op.out.grad.data_ptr(), amax.data_ptr(), op.wpk_bwd.data_ptr(), op.w_absmax.data_ptr(), op.outs.data_ptr(),
+                           B, cin, cout, di, hi, wi, 0)
 
     def fwd_dense():
         L.conv133_fwd_dense(op.chans.data_ptr(), cin, w.data_ptr(), p["b.conv.bias"].data_ptr(),
@@ -110,7 +110,7 @@ def conv_case(B, srcs, cout, dims, stride, density, tag):
 
     def wgrad():
         L.conv133_wgrad(op.chans.data_ptr(), op.out.grad.data_ptr(), e.grads["b.conv.weight"].data_ptr(), e.wgrad_ws.data_ptr(),
-                        B, cin, cout, di, hi, wi, *stride, None if os.environ.get("KB_NO_ABSMAX") else amax.data_ptr(), 0)
+                        B, cin, cout, di, hi, wi, *stride, None if os.environ.get("KB_NO_ABSMAX") else amax.data_ptr(), op.x_absmax_ptr(), 0)
     def fwd_planned():
         sp = op.sp_fwd
         L.conv133_fwd_sparse(sp.table.data_ptr(), cin, sp.wpk.data_ptr(), p["b.conv.bias"].data_ptr(), sp.quads.data_ptr(),
