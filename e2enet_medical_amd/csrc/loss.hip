@@ -31,22 +31,25 @@ __global__ __launch_bounds__(256) void dc_ce_reduce_kernel(const float* __restri
       l[k] = (k < K) ? lp[(long long)k * spatial + v] : -INFINITY;
       m = fmaxf(m, l[k]);
     }
+    const int t = (int)tp_[v];
+    // cross entropy as torch's log_softmax forms it: (l_t - max) - log(sum exp(l - max)); -log(p_t) would turn into +Inf where
+    // p_t underflows (logits apart by more than ~100: large InstanceNorm weights) although the loss is finite
+    float lt = (unsigned)t < (unsigned)K ? 0.f : NAN;     // label outside [0, K): torch's CrossEntropyLoss raises; here the loss turns NaN
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < KB; ++k) {
+      if (k == t) lt = l[k] - m;
       l[k] = (k < K) ? expf(l[k] - m) : 0.f;
       s += l[k];
     }
     const float inv = 1.f / s;
-    const int t = (int)tp_[v];
-    float pt = (unsigned)t < (unsigned)K ? 0.f : NAN;     // label outside [0, K): torch's CrossEntropyLoss raises; here the loss turns NaN
 #pragma unroll
     for (int k = 0; k < KB; ++k) {
       const float pk = l[k] * inv;
-      if (k == t) { tp[k] += pk; fn[k] += 1.f - pk; pt = pk; }
+      if (k == t) { tp[k] += pk; fn[k] += 1.f - pk; }
       else fp[k] += pk;
     }
-    ce -= (double)logf(pt);
+    ce -= (double)(lt - logf(s));
     if ((++it & 31) == 0) {
 #pragma unroll
       for (int k = 0; k < KB; ++k) {

@@ -295,12 +295,19 @@ def test_whole_net_with_large_activations_stays_finite_and_on_the_matrix_pipe(wh
     leaves = {n: p.clone().requires_grad_(True) for n, p in params.items()}
     ref = oracle.forward(spec, leaves, x)
     ref_loss = oracle.deep_supervision_loss(ref, targets, w, False)
-    for i, (o, r) in enumerate(zip(outs, ref)):
-        sc = max(1.0, float(r.detach().abs().max()))
+    with torch.no_grad():
+        ref64 = oracle.forward(spec, {n: p.double() for n, p in params.items()}, x.double())
+    for i, (o, r, r64) in enumerate(zip(outs, ref, ref64)):
+        sc = max(1.0, float(r64.abs().max()))
         err = float((o.cpu() - r.detach()).abs().max())
-        print("[%s] head %d: max |logit| %.3e, max |dlogit| %.3e" % (what, i, sc, err))
-        assert err <= 1e-4 * sc, (i, err, sc)
-    assert abs(loss.item() - ref_loss.item()) <= 1e-4 * max(1.0, abs(ref_loss.item()))
+        e64 = float((o.cpu().double() - r64).abs().max())
+        c64 = float((r.detach().double() - r64).abs().max())
+        print("[%s] head %d: max |logit| %.3e, engine-cpu32 %.3e, engine-fp64 %.3e, cpu32-fp64 %.3e" % (what, i, sc, err, e64, c64))
+        # 1e-4 of the logit scale where fp32 defines the logits that well ('gamma50', 'in1e6': measured 1e-5); the 'up1e3' network
+        # amplifies every rounding by ~2 per block (un-normalised sources 1e3 x their normalised neighbours: the fp32 CPU path itself
+        # ends 4e-3 from fp64, tools/scratch/range_diag.py) -- there the engine has to stay in the CPU path's noise class
+        assert e64 <= max(1e-4 * sc, 10.0 * c64), (i, e64, c64, sc)
+    assert abs(loss.item() - ref_loss.item()) <= max(1e-4, 10.0 * abs(ref_loss.item() - float(oracle.deep_supervision_loss(ref64, targets, w, False)))) * max(1.0, abs(ref_loss.item()))
     check_grads_same_branches(eng, spec, params, x, targets, w, shapes)
 
 

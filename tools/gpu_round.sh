@@ -18,7 +18,7 @@ cd $R
 mkdir -p gpurun_out/$TAG
 while [ $# -gt 0 ]; do
   case $1 in
-    tests)  timeout 1500 python -m pytest tests -m gpu -x -q --tb=short -rs 2>&1 | grep -v "curr_density\|amdgpu.ids" | tail -150 > gpurun_out/$TAG/tests.log ;;
+    tests)  timeout 1500 python -m pytest tests -m gpu -q --tb=short -rs 2>&1 | grep -v "curr_density\|amdgpu.ids" | tail -150 > gpurun_out/$TAG/tests.log ;;
     ktests) shift; timeout 1500 python -m pytest tests -m gpu -x -q --tb=short -k "$1" 2>&1 | grep -v "curr_density\|amdgpu.ids" | tail -150 > gpurun_out/$TAG/ktests.log ;;
     bench)  timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench.err ;;
     prof)   bash tools/prof_bench.sh $TAG 2>&1 | tail -20 > gpurun_out/$TAG/prof.log ;;
