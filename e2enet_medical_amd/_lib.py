@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("E2E_LIB_PATH") or os.path.join(_HERE, "csrc", "libe2e
 KNOWN_ENV = frozenset({
     # library (csrc/*.hip)
     "E2E_CONV_MM", "E2E_MM_GRID", "E2E_MM_GEOM", "E2E_CONV_DENSE", "E2E_CONV_SPARSE2", "E2E_CONV_PERSIST", "E2E_CONV_WGS",
-    "E2E_CONV_KSPLIT", "E2E_WG_H2", "E2E_WG_BF3", "E2E_CT_BF3",
+    "E2E_CONV_KSPLIT", "E2E_WG_H2", "E2E_WG_BF3", "E2E_CT_BF3", "E2E_CT_H2",
     # diagnostic builds of the library only (-DE2E_CONV_DEBUG / -DMM_STAMPS); ignored by the shipped build
     "E2E_CONV_DBG", "E2E_MM_STAMPS",
     # host side
@@ -122,7 +122,8 @@ SIGNATURES = {
     "e2e_conv133_fwd_dense": (I, [P, I, P, P, P, P, P, I, I, I, I, I, P, LL, P]),
     "e2e_conv133_mm_ws_bytes": (LL, [I, I, I, I, I, I, I, I, I]),
     "e2e_conv133_mm_pack": (I, [P, I, LL, P]),
-    "e2e_conv133_input_ranges": (I, [P, I, P]),
+    "e2e_conv133_input_ranges_ws_bytes": (LL, [I]),
+    "e2e_conv133_input_ranges": (I, [P, I, P, P]),
     "e2e_absmax_word": (I, [P, LL, P, P]),
     "e2e_conv133_fwd_mm": (I, [P, I, P, P, P, P, P, P, I, I, I, I, I, P]),
     "e2e_conv133_dgrad_mm": (I, [P, P, P, P, P, I, I, I, I, I, I, P]),
@@ -132,11 +133,12 @@ SIGNATURES = {
     "e2e_diag_split_gemm": (I, [P, P, P, I, I, P, P]),
     "e2e_diag_kernel_clock": (I, [I, P, P, I]),
     "e2e_in_stats_finalize": (I, [P, I, P, P, F, P, P, P, P, I, I, P]),
+    "e2e_in_lrelu_bwd_ws_doubles": (LL, [I, I]),
     "e2e_in_lrelu_bwd": (I, [P, P, P, P, P, P, P, F, P, P, P, P, I, I, LL, P, I, P, P]),
-    "e2e_convT_fwd": (I, [P, P, P, F, P, P, P, I, I, I, I, I, I, I, I, I, P]),
-    "e2e_convT_dgrad": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
+    "e2e_convT_fwd": (I, [P, P, P, F, P, P, P, I, I, I, I, I, I, I, I, I, P, P, P]),
+    "e2e_convT_dgrad": (I, [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, P, P, P]),
     "e2e_convT_wgrad_ws_bytes": (LL, [I, I, I, I, I, I, I, I, I]),
-    "e2e_convT_wgrad": (I, [P, P, P, F, P, P, P, I, I, I, I, I, I, I, I, I, P]),
+    "e2e_convT_wgrad": (I, [P, P, P, F, P, P, P, I, I, I, I, I, I, I, I, I, P, P, P, P]),
     "e2e_maxpool_fwd": (I, [P, P, P, F, P, I, I, I, I, I, I, I, I, P]),
     "e2e_maxpool_bwd_num_records": (I, [I, I, I, I, I, I]),
     "e2e_maxpool_bwd": (I, [P, P, P, F, P, P, I, I, I, I, I, I, I, I, I, P, P, P, P]),
@@ -182,7 +184,7 @@ SIGNATURES = {
 }
 
 _NO_STATUS = {"e2e_last_error", "e2e_abi_version", "e2e_last_kernel", "e2e_conv133_num_partials", "e2e_conv133_wgrad_ws_bytes", "e2e_conv133_dense_ws_bytes", "e2e_conv133_mm_ws_bytes", "e2e_conv133_sparse_eligible", "e2e_conv133_sparse_wpk_floats", "e2e_maxpool_bwd_num_records", "e2e_conv133_fwd_ws_bytes", "e2e_conv133_dgrad_ws_bytes",
-              "e2e_convT_wgrad_ws_bytes", "e2e_head1x1_wgrad_ws_bytes", "e2e_loss_ws_bytes", "e2e_aug_stats_ws_bytes"}
+              "e2e_convT_wgrad_ws_bytes", "e2e_conv133_input_ranges_ws_bytes", "e2e_in_lrelu_bwd_ws_doubles", "e2e_head1x1_wgrad_ws_bytes", "e2e_loss_ws_bytes", "e2e_aug_stats_ws_bytes"}
 
 
 class E2EError(RuntimeError):

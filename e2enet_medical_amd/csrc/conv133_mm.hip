@@ -490,6 +490,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
 
     using R0 = std::integral_constant<int, 0>; using R1 = std::integral_constant<int, 1>;
+    const bool w_resident = p.nchunks == 2 && p.qblocks == 1;         // (wave-uniform)
     // prologue: chunk 0 requested and staged, chunk 1 in flight
     Cur q1{0, 0, decode(0)};                                  // the chunk being converted (s + 1 inside the loop)
     Cur q2 = q1;                                              // the chunk being requested (s + 2)
@@ -509,7 +510,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       q1 = q2;                                                // chunk s + 1 (requested last iteration into set PAR ^ 1)
       advance(q2);                                            // chunk s + 2 -> set PAR
       MMT(t0);
-      request_w(q1, PAR ^ 1);
+      // layers of two chunks and one out-channel block (32 -> 32 at full resolution, both directions): the two weight buffers hold
+      // the layer's whole packed tensor from the second chunk on -- no weight request at all after that (18 KB of the ~67 KB a
+      // chunk moves through the CU's memory path: the path is what bounds this kernel)
+      if (!(w_resident && s >= 1)) request_w(q1, PAR ^ 1);
       MMT(t1);
       // table of the item after q1's, written while q1's first chunk is converted: a barrier before its first reader (nchunks >= 2);
       // LDS-to-LDS (no global load: a branch around a load would cost the exact vmcnt distances of this loop)
@@ -837,48 +841,86 @@ static bool mm_fits(int geom, int B, int Cin, int Cout) {
 //           voxels of an instance (biased variance, rstd <= 1 / sigma)  =>  |x| <= |gamma_c| sqrt(N - 1) + |beta_c|
 //   kind 2  transposed conv (k = stride, no bias) of a normalised source: |z[o, 2v + k]| <= sum_c bound_c |W[c, o, k]|, max over (o, k)
 //   kind 3  a tensor whose max |x| somebody measured (the network input: e2e_absmax_word)
+//   kind 4  max |w| of a weight tensor (the transposed convs split their weights inside the kernels)
+//   kind 5  max_c sum_{o, tap} |w[o, c, tap]| over a channel range of a conv: x max |dy| (recorded at run time) it bounds the conv's
+//           data gradient w.r.t. those channels -- the dy of the transposed conv that produced them
 // The result (bit pattern of a float, 2^-10 relative head room for the fp32 rounding of fma(y, a, b)) is what e2e_conv133_fwd_mm and
 // e2e_conv133_wgrad take as x_absmax.  How tight: sqrt(N - 1) is 2^10.5 above a typical |xhat| ~ 1 at 128^3, which leaves typical
 // values at 2^4 after scaling -- lo pieces normal down to 2^-7 of typical, an absolute error of 2^-25 / 2^4 below that (fp32 eps of
 // typical: 2^-24); at the benchmarked configuration the derived exponent is the 3 that rounds 5 hard-coded.
-__global__ __launch_bounds__(256) void input_ranges_kernel(const e2e_range_job_t* __restrict__ jobs) {
+// Two launches: (job, part) workgroups leave partial maxima in the workspace (plain stores), one workgroup per job folds them.
+// RANGE_PARTS workgroups share the long reductions (a 320 x 320 x 8 transposed-conv weight is 3.3 MB: one workgroup needs 250 us).
+constexpr int RANGE_PARTS = 16;
+__global__ __launch_bounds__(256) void input_ranges_kernel(const e2e_range_job_t* __restrict__ jobs, float* __restrict__ ws) {
   const e2e_range_job_t jb = jobs[blockIdx.x];
+  const int part = blockIdx.y;
   __shared__ float red[4];
-  __shared__ float cb[1024];                                  // per-channel bounds of a kind-2 source (Cin <= 1024)
-  float best = 0.f;                                           // (thread 0's value is the job's)
+  __shared__ float cb[1024];                                  // per-channel bounds of a kind-2 source (C <= 1024)
   for (int si = 0; si < 3; ++si) {
     const e2e_range_src_t s = jb.src[si];
     float m = 0.f;
     if (s.kind == 1 || s.kind == 2) {
       const float root = sqrtf((float)(s.N > 1 ? s.N - 1 : 1));
       if (s.kind == 1) {
-        for (int c = threadIdx.x; c < s.C; c += 256) {
-          const float b = fmaf(fabsf(s.gamma[c]), root, fabsf(s.beta[c]));
-          m = (b == b) ? fmaxf(m, b) : __builtin_inff();
-        }
+        if (part == 0)
+          for (int c = threadIdx.x; c < s.C; c += 256) {
+            const float b = fmaf(fabsf(s.gamma[c]), root, fabsf(s.beta[c]));
+            m = (b == b) ? fmaxf(m, b) : __builtin_inff();
+          }
       } else {
         for (int c = threadIdx.x; c < s.C; c += 256) cb[c] = fmaf(fabsf(s.gamma[c]), root, fabsf(s.beta[c]));
         __syncthreads();
         const int cols = s.wCout * s.wks;                     // W [C][wCout][wks]
-        for (int col = threadIdx.x; col < cols; col += 256) {
-          float acc = 0.f;
-          for (int c = 0; c < s.C; ++c) acc = fmaf(cb[c], fabsf(s.w[(long long)c * cols + col]), acc);
+        for (int col = part * 256 + threadIdx.x; col < cols; col += RANGE_PARTS * 256) {
+          float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;       // (independent chains: the loads of four channels in flight)
+          int c = 0;
+          for (; c + 3 < s.C; c += 4) {
+            a0 = fmaf(cb[c], fabsf(s.w[(long long)c * cols + col]), a0);
+            a1 = fmaf(cb[c + 1], fabsf(s.w[(long long)(c + 1) * cols + col]), a1);
+            a2 = fmaf(cb[c + 2], fabsf(s.w[(long long)(c + 2) * cols + col]), a2);
+            a3 = fmaf(cb[c + 3], fabsf(s.w[(long long)(c + 3) * cols + col]), a3);
+          }
+          for (; c < s.C; ++c) a0 = fmaf(cb[c], fabsf(s.w[(long long)c * cols + col]), a0);
+          const float acc = (a0 + a1) + (a2 + a3);
           m = (acc == acc) ? fmaxf(m, acc) : __builtin_inff();
         }
         __syncthreads();
       }
     } else if (s.kind == 3) {
-      if (threadIdx.x == 0) m = __builtin_bit_cast(float, *s.word);
+      if (part == 0 && threadIdx.x == 0) m = __builtin_bit_cast(float, *s.word);
       if (!(m == m)) m = __builtin_inff();
+    } else if (s.kind == 4) {                                 // max |w| over N floats (transposed-conv weights)
+      for (long long i = (long long)part * 256 + threadIdx.x; i < s.N; i += RANGE_PARTS * 256) {
+        const float v = s.w[i];
+        m = (v == v) ? fmaxf(m, fabsf(v)) : __builtin_inff();
+      }
+    } else if (s.kind == 5) {
+      // what a conv's data gradient can reach per unit of max |dy|: max over the input channels c in [C, C + wks) of
+      // sum_{o, tap} |w[o][c][tap]| (w [wCout][Cin = (int)N][9]); the gradient buffer of those channels is bounded by this x max |dy|
+      const int Cin = (int)s.N;
+      for (int c = s.C + part * 256 + threadIdx.x; c < s.C + s.wks; c += RANGE_PARTS * 256) {
+        float acc = 0.f;
+        for (int o = 0; o < s.wCout; ++o) {
+          const float* wp = s.w + ((long long)o * Cin + c) * 9;
+#pragma unroll
+          for (int t = 0; t < 9; ++t) acc += fabsf(wp[t]);
+        }
+        m = (acc == acc) ? fmaxf(m, acc) : __builtin_inff();
+      }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    best = fmaxf(best, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    if (threadIdx.x == 0) ws[((long long)blockIdx.x * 3 + si) * RANGE_PARTS + part] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     __syncthreads();
   }
-  if (threadIdx.x == 0) *jb.out = __builtin_bit_cast(unsigned, best * (1.f + 0x1p-10f));
+}
+__global__ __launch_bounds__(64) void input_ranges_fold_kernel(const e2e_range_job_t* __restrict__ jobs, const float* __restrict__ ws) {
+  float m = threadIdx.x < 3 * RANGE_PARTS ? ws[(long long)blockIdx.x * 3 * RANGE_PARTS + threadIdx.x] : 0.f;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if (threadIdx.x == 0) *jobs[blockIdx.x].out = __builtin_bit_cast(unsigned, m * (1.f + 0x1p-10f));
 }
 
 __global__ __launch_bounds__(256) void absmax_word_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ word) {
@@ -892,9 +934,12 @@ __global__ __launch_bounds__(256) void absmax_word_kernel(const float* __restric
   if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(word, __builtin_bit_cast(unsigned, m));   // non-negative floats order like their bit patterns
 }
 
-extern "C" int e2e_conv133_input_ranges(const e2e_range_job_t* jobs, int njobs, void* stream) {
-  E2E_REQUIRE(jobs != nullptr && njobs > 0, "conv133_input_ranges: bad arguments");
-  hipLaunchKernelGGL(input_ranges_kernel, dim3(njobs), dim3(256), 0, (hipStream_t)stream, jobs);
+extern "C" long long e2e_conv133_input_ranges_ws_bytes(int njobs) { return (long long)njobs * 3 * RANGE_PARTS * (long long)sizeof(float); }
+
+extern "C" int e2e_conv133_input_ranges(const e2e_range_job_t* jobs, int njobs, void* ws, void* stream) {
+  E2E_REQUIRE(jobs != nullptr && njobs > 0 && ws != nullptr, "conv133_input_ranges: bad arguments");
+  hipLaunchKernelGGL(input_ranges_kernel, dim3(njobs, RANGE_PARTS), dim3(256), 0, (hipStream_t)stream, jobs, reinterpret_cast<float*>(ws));
+  hipLaunchKernelGGL(input_ranges_fold_kernel, dim3(njobs), dim3(64), 0, (hipStream_t)stream, jobs, reinterpret_cast<const float*>(ws));
   return e2e::check_launch("input_ranges_kernel");
 }
 

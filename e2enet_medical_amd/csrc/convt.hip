@@ -446,15 +446,102 @@ __device__ __forceinline__ void split3(float v, unsigned& h, unsigned& m, unsign
 // (S1 >> 16) | (S0 & 0xffff0000): the bf16 (truncated) pieces of two values in one word, `lo` in the low half
 __device__ __forceinline__ unsigned pack_hi16(unsigned lo, unsigned hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
 
+// ---- round 6: the same three GEMMs with fp16 TWO-piece operands (NP = 2: three products per fp32 product instead of six; NP = 3
+// keeps the bf16 three-piece form).  x = hi + lo, hi = rn16(x), lo = rn16(x - hi): 11 + 11 significant bits, products lo*hi +
+// hi*lo + hi*hi through v_mfma_f32_16x16x32_f16, fp32 accumulation (conv133_mm.hip, conv133_wgrad_bf3.hip; numerics gate:
+// tests/test_gpu_ops.py::test_split_operand_products_vs_fp64).  fp16 has 5 exponent bits, so every operand is moved into range by
+// an exact power of two taken from a device word (bit pattern of a bound of max |operand|): the activations from the bound
+// e2e_conv133_input_ranges derives from the producer's InstanceNorm parameters, the weights from their measured maximum, dy from
+// max |dy of the consuming conv| x the L1 norm of that conv's weights over this tensor's channels.  Without the words a launch
+// stays on the bf16 form (8 exponent bits: no range to manage).
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_ct __attribute__((ext_vector_type(2)));
+typedef float f32x2_ct __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2_pair(float a, float b, unsigned& hw, unsigned& lw) {
+  const f16x2_ct h2 = __builtin_convertvector((f32x2_ct{a, b}), f16x2_ct);
+  hw = __builtin_bit_cast(unsigned, h2);
+  // lo = rn16(v - hi) as ONE mixed-precision FMA per value: fma(hi as f16, -1, v) is exact in fp32, rounded to fp16 into the low / high half
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(lw) : "v"(hw), "v"(a), "v"(b));
+}
+// the NP packed words (two values each: `a` in the low half) of a value pair, piece p at dst + p * pstride
+template <int NP>
+__device__ __forceinline__ void store_pair(unsigned char* dst, int pstride, float a, float b) {
+  if constexpr (NP == 2) {
+    unsigned hw, lw;
+    split2_pair(a, b, hw, lw);
+    *reinterpret_cast<unsigned*>(dst) = hw;
+    *reinterpret_cast<unsigned*>(dst + pstride) = lw;
+  } else {
+    unsigned ha, ma, la, hb, mb, lb;
+    split3(a, ha, ma, la);
+    split3(b, hb, mb, lb);
+    *reinterpret_cast<unsigned*>(dst) = pack_hi16(ha, hb);
+    *reinterpret_cast<unsigned*>(dst + pstride) = pack_hi16(ma, mb);
+    *reinterpret_cast<unsigned*>(dst + 2 * pstride) = pack_hi16(la, lb);
+  }
+}
+// a fragment of eight values held in registers (weights): piece p -> out[p]
+template <int NP>
+__device__ __forceinline__ void split_frag(const float (&v)[8], bf16x8_t (&out)[NP]) {
+  if constexpr (NP == 2) {
+    unsigned hw[4], lw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split2_pair(v[2 * j], v[2 * j + 1], hw[j], lw[j]);
+    out[0] = __builtin_bit_cast(bf16x8_t, u32x4_t{hw[0], hw[1], hw[2], hw[3]});
+    out[1] = __builtin_bit_cast(bf16x8_t, u32x4_t{lw[0], lw[1], lw[2], lw[3]});
+  } else {
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) split3(v[j], h[j], m[j], l[j]);
+    out[0] = __builtin_bit_cast(bf16x8_t, u32x4_t{pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]), pack_hi16(h[4], h[5]), pack_hi16(h[6], h[7])});
+    out[1] = __builtin_bit_cast(bf16x8_t, u32x4_t{pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]), pack_hi16(m[4], m[5]), pack_hi16(m[6], m[7])});
+    out[2] = __builtin_bit_cast(bf16x8_t, u32x4_t{pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]), pack_hi16(l[4], l[5]), pack_hi16(l[6], l[7])});
+  }
+}
+// acc += A B rebuilt from the pieces: small terms first
+template <int NP>
+__device__ __forceinline__ f32x4 mma_pieces(const bf16x8_t (&a)[NP], const bf16x8_t (&b)[NP], f32x4 c) {
+  if constexpr (NP == 2) {
+    const f16x8_t a0 = __builtin_bit_cast(f16x8_t, a[0]), a1 = __builtin_bit_cast(f16x8_t, a[1]);
+    const f16x8_t b0 = __builtin_bit_cast(f16x8_t, b[0]), b1 = __builtin_bit_cast(f16x8_t, b[1]);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b0, c, 0, 0, 0);      // lo * hi
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b1, c, 0, 0, 0);      // hi * lo
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, c, 0, 0, 0);      // hi * hi
+  } else {
+    // lo*hi, mid*mid, hi*lo, then mid*hi, hi*mid, then hi*hi
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], c, 0, 0, 0);
+  }
+  return c;
+}
+// exponent k of the power of two that moves a tensor bounded by the product of the floats whose bit patterns are *wa and *wb (either
+// may be null = 1) into [2^14, 2^15): k = 141 - E, clamped to +-100 (2^k and 2^-k normal); a zero bound takes E = 1, Inf / NaN propagate
+__device__ __forceinline__ int ct_scale_exp(const unsigned* wa, const unsigned* wb) {
+  float b = 1.f;
+  if (wa != nullptr) b *= __builtin_bit_cast(float, __builtin_nontemporal_load(wa));
+  if (wb != nullptr) b *= __builtin_bit_cast(float, __builtin_nontemporal_load(wb));
+  int E = (int)((__builtin_bit_cast(unsigned, b) >> 23) & 0xffu);
+  E = E < 1 ? 1 : E;
+  const int k = 141 - E;
+  return k > 100 ? 100 : (k < -100 ? -100 : k);
+}
+__device__ __forceinline__ float ct_pow2(int k) { return __builtin_bit_cast(float, (unsigned)(127 + k) << 23); }
+
 // TPX = input voxels per tile: 64 (one 138 KB workgroup per CU) or, for KDH = 4, 32: two 77 KB workgroups per CU, one converting
 // and committing its tile while the other issues its matrix instructions (the phases of ONE workgroup are serial: commit, barrier,
 // matrix phase, barrier, with a single LDS image).
-template <int KDH, int NCB, int TPX>     // KDH = kd * kh (output rows per input voxel row), KT = 2 * KDH
+template <int KDH, int NCB, int TPX, int NP>     // KDH = kd * kh (output rows per input voxel row), KT = 2 * KDH; NP pieces per operand
 __global__ __launch_bounds__(256 * NCB, TPX == 32 ? 2 : 1) void convT_wgrad_bf3_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                                    const float* __restrict__ shift, float slope,
                                                                    const float* __restrict__ dy, float* __restrict__ slab,
                                                                    int B, int Cin, int Cout, int D, int H, int W, int kd, int kh,
-                                                                   int tiles_per_chunk, int cgroups) {
+                                                                   int tiles_per_chunk, int cgroups, const unsigned* __restrict__ x_word,
+                                                                   const unsigned* __restrict__ dy_word_a, const unsigned* __restrict__ dy_word_b) {
   constexpr int KT = 2 * KDH;
   constexpr int RS = TPX * 2 + 16;                     // bytes per staged row (TPX voxels bf16 + 16: odd multiple of 16, conflict-free b128)
   constexpr int ZG = TPX / 4;                          // float4 groups per input channel row
@@ -464,9 +551,12 @@ __global__ __launch_bounds__(256 * NCB, TPX == 32 ? 2 : 1) void convT_wgrad_bf3_
   constexpr int YCW = 32 / (4 * NCB);                  // dy channels staged per wave
   constexpr int YIT = KDH * VP / 64;                   // wave iterations per dy channel (KDH rows x VP voxel pairs)
   static_assert((KDH == 2 || KDH == 4) && (TPX == 64 || (TPX == 32 && KDH == 4)), "kd*kh in {2,4}; 32-voxel tiles for kd*kh = 4");
-  static_assert((TPX == 32 ? 2 : 1) * 3 * (NCB * 32 + 2 * KDH * 32) * RS <= 163840, "LDS budget");
-  __shared__ __attribute__((aligned(16))) unsigned char zs[3 * ZP];     // [piece][channel][voxel] bf16
-  __shared__ __attribute__((aligned(16))) unsigned char ds[3 * YP];     // [piece][tap][out channel][voxel] bf16
+  static_assert((TPX == 32 ? 2 : 1) * NP * (NCB * 32 + 2 * KDH * 32) * RS <= 163840, "LDS budget");
+  __shared__ __attribute__((aligned(16))) unsigned char zs[NP * ZP];     // [piece][channel][voxel] bf16 / fp16
+  __shared__ __attribute__((aligned(16))) unsigned char ds[NP * YP];     // [piece][tap][out channel][voxel]
+  // fp16 two-piece form: operand scales 2^kx (activations) and 2^ky (dy), the slab un-scaled by the two exact factors
+  const int kx = NP == 2 ? ct_scale_exp(x_word, nullptr) : 0, ky = NP == 2 ? ct_scale_exp(dy_word_a, dy_word_b) : 0;
+  const float xsc = ct_pow2(kx), ysc = ct_pow2(ky), unx = ct_pow2(-kx), uny = ct_pow2(-ky);
 
   const int chunk = blockIdx.x;
   const int cg = blockIdx.y % cgroups, ob = blockIdx.y / cgroups;
@@ -587,16 +677,15 @@ __global__ __launch_bounds__(256 * NCB, TPX == 32 ? 2 : 1) void convT_wgrad_bf3_
       const long long vi = vbase + (g % ZG) * 4;
       const bool ok = cbase + cl < Cin && vi + 3 < spatial;
       unsigned char* dst = zs + cl * RS + (g % ZG) * 8;
-      unsigned h[4], m[4], l[4];
+      float tz[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float t = vz[it][j];
         if (scale != nullptr) t = e2e::in_act(t, za[it], zb[it], slope);
-        split3(ok ? t : 0.f, h[j], m[j], l[j]);
+        tz[j] = ok ? (NP == 2 ? t * xsc : t) : 0.f;
       }
-      *reinterpret_cast<uint2*>(dst) = make_uint2(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]));
-      *reinterpret_cast<uint2*>(dst + ZP) = make_uint2(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]));
-      *reinterpret_cast<uint2*>(dst + 2 * ZP) = make_uint2(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]));
+      store_pair<NP>(dst, ZP, tz[0], tz[1]);
+      store_pair<NP>(dst + 4, ZP, tz[2], tz[3]);
     }
 #pragma unroll
     for (int k = 0; k < YCW; ++k) {
@@ -606,18 +695,13 @@ __global__ __launch_bounds__(256 * NCB, TPX == 32 ? 2 : 1) void convT_wgrad_bf3_
         const int g = lane + 64 * it;
         const int rr = g / VP, vp = g % VP;
         const bool ok = ob * 32 + ol < Cout && vbase + 2 * vp + 1 < spatial;
-        const f32x4_t q = vy[k][it];                  // (k=0,v) (k=1,v) (k=0,v+1) (k=1,v+1)
-        unsigned h[4], m[4], l[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) split3(ok ? q[j] : 0.f, h[j], m[j], l[j]);
+        f32x4_t q = vy[k][it];                        // (k=0,v) (k=1,v) (k=0,v+1) (k=1,v+1)
+        if (!ok) q = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (NP == 2) q *= ysc;
         unsigned char* d0 = ds + ((rr * 2 + 0) * 32 + ol) * RS + 4 * vp;      // tap (rr, 0): voxels 2 vp, 2 vp + 1
         unsigned char* d1 = ds + ((rr * 2 + 1) * 32 + ol) * RS + 4 * vp;
-        *reinterpret_cast<unsigned*>(d0) = pack_hi16(h[0], h[2]);
-        *reinterpret_cast<unsigned*>(d1) = pack_hi16(h[1], h[3]);
-        *reinterpret_cast<unsigned*>(d0 + YP) = pack_hi16(m[0], m[2]);
-        *reinterpret_cast<unsigned*>(d1 + YP) = pack_hi16(m[1], m[3]);
-        *reinterpret_cast<unsigned*>(d0 + 2 * YP) = pack_hi16(l[0], l[2]);
-        *reinterpret_cast<unsigned*>(d1 + 2 * YP) = pack_hi16(l[1], l[3]);
+        store_pair<NP>(d0, YP, q[0], q[2]);
+        store_pair<NP>(d1, YP, q[1], q[3]);
       }
     }
   };
@@ -645,23 +729,15 @@ __global__ __launch_bounds__(256 * NCB, TPX == 32 ? 2 : 1) void convT_wgrad_bf3_
       const unsigned char* bp = ds + (oh * 16 + li) * RS + lk * 16;
 #pragma unroll
       for (int kb = 0; kb < TPX / 32; ++kb) {
-        bf16x8_t af[3];
+        bf16x8_t af[NP];
 #pragma unroll
-        for (int sp = 0; sp < 3; ++sp) af[sp] = *reinterpret_cast<const bf16x8_t*>(ap + sp * ZP + kb * 64);
+        for (int sp = 0; sp < NP; ++sp) af[sp] = *reinterpret_cast<const bf16x8_t*>(ap + sp * ZP + kb * 64);
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
-          bf16x8_t bf[3];
+          bf16x8_t bf[NP];
 #pragma unroll
-          for (int sp = 0; sp < 3; ++sp) bf[sp] = *reinterpret_cast<const bf16x8_t*>(bp + sp * YP + t * 32 * RS + kb * 64);
-          f32x4 a = acc[t];
-          // small terms first: lo*hi, mid*mid, hi*lo, then mid*hi, hi*mid, then hi*hi
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bf[0], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[1], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[2], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[0], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[1], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[0], a, 0, 0, 0);
-          acc[t] = a;
+          for (int sp = 0; sp < NP; ++sp) bf[sp] = *reinterpret_cast<const bf16x8_t*>(bp + sp * YP + t * 32 * RS + kb * 64);
+          acc[t] = mma_pieces<NP>(af, bf, acc[t]);
         }
       }
       CSTAMP();
@@ -683,7 +759,7 @@ __global__ __launch_bounds__(256 * NCB, TPX == 32 ? 2 : 1) void convT_wgrad_bf3_
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int c = cbase + cbl * 32 + ch * 16 + (lane >> 4) * 4 + r;
-      if (c < Cin && o < Cout) sp[((long long)c * Cout + o) * KT + t] = acc[t][r];
+      if (c < Cin && o < Cout) sp[((long long)c * Cout + o) * KT + t] = NP == 2 ? acc[t][r] * unx * uny : acc[t][r];
     }
 }
 
@@ -961,12 +1037,13 @@ __global__ __launch_bounds__(256) void convT_dgrad_v3_kernel(const float* __rest
 //     tile for all columns of the workgroup (4 waves x 8 / NKB x 16 columns); the next tile's loads fly during the matrix phase;
 //   * D[voxel][column]: a lane holds 4 consecutive voxels of one (o, i, j, k) column; the k = 0 / 1 columns are neighbouring
 //     lanes, so one DPP pair swap turns them into two aligned float4 stores of the interleaved output row.
-template <int KDH, int NKB>
+template <int KDH, int NKB, int NP>
 __global__ __launch_bounds__(256, 2) void convT_fwd_bf3_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, float slope,
                                                                const float* __restrict__ w, const unsigned* __restrict__ live,
                                                                float* __restrict__ y, int B, int Cin,
-                                                               int Cout, int D, int H, int W, int kd, int kh, int tiles_per_wg) {
+                                                               int Cout, int D, int H, int W, int kd, int kh, int tiles_per_wg,
+                                                               const unsigned* __restrict__ x_word, const unsigned* __restrict__ w_word) {
   constexpr int KT = 2 * KDH;
   constexpr int TV = 32;
   constexpr int K = NKB * 32;
@@ -974,7 +1051,9 @@ __global__ __launch_bounds__(256, 2) void convT_fwd_bf3_kernel(const float* __re
   constexpr int RS = K * 2 + 16;                        // bytes per staged voxel and piece (odd multiple of 16)
   constexpr int PSZ = TV * RS;
   constexpr int NRD = K / 64;                           // staging rounds: 256 threads x (2 channels x 4 voxels)
-  __shared__ __attribute__((aligned(16))) unsigned char zs[3 * PSZ];
+  __shared__ __attribute__((aligned(16))) unsigned char zs[NP * PSZ];
+  const int kx = NP == 2 ? ct_scale_exp(x_word, nullptr) : 0, kwt = NP == 2 ? ct_scale_exp(w_word, nullptr) : 0;
+  const float xsc = ct_pow2(kx), wsc = ct_pow2(kwt), unx = ct_pow2(-kx), unw = ct_pow2(-kwt);
 
   const long long spatial = (long long)D * H * W;
   const long long tiles_per_n = spatial / TV;
@@ -992,7 +1071,7 @@ __global__ __launch_bounds__(256, 2) void convT_fwd_bf3_kernel(const float* __re
   if (tile_lo >= tile_hi) return;
 
   // B fragments: column n = col0 + 16 nt + li = (o, t), k = 32 kb + 8 lk + j = input channel
-  bf16x8_t bfr[NTW][NKB][3];
+  bf16x8_t bfr[NTW][NKB][NP];
   long long coff[NTW];                                   // offset of the column's output row origin inside a sample
   bool cok[NTW];
 #pragma unroll
@@ -1005,16 +1084,14 @@ __global__ __launch_bounds__(256, 2) void convT_fwd_bf3_kernel(const float* __re
     coff[nt] = (long long)o * ospatial + ((long long)ii * Ho + jj) * Wo + 4 * kk;   // + 4 kk: the second float4 of the pair
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-      unsigned h[8], m[8], l[8];
+      float wv[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int c = kb * 32 + lk * 8 + j;
-        const float wv = (cok[nt] && c < Cin && ct_alive_cols(live, Cin, c, o)) ? w[((long long)c * Cout + o) * KT + t] : 0.f;
-        split3(wv, h[j], m[j], l[j]);
+        wv[j] = (cok[nt] && c < Cin && ct_alive_cols(live, Cin, c, o)) ? w[((long long)c * Cout + o) * KT + t] : 0.f;
+        if (NP == 2) wv[j] *= wsc;
       }
-      bfr[nt][kb][0] = __builtin_bit_cast(bf16x8_t, u32x4_t{pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]), pack_hi16(h[4], h[5]), pack_hi16(h[6], h[7])});
-      bfr[nt][kb][1] = __builtin_bit_cast(bf16x8_t, u32x4_t{pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]), pack_hi16(m[4], m[5]), pack_hi16(m[6], m[7])});
-      bfr[nt][kb][2] = __builtin_bit_cast(bf16x8_t, u32x4_t{pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]), pack_hi16(l[4], l[5]), pack_hi16(l[6], l[7])});
+      split_frag<NP>(wv, bfr[nt][kb]);
     }
   }
 
@@ -1039,7 +1116,7 @@ __global__ __launch_bounds__(256, 2) void convT_fwd_bf3_kernel(const float* __re
   auto commit = [&]() {
 #pragma unroll
     for (int r = 0; r < NRD; ++r) {
-      unsigned h[2][4], m[2][4], l[2][4];
+      float tz[2][4];
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const bool ok = r * 64 + cp * 2 + e < Cin;
@@ -1047,16 +1124,12 @@ __global__ __launch_bounds__(256, 2) void convT_fwd_bf3_kernel(const float* __re
         for (int q = 0; q < 4; ++q) {
           float t = vx[r][e][q];
           if (scale != nullptr) t = e2e::in_act(t, za[r][e], zb[r][e], slope);
-          split3(ok ? t : 0.f, h[e][q], m[e][q], l[e][q]);
+          tz[e][q] = ok ? (NP == 2 ? t * xsc : t) : 0.f;
         }
       }
       unsigned char* dst = zs + (vq * 4) * RS + (r * 64 + cp * 2) * 2;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        *reinterpret_cast<unsigned*>(dst + q * RS) = pack_hi16(h[0][q], h[1][q]);
-        *reinterpret_cast<unsigned*>(dst + q * RS + PSZ) = pack_hi16(m[0][q], m[1][q]);
-        *reinterpret_cast<unsigned*>(dst + q * RS + 2 * PSZ) = pack_hi16(l[0][q], l[1][q]);
-      }
+      for (int q = 0; q < 4; ++q) store_pair<NP>(dst + q * RS, PSZ, tz[0][q], tz[1][q]);
     }
   };
 
@@ -1076,21 +1149,11 @@ __global__ __launch_bounds__(256, 2) void convT_fwd_bf3_kernel(const float* __re
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
-        bf16x8_t af[3];
+        bf16x8_t af[NP];
 #pragma unroll
-        for (int sp = 0; sp < 3; ++sp) af[sp] = *reinterpret_cast<const bf16x8_t*>(ap + sp * PSZ + mt * 16 * RS + kb * 64);
+        for (int sp = 0; sp < NP; ++sp) af[sp] = *reinterpret_cast<const bf16x8_t*>(ap + sp * PSZ + mt * 16 * RS + kb * 64);
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-          f32x4 a = acc[mt][nt];
-          // small terms first: lo*hi, mid*mid, hi*lo, then mid*hi, hi*mid, then hi*hi
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bfr[nt][kb][0], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bfr[nt][kb][1], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bfr[nt][kb][2], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bfr[nt][kb][0], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bfr[nt][kb][1], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bfr[nt][kb][0], a, 0, 0, 0);
-          acc[mt][nt] = a;
-        }
+        for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = mma_pieces<NP>(af, bfr[nt][kb], acc[mt][nt]);
       }
     // D: row (voxel) = 16 mt + 4 lk + i, column = lane & 15.  Lanes 2p, 2p + 1 hold taps k = 0, 1 of one (o, i, j): after the
     // pair swap lane k = 0 owns output floats [2 v .. 2 v + 3] and lane k = 1 the next four of the interleaved row.
@@ -1104,7 +1167,8 @@ __global__ __launch_bounds__(256, 2) void convT_fwd_bf3_kernel(const float* __re
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) {
-        const f32x4 a = acc[mt][nt];
+        f32x4 a = acc[mt][nt];
+        if (NP == 2) a = a * unx * unw;
         const float s0 = odd ? a[0] : a[2], s1 = odd ? a[1] : a[3];
         // quad_perm [1, 0, 3, 2]: swap with the neighbouring lane
         const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s0), 0xb1, 0xf, 0xf, true));
@@ -1126,17 +1190,21 @@ __global__ __launch_bounds__(256, 2) void convT_fwd_bf3_kernel(const float* __re
 //   * the dy tile is staged voxel-major, [piece][32 voxels][K bf16 + 16 B] (row stride an odd multiple of 16 B:
 //     conflict-free ds_read_b128 B fragments); a float4 of dy (two voxels x taps (2 rr, 2 rr + 1) of one output channel)
 //     becomes one packed word per voxel and piece; the loads of the next tile are in flight during the matrix phase.
-template <int KDH>
+template <int KDH, int NP>
 __global__ __launch_bounds__(256, 2) void convT_dgrad_bf3_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                                  const unsigned* __restrict__ live_t, float* __restrict__ dx, int accumulate, int B, int Cin, int Cout,
-                                                                 int D, int H, int W, int kd, int kh, int tiles_per_wg) {
+                                                                 int D, int H, int W, int kd, int kh, int tiles_per_wg,
+                                                                 const unsigned* __restrict__ w_word, const unsigned* __restrict__ dy_word_a,
+                                                                 const unsigned* __restrict__ dy_word_b) {
   constexpr int KT = 2 * KDH;
   constexpr int OC = 32, TV = 32;
   constexpr int K = OC * KT, NKB = K / 32;             // 16x16x32 k-blocks per chunk
   constexpr int S = K * 2 + 16;                        // bytes per staged voxel and piece (528 / 272: odd multiples of 16)
   constexpr int PSZ = TV * S;
   constexpr int NUY = OC * KDH * (TV / 2) / 256;       // float4 loads per thread per tile
-  __shared__ __attribute__((aligned(16))) unsigned char ds[3 * PSZ];
+  __shared__ __attribute__((aligned(16))) unsigned char ds[NP * PSZ];
+  const int kwt = NP == 2 ? ct_scale_exp(w_word, nullptr) : 0, ky = NP == 2 ? ct_scale_exp(dy_word_a, dy_word_b) : 0;
+  const float wsc = ct_pow2(kwt), ysc = ct_pow2(ky), unw = ct_pow2(-kwt), uny = ct_pow2(-ky);
 
   const long long spatial = (long long)D * H * W;
   const long long tiles_per_n = spatial / TV;          // (W % 32 == 0: a tile is 32 consecutive voxels of one row)
@@ -1182,22 +1250,17 @@ __global__ __launch_bounds__(256, 2) void convT_dgrad_bf3_kernel(const float* __
     for (int i = 0; i < NUY; ++i) {
       const int ol = (tid + i * 256) / (KDH * (TV / 2));
       const bool ok = o0 + ol < Cout;
-      unsigned h[4], m[4], l[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) split3(ok ? v[i][e] : 0.f, h[e], m[e], l[e]);
+      f32x4_t q = ok ? v[i] : f32x4_t{0.f, 0.f, 0.f, 0.f};
+      if (NP == 2) q *= ysc;
       unsigned char* d0 = ds + ulds[i];
-      *reinterpret_cast<unsigned*>(d0) = pack_hi16(h[0], h[1]);
-      *reinterpret_cast<unsigned*>(d0 + S) = pack_hi16(h[2], h[3]);
-      *reinterpret_cast<unsigned*>(d0 + PSZ) = pack_hi16(m[0], m[1]);
-      *reinterpret_cast<unsigned*>(d0 + PSZ + S) = pack_hi16(m[2], m[3]);
-      *reinterpret_cast<unsigned*>(d0 + 2 * PSZ) = pack_hi16(l[0], l[1]);
-      *reinterpret_cast<unsigned*>(d0 + 2 * PSZ + S) = pack_hi16(l[2], l[3]);
+      store_pair<NP>(d0, PSZ, q[0], q[1]);
+      store_pair<NP>(d0 + S, PSZ, q[2], q[3]);
     }
   };
 
   for (int o0 = 0; o0 < Cout; o0 += OC) {
     // A fragments of this wave: row c = cbase + li, k-block kb, k = 32 kb + 8 lk + j  <->  W[c][o0 + k / KT][k % KT]
-    bf16x8_t af[NKB][3];
+    bf16x8_t af[NKB][NP];
     {
       const int c = cbase + li;
 #pragma unroll
@@ -1208,13 +1271,9 @@ __global__ __launch_bounds__(256, 2) void convT_dgrad_bf3_kernel(const float* __
         for (int j = 0; j < 8; ++j) {
           const int o = o0 + (k0 + j) / KT;
           wv[j] = (c < Cin && o < Cout && ct_alive_rows(live_t, Cout, c, o)) ? w[((long long)c * Cout + o0) * KT + k0 + j] : 0.f;
+          if (NP == 2) wv[j] *= wsc;
         }
-        unsigned h[8], m[8], l[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) split3(wv[j], h[j], m[j], l[j]);
-        af[kb][0] = __builtin_bit_cast(bf16x8_t, u32x4_t{pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]), pack_hi16(h[4], h[5]), pack_hi16(h[6], h[7])});
-        af[kb][1] = __builtin_bit_cast(bf16x8_t, u32x4_t{pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]), pack_hi16(m[4], m[5]), pack_hi16(m[6], m[7])});
-        af[kb][2] = __builtin_bit_cast(bf16x8_t, u32x4_t{pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]), pack_hi16(l[4], l[5]), pack_hi16(l[6], l[7])});
+        split_frag<NP>(wv, af[kb]);
       }
     }
     prefetch(tile_lo, o0);
@@ -1242,39 +1301,29 @@ __global__ __launch_bounds__(256, 2) void convT_dgrad_bf3_kernel(const float* __
       for (int b = 0; b < TV / 16; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
       // B fragment: voxel 16 b + li, k = 32 kb + 8 lk .. + 7
       const unsigned char* bp = ds + li * S + lk * 16;
-      bf16x8_t bf[2][TV / 16][3];
+      bf16x8_t bf[2][TV / 16][NP];
 #pragma unroll
       for (int b = 0; b < TV / 16; ++b)
 #pragma unroll
-        for (int sp = 0; sp < 3; ++sp) bf[0][b][sp] = *reinterpret_cast<const bf16x8_t*>(bp + sp * PSZ + b * 16 * S);
+        for (int sp = 0; sp < NP; ++sp) bf[0][b][sp] = *reinterpret_cast<const bf16x8_t*>(bp + sp * PSZ + b * 16 * S);
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb) {
         if (kb + 1 < NKB) {
 #pragma unroll
           for (int b = 0; b < TV / 16; ++b)
 #pragma unroll
-            for (int sp = 0; sp < 3; ++sp)
+            for (int sp = 0; sp < NP; ++sp)
               bf[(kb + 1) & 1][b][sp] = *reinterpret_cast<const bf16x8_t*>(bp + sp * PSZ + b * 16 * S + (kb + 1) * 64);
         }
 #pragma unroll
-        for (int b = 0; b < TV / 16; ++b) {
-          f32x4 a = acc[b];
-          // small terms first: lo*hi, mid*mid, hi*lo, then mid*hi, hi*mid, then hi*hi
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kb][2], bf[kb & 1][b][0], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kb][1], bf[kb & 1][b][1], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kb][0], bf[kb & 1][b][2], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kb][1], bf[kb & 1][b][0], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kb][0], bf[kb & 1][b][1], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kb][0], bf[kb & 1][b][0], a, 0, 0, 0);
-          acc[b] = a;
-        }
+        for (int b = 0; b < TV / 16; ++b) acc[b] = mma_pieces<NP>(af[kb], bf[kb & 1][b], acc[b]);
       }
       // D[i = c][j = v]: col = lane & 15 -> v, row = (lane >> 4) * 4 + reg -> c
 #pragma unroll
       for (int b = 0; b < TV / 16; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (cbase + lk * 4 + r < Cin) *dstp[b][r] = acc[b][r] + old[b][r];
+          if (cbase + lk * 4 + r < Cin) *dstp[b][r] = (NP == 2 ? acc[b][r] * unw * uny : acc[b][r]) + old[b][r];
       __syncthreads();
     }
   }
@@ -1330,9 +1379,12 @@ static int check_k(int kd, int kh, int kw) {
   return (kd == 1 || kd == 2) && (kh == 1 || kh == 2) && (kw == 1 || kw == 2);
 }
 
+// fp16 two-piece operands (round 6) where the caller hands over the range words; E2E_CT_H2=0 keeps the bf16 three-piece form
+static int ct_h2_env() { static const int v = getenv("E2E_CT_H2") ? atoi(getenv("E2E_CT_H2")) : 1; return v; }
+
 extern "C" int e2e_convT_fwd(const float* x, const float* scale, const float* shift, float slope, const float* w,
                              const unsigned* live, float* y, int B, int Cin, int Cout, int D, int H, int W, int kd,
-                             int kh, int kw, void* stream) {
+                             int kh, int kw, const unsigned* x_absmax, const unsigned* w_absmax, void* stream) {
   E2E_REQUIRE(x && w && y, "convT_fwd: null pointer");
   E2E_REQUIRE(check_k(kd, kh, kw), "convT_fwd: kernel must be in {1,2}^3");
   E2E_REQUIRE((long long)D * H * W * kd * kh * kw < (1ll << 31), "convT_fwd: a sample must have fewer than 2^31 output voxels");
@@ -1352,11 +1404,17 @@ extern "C" int e2e_convT_fwd(const float* x, const float* scale, const float* sh
     int tpw = (int)e2e::cdivll(total_tiles, wgs);
     if (tpw < 4) tpw = 4;
     dim3 grid((unsigned)e2e::cdivll(total_tiles, tpw), cgroups);
-    e2e::note_kernel("convT_fwd_bf3<%d,%d> wgs=%u cgroups=%d tiles_per_wg=%d", kdh, nkb, grid.x, cgroups, tpw);
-#define LAUNCH_F3(KDH, NKB) hipLaunchKernelGGL((convT_fwd_bf3_kernel<KDH, NKB>), grid, dim3(256), 0, st, x, scale, shift, slope, w, live, y, \
-                                               B, Cin, Cout, D, H, W, kd, kh, tpw)
-    if (kdh == 4) { if (nkb == 2) LAUNCH_F3(4, 2); else if (nkb == 4) LAUNCH_F3(4, 4); else LAUNCH_F3(4, 8); }
-    else { if (nkb == 2) LAUNCH_F3(2, 2); else if (nkb == 4) LAUNCH_F3(2, 4); else LAUNCH_F3(2, 8); }
+    const bool h2 = ct_h2_env() && x_absmax != nullptr && w_absmax != nullptr;
+    e2e::note_kernel("convT_fwd_%s<%d,%d> wgs=%u cgroups=%d tiles_per_wg=%d", h2 ? "h2" : "bf3", kdh, nkb, grid.x, cgroups, tpw);
+#define LAUNCH_F3(KDH, NKB, NP) hipLaunchKernelGGL((convT_fwd_bf3_kernel<KDH, NKB, NP>), grid, dim3(256), 0, st, x, scale, shift, slope, w, live, y, \
+                                                   B, Cin, Cout, D, H, W, kd, kh, tpw, x_absmax, w_absmax)
+    if (h2) {
+      if (kdh == 4) { if (nkb == 2) LAUNCH_F3(4, 2, 2); else if (nkb == 4) LAUNCH_F3(4, 4, 2); else LAUNCH_F3(4, 8, 2); }
+      else { if (nkb == 2) LAUNCH_F3(2, 2, 2); else if (nkb == 4) LAUNCH_F3(2, 4, 2); else LAUNCH_F3(2, 8, 2); }
+    } else {
+      if (kdh == 4) { if (nkb == 2) LAUNCH_F3(4, 2, 3); else if (nkb == 4) LAUNCH_F3(4, 4, 3); else LAUNCH_F3(4, 8, 3); }
+      else { if (nkb == 2) LAUNCH_F3(2, 2, 3); else if (nkb == 4) LAUNCH_F3(2, 4, 3); else LAUNCH_F3(2, 8, 3); }
+    }
 #undef LAUNCH_F3
     return e2e::check_launch("convT_fwd_bf3_kernel");
   }
@@ -1382,7 +1440,8 @@ static int dg_min_tiles() {
 }
 
 extern "C" int e2e_convT_dgrad(const float* dy, const float* w, const unsigned* live_t, float* dx, int accumulate,
-                               int B, int Cin, int Cout, int D, int H, int W, int kd, int kh, int kw, void* stream) {
+                               int B, int Cin, int Cout, int D, int H, int W, int kd, int kh, int kw, const unsigned* w_absmax,
+                               const unsigned* dy_bound_a, const unsigned* dy_bound_b, void* stream) {
   E2E_REQUIRE(dy && w && dx, "convT_dgrad: null pointer");
   E2E_REQUIRE(check_k(kd, kh, kw), "convT_dgrad: kernel must be in {1,2}^3");
   E2E_REQUIRE((long long)D * H * W * kd * kh * kw < (1ll << 31), "convT_dgrad: a sample must have fewer than 2^31 output voxels");
@@ -1401,11 +1460,13 @@ extern "C" int e2e_convT_dgrad(const float* dy, const float* w, const unsigned* 
     if (tpw < 4) tpw = 4;
     dim3 grid((unsigned)e2e::cdivll(total_tiles, tpw), cgroups);
     if (use_bf3 && W % 32 == 0) {
-      e2e::note_kernel("convT_dgrad_bf3<%d> wgs=%u cgroups=%d tiles_per_wg=%d", kd * kh, grid.x, cgroups, tpw);
-      if (kd * kh == 4)
-        hipLaunchKernelGGL((convT_dgrad_bf3_kernel<4>), grid, dim3(256), 0, st, dy, w, live_t, dx, accumulate, B, Cin, Cout, D, H, W, kd, kh, tpw);
-      else
-        hipLaunchKernelGGL((convT_dgrad_bf3_kernel<2>), grid, dim3(256), 0, st, dy, w, live_t, dx, accumulate, B, Cin, Cout, D, H, W, kd, kh, tpw);
+      const bool h2 = ct_h2_env() && w_absmax != nullptr && dy_bound_a != nullptr;
+      e2e::note_kernel("convT_dgrad_%s<%d> wgs=%u cgroups=%d tiles_per_wg=%d", h2 ? "h2" : "bf3", kd * kh, grid.x, cgroups, tpw);
+#define LAUNCH_D3(KDH, NP) hipLaunchKernelGGL((convT_dgrad_bf3_kernel<KDH, NP>), grid, dim3(256), 0, st, dy, w, live_t, dx, accumulate, B, Cin, Cout, \
+                                              D, H, W, kd, kh, tpw, w_absmax, dy_bound_a, dy_bound_b)
+      if (h2) { if (kd * kh == 4) LAUNCH_D3(4, 2); else LAUNCH_D3(2, 2); }
+      else { if (kd * kh == 4) LAUNCH_D3(4, 3); else LAUNCH_D3(2, 3); }
+#undef LAUNCH_D3
       return e2e::check_launch("convT_dgrad_bf3_kernel");
     }
     e2e::note_kernel("convT_dgrad_v3<%d> wgs=%u cgroups=%d tiles_per_wg=%d", kd * kh, grid.x, cgroups, tpw);
@@ -1451,7 +1512,7 @@ extern "C" long long e2e_convT_wgrad_ws_bytes(int B, int Cin, int Cout, int D, i
 
 extern "C" int e2e_convT_wgrad(const float* x, const float* scale, const float* shift, float slope, const float* dy,
                                float* dw, void* ws, int B, int Cin, int Cout, int D, int H, int W, int kd, int kh,
-                               int kw, void* stream) {
+                               int kw, const unsigned* x_absmax, const unsigned* dy_bound_a, const unsigned* dy_bound_b, void* stream) {
   E2E_REQUIRE(x && dy && dw && ws, "convT_wgrad: null pointer");
   E2E_REQUIRE(check_k(kd, kh, kw), "convT_wgrad: kernel must be in {1,2}^3");
   E2E_REQUIRE((long long)D * H * W * kd * kh * kw < (1ll << 31), "convT_wgrad: a sample must have fewer than 2^31 output voxels");
@@ -1470,11 +1531,17 @@ extern "C" int e2e_convT_wgrad(const float* x, const float* scale, const float* 
     const int kdh = kd * kh;
     static const int use_bf3 = getenv("E2E_CT_BF3") ? atoi(getenv("E2E_CT_BF3")) : 1;
     if (use_bf3) {
-      e2e::note_kernel("convT_wgrad_bf3<%d,%d> chunks=%d pairs=%d", kdh, ncb, nch, pairs2);
-#define LAUNCH_B3(KDH, NCB, TPX) hipLaunchKernelGGL((convT_wgrad_bf3_kernel<KDH, NCB, TPX>), grid2, dim3(256 * NCB), 0, st, x, scale, shift, \
-                                                    slope, dy, slab, B, Cin, Cout, D, H, W, kd, kh, tpc, cgroups)
-      if (kdh == 4) { if (ncb == 2) LAUNCH_B3(4, 2, 64); else LAUNCH_B3(4, 1, 64); }
-      else { if (ncb == 2) LAUNCH_B3(2, 2, 64); else LAUNCH_B3(2, 1, 64); }
+      const bool h2 = ct_h2_env() && x_absmax != nullptr && dy_bound_a != nullptr;
+      e2e::note_kernel("convT_wgrad_%s<%d,%d> chunks=%d pairs=%d", h2 ? "h2" : "bf3", kdh, ncb, nch, pairs2);
+#define LAUNCH_B3(KDH, NCB, TPX, NP) hipLaunchKernelGGL((convT_wgrad_bf3_kernel<KDH, NCB, TPX, NP>), grid2, dim3(256 * NCB), 0, st, x, scale, shift, \
+                                                        slope, dy, slab, B, Cin, Cout, D, H, W, kd, kh, tpc, cgroups, x_absmax, dy_bound_a, dy_bound_b)
+      if (h2) {
+        if (kdh == 4) { if (ncb == 2) LAUNCH_B3(4, 2, 64, 2); else LAUNCH_B3(4, 1, 64, 2); }
+        else { if (ncb == 2) LAUNCH_B3(2, 2, 64, 2); else LAUNCH_B3(2, 1, 64, 2); }
+      } else {
+        if (kdh == 4) { if (ncb == 2) LAUNCH_B3(4, 2, 64, 3); else LAUNCH_B3(4, 1, 64, 3); }
+        else { if (ncb == 2) LAUNCH_B3(2, 2, 64, 3); else LAUNCH_B3(2, 1, 64, 3); }
+      }
 #undef LAUNCH_B3
       hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)e2e::cdivll(numel_all, 64)), dim3(256), 0, st, slab, dw, numel_all, nch);
       return e2e::check_launch("convT_wgrad_bf3");

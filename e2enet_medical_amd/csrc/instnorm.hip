@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const double* __restri
 }
 
 // ---- backward ---------------------------------------------------------------------------------------------------
-// pass 1: s1 = sum du, s2 = sum du * xhat   per (n, c), fp64 accumulation
+// pass 1: s1 = sum du, s2 = sum du * xhat   per (n, c), fp64 accumulation; every block leaves ONE record (s1, s2) -- plain stores,
+// no atomics, no zeroing launch in front (round 6) -- which the apply pass adds up in a fixed order
 __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const float* __restrict__ dz, const float* __restrict__ y,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd,
@@ -115,28 +116,52 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const float* __restr
   if (lane == 0) { sh[0][wave] = d1; sh[1][wave] = d2; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    atomicAdd(&sums[(long long)nc * 3 + 0], sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]);
-    atomicAdd(&sums[(long long)nc * 3 + 1], sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
+    double* r = sums + ((long long)nc * gridDim.x + blockIdx.x) * 2;         // (here `sums` is the record area of the workspace)
+    r[0] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+    r[1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
   }
 }
 
 // pass 2: dy = gamma * rstd * (du - s1/N - xhat * s2/N), in place; s3 = sum dy (bias gradient); absmax (optional): the bit
 // pattern of max |dy| over the whole tensor (atomicMax on the unsigned pattern of a non-negative float: order-independent, so
-// deterministic), from which the fp16 two-piece weight gradient takes its power-of-two scale (conv133_wgrad_bf3.hip)
+// deterministic), from which the fp16 two-piece weight gradient takes its power-of-two scale (conv133_wgrad_bf3.hip).
+// Round 6: (s1, s2) of the block's (n, c) are the sum of `nrec` records (of pass 1, or of the last writers of dz: rec != nullptr),
+// added up by the block's first wave in a fixed order; with rec == nullptr they are read from sums[nc] (in_bwd_tile_sums_kernel).
+// The parameter gradients (dgamma, dbeta, dbias: sums over the batch) are formed by whichever block finishes LAST (ticket counter
+// behind the workspace; the block also leaves s3 and the counter zeroed for the next launch): no params launch behind this one.
 __global__ __launch_bounds__(256) void in_bwd_apply_kernel(float* __restrict__ dz, const float* __restrict__ y,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ rstd,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
                                                            const float* __restrict__ gamma, float slope,
-                                                           double* __restrict__ sums, int C, long long spatial,
-                                                           unsigned* __restrict__ absmax) {
+                                                           double* __restrict__ sums, const double* __restrict__ rec, int nrec,
+                                                           int B, int C, long long spatial, unsigned* __restrict__ absmax,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           float* __restrict__ dbias, unsigned* __restrict__ counter) {
   const int nc = blockIdx.y;
   const int c = nc % C;
   const float mu = mean[nc], rs = rstd[nc], g = gamma[c], sca = scale[nc], shf = shift[nc];
+  __shared__ double s12[2];
+  if (rec != nullptr) {
+    if (threadIdx.x < 64) {
+      const double* r = rec + (long long)nc * nrec * 2;
+      double a = 0.0, b = 0.0;
+      for (int i = threadIdx.x; i < nrec; i += 64) { a += r[2 * i]; b += r[2 * i + 1]; }
+      a = e2e::wave_sum_d(a);
+      b = e2e::wave_sum_d(b);
+      if (threadIdx.x == 0) {
+        s12[0] = a; s12[1] = b;
+        if (blockIdx.x == 0) { sums[(long long)nc * 3] = a; sums[(long long)nc * 3 + 1] = b; }     // for the last block's parameter sums
+      }
+    }
+  } else if (threadIdx.x == 0) {
+    s12[0] = sums[(long long)nc * 3]; s12[1] = sums[(long long)nc * 3 + 1];
+  }
+  __syncthreads();
   const double inv_n = 1.0 / (double)spatial;
-  const float m1 = (float)(sums[(long long)nc * 3 + 0] * inv_n);
-  const float m2 = (float)(sums[(long long)nc * 3 + 1] * inv_n);
+  const float m1 = (float)(s12[0] * inv_n);
+  const float m2 = (float)(s12[1] * inv_n);
   const float grs = g * rs;
   float* dzp = dz + (long long)nc * spatial;
   const float* yp = y + (long long)nc * spatial;
@@ -182,13 +207,33 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(float* __restrict__ d
   for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
   __shared__ double sh[4];
   __shared__ float shm[4];
+  __shared__ unsigned ticket;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (lane == 0) { sh[wave] = acc; shm[wave] = amax; }
   __syncthreads();
   if (threadIdx.x == 0) {
     atomicAdd(&sums[(long long)nc * 3 + 2], sh[0] + sh[1] + sh[2] + sh[3]);
     if (absmax != nullptr) atomicMax(absmax, __builtin_bit_cast(unsigned, fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3]))));
+    __threadfence();                                  // this block's sums are visible device-wide before its ticket is drawn
+    ticket = atomicAdd(counter, 1u);
   }
+  __syncthreads();
+  if (ticket != gridDim.x * gridDim.y - 1) return;
+  __threadfence();                                    // the last block: every other block's sums are visible from here
+  for (int cc = threadIdx.x; cc < C; cc += 256) {
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int n = 0; n < B; ++n) {
+      double* r = sums + ((long long)n * C + cc) * 3;
+      s1 += *reinterpret_cast<volatile double*>(r);
+      s2 += *reinterpret_cast<volatile double*>(r + 1);
+      s3 += atomicAdd(r + 2, 0.0);                    // (read where the atomics landed: L2)
+      r[2] = 0.0;                                     // zero for the next launch (it is behind this one on the stream)
+    }
+    dbeta[cc] = (float)s1;
+    dgamma[cc] = (float)s2;
+    if (dbias) dbias[cc] = (float)s3;
+  }
+  if (threadIdx.x == 0) *counter = 0u;
 }
 
 // first pass done by the last writers of dz (conv133_sparse.hip): add their tile records up, one wave per (n, c), fixed order
@@ -201,23 +246,7 @@ __global__ __launch_bounds__(64) void in_bwd_tile_sums_kernel(const double* __re
   for (int i = threadIdx.x; i < np; i += 64) { a += p[2 * i]; b += p[2 * i + 1]; }
   a = e2e::wave_sum_d(a);
   b = e2e::wave_sum_d(b);
-  if (threadIdx.x == 0) { sums[(long long)nc * 3] = a; sums[(long long)nc * 3 + 1] = b; sums[(long long)nc * 3 + 2] = 0.0; }
-}
-
-__global__ void in_bwd_params_kernel(double* __restrict__ sums, float* __restrict__ dgamma,
-                                     float* __restrict__ dbeta, float* __restrict__ dbias, int B, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  for (int n = 0; n < B; ++n) {
-    const double* r = sums + ((long long)n * C + c) * 3;
-    s1 += r[0];
-    s2 += r[1];
-    s3 += r[2];
-  }
-  dbeta[c] = (float)s1;
-  dgamma[c] = (float)s2;
-  if (dbias) dbias[c] = (float)s3;
+  if (threadIdx.x == 0) { sums[(long long)nc * 3] = a; sums[(long long)nc * 3 + 1] = b; }     // (s3 is kept zero by the apply pass's last block)
 }
 
 }  // namespace
@@ -232,6 +261,10 @@ extern "C" int e2e_in_stats_finalize(const double* part, int np, const float* ga
   return e2e::check_launch("in_finalize_kernel");
 }
 
+// doubles of workspace e2e_in_lrelu_bwd needs for (B, C): sums [B*C*3] + pass-1 records [B*C*256*2] + the ticket counter.  The caller
+// ZEROES it once when it allocates it; every launch leaves it ready for the next one
+extern "C" long long e2e_in_lrelu_bwd_ws_doubles(int B, int C) { return (long long)B * C * (3 + 2 * 256) + 2; }
+
 extern "C" int e2e_in_lrelu_bwd(float* dz_dy, const float* y, const float* mean, const float* rstd, const float* scale,
                                 const float* shift, const float* gamma, float slope, float* dgamma, float* dbeta,
                                 float* dbias, float* sums, int B, int C, long long spatial, const double* tile_sums, int np,
@@ -240,20 +273,23 @@ extern "C" int e2e_in_lrelu_bwd(float* dz_dy, const float* y, const float* mean,
   E2E_REQUIRE(B > 0 && C > 0 && spatial > 0, "in_lrelu_bwd: bad dims");
   hipStream_t st = (hipStream_t)stream;
   double* ds = reinterpret_cast<double*>(sums);
+  double* recs = ds + (long long)B * C * 3;
+  unsigned* counter = reinterpret_cast<unsigned*>(ds + (long long)B * C * (3 + 2 * 256));
   long long blocks = e2e::cdivll(spatial, 256 * 4 * 4);
   if (blocks > 256) blocks = 256;
   if (blocks < 1) blocks = 1;
   dim3 grid((unsigned)blocks, B * C);
+  // two launches per conv block (round 5: zero + reduce + apply + params, or tile sums + apply + params)
   if (tile_sums == nullptr) {
-    e2e::zero_async(ds, (size_t)B * C * 3 * sizeof(double), st);
-    hipLaunchKernelGGL(in_bwd_reduce_kernel, grid, dim3(256), 0, st, dz_dy, y, mean, rstd, scale, shift, slope, ds, C,
+    hipLaunchKernelGGL(in_bwd_reduce_kernel, grid, dim3(256), 0, st, dz_dy, y, mean, rstd, scale, shift, slope, recs, C,
                        spatial, dy_absmax);
+    hipLaunchKernelGGL(in_bwd_apply_kernel, grid, dim3(256), 0, st, dz_dy, y, mean, rstd, scale, shift, gamma, slope, ds,
+                       (const double*)recs, (int)blocks, B, C, spatial, dy_absmax, dgamma, dbeta, dbias, counter);
   } else {
     E2E_REQUIRE(np > 0, "in_lrelu_bwd: tile_sums without a record count");
     hipLaunchKernelGGL(in_bwd_tile_sums_kernel, dim3(B * C), dim3(64), 0, st, tile_sums, ds, np, dy_absmax);
+    hipLaunchKernelGGL(in_bwd_apply_kernel, grid, dim3(256), 0, st, dz_dy, y, mean, rstd, scale, shift, gamma, slope, ds,
+                       (const double*)nullptr, 0, B, C, spatial, dy_absmax, dgamma, dbeta, dbias, counter);
   }
-  hipLaunchKernelGGL(in_bwd_apply_kernel, grid, dim3(256), 0, st, dz_dy, y, mean, rstd, scale, shift, gamma, slope, ds, C,
-                     spatial, dy_absmax);
-  hipLaunchKernelGGL(in_bwd_params_kernel, dim3(e2e::cdiv(C, 64)), dim3(64), 0, st, ds, dgamma, dbeta, dbias, B, C);
   return e2e::check_launch("in_lrelu_bwd");
 }

@@ -227,6 +227,11 @@ class ConvOp:
                 c += 1
         self.chans = _upload_structs(structs, eng.device)
         self.in_structs = structs
+        c0 = 0
+        for s in sources:            # the transposed conv behind a source learns who consumes it and where (operand range of its dy)
+            if getattr(s, "up_of", None) is not None:
+                s.up_of.consumer = (self, c0, s.shape[1])
+            c0 += s.shape[1]
         self.out_structs = None
         self.shifts = shifts
         self.outs = None
@@ -524,6 +529,37 @@ class UpOp:
         self.live = None      # [Cout, ceil(Cin/32)]
         self.live_t = None    # [Cin, ceil(Cout/32)]
         self.acc = 0
+        # operand ranges of the fp16 two-piece GEMMs (convt.hip, round 6): words [x bound, max |w|, dy factor] filled by
+        # e2e_conv133_input_ranges (Engine._refresh_weight_caches); the bound of dy is words[2] x the consuming conv's max |dy| word
+        self.words = torch.zeros(3, dtype=torch.int32, device=eng.device)
+        self.consumer = None          # (ConvOp, first channel, channels) of the concat this output feeds
+        self.ranges_known = False
+
+    def range_jobs(self):
+        """e2e_range_job_t x 3 (activations, weights, dy factor) or None when a bound cannot be derived (raw source, no consumer)"""
+        e, s = self.eng, self.src
+        if not (s.normed and s.producer is not None and self.consumer is not None):
+            return None
+        none = RangeSrc(0, 0, 0, None, None, None, 0, 0, None)
+        prod = s.producer
+        w = e.params[self.w_name]
+        conv, c0, cs = self.consumer
+        wc = e.params[conv.w_name]
+        base = self.words.data_ptr()
+        jx = RangeJob((RangeSrc * 3)(RangeSrc(1, prod.cout, prod.out.spatial, e.params[prod.prefix + ".instnorm.weight"].data_ptr(),
+                                              e.params[prod.prefix + ".instnorm.bias"].data_ptr(), None, 0, 0, None), none, none), base)
+        jw = RangeJob((RangeSrc * 3)(RangeSrc(4, 0, w.numel(), None, None, w.data_ptr(), 0, 0, None), none, none), base + 4)
+        jd = RangeJob((RangeSrc * 3)(RangeSrc(5, c0, conv.cin, None, None, wc.data_ptr(), conv.cout, cs, None), none, none), base + 8)
+        return [jx, jw, jd]
+
+    def set_ranges(self, x_max, w_max, dy_factor):
+        """operator tests: measured maxima instead of the derived bounds (None: no words -> bf16 three-piece operands)"""
+        self.ranges_known = x_max is not None
+        if x_max is not None:
+            self.words.copy_(torch.tensor([float(x_max), float(w_max), float(dy_factor)], dtype=torch.float32).view(torch.int32))
+
+    def _w(self, i):
+        return self.words.data_ptr() + 4 * i if self.ranges_known else None
 
     def plan_backward(self):
         self.src.alloc_grad()
@@ -533,18 +569,23 @@ class UpOp:
         s = self.src
         b, cin, d, h, w = s.shape
         lib().convT_fwd(s.data.data_ptr(), _ptr(s.scale), _ptr(s.shift), LRELU_SLOPE, self.eng.params[self.w_name].data_ptr(),
-                        _ptr(self.live), self.out.data.data_ptr(), b, cin, self.cout, d, h, w, *self.kernel, _stream())
+                        _ptr(self.live), self.out.data.data_ptr(), b, cin, self.cout, d, h, w, *self.kernel, self._w(0), self._w(1),
+                        _stream())
 
     def backward(self):
         s, e = self.src, self.eng
         b, cin, d, h, w = s.shape
         L = lib()
+        # the bound of dy = (the consuming conv's max |dy| word, written by its e2e_in_lrelu_bwd earlier in this pass) x words[2]
+        dya = self.dy_word if getattr(self, "dy_word", None) is not None else \
+            (self.consumer[0].dy_absmax.data_ptr() if (self.ranges_known and self.consumer is not None) else None)
         with _wgrad_stream(e, self.out.data.numel()) as ws:
             L.convT_wgrad(s.data.data_ptr(), _ptr(s.scale), _ptr(s.shift), LRELU_SLOPE, self.out.grad.data_ptr(),
                           e.grads[self.w_name].data_ptr(), ws.data_ptr(), b, cin, self.cout, d, h, w, *self.kernel,
-                          _stream())
+                          self._w(0), dya, self._w(2) if dya is not None else None, _stream())
         L.convT_dgrad(self.out.grad.data_ptr(), e.params[self.w_name].data_ptr(), _ptr(self.live_t), s.grad.data_ptr(),
-                      self.acc, b, cin, self.cout, d, h, w, *self.kernel, _stream())
+                      self.acc, b, cin, self.cout, d, h, w, *self.kernel, self._w(1), dya, self._w(2) if dya is not None else None,
+                      _stream())
 
     def wgrad_ws_bytes(self):
         b, cin, d, h, w = self.src.shape
@@ -904,9 +945,15 @@ class Engine:
                     op.range_known = jb is not None
                     if jb is not None:
                         jobs.append(jb)
-                self._range_table = (_upload_structs(jobs, self.device) if jobs else None, len(jobs), ptrs)
+                for up in self.up_ops.values():
+                    jbs = up.range_jobs()
+                    up.ranges_known = jbs is not None
+                    if jbs is not None:
+                        jobs += jbs
+                ws = torch.empty(max(4, int(L.conv133_input_ranges_ws_bytes(len(jobs))) // 4), dtype=torch.float32, device=self.device)
+                self._range_table = (_upload_structs(jobs, self.device) if jobs else None, len(jobs), ptrs, ws)
             if self._range_table[1]:
-                L.conv133_input_ranges(self._range_table[0].data_ptr(), self._range_table[1], _stream())
+                L.conv133_input_ranges(self._range_table[0].data_ptr(), self._range_table[1], self._range_table[3].data_ptr(), _stream())
             self._range_key = (ptrs, state)
         # which layers run on K1m in which direction is part of what a packed set is valid for (tests and knobs move it)
         dkey = (tuple(op.use_mm() for op in self.conv_ops.values()), MM_FORWARD, MM_BACKWARD, self.maps_generation, ptrs)
@@ -1124,7 +1171,9 @@ class Engine:
                  [lib().head1x1_wgrad_ws_bytes(self.batch, h.src.shape[1], h.k, h.src.spatial) for h in self.heads])
         self._wgrad_ws = [torch.empty((ws + 3) // 4, dtype=torch.float32, device=self.device) for _ in range(len(self.lane_divs) + 1)]
         cmax = max(op.cout for op in self.conv_ops.values())
-        self._in_sums = [torch.empty(self.batch * cmax * 3, dtype=torch.float64, device=self.device) for _ in range(len(self.lane_divs) + 1)]
+        # (zeroed once: e2e_in_lrelu_bwd leaves its workspace ready for the next call)
+        self._in_sums = [torch.zeros(int(lib().in_lrelu_bwd_ws_doubles(self.batch, cmax)), dtype=torch.float64, device=self.device)
+                         for _ in range(len(self.lane_divs) + 1)]
         for op in self.conv_ops.values():       # records of the fused InstanceNorm-backward sums, laid out for the buffer's last writer
             d_, h_, w_ = op.out_dims
             lw = op.out.last_writer

@@ -196,7 +196,8 @@ typedef struct {
   int owns_absmax;           /* this job computes *w_absmax (one job per layer) */
 } e2e_mm_pack_job_t;
 typedef struct {
-  int kind;                  /* 0 none, 1 normalised source (or its max-pool), 2 transposed conv of a normalised source, 3 measured word */
+  int kind;                  /* 0 none, 1 normalised source (or its max-pool), 2 transposed conv of a normalised source, 3 measured word,
+                              * 4 max |w| over N floats, 5 max over channels [C, C + wks) of sum_{o, tap} |w[o, c, tap]|, w [wCout][N][9] */
   int C;                     /* channels of the normalised tensor */
   long long N;               /* voxels per instance of the normalised tensor */
   const float* gamma;        /* [C] instnorm.weight of its producer */
@@ -212,8 +213,10 @@ typedef struct {
 long long e2e_conv133_mm_ws_bytes(int B, int Cin, int Cout, int Di, int Hi, int Wi, int sd, int sh, int sw);
 /* jobs: DEVICE table; max_elems >= the largest ceil(Q/32)*ceil(P/16)*9*512 of the table */
 int e2e_conv133_mm_pack(const e2e_mm_pack_job_t* jobs, int njobs, long long max_elems, void* stream);
-/* jobs: DEVICE table, one per conv whose forward or weight gradient runs on split operands */
-int e2e_conv133_input_ranges(const e2e_range_job_t* jobs, int njobs, void* stream);
+/* jobs: DEVICE table, one per range word (a conv's input planes; a transposed conv's activations, weights, dy factor);
+ * ws: e2e_conv133_input_ranges_ws_bytes(njobs) bytes of scratch (two launches: partial maxima, fold) */
+long long e2e_conv133_input_ranges_ws_bytes(int njobs);
+int e2e_conv133_input_ranges(const e2e_range_job_t* jobs, int njobs, void* ws, void* stream);
 /* *word = bit pattern of max |x| over n floats (a non-finite element gives +Inf) */
 int e2e_absmax_word(const float* x, long long n, unsigned* word, void* stream);
 int e2e_conv133_fwd_mm(const e2e_in_chan_t* chans, int Cin, const void* wpk, const unsigned* w_absmax, const float* bias,
@@ -261,7 +264,9 @@ int e2e_in_stats_finalize(const double* part, int np, const float* gamma, const 
 /* ---- K7: InstanceNorm + LeakyReLU backward -------------------------------------------
  * Given dz = dL/d(lrelu(IN(y))) and the saved pre-norm y, overwrite dz with dy = dL/dy and
  * produce dgamma, dbeta (accumulated over the batch) and dbias = sum(dy).
- *   sums  workspace of B*C*3 doubles (s1 = sum du, s2 = sum du*xhat, s3 = sum dy)
+ *   sums  workspace of e2e_in_lrelu_bwd_ws_doubles(B, C) doubles (s1 = sum du, s2 = sum du*xhat, s3 = sum dy per (n, c); the
+ *         per-block records of the first pass; a ticket counter), ZEROED ONCE by the caller when it is allocated: every launch
+ *         leaves it ready for the next (two launches per call since round 6: no zeroing and no parameter launch)
  *   tile_sums  NULL: the first pass (s1, s2) runs here.  Otherwise the per-tile records [B][C][np][2] that the last writers of
  *              dz have produced (e2e_in_sum_chan_t): they are added up in a fixed order and only the apply pass runs
  *   dy_absmax  NULL, or one device word that receives the bit pattern of max |dy| over the tensor (consumed by e2e_conv133_wgrad)
@@ -270,6 +275,7 @@ int e2e_in_stats_finalize(const double* part, int np, const float* gamma, const 
  *              differentiates exactly the function the forward evaluated (until round 5 it was re-derived as gamma * xhat + beta,
  *              whose sign differs for |u| ~ 1e-7: found by the same-branch gradient check of tests/test_gpu_configs.py)
  */
+long long e2e_in_lrelu_bwd_ws_doubles(int B, int C);
 int e2e_in_lrelu_bwd(float* dz_dy, const float* y, const float* mean, const float* rstd, const float* scale, const float* shift,
                      const float* gamma, float slope, float* dgamma, float* dbeta, float* dbias, float* sums,
                      int B, int C, long long spatial, const double* tile_sums, int np, unsigned* dy_absmax, void* stream);
@@ -279,19 +285,24 @@ int e2e_in_lrelu_bwd(float* dz_dy, const float* y, const float* mean, const floa
  *   x   [B,Cin,D,H,W] pre-norm producer output + (scale,shift) [B,Cin] (NULL => raw), slope
  *   w   [Cin,Cout,kd,kh,kw];  live [Cout, ceil(Cin/32)] bits or NULL
  *   y   [B,Cout,D*kd,H*kh,W*kw]
- */
+ * Operand ranges (round 6): the matrix-pipe kernels (kw == 2, W % 32 == 0 ...) run on fp16 TWO-piece operands -- three matrix
+ * products per fp32 product instead of the six of the bf16 three-piece form -- when the caller hands over the device words that
+ * bound their operands (e2e_conv133_input_ranges: x_absmax = kind 1 of the source, w_absmax = kind 4 of w, dy_bound_b = kind 5 of
+ * the conv that consumes y, dy_bound_a = that conv's dy_absmax word of e2e_in_lrelu_bwd; the bound of dy is their product); with
+ * NULL words (or E2E_CT_H2=0) they keep the bf16 form, which needs no range. */
 int e2e_convT_fwd(const float* x, const float* scale, const float* shift, float slope, const float* w,
                   const unsigned* live, float* y, int B, int Cin, int Cout, int D, int H, int W, int kd,
-                  int kh, int kw, void* stream);
+                  int kh, int kw, const unsigned* x_absmax, const unsigned* w_absmax, void* stream);
 /* dgrad: dx (gradient w.r.t. the *post-activation* input) [B,Cin,D,H,W]; accumulate != 0 adds.
  * live_t [Cin, ceil(Cout/32)] or NULL. */
 int e2e_convT_dgrad(const float* dy, const float* w, const unsigned* live_t, float* dx, int accumulate, int B,
-                    int Cin, int Cout, int D, int H, int W, int kd, int kh, int kw, void* stream);
+                    int Cin, int Cout, int D, int H, int W, int kd, int kh, int kw, const unsigned* w_absmax,
+                    const unsigned* dy_bound_a, const unsigned* dy_bound_b, void* stream);
 /* wgrad (dense): dw [Cin,Cout,kd,kh,kw] overwritten; ws of e2e_convT_wgrad_ws_bytes bytes. */
 long long e2e_convT_wgrad_ws_bytes(int B, int Cin, int Cout, int D, int H, int W, int kd, int kh, int kw);
 int e2e_convT_wgrad(const float* x, const float* scale, const float* shift, float slope, const float* dy,
                     float* dw, void* ws, int B, int Cin, int Cout, int D, int H, int W, int kd, int kh, int kw,
-                    void* stream);
+                    const unsigned* x_absmax, const unsigned* dy_bound_a, const unsigned* dy_bound_b, void* stream);
 
 /* ---- K4: max pooling, kernel == stride ------------------------------------------------
  * Replaces: nn.MaxPool3d(k) (unetpp_d.py:523-524) on a normalise-on-load source. */

@@ -27,7 +27,7 @@ def _eng_stub(params):
     e.params = {k: v.to(e.device) for k, v in params.items()}
     e.grads = {k: torch.zeros_like(v) for k, v in e.params.items()}
     e.wgrad_ws = torch.empty(64 << 20, dtype=torch.float32, device=e.device)   # 256 MiB
-    e.in_sums = torch.empty(4096 * 3, dtype=torch.float64, device=e.device)
+    e.in_sums = torch.zeros(1024 * (3 + 512) + 2, dtype=torch.float64, device=e.device)   # e2e_in_lrelu_bwd_ws_doubles for B * C <= 1024, zeroed once
     e.batch = 1
     return e
 
@@ -1010,3 +1010,56 @@ def test_input_range_words_bound_the_activations():
     y[0, 0, 0] = 1.0
     xhat = (y - y.mean()) / y.var(unbiased=False).sqrt()
     assert abs(float(xhat.abs().max()) - root) < 1e-3 * root
+
+
+@pytest.mark.parametrize("cin,cout,dims,kernel,mag", [(64, 32, (4, 32, 64), (2, 2, 2), 1.0), (40, 24, (3, 16, 32), (1, 2, 2), 1.0),
+                                                     (128, 64, (2, 16, 32), (2, 2, 2), 1e4), (64, 32, (4, 32, 64), (2, 2, 2), 1e-5)])
+def test_convT_h2_and_bf3_vs_fp64(cin, cout, dims, kernel, mag):
+    """Round 6: the three transposed-conv GEMMs (forward, data gradient, weight gradient; reference nn.ConvTranspose3d,
+    unetpp_d.py:521-522) on fp16 two-piece operands (three products) against an fp64 evaluation, next to the bf16 three-piece form
+    (six products) they replace: both within the usual relative bars, the fp16 form no further than 1.5 x the bf16 form's error
+    -- with activations of 1e4 and 1e-5 as well (operand scales from the range words), kernel names asserted."""
+    from e2enet_medical_amd.engine import UpOp
+    from e2enet_medical_amd._lib import lib
+    B = 2
+    src = _make_act((B, cin) + dims, True, 501)
+    src.scale.mul_(mag)
+    src.shift.mul_(mag)
+    w = seeded_input((cin, cout) + kernel, seed=502) * (1.0 / math.sqrt(cin))
+    e = _eng_stub({"up.weight": w})
+    op = UpOp(e, "up.weight", src, cout, kernel)
+    x64 = _act_value(src).double().requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    y64 = F.conv_transpose3d(x64, w64, stride=kernel)
+    dy = _heavy_tailed(tuple(y64.shape), 503, 1e-6)
+    y64.backward(dy.double())
+    op.out.alloc_grad()
+    op.plan_backward()
+    L = lib()
+    res = {}
+    for form in ("h2", "bf3"):
+        if form == "h2":
+            op.set_ranges(float(x64.detach().abs().max()), float(w.abs().max()), 1.0)
+            word = _absmax_word(dy.cuda())
+            op.dy_word = word.data_ptr()
+        else:
+            op.set_ranges(None, None, None)
+            op.dy_word = None
+        op.out.data.fill_(float("nan"))
+        op.forward()
+        torch.cuda.synchronize()
+        kf = L.last_kernel().decode()
+        yv = op.out.data.cpu().double()
+        op.out.grad.copy_(dy)
+        src.grad.fill_(float("nan"))
+        e.grads["up.weight"].fill_(float("nan"))
+        op.backward()
+        torch.cuda.synchronize()
+        assert kf.startswith("convT_fwd_" + form), kf
+        gx, gw = src.grad.cpu().double(), e.grads["up.weight"].cpu().double()
+        assert torch.isfinite(yv).all() and torch.isfinite(gx).all() and torch.isfinite(gw).all(), form
+        res[form] = tuple(float((a - b).norm() / b.norm()) for a, b in ((yv, y64.detach()), (gx, x64.grad), (gw, w64.grad)))
+    print("convT %d->%d %s x%g: rel-L2 vs fp64 (fwd, dgrad, wgrad): h2 %s  bf3 %s" % (cin, cout, dims, mag, res["h2"], res["bf3"]))
+    for i, name in enumerate(("forward", "data gradient", "weight gradient")):
+        assert res["h2"][i] <= 2e-6 and res["bf3"][i] <= 2e-6, (name, res)
+        assert res["h2"][i] <= 1.5 * res["bf3"][i] + 1e-7, (name, res)

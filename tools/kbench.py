@@ -50,7 +50,7 @@ def conv_case(B, srcs, cout, dims, stride, density, tag):
     e.grads = {k: torch.zeros_like(v) for k, v in e.params.items()}
     op = ConvOp(e, "b", acts, cout, stride)
     e.wgrad_ws = torch.empty(max(op.wgrad_ws_bytes() // 4, 1), dtype=torch.float32, device=dev)
-    e.in_sums = torch.empty(B * cout * 3, dtype=torch.float64, device=dev)
+    e.in_sums = torch.zeros(int(lib().in_lrelu_bwd_ws_doubles(B, cout)), dtype=torch.float64, device=dev)
     if density < 1.0:
         km = (torch.rand(cout, cin, device=dev) < density).to(torch.uint8)
         if os.environ.get("KB_BALANCED"):      # diagnostic: exactly round(8*density) live kernels per (row, 8-plane chunk)
@@ -194,13 +194,22 @@ def convt_case(B, cin, cout, dims, kernel, density, tag):
     L = lib()
     b_, _, d_, h_, w_ = src.shape
 
+    # operand ranges: measured maxima (the engine derives bounds from the parameters); KB_NO_RANGES: bf16 three-piece operands
+    dyw = op.out.grad.abs().max().reshape(1).view(torch.int32)
+    if not os.environ.get("KB_NO_RANGES"):
+        xv = torch.nn.functional.leaky_relu(src.data * src.scale.view(b_, cin, 1, 1, 1) + src.shift.view(b_, cin, 1, 1, 1), 0.01)
+        op.set_ranges(float(xv.abs().max()), float(w.abs().max()), 1.0)
+        op.dy_word = dyw.data_ptr()
+
     def wgrad():
         L.convT_wgrad(src.data.data_ptr(), src.scale.data_ptr(), src.shift.data_ptr(), 0.01, op.out.grad.data_ptr(),
-                      e.grads["up.weight"].data_ptr(), e.wgrad_ws.data_ptr(), b_, cin, cout, d_, h_, w_, *kernel, 0)
+                      e.grads["up.weight"].data_ptr(), e.wgrad_ws.data_ptr(), b_, cin, cout, d_, h_, w_, *kernel,
+                      op._w(0), getattr(op, "dy_word", None), None, 0)
 
     def dgrad():
         L.convT_dgrad(op.out.grad.data_ptr(), e.params["up.weight"].data_ptr(), op.live_t.data_ptr() if op.live_t is not None else None,
-                      src.grad.data_ptr(), int(os.environ.get("KB_ACC", "0")), b_, cin, cout, d_, h_, w_, *kernel, 0)
+                      src.grad.data_ptr(), int(os.environ.get("KB_ACC", "0")), b_, cin, cout, d_, h_, w_, *kernel,
+                      op._w(1), getattr(op, "dy_word", None), None, 0)
     for name, fn, fl in (("fwd", op.forward, dense * density), ("wgrad", wgrad, dense), ("dgrad", dgrad, dense * density)):
         ms = time_ms(fn)
         print("%-26s %-8s %8.3f ms  %7.1f GB/s(alg)  %6.1f TFLOP/s" % (tag, name, ms, (vin + vout) * 4 / ms / 1e6, fl / ms / 1e9))
