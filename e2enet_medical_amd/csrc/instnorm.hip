@@ -70,9 +70,10 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift, float slope,
                                                             double* __restrict__ sums, int C, long long spatial,
-                                                            unsigned* __restrict__ absmax) {
+                                                            unsigned* __restrict__ absmax, double* __restrict__ s3_zero) {
   const int nc = blockIdx.y;
   if (absmax != nullptr && blockIdx.x == 0 && nc == 0 && threadIdx.x == 0) *absmax = 0u;   // the apply pass (next launch) records max |dy|
+  if (blockIdx.x == 0 && threadIdx.x == 0) s3_zero[(long long)nc * 3 + 2] = 0.0;            // ... and accumulates sum dy here
   const float mu = mean[nc], rs = rstd[nc], sca = scale[nc], shf = shift[nc];
   const float* dzp = dz + (long long)nc * spatial;
   const float* yp = y + (long long)nc * spatial;
@@ -127,8 +128,6 @@ __global__ __launch_bounds__(256) void in_bwd_reduce_kernel(const float* __restr
 // deterministic), from which the fp16 two-piece weight gradient takes its power-of-two scale (conv133_wgrad_bf3.hip).
 // Round 6: (s1, s2) of the block's (n, c) are the sum of `nrec` records (of pass 1, or of the last writers of dz: rec != nullptr),
 // added up by the block's first wave in a fixed order; with rec == nullptr they are read from sums[nc] (in_bwd_tile_sums_kernel).
-// The parameter gradients (dgamma, dbeta, dbias: sums over the batch) are formed by whichever block finishes LAST (ticket counter
-// behind the workspace; the block also leaves s3 and the counter zeroed for the next launch): no params launch behind this one.
 __global__ __launch_bounds__(256) void in_bwd_apply_kernel(float* __restrict__ dz, const float* __restrict__ y,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ rstd,
@@ -136,9 +135,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(float* __restrict__ d
                                                            const float* __restrict__ shift,
                                                            const float* __restrict__ gamma, float slope,
                                                            double* __restrict__ sums, const double* __restrict__ rec, int nrec,
-                                                           int B, int C, long long spatial, unsigned* __restrict__ absmax,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                           float* __restrict__ dbias, unsigned* __restrict__ counter) {
+                                                           int B, int C, long long spatial, unsigned* __restrict__ absmax) {
   const int nc = blockIdx.y;
   const int c = nc % C;
   const float mu = mean[nc], rs = rstd[nc], g = gamma[c], sca = scale[nc], shf = shift[nc];
@@ -152,7 +149,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(float* __restrict__ d
       b = e2e::wave_sum_d(b);
       if (threadIdx.x == 0) {
         s12[0] = a; s12[1] = b;
-        if (blockIdx.x == 0) { sums[(long long)nc * 3] = a; sums[(long long)nc * 3 + 1] = b; }     // for the last block's parameter sums
+        if (blockIdx.x == 0) { sums[(long long)nc * 3] = a; sums[(long long)nc * 3 + 1] = b; }     // for the parameter sums
       }
     }
   } else if (threadIdx.x == 0) {
@@ -207,33 +204,32 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(float* __restrict__ d
   for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
   __shared__ double sh[4];
   __shared__ float shm[4];
-  __shared__ unsigned ticket;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (lane == 0) { sh[wave] = acc; shm[wave] = amax; }
   __syncthreads();
   if (threadIdx.x == 0) {
     atomicAdd(&sums[(long long)nc * 3 + 2], sh[0] + sh[1] + sh[2] + sh[3]);
     if (absmax != nullptr) atomicMax(absmax, __builtin_bit_cast(unsigned, fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3]))));
-    __threadfence();                                  // this block's sums are visible device-wide before its ticket is drawn
-    ticket = atomicAdd(counter, 1u);
   }
-  __syncthreads();
-  if (ticket != gridDim.x * gridDim.y - 1) return;
-  __threadfence();                                    // the last block: every other block's sums are visible from here
-  for (int cc = threadIdx.x; cc < C; cc += 256) {
-    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    for (int n = 0; n < B; ++n) {
-      double* r = sums + ((long long)n * C + cc) * 3;
-      s1 += *reinterpret_cast<volatile double*>(r);
-      s2 += *reinterpret_cast<volatile double*>(r + 1);
-      s3 += atomicAdd(r + 2, 0.0);                    // (read where the atomics landed: L2)
-      r[2] = 0.0;                                     // zero for the next launch (it is behind this one on the stream)
-    }
-    dbeta[cc] = (float)s1;
-    dgamma[cc] = (float)s2;
-    if (dbias) dbias[cc] = (float)s3;
+}
+
+// parameter gradients: sums over the batch (s3 was zeroed by the first pass of this call, accumulated by the apply pass).
+// (A "last block of the apply pass does this" variant was measured in round 6: the device-scope fence it needs in EVERY block
+//  writes the XCD's L2 back -- 16 k fences per launch took the apply pass from 3.4 to ~12 ms per step.  A separate 5 us launch it is.)
+__global__ void in_bwd_params_kernel(double* __restrict__ sums, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta, float* __restrict__ dbias, int B, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  for (int n = 0; n < B; ++n) {
+    double* r = sums + ((long long)n * C + c) * 3;
+    s1 += r[0];
+    s2 += r[1];
+    s3 += r[2];
   }
-  if (threadIdx.x == 0) *counter = 0u;
+  dbeta[c] = (float)s1;
+  dgamma[c] = (float)s2;
+  if (dbias) dbias[c] = (float)s3;
 }
 
 // first pass done by the last writers of dz (conv133_sparse.hip): add their tile records up, one wave per (n, c), fixed order
@@ -246,7 +242,7 @@ __global__ __launch_bounds__(64) void in_bwd_tile_sums_kernel(const double* __re
   for (int i = threadIdx.x; i < np; i += 64) { a += p[2 * i]; b += p[2 * i + 1]; }
   a = e2e::wave_sum_d(a);
   b = e2e::wave_sum_d(b);
-  if (threadIdx.x == 0) { sums[(long long)nc * 3] = a; sums[(long long)nc * 3 + 1] = b; }     // (s3 is kept zero by the apply pass's last block)
+  if (threadIdx.x == 0) { sums[(long long)nc * 3] = a; sums[(long long)nc * 3 + 1] = b; sums[(long long)nc * 3 + 2] = 0.0; }
 }
 
 }  // namespace
@@ -261,8 +257,7 @@ extern "C" int e2e_in_stats_finalize(const double* part, int np, const float* ga
   return e2e::check_launch("in_finalize_kernel");
 }
 
-// doubles of workspace e2e_in_lrelu_bwd needs for (B, C): sums [B*C*3] + pass-1 records [B*C*256*2] + the ticket counter.  The caller
-// ZEROES it once when it allocates it; every launch leaves it ready for the next one
+// doubles of workspace e2e_in_lrelu_bwd needs for (B, C): sums [B*C*3] + pass-1 records [B*C*256*2]; no state survives a call
 extern "C" long long e2e_in_lrelu_bwd_ws_doubles(int B, int C) { return (long long)B * C * (3 + 2 * 256) + 2; }
 
 extern "C" int e2e_in_lrelu_bwd(float* dz_dy, const float* y, const float* mean, const float* rstd, const float* scale,
@@ -274,22 +269,23 @@ extern "C" int e2e_in_lrelu_bwd(float* dz_dy, const float* y, const float* mean,
   hipStream_t st = (hipStream_t)stream;
   double* ds = reinterpret_cast<double*>(sums);
   double* recs = ds + (long long)B * C * 3;
-  unsigned* counter = reinterpret_cast<unsigned*>(ds + (long long)B * C * (3 + 2 * 256));
   long long blocks = e2e::cdivll(spatial, 256 * 4 * 4);
   if (blocks > 256) blocks = 256;
   if (blocks < 1) blocks = 1;
   dim3 grid((unsigned)blocks, B * C);
-  // two launches per conv block (round 5: zero + reduce + apply + params, or tile sums + apply + params)
+  // three launches per conv block (round 5: zero + reduce + apply + params); the first pass leaves per-block records (plain stores:
+  // deterministic, nothing to zero) that the apply pass adds up in a fixed order
   if (tile_sums == nullptr) {
     hipLaunchKernelGGL(in_bwd_reduce_kernel, grid, dim3(256), 0, st, dz_dy, y, mean, rstd, scale, shift, slope, recs, C,
-                       spatial, dy_absmax);
+                       spatial, dy_absmax, ds);
     hipLaunchKernelGGL(in_bwd_apply_kernel, grid, dim3(256), 0, st, dz_dy, y, mean, rstd, scale, shift, gamma, slope, ds,
-                       (const double*)recs, (int)blocks, B, C, spatial, dy_absmax, dgamma, dbeta, dbias, counter);
+                       (const double*)recs, (int)blocks, B, C, spatial, dy_absmax);
   } else {
     E2E_REQUIRE(np > 0, "in_lrelu_bwd: tile_sums without a record count");
     hipLaunchKernelGGL(in_bwd_tile_sums_kernel, dim3(B * C), dim3(64), 0, st, tile_sums, ds, np, dy_absmax);
     hipLaunchKernelGGL(in_bwd_apply_kernel, grid, dim3(256), 0, st, dz_dy, y, mean, rstd, scale, shift, gamma, slope, ds,
-                       (const double*)nullptr, 0, B, C, spatial, dy_absmax, dgamma, dbeta, dbias, counter);
+                       (const double*)nullptr, 0, B, C, spatial, dy_absmax);
   }
+  hipLaunchKernelGGL(in_bwd_params_kernel, dim3(e2e::cdiv(C, 64)), dim3(64), 0, st, ds, dgamma, dbeta, dbias, B, C);
   return e2e::check_launch("in_lrelu_bwd");
 }

@@ -115,7 +115,7 @@ def engine_branches(eng):
     return br
 
 
-def check_grads_same_branches(eng, spec, params, x, targets, w, shapes, tol_global=1e-4, tol_tensor=3e-4):
+def check_grads_same_branches(eng, spec, params, x, targets, w, shapes, tol_global=1e-4, tol_tensor=3e-4, factor=3.0):
     """The sharp gradient check: the fp64 oracle evaluated WITH the engine's own LeakyReLU / pooling decisions is a smooth function
     the engine's backward pass differentiates too, so the two gradients differ by rounding only -- against the per cents any two
     plain evaluations differ by (_check_all_grads).  The fp32 CPU oracle is put through the same decisions as the yardstick of
@@ -137,6 +137,7 @@ def check_grads_same_branches(eng, spec, params, x, targets, w, shapes, tol_glob
     worst = {"engine": (0.0, None), "cpu32": (0.0, None)}
     num = {"engine": 0.0, "cpu32": 0.0}
     den = 0.0
+    gscale = max(1.0, max(float(g64[n].abs().max()) for n in shapes))      # (networks with large activations have large gradients)
     for n in shapes:
         r = g64[n]
         den += r.pow(2).sum().item()
@@ -148,12 +149,12 @@ def check_grads_same_branches(eng, spec, params, x, targets, w, shapes, tol_glob
                 if e > worst[who][0]:
                     worst[who] = (e, n)
             elif who == "engine":
-                assert d.abs().max().item() <= 2e-3, (n, "zero-gradient tensor", d.abs().max().item())
+                assert d.abs().max().item() <= 2e-3 * gscale, (n, "zero-gradient tensor", d.abs().max().item(), gscale)
     glob = {k: (v / den) ** 0.5 for k, v in num.items()}
     print("[grad, same branches] vs fp64: engine global rel-L2 %.3e worst tensor %.3e (%s) | cpu32 global %.3e worst %.3e (%s)"
           % (glob["engine"], worst["engine"][0], worst["engine"][1], glob["cpu32"], worst["cpu32"][0], worst["cpu32"][1]))
-    assert glob["engine"] <= max(tol_global, 3.0 * glob["cpu32"]), ("global", glob)
-    assert worst["engine"][0] <= max(tol_tensor, 3.0 * worst["cpu32"][0]), ("worst tensor", worst)
+    assert glob["engine"] <= max(tol_global, factor * glob["cpu32"]), ("global", glob)
+    assert worst["engine"][0] <= max(tol_tensor, factor * worst["cpu32"][0]), ("worst tensor", worst)
     return glob, worst
 
 
