@@ -1399,7 +1399,8 @@ extern "C" int e2e_convT_fwd(const float* x, const float* scale, const float* sh
     const int cols_per_wg = 4 * (8 / nkb) * 16;
     const int cgroups = e2e::cdiv(Cout * kt, cols_per_wg);
     const long long total_tiles = (spatial / 32) * B;
-    long long wgs = 512 / cgroups;                         // two 4-wave workgroups per CU: one round
+    static const int fwd_wgs = getenv("E2E_CT_TUNE_FWD") ? atoi(getenv("E2E_CT_TUNE_FWD")) : 512;   // (tuning probe)
+    long long wgs = fwd_wgs / cgroups;                     // two 4-wave workgroups per CU: one round
     if (wgs < 1) wgs = 1;
     int tpw = (int)e2e::cdivll(total_tiles, wgs);
     if (tpw < 4) tpw = 4;
@@ -1453,7 +1454,8 @@ extern "C" int e2e_convT_dgrad(const float* dy, const float* w, const unsigned* 
   if (!no_v3 && kw == 2 && (kd * kh == 2 || kd * kh == 4) && (W % 2) == 0 && spatial % 4 == 0 && e2e::cdivll(spatial, 32) * B >= dg_min_tiles()) {
     const long long total_tiles = e2e::cdivll(spatial, 32) * B;
     const int cgroups = e2e::cdiv(Cin, 64);
-    const int target = 512;                                 // two 4-wave workgroups fit a CU (186 VGPRs): exactly one round
+    static const int dg_wgs = getenv("E2E_CT_TUNE_DG") ? atoi(getenv("E2E_CT_TUNE_DG")) : 512;   // (tuning probe)
+    const int target = dg_wgs;                              // two 4-wave workgroups fit a CU (186 VGPRs): exactly one round
     long long wgs = target / cgroups;
     if (wgs < 1) wgs = 1;
     int tpw = (int)e2e::cdivll(total_tiles, wgs);

@@ -465,9 +465,9 @@ def test_conv133_at_benchmarked_shapes(name, case, k_fwd, k_wgrad, k_dgrad):
 
 
 @pytest.mark.parametrize("B,cin,cout,dims,density,k_dgrad,k_wgrad", [
-    (2, 64, 32, (64, 64, 64), 0.2, "convT_dgrad_bf3<4>", "convT_wgrad_bf3<4,2>"),        # up*.{L0}: 64^3 -> 128^3
-    (2, 128, 64, (32, 32, 32), 0.2, "convT_dgrad_bf3<4>", "convT_wgrad_bf3<4,2>"),
-    (2, 320, 256, (8, 8, 8), 0.2, "convT_dgrad_gather", "convT_wgrad_bf3<4,2>"),
+    (2, 64, 32, (64, 64, 64), 0.2, "convT_dgrad_h2<4>", "convT_wgrad_h2<4,2>"),          # up*.{L0}: 64^3 -> 128^3
+    (2, 128, 64, (32, 32, 32), 0.2, "convT_dgrad_h2<4>", "convT_wgrad_h2<4,2>"),
+    (2, 320, 256, (8, 8, 8), 0.2, "convT_dgrad_gather", "convT_wgrad_h2<4,2>"),
 ])
 def test_convT_at_benchmarked_shapes(B, cin, cout, dims, density, k_dgrad, k_wgrad):
     with KernelLog(["convT_fwd", "convT_wgrad", "convT_dgrad"]) as kl:
@@ -827,7 +827,7 @@ def test_config3_btcv_full_shape_vs_oracle_and_dsff_update_replay():
     for n, k in variants:
         print("   %-22s %s" % (n, k))
     fams = {k.split("<")[0].split(" ")[0] for _, k in variants}
-    assert {"conv133_kernel", "conv133_mm_h2", "convT_fwd_bf3", "convT_dgrad_bf3"} <= fams, fams
+    assert {"conv133_kernel", "conv133_mm_h2", "convT_fwd_h2", "convT_dgrad_h2", "convT_wgrad_h2"} <= fams, fams
     # ---- the CPU oracle on the identical batch (forward + loss, fp32)
     spec = oracle.make_spec(C["cin"], bench.BASE, C["k"], C["pools"])
     params = {n: p.detach().cpu().clone() for n, p in net.named_parameters()}

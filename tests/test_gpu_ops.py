@@ -264,6 +264,9 @@ def test_convT_fwd_bwd(B, cin, cout, dims, kernel, density, normed):
         kmd = km.to(e.device)
         lib().dsff_expand(kmd.data_ptr(), None, rows.data_ptr(), cols.data_ptr(), cin, cout, 1, 0)
         op.live, op.live_t = cols, rows
+    # operand ranges as the engine hands them over (here: measured maxima): the matrix-pipe shapes then run on fp16 two-piece
+    # operands, the product's default (test_convT_h2_and_bf3_vs_fp64 holds the bf16 three-piece form against the same fp64 values)
+    op.set_ranges(float(_act_value(src).abs().max()), float(w.abs().max()), 1.0)
     op.forward()
     xl = _act_value(src).requires_grad_(True)
     wl = w.clone().requires_grad_(True)
@@ -274,6 +277,8 @@ def test_convT_fwd_bwd(B, cin, cout, dims, kernel, density, normed):
     op.out.alloc_grad()
     op.plan_backward()
     op.out.grad.copy_(dy)
+    dy_word = _absmax_word(op.out.grad)
+    op.dy_word = dy_word.data_ptr()
     src.grad.fill_(float("nan"))
     op.backward()
     torch.cuda.synchronize()
