@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("E2E_LIB_PATH") or os.path.join(_HERE, "csrc", "libe2e
 # E2E_STRICT_ENV=1 (benchmark and A/B scripts) turns it into a refusal to load the library.
 KNOWN_ENV = frozenset({
     # library (csrc/*.hip)
-    "E2E_CONV_MM", "E2E_MM_GRID", "E2E_MM_GEOM", "E2E_CONV_DENSE", "E2E_CONV_SPARSE2", "E2E_CONV_PERSIST", "E2E_CONV_WGS",
+    "E2E_CONV_MM", "E2E_MM_GRID", "E2E_MM_GEOM", "E2E_MM_PAIRQ", "E2E_CONV_DENSE", "E2E_CONV_SPARSE2", "E2E_CONV_PERSIST", "E2E_CONV_WGS",
     "E2E_CONV_KSPLIT", "E2E_WG_H2", "E2E_WG_BF3", "E2E_CT_BF3", "E2E_CT_H2",
     # diagnostic builds of the library only (-DE2E_CONV_DEBUG / -DMM_STAMPS); ignored by the shipped build
     "E2E_CONV_DBG", "E2E_MM_STAMPS",

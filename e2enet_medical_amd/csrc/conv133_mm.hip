@@ -126,6 +126,8 @@ struct MmParams {
   const e2e_out_chan_t* outs;     // MODE 1: Q destination planes
   int P, Q, B, D, H, W;
   int nchunks, qblocks, tiles_x, tiles_y, tiles_per_n, total, grid;
+  int pairq;                      // two chunks x two out-channel blocks: a workgroup walks BOTH blocks of a tile back to back and
+                                  // stages the tile's planes once (they stay in the two LDS images): `total` counts tiles then
 };
 
 struct ChanRec {                   // 24 bytes: one input plane of one batch item, resolved once per launch
@@ -226,16 +228,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int l0 = e2e::xcd_remap(blockIdx.x, G);
   if (l0 >= p.total) return;
   const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_r0 = __builtin_amdgcn_s_memrealtime();
-  const int nitems = (p.total - l0 + G - 1) / G;
+  const bool pairq = p.pairq != 0;                           // (wave-uniform)
+  const int nitems = ((p.total - l0 + G - 1) / G) << (pairq ? 1 : 0);
   const int S = nitems * p.nchunks;                          // chunks of this workgroup's pipeline
   const int plane = p.H * p.W;                               // (host: H * W < 2^31 / 4)
 
   struct Item { int n, d, h0, w0, qb, tile_in_n; };
   auto decode = [&](int k) __attribute__((always_inline)) {
     Item it;
-    int id = l0 + k * G;
-    it.qb = id % p.qblocks;
-    id /= p.qblocks;
+    int id;
+    if (pairq) {                                             // items 2 j, 2 j + 1 of a workgroup: the two out-channel blocks of its j-th tile
+      id = l0 + (k >> 1) * G;
+      it.qb = k & 1;
+    } else {
+      id = l0 + k * G;
+      it.qb = id % p.qblocks;
+      id /= p.qblocks;
+    }
     it.n = id / p.tiles_per_n;
     it.tile_in_n = id - it.n * p.tiles_per_n;
     const int tx = it.tile_in_n % p.tiles_x, t2 = it.tile_in_n / p.tiles_x;
@@ -426,10 +435,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     };
     // register set CUR (chunk qc) -> image buf, with the sixteen plane requests of chunk qn into set NEW dealt two per pixel step
-    auto stage = [&](auto CURC, auto NEWC, const Cur& qc, const Cur& qn, int buf) __attribute__((always_inline)) {
-      constexpr int CUR = decltype(CURC)::value;
-      MMT(u0);
+    // pairq: the second out-channel block of a tile finds the tile's two chunks in the two images (nchunks == 2: image = chunk):
+    // nothing is requested and nothing converted for it.  The (convert, request) combination of the common case stays ONE
+    // straight-line block (the conversion steps hide the requests dealt between them; a branch around a load inside it would
+    // make the compiler drain vmcnt); the three other combinations are blocks of their own.
+    auto request_only = [&](auto NEWC, const Cur& qn) __attribute__((always_inline)) {
       const Req rq = prepare(NEWC, qn);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) issue(NEWC, rq, i);
+    };
+    auto stage = [&](auto CURC, auto NEWC, const Cur& qc, const Cur& qn, int buf, auto REQC) __attribute__((always_inline)) {
+      constexpr int CUR = decltype(CURC)::value;
+      constexpr bool REQ = decltype(REQC)::value;            // false: convert only (no request dealt between the steps)
+      MMT(u0);
+      Req rq{};
+      if constexpr (REQ) rq = prepare(NEWC, qn);
       unsigned char* img = lds_x + buf * IMG;
       const int parc = (qc.k < nitems ? qc.k : nitems - 1) & 1;
       const CtEntry* tab = ctab[parc] + qc.c * 16 + shalf * 8;
@@ -447,8 +467,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int j = 0; j < 8; ++j) { ae[j] = inside[CUR][r] ? ca[j] : 0.f; be[j] = inside[CUR][r] ? cb[j] : 0.f; }
 #pragma unroll
         for (int kx = 0; kx < 4; ++kx) {
-          issue(NEWC, rq, (r * 4 + kx) * 2);
-          issue(NEWC, rq, (r * 4 + kx) * 2 + 1);
+          if constexpr (REQ) {
+            issue(NEWC, rq, (r * 4 + kx) * 2);
+            issue(NEWC, rq, (r * 4 + kx) * 2 + 1);
+          }
           const int hc = FULLW ? 1 : 4 * s_g[r] - 3 + kx;     // halo column of this pixel (general tiles: may fall outside the halo'd row)
           float t[8];
 #pragma unroll
@@ -502,7 +524,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     advance(q2);                                              // chunk 1 (item 0: nchunks >= 2)
     if (nitems > 1) { build_ctab(decode(1), 1, tid - 256, 256); build_odesc(decode(1), 1, tid - 256); }
-    stage(R0{}, R1{}, q1, q2, 0);                             // chunk 0 -> image 0, chunk 1 -> set 1
+    stage(R0{}, R1{}, q1, q2, 0, std::true_type{});           // chunk 0 -> image 0, chunk 1 -> set 1
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     __syncthreads();                                          // barrier #1: image 0 and weights 0 are in LDS
     auto iteration = [&](auto PARC, int s) __attribute__((always_inline)) {            // PAR = s & 1
@@ -523,9 +545,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         build_odesc(itn, (q1.k + 1) % 3, tid - 256);
       }
       MMT(t2);
-      stage(std::integral_constant<int, PAR ^ 1>{}, std::integral_constant<int, PAR>{}, q1, q2, PAR ^ 1);
+      // (past the end the position is clamped to the last item -- in pairq mode a second block: nothing to do, as it should be)
+      const bool conv = !(pairq && ((q1.k < nitems ? q1.k : nitems - 1) & 1));
+      const bool req = !(pairq && ((q2.k < nitems ? q2.k : nitems - 1) & 1));
+      using CURC = std::integral_constant<int, PAR ^ 1>; using NEWC = std::integral_constant<int, PAR>;
+      if (conv && req) stage(CURC{}, NEWC{}, q1, q2, PAR ^ 1, std::true_type{});
+      else if (conv) stage(CURC{}, NEWC{}, q1, q2, PAR ^ 1, std::false_type{});
+      else if (req) request_only(NEWC{}, q2);
       MMT(t4);
-      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // the weight DMA has landed; the 16 plane loads stay in flight
+      if (req) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // the weight DMA has landed; the 16 plane loads stay in flight
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (no plane loads behind the DMA: wait for everything)
       MMT(t5);
       __syncthreads();                                        // barrier #(s + 2)
       MMT(t6);
@@ -1008,7 +1037,11 @@ static int mm_launch(int mode, const e2e_in_chan_t* chans, const float* xin, con
   const int th = geom == 1 ? 8 : (geom == 2 ? 4 : 16), tw = geom == 1 ? 64 : (geom == 2 ? 128 : 32);
   p.tiles_x = W / tw; p.tiles_y = H / th;
   p.tiles_per_n = D * p.tiles_y * p.tiles_x;
-  p.total = B * p.tiles_per_n * p.qblocks;
+  // data gradient of a 64 -> 32 layer (two chunks of dy, two blocks of 32 destinations): a workgroup takes both blocks of a tile
+  // back to back and stages dy once -- the second block's planes are still in the two LDS images (E2E_MM_PAIRQ=0: off, A/B)
+  static const int pairq_knob = getenv("E2E_MM_PAIRQ") ? atoi(getenv("E2E_MM_PAIRQ")) : 1;
+  p.pairq = (pairq_knob && p.nchunks == 2 && p.qblocks == 2) ? 1 : 0;
+  p.total = B * p.tiles_per_n * (p.pairq ? 1 : p.qblocks);
   const int ncu = mm_num_cus();
   static const int grid_knob = getenv("E2E_MM_GRID") ? atoi(getenv("E2E_MM_GRID")) : 0;
   int grid = grid_knob > 0 ? (grid_knob & ~7) : ncu;
@@ -1016,7 +1049,8 @@ static int mm_launch(int mode, const e2e_in_chan_t* chans, const float* xin, con
   const int padded = (p.total + 7) & ~7;
   if (grid > padded) grid = padded;
   p.grid = grid;
-  e2e::note_kernel("conv133_mm_h2<mode=%d,tile=%dx%d> wgs=%d items=%d chunks=%d", mode, th, tw, grid, p.total, p.nchunks);
+  e2e::note_kernel("conv133_mm_h2<mode=%d,tile=%dx%d> wgs=%d items=%d chunks=%d%s", mode, th, tw, grid, p.total * (p.pairq ? 2 : 1), p.nchunks,
+                   p.pairq ? " pairq" : "");
 #define MM_LAUNCH(M, G_) hipLaunchKernelGGL((conv133_mm_kernel<M, G_>), dim3(grid), dim3(512), 0, st, p)
   if (mode == 0) { if (geom == 0) MM_LAUNCH(0, 0); else if (geom == 1) MM_LAUNCH(0, 1); else if (geom == 2) MM_LAUNCH(0, 2); else MM_LAUNCH(0, 3); }
   else { if (geom == 0) MM_LAUNCH(1, 0); else if (geom == 1) MM_LAUNCH(1, 1); else if (geom == 2) MM_LAUNCH(1, 2); else MM_LAUNCH(1, 3); }

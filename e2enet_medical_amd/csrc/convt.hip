@@ -1399,13 +1399,15 @@ extern "C" int e2e_convT_fwd(const float* x, const float* scale, const float* sh
     const int cols_per_wg = 4 * (8 / nkb) * 16;
     const int cgroups = e2e::cdiv(Cout * kt, cols_per_wg);
     const long long total_tiles = (spatial / 32) * B;
-    static const int fwd_wgs = getenv("E2E_CT_TUNE_FWD") ? atoi(getenv("E2E_CT_TUNE_FWD")) : 512;   // (tuning probe)
-    long long wgs = fwd_wgs / cgroups;                     // two 4-wave workgroups per CU: one round
+    const bool h2 = ct_h2_env() && x_absmax != nullptr && w_absmax != nullptr;
+    // two 4-wave workgroups per CU, one round; the fp16 two-piece form with <= 64 input channels needs 164 registers: THREE
+    // workgroups per CU, i.e. half again as many requests in flight on a kernel bound by the CU's request path (64 -> 32 @64^3 x 2:
+    // 0.189 -> 0.165 ms; 1024 workgroups 0.193; the 128-channel form does not move: profiles/r06_kbench_convt.txt)
+    long long wgs = ((h2 && nkb == 2) ? 768 : 512) / cgroups;
     if (wgs < 1) wgs = 1;
     int tpw = (int)e2e::cdivll(total_tiles, wgs);
     if (tpw < 4) tpw = 4;
     dim3 grid((unsigned)e2e::cdivll(total_tiles, tpw), cgroups);
-    const bool h2 = ct_h2_env() && x_absmax != nullptr && w_absmax != nullptr;
     e2e::note_kernel("convT_fwd_%s<%d,%d> wgs=%u cgroups=%d tiles_per_wg=%d", h2 ? "h2" : "bf3", kdh, nkb, grid.x, cgroups, tpw);
 #define LAUNCH_F3(KDH, NKB, NP) hipLaunchKernelGGL((convT_fwd_bf3_kernel<KDH, NKB, NP>), grid, dim3(256), 0, st, x, scale, shift, slope, w, live, y, \
                                                    B, Cin, Cout, D, H, W, kd, kh, tpw, x_absmax, w_absmax)
@@ -1454,8 +1456,7 @@ extern "C" int e2e_convT_dgrad(const float* dy, const float* w, const unsigned* 
   if (!no_v3 && kw == 2 && (kd * kh == 2 || kd * kh == 4) && (W % 2) == 0 && spatial % 4 == 0 && e2e::cdivll(spatial, 32) * B >= dg_min_tiles()) {
     const long long total_tiles = e2e::cdivll(spatial, 32) * B;
     const int cgroups = e2e::cdiv(Cin, 64);
-    static const int dg_wgs = getenv("E2E_CT_TUNE_DG") ? atoi(getenv("E2E_CT_TUNE_DG")) : 512;   // (tuning probe)
-    const int target = dg_wgs;                              // two 4-wave workgroups fit a CU (186 VGPRs): exactly one round
+    const int target = 512;                                 // two 4-wave workgroups fit a CU (218 VGPRs): exactly one round (768: 0.174 -> 0.203 ms)
     long long wgs = target / cgroups;
     if (wgs < 1) wgs = 1;
     int tpw = (int)e2e::cdivll(total_tiles, wgs);
