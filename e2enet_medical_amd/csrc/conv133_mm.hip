@@ -229,7 +229,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (l0 >= p.total) return;
   const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_r0 = __builtin_amdgcn_s_memrealtime();
   const bool pairq = p.pairq != 0;                           // (wave-uniform)
-  const int nitems = ((p.total - l0 + G - 1) / G) << (pairq ? 1 : 0);
+  const int qrun = pairq ? p.qblocks : 1;                    // out-channel blocks a workgroup walks per tile
+  const int nitems = ((p.total - l0 + G - 1) / G) * qrun;
   const int S = nitems * p.nchunks;                          // chunks of this workgroup's pipeline
   const int plane = p.H * p.W;                               // (host: H * W < 2^31 / 4)
 
@@ -237,9 +238,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   auto decode = [&](int k) __attribute__((always_inline)) {
     Item it;
     int id;
-    if (pairq) {                                             // items 2 j, 2 j + 1 of a workgroup: the two out-channel blocks of its j-th tile
-      id = l0 + (k >> 1) * G;
-      it.qb = k & 1;
+    if (pairq) {                                             // items Q j .. Q j + Q - 1 of a workgroup: the Q out-channel blocks of its j-th tile
+      const int j = k / qrun;
+      id = l0 + j * G;
+      it.qb = k - j * qrun;
     } else {
       id = l0 + k * G;
       it.qb = id % p.qblocks;
@@ -546,8 +548,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
       MMT(t2);
       // (past the end the position is clamped to the last item -- in pairq mode a second block: nothing to do, as it should be)
-      const bool conv = !(pairq && ((q1.k < nitems ? q1.k : nitems - 1) & 1));
-      const bool req = !(pairq && ((q2.k < nitems ? q2.k : nitems - 1) & 1));
+      const bool conv = !(pairq && ((q1.k < nitems ? q1.k : nitems - 1) % qrun));
+      const bool req = !(pairq && ((q2.k < nitems ? q2.k : nitems - 1) % qrun));
       using CURC = std::integral_constant<int, PAR ^ 1>; using NEWC = std::integral_constant<int, PAR>;
       if (conv && req) stage(CURC{}, NEWC{}, q1, q2, PAR ^ 1, std::true_type{});
       else if (conv) stage(CURC{}, NEWC{}, q1, q2, PAR ^ 1, std::false_type{});
@@ -1040,7 +1042,7 @@ static int mm_launch(int mode, const e2e_in_chan_t* chans, const float* xin, con
   // data gradient of a 64 -> 32 layer (two chunks of dy, two blocks of 32 destinations): a workgroup takes both blocks of a tile
   // back to back and stages dy once -- the second block's planes are still in the two LDS images (E2E_MM_PAIRQ=0: off, A/B)
   static const int pairq_knob = getenv("E2E_MM_PAIRQ") ? atoi(getenv("E2E_MM_PAIRQ")) : 1;
-  p.pairq = (pairq_knob && p.nchunks == 2 && p.qblocks == 2) ? 1 : 0;
+  p.pairq = (pairq_knob && p.nchunks == 2 && p.qblocks >= 2) ? 1 : 0;
   p.total = B * p.tiles_per_n * (p.pairq ? 1 : p.qblocks);
   const int ncu = mm_num_cus();
   static const int grid_knob = getenv("E2E_MM_GRID") ? atoi(getenv("E2E_MM_GRID")) : 0;
@@ -1049,7 +1051,7 @@ static int mm_launch(int mode, const e2e_in_chan_t* chans, const float* xin, con
   const int padded = (p.total + 7) & ~7;
   if (grid > padded) grid = padded;
   p.grid = grid;
-  e2e::note_kernel("conv133_mm_h2<mode=%d,tile=%dx%d> wgs=%d items=%d chunks=%d%s", mode, th, tw, grid, p.total * (p.pairq ? 2 : 1), p.nchunks,
+  e2e::note_kernel("conv133_mm_h2<mode=%d,tile=%dx%d> wgs=%d items=%d chunks=%d%s", mode, th, tw, grid, p.total * (p.pairq ? p.qblocks : 1), p.nchunks,
                    p.pairq ? " pairq" : "");
 #define MM_LAUNCH(M, G_) hipLaunchKernelGGL((conv133_mm_kernel<M, G_>), dim3(grid), dim3(512), 0, st, p)
   if (mode == 0) { if (geom == 0) MM_LAUNCH(0, 0); else if (geom == 1) MM_LAUNCH(0, 1); else if (geom == 2) MM_LAUNCH(0, 2); else MM_LAUNCH(0, 3); }

@@ -375,6 +375,67 @@ def test_masking_refuses_unimplemented_modes():
             Masking(None, **kw)
 
 
+def test_packed_weights_follow_the_parameters():
+    """Round 6: the fp16 two-piece weights of the matrix-pipe convs and the operand-range words are cached per plan and rebuilt when
+    the parameters change -- seen through torch's version counters (optimizer steps, load_state_dict, any in-place op on a
+    parameter), a new storage (`p.data = ...`, what the reference's Masking.apply_mask does, core_channel.py:431) and the
+    native-write epoch of this package's own kernels; in-place writes through `parameter.data` are invisible to all three and need
+    `network.weights_changed()`.  The cached state must never serve a forward with other weights than the module holds."""
+    from e2enet_medical_amd import engine as E
+    patch = (16, 64, 64)                                  # L0 planes 64 x 64, base 32: the 64 -> 32 / 32 -> 32 layers run on conv133_mm_h2
+    net = build_net(patch, 2, 32, 3, [(2, 2, 2)] * 3 + [(1, 2, 2)] * 2)
+    shapes, params = load_closed_form(net)
+    spec = oracle.make_spec(2, 32, 3, [(2, 2, 2)] * 3 + [(1, 2, 2)] * 2)
+    x = seeded_input((1, 2) + patch, seed=5)
+    net.eval()
+    eng = net.engine(x.cuda())
+    assert any(op.use_mm() for op in eng.conv_ops.values())
+
+    last = {}
+
+    def check(tag):
+        # the bar is the noise class of this graph (InstanceNorms over 8 voxels at the deepest level: two fp32 evaluations differ by
+        # 3e-4), the signal is two orders above it: every step below must move the reference logits by more than 20 bars
+        with torch.no_grad():
+            got = net(x.cuda())[0].cpu()
+            ref = oracle.forward(spec, {n: p.detach().cpu() for n, p in net.named_parameters()}, x)[0]
+        err = float((got - ref).abs().max())
+        assert err <= 1e-3, (tag, err)
+        if "ref" in last:
+            moved = float((ref - last["ref"]).abs().max())
+            assert moved >= 0.1 or tag == "fused optimizer step", (tag, "the step did not change the logits enough to prove anything", moved)
+        last["ref"] = ref
+    check("initial")
+    name = "loc0.4.1.blocks.0.conv.weight"
+    w = net.get_parameter(name)
+    # (a uniform factor on a conv weight is cancelled by the InstanceNorm behind it: the changes below are not uniform)
+    with torch.no_grad():
+        w[::2].mul_(-1.0)                                # in-place on the parameter: version counter
+    check("in-place op")
+    w.data = w.data.flip(1)                              # new storage (the reference's apply_mask idiom)
+    check("new storage")
+    sd = {k: (torch.roll(v, 3, 0) if k == name else v.clone()) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    check("load_state_dict")
+    key0 = eng._weights_key()
+    w.data[1::2].mul_(-1.0)                              # through .data: nobody can see this one
+    assert eng._weights_key() == key0
+    net.weights_changed()
+    check("weights_changed()")
+    epoch = E.PARAM_EPOCH
+    opt = torch.optim.SGD(net.parameters(), 1e-2, momentum=0.99, nesterov=True, weight_decay=3e-5)
+    from e2enet_medical_amd.training.fused_optim import FusedClipSGD
+    fused = FusedClipSGD(opt, list(net.named_parameters()), 12.0)
+    net.train()
+    outs = eng.forward(x.cuda(), True)
+    tg = [seeded_labels((1, 1) + tuple(o.shape[2:]), 3, seed=60 + i).cuda() for i, o in enumerate(outs)]
+    eng.loss_backward(tg, oracle.ds_weights(5), batch_dice=False)
+    fused.step(eng.grads, None)                          # raw-pointer writes: the native-write epoch
+    assert E.PARAM_EPOCH == epoch + 1
+    net.eval()
+    check("fused optimizer step")
+
+
 def test_trainer_surface_runs_iterations():
     """nnUNetTrainer_simple surface: plans dict -> initialize -> run_iteration with Masking; loss finite, masks kept."""
     from e2enet_medical_amd.training.network_training.nnUNetTrainer_simple import nnUNetTrainer_simple

@@ -158,6 +158,9 @@ CASES = {
     "L1_64x64d": (2, [(64, True)], 64, (64, 64, 64), (1, 1, 1), 1.0),
     "L0_64x32": (2, [(32, True), (32, False)], 32, (128, 128, 128), (1, 1, 1), 0.2),
     "L0_32x32d": (2, [(32, True)], 32, (128, 128, 128), (1, 1, 1), 1.0),
+    "L0_96x32": (2, [(32, True), (32, True), (32, False)], 32, (128, 128, 128), (1, 1, 1), 0.2),
+    "L0_128x32": (2, [(32, True), (32, True), (32, True), (32, False)], 32, (128, 128, 128), (1, 1, 1), 0.2),
+    "L0_160x32": (2, [(32, True), (32, True), (32, True), (32, True), (32, False)], 32, (128, 128, 128), (1, 1, 1), 0.2),
     "L0_4x32d": (2, [(4, False)], 32, (128, 128, 128), (1, 1, 1), 1.0),
     "L1_160x64": (2, [(64, True), (64, False), (32, False)], 64, (64, 64, 64), (1, 1, 1), 0.2),
     "L1_s2_32x64d": (2, [(32, True)], 64, (128, 128, 128), (2, 2, 2), 1.0),

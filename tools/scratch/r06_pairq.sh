@@ -6,8 +6,8 @@ E2E_MM_GRID=8 timeout 600 python tools/scratch/fuzz_pairq.py 40 2 2>&1 | grep -v
 E2E_MM_GRID=24 timeout 600 python tools/scratch/fuzz_pairq.py 40 3 2>&1 | grep -v "amdgpu.ids"
 echo "--- kbench, E2E_MM_PAIRQ=1 (default) then 0, interleaved twice"
 for r in 1 2; do
-  timeout 300 python tools/kbench.py L0_64x32 L0_32x32d 2>&1 | grep -v "amdgpu.ids" | grep "\[mm\]"
-  E2E_MM_PAIRQ=0 timeout 300 python tools/kbench.py L0_64x32 L0_32x32d 2>&1 | grep -v "amdgpu.ids\|unknown E2E" | grep "\[mm\]" | sed 's/^/PAIRQ=0 /'
+  timeout 300 python tools/kbench.py L0_64x32 L0_96x32 L0_128x32 L0_160x32 2>&1 | grep -v "amdgpu.ids" | grep "\[mm\]"
+  E2E_MM_PAIRQ=0 timeout 300 python tools/kbench.py L0_64x32 L0_96x32 L0_128x32 L0_160x32 2>&1 | grep -v "amdgpu.ids\|unknown E2E" | grep "\[mm\]" | sed 's/^/PAIRQ=0 /'
 done
 } > $O/out.txt 2>&1
 tail -40 $O/out.txt
