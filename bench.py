@@ -53,7 +53,7 @@ FP32_PEAK_TF = 157.3           # fp32 vector FMA peak = fp32-input MFMA peak (MI
 BF16_PEAK_TF = 2500.0          # dense bf16 MFMA peak (MI355X_MICROARCH.md; the 5 PF headline figure includes 2:1 sparsity)
 FWD_BYTES_PER_VOXEL = 5393.0   # BASELINE.md section 3 / SURVEY section 8(d): algorithmic fwd bytes per voxel at 32 ch
 TRAIN_BYTES_PER_VOXEL = 3 * FWD_BYTES_PER_VOXEL
-TRAFFIC_FILE = "r05_pmc_traffic.json"
+TRAFFIC_FILE = "r06_pmc_traffic.json"
 DTYPE_NOTE = "f32 (fp16x2 split products, f32 accumulate)"   # inputs, outputs, statistics fp32 / fp64; conv products = three fp16 MFMAs on 11+11-bit pieces
 PURE_FP32_ENV = {"E2E_CONV_MM": "0", "E2E_CONV_DENSE": "0", "E2E_WG_BF3": "0", "E2E_CT_BF3": "0"}   # every product an fp32 FMA / fp32-input MFMA
 NOMINAL_MHZ = 2400.0           # the shader clock the guide's compute peaks are quoted at
@@ -127,13 +127,53 @@ class KernelTimer:
         return sum(e0.elapsed_time(e1) for e0, e1, _ in self.events)
 
 
+LIVE_TRAFFIC = None          # --live-traffic: the summary collected by this very invocation (collect_live_traffic)
+
+
+def collect_live_traffic():
+    """--live-traffic: run the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate passes, counters only, one stream -- the
+    recipe of tools/prof_bench.sh and of the guide's HBM section) over two steps of this benchmark as CHILD processes, before this
+    process touches a GPU, and summarise them per kernel (tools/traffic_summary.py).  `roofline.traffic` then comes from the code
+    that is being benchmarked instead of from the committed summary."""
+    import shutil
+    import subprocess
+    import tempfile
+    import importlib.util
+    global LIVE_TRAFFIC
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    root = tempfile.mkdtemp(prefix="e2e_live_traffic_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", E2E_LANES="0", E2E_WGRAD_STREAM="0")
+    env.pop("WORLD_SIZE", None)
+    for sub, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        cmd = [prof, "--pmc", ctr, "--output-format", "csv", "-d", os.path.join(root, sub), "--", sys.executable,
+               os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
+        r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=900)
+        if r.returncode != 0:
+            sys.stderr.write("bench.py --live-traffic: %s pass failed (rc %d): %s\n" % (ctr, r.returncode, r.stderr[-400:]))
+            return
+    spec = importlib.util.spec_from_file_location("traffic_summary", os.path.join(ROOT, "tools", "traffic_summary.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    LIVE_TRAFFIC = mod.summarise(root)
+    shutil.rmtree(root, ignore_errors=True)
+
+
+def traffic_source():
+    if LIVE_TRAFFIC is not None:
+        return ("live: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) and WRITE_SIZE passes run by this invocation over two steps "
+                "of this benchmark (child processes, one stream), bytes per launch")
+    return ("profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch; null when the summary was collected from "
+            "another ABI version of the library; `bench.py --live-traffic` collects it in the run)" % TRAFFIC_FILE)
+
+
 def pmc_traffic(*prefixes):
-    """HBM bytes per launch of the kernels whose name starts with one of `prefixes`, from the committed PMC summary
-    (measured by rocprofv3 outside this process, separate --pmc passes: tools/prof_bench.sh)."""
+    """HBM bytes per launch of the kernels whose name starts with one of `prefixes`: from this invocation's own counter passes
+    (--live-traffic) or from the committed PMC summary (measured by rocprofv3 outside this process, separate --pmc passes:
+    tools/prof_bench.sh)."""
     path = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
-    if not os.path.exists(path):
+    if LIVE_TRAFFIC is None and not os.path.exists(path):
         return None
-    d = json.load(open(path))
+    d = dict(LIVE_TRAFFIC) if LIVE_TRAFFIC is not None else json.load(open(path))
     meta = d.pop("_meta", None)
     from e2enet_medical_amd._lib import ABI_VERSION
     if meta is None or meta.get("abi_version") != ABI_VERSION:
@@ -587,6 +627,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the forward_only / sliding_window / dsff_update sub-records")
     ap.add_argument("--forward-only", action="store_true", help="time the inference forward as the main loop (diagnostic)")
     ap.add_argument("--op-profile", action="store_true", help="print per-entry-point GPU time (diagnostic)")
+    ap.add_argument("--live-traffic", action="store_true",
+                    help="collect roofline.traffic in this run (two rocprofv3 --pmc child passes first; N = 1 only; adds ~2 minutes)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -597,6 +639,8 @@ def main():
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (start it as `python bench.py --gpus N` or under torch.distributed.run "
                  "with --nproc-per-node N)" % (args.gpus, world))
+    if args.live_traffic and world == 1:
+        collect_live_traffic()                                     # child processes; nothing has touched a GPU here yet
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
@@ -775,8 +819,7 @@ def main():
                                           "operands incl. the per-step weight-packing and operand-range launches; strided convs and planes <= 16 wide on the vector walk)",
                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                 "traffic": pmc_traffic("conv133_kernel", "conv133_dense_kernel", "conv133_sparse_kernel", "conv133_mm_kernel"),
-                "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch; null when the summary was "
-                                  "collected from another ABI version of the library)" % TRAFFIC_FILE,
+                "traffic_source": traffic_source(),
                 "algorithmic_bytes_per_launch": byt / len(ev), "launches_per_step": len(ev) // isteps,
                 "avg_ms": ms / len(ev), "ms_per_step": ms / isteps, "share_of_step": (ms / isteps) / ms_step,
                 "timing": "HIP events around each launch in %d instrumented steps issued on ONE stream; the timed steps run the "

@@ -6,6 +6,7 @@
 #   tests   python -m pytest tests -m gpu -x -q                          -> gpurun_out/<tag>/tests.log
 #   ktests "<expr>"   the same with -k <expr>                            -> gpurun_out/<tag>/ktests.log
 #   bench   python bench.py --steps 20 --warmup 5                        -> gpurun_out/<tag>/bench.json
+#   benchlive  the same with --live-traffic (roofline.traffic collected by the run itself)  -> gpurun_out/<tag>/bench_live.json
 #   prof    tools/prof_bench.sh <tag> (rocprofv3 --kernel-trace --stats, default + one-stream; FETCH_SIZE / WRITE_SIZE passes)
 #   kbench  python tools/kbench.py <args> (single-kernel timings)        -> gpurun_out/<tag>/kbench.log
 #
@@ -21,6 +22,7 @@ while [ $# -gt 0 ]; do
     tests)  timeout 1500 python -m pytest tests -m gpu -q --tb=short -rs 2>&1 | grep -v "curr_density\|amdgpu.ids" | tail -150 > gpurun_out/$TAG/tests.log ;;
     ktests) shift; timeout 1500 python -m pytest tests -m gpu -x -q --tb=short -k "$1" 2>&1 | grep -v "curr_density\|amdgpu.ids" | tail -150 > gpurun_out/$TAG/ktests.log ;;
     bench)  timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench.err ;;
+    benchlive) timeout 1500 python bench.py --steps 20 --warmup 5 --live-traffic > gpurun_out/$TAG/bench_live.json 2> gpurun_out/$TAG/bench_live.err ;;
     prof)   bash tools/prof_bench.sh $TAG 2>&1 | tail -20 > gpurun_out/$TAG/prof.log ;;
     kbench) shift; timeout 600 python tools/kbench.py $1 > gpurun_out/$TAG/kbench.log 2>&1 ;;
   esac

@@ -157,6 +157,9 @@ CASES = {
     "L0_64x32_d05": (2, [(32, True), (32, False)], 32, (128, 128, 128), (1, 1, 1), 0.5),
     "L1_64x64d": (2, [(64, True)], 64, (64, 64, 64), (1, 1, 1), 1.0),
     "L0_64x32": (2, [(32, True), (32, False)], 32, (128, 128, 128), (1, 1, 1), 0.2),
+    "L0_64x32_d01": (2, [(32, True), (32, False)], 32, (128, 128, 128), (1, 1, 1), 0.1),
+    "L0_64x32_d005": (2, [(32, True), (32, False)], 32, (128, 128, 128), (1, 1, 1), 0.05),
+    "L1_160x64_d005": (2, [(64, True), (64, False), (32, False)], 64, (64, 64, 64), (1, 1, 1), 0.05),
     "L0_32x32d": (2, [(32, True)], 32, (128, 128, 128), (1, 1, 1), 1.0),
     "L0_96x32": (2, [(32, True), (32, True), (32, False)], 32, (128, 128, 128), (1, 1, 1), 0.2),
     "L0_128x32": (2, [(32, True), (32, True), (32, True), (32, False)], 32, (128, 128, 128), (1, 1, 1), 0.2),

@@ -11,3 +11,5 @@ for r in 1 2; do
 done
 } > $O/out.txt 2>&1
 tail -40 $O/out.txt
+timeout 600 python -m pytest tests/test_gpu_net.py -q -m gpu -k "packed_weights" 2>&1 | tail -5 >> $O/out.txt
+tail -8 $O/out.txt
