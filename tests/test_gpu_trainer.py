@@ -322,6 +322,12 @@ def test_sharded_predict_3d_branch_single_rank_rccl(rccl_single_rank, tag, kw):
     ref_seg = g["pred_%s_seg" % tag].astype(np.int64)
     assert (seg1 != ref_seg).mean() < 1e-3
     assert np.abs(probs1[:, 6, ::2, ::2] - g["pred_%s_probs_slice" % tag]).max() <= 2e-5
+    # the other exchange (round 6): per-rank partial volumes + ONE RCCL all-reduce (weight map accumulated through the NULL-patch
+    # mode of e2e_sw_accumulate); a different summation order is allowed, 1e-6 is the bar of the gloo test
+    net.shard_tiles(0, 1, None, force=True, exchange="allreduce")
+    seg2, probs2 = net.predict_3D(vol, **args)
+    assert np.abs(probs2 - probs0).max() <= 1e-6
+    assert (seg2 != seg0).mean() < 1e-4
 
 
 # ------------------------------------------------------------------------------------------------ N1: ensemble + export
