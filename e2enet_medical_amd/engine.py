@@ -48,9 +48,12 @@ FUSE_IN_SUMS = 1
 SPARSE2 = os.environ.get("E2E_CONV_SPARSE2", "1") != "0"         # load-balanced kernel for the DSFF-masked full-resolution layers
 DENSE_ENABLED = True          # tests switch the matrix-core conv paths off to compare the sparse walk with itself
 MM_FORWARD = MM_BACKWARD = True   # tests / diagnostics: K1m in one direction only (the other takes the next kernel in the dispatch order)
-# fp16 two-piece matrix-pipe conv (conv133_mm.hip, round 5) for every layer it serves whose kernel map is at least this dense
-# (0: all of them -- measured faster than the sparse walk down to density 0.1); E2E_CONV_MM=0 switches the path off in the library
-MM_MIN_DENSITY = float(os.environ.get("E2E_MM_MIN_DENSITY", "0.0"))
+# fp16 two-piece matrix-pipe conv (conv133_mm.hip, round 5) for every layer it serves whose kernel map is at least this dense; below
+# it a DSFF-masked layer runs on the load-balanced sparse walk (round 4), whose time falls with the density while K1m's does not.
+# Round 6 A/B on whole training steps of the config-5 network (profiles/r06_density_switch.txt, K1m / walk): d = 0.05 32.8 / 31.1 ms,
+# 0.1 33.3 / 32.4, 0.15 33.4 / 33.8, 0.2 33.7 / 35.4, 0.3 34.4 / 38.4 -- the crossover sits at d ~ 0.13.
+# E2E_CONV_MM=0 switches the matrix path off in the library.
+MM_MIN_DENSITY = float(os.environ.get("E2E_MM_MIN_DENSITY", "0.125"))
 
 
 # Native kernels of this package write parameters through raw pointers (the fused optimizer step, Masking.apply_mask): torch's
@@ -349,12 +352,12 @@ class ConvOp:
         w = self.eng.params[self.w_name]
         dev = self.eng.device
         jobs = []
-        if "f" in directions and MM_FORWARD:
+        if "f" in directions and self.use_mm("f"):
             if self.wpk_fwd is None:
                 self.wpk_fwd = torch.empty(self.mm_ws_bytes, dtype=torch.uint8, device=dev)
             jobs.append(MmPackJob(w.data_ptr(), _ptr(self.live), self.wpk_fwd.data_ptr(), self.w_absmax.data_ptr(), self.cin, self.cout,
                                   self.cin * 9, 9, 0, 1))
-        if "b" in directions and MM_BACKWARD and self.do_dgrad:
+        if "b" in directions and self.use_mm("b") and self.do_dgrad:
             if self.wpk_bwd is None:
                 self.wpk_bwd = torch.empty(self.mm_ws_bytes, dtype=torch.uint8, device=dev)
             jobs.append(MmPackJob(w.data_ptr(), _ptr(self.live_t), self.wpk_bwd.data_ptr(), self.w_absmax.data_ptr(), self.cout, self.cin,
@@ -376,12 +379,14 @@ class ConvOp:
         if max_abs is not None:
             self.x_absmax.copy_(torch.tensor([float(max_abs)], dtype=torch.float32).view(torch.int32))
 
-    def use_mm(self):
+    def use_mm(self, direction=None):
         """fp16 two-piece matrix-pipe kernel (conv133_mm.hip): stride-1 layers of the 16 x 32 tile class with 17..320 channels,
         DSFF-masked or not (the mask is packed into the weights)."""
         if not DENSE_ENABLED or self.mm_ws_bytes <= 0:
             return False
-        return self.live is None or self.density >= MM_MIN_DENSITY
+        if direction == "f" and not MM_FORWARD or direction == "b" and not MM_BACKWARD:
+            return False
+        return self.live is None or self.density >= MM_MIN_DENSITY or not (self.sparse_ok and SPARSE2)
 
     def use_dense(self):
         """Dense layers (no DSFF map, or a map too dense for the kernel-granular sparse walk to pay) run on the bf16 matrix
@@ -399,7 +404,7 @@ class ConvOp:
         sd, sh, sw = self.stride
         L = lib()
         ws = getattr(e, "fwd_ws", None)
-        if self.use_mm() and MM_FORWARD:
+        if self.use_mm("f"):
             if not hasattr(e, "_refresh_weight_caches"):
                 self.pack_mm_standalone("f")
             L.conv133_fwd_mm(self.chans.data_ptr(), self.cin, self.wpk_fwd.data_ptr(), self.w_absmax.data_ptr(),
@@ -451,7 +456,7 @@ class ConvOp:
             self._wgrad(e, L, g, o, b, di, hi, wi, sd, sh, sw, o.data.numel())
         if self.do_dgrad:
             ws = getattr(e, "fwd_ws", None)
-            if self.use_mm() and MM_BACKWARD:
+            if self.use_mm("b"):
                 if not hasattr(e, "_refresh_weight_caches"):
                     self.pack_mm_standalone("b")
                 L.conv133_dgrad_mm(o.grad.data_ptr(), self.dy_absmax.data_ptr(), self.wpk_bwd.data_ptr(), self.w_absmax.data_ptr(),
@@ -906,7 +911,7 @@ class Engine:
         # the job table is cached under the dispatch decisions it was built for (advisor, round 4: a table built while an op went to a
         # matrix-pipe kernel left that op's packed weights zero when tests / knobs sent it to the planned walk afterwards)
         def matrix_only(op):
-            return (op.use_mm() and MM_FORWARD and MM_BACKWARD) or op.use_dense()
+            return (op.use_mm("f") and op.use_mm("b")) or op.use_dense()
         key = tuple(matrix_only(op) for op in self.conv_ops.values())
         if self._sparse_jobs is None or self._sparse_jobs[0] != key:
             jobs = [j for op in self.conv_ops.values() if not matrix_only(op) for j in op.sparse_jobs()]
@@ -956,7 +961,7 @@ class Engine:
                 L.conv133_input_ranges(self._range_table[0].data_ptr(), self._range_table[1], self._range_table[3].data_ptr(), _stream())
             self._range_key = (ptrs, state)
         # which layers run on K1m in which direction is part of what a packed set is valid for (tests and knobs move it)
-        dkey = (tuple(op.use_mm() for op in self.conv_ops.values()), MM_FORWARD, MM_BACKWARD, self.maps_generation, ptrs)
+        dkey = (tuple((op.use_mm("f"), op.use_mm("b")) for op in self.conv_ops.values()), self.maps_generation, ptrs)
         todo = "".join(d for d in directions if always or self._mm_packed.get(d) != (dkey, state))
         if not todo:
             return
