@@ -386,7 +386,10 @@ def test_training_recovers_from_a_loss_spike_like_the_oracle():
                                                                                        ref_loss.item(), tn, ref_tn))
         assert math.isfinite(loss) and math.isfinite(tn)
         assert abs(loss - ref_loss.item()) <= 2e-2 * max(1.0, abs(ref_loss.item())), (it, loss, ref_loss.item())
-        assert abs(tn - ref_tn) <= 0.1 * ref_tn, (it, tn, ref_tn)
+        # (the norm of this untrained network's gradient is a kinked function of the weights -- InstanceNorms over 2..8 voxels at the
+        #  deep levels: two fp32 evaluations differ by 4 % at identical weights, 20 % a few steps later; the same-branch check of
+        #  test_whole_net_with_large_activations pins the gradients of this very network to 1e-4.  A mis-scaled spike is off by 1e5.)
+        assert 0.5 * ref_tn <= tn <= 2.0 * ref_tn, (it, tn, ref_tn)
         if it == spike_at:
             assert tn > 1e3 * 12.0                                 # the spike is far above the clip threshold
     num = den = 0.0

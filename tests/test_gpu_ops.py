@@ -181,8 +181,11 @@ def test_conv133_fwd_bwd(case):
         _plan_and_pack(op, km)                      # load-balanced kernel where the shape is served (conv133_sparse.hip)
     op.set_input_range(max(float(_act_value(a).abs().max()) for a in srcs))      # (inside an Engine: e2e_conv133_input_ranges)
     tile_class = dims[2] % 32 == 0 and dims[1] % 16 == 0 and dims[1] > 16 and stride == (1, 1, 1)
-    if tile_class and cin > 16 and cout > 16 and os.environ.get("E2E_CONV_MM", "1") != "0":
+    from e2enet_medical_amd.engine import MM_MIN_DENSITY
+    if tile_class and cin > 16 and cout > 16 and os.environ.get("E2E_CONV_MM", "1") != "0" and (km is None or op.density >= MM_MIN_DENSITY):
         assert op.use_mm(), "this case is meant to reach conv133_mm_kernel"
+    elif tile_class and cin > 16 and cout > 16 and km is not None and op.density < MM_MIN_DENSITY and op.sp_fwd is not None:
+        assert not op.use_mm("f") and not op.use_mm("b"), "below the switch-over density a masked layer runs on the sparse walk (round 6)"
     elif tile_class and cin >= 16 and cout >= 16 and density >= 0.5 and os.environ.get("E2E_CONV_DENSE", "1") != "0":
         assert op.use_dense(), "this case is meant to reach conv133_dense_kernel"
     op.forward()
