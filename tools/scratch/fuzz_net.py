@@ -44,10 +44,15 @@ def one(rng, idx):
     ref_loss = oracle.deep_supervision_loss(ref, targets, w, False)
     ref_loss.backward()
     msgs = []
-    for i, (o, r) in enumerate(zip(outs, ref)):
+    with torch.no_grad():
+        ref64 = oracle.forward(spec, {n: p.double() for n, p in params.items()}, x.double())
+    for i, (o, r, r64) in enumerate(zip(outs, ref, ref64)):
         err = float((o.cpu() - r.detach()).abs().max())
         if err > 1e-4:
-            msgs.append("logits[%d] %.2e" % (i, err))
+            # two fp32 evaluations further apart than 1e-4: a kernel problem only if the ENGINE is the one far from exact arithmetic
+            e64, c64 = float((o.cpu().double() - r64).abs().max()), float((r.detach().double() - r64).abs().max())
+            tag = "noise class" if e64 <= 3.0 * c64 + 1e-5 else "ENGINE FAR FROM fp64"
+            msgs.append("logits[%d] %.2e (engine-fp64 %.2e, cpu32-fp64 %.2e: %s)" % (i, err, e64, c64, tag))
     if abs(loss.item() - ref_loss.item()) > 5e-5:
         msgs.append("loss %.2e" % abs(loss.item() - ref_loss.item()))
     worst = (0.0, None)
