@@ -633,6 +633,9 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))           # before anything touches a GPU
+    # RCCL between processes on this image needs dmabuf IPC; the variable is read when the HIP runtime initialises (under
+    # torch.distributed.run nothing has touched a GPU yet at this point)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
