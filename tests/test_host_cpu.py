@@ -708,3 +708,44 @@ def test_evaluator_matches_reference_aggregate_scores(tmp_path):
     js = json.load(open(jf))
     assert sorted(js.keys()) == [str(k) for k in g["summary_keys"]]
     assert js["name"] == "n" and js["task"] == "t" and len(js["id"]) == 12 and len(js["results"]["all"]) == 3
+
+
+def test_live_traffic_summary_and_bench_selection(tmp_path, monkeypatch):
+    """bench.py --live-traffic: the per-kernel summary of two rocprofv3 --pmc passes (FETCH_SIZE in KiB, doubled on gfx950; WRITE_SIZE)
+    and its use for `roofline.traffic`: a summary collected by the run itself takes precedence over the committed one, a committed
+    summary of another ABI version is not reported, a failed counter pass leaves the committed summary in charge."""
+    import importlib.util
+    import bench
+    from e2enet_medical_amd._lib import ABI_VERSION
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("traffic_summary", os.path.join(root, "tools", "traffic_summary.py"))
+    ts = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ts)
+    kname = "void (anonymous namespace)::conv133_mm_kernel<0, 2>((anonymous namespace)::MmParams)"
+    for sub, ctr, vals in (("pmc_fetch", "FETCH_SIZE", [1000.0, 3000.0]), ("pmc_write", "WRITE_SIZE", [500.0, 500.0])):
+        d = tmp_path / sub / "host"
+        d.mkdir(parents=True)
+        with open(d / "1_counter_collection.csv", "w") as fh:
+            fh.write("Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value\n")
+            for i, v in enumerate(vals):
+                fh.write('%d,"%s",%s,%s\n' % (i, kname, ctr, v))
+            fh.write('9,"%s",GRBM_GUI_ACTIVE,7\n' % kname)
+    doc = ts.summarise(str(tmp_path))
+    rec = doc["conv133_mm_kernel<0, 2>"]
+    assert rec["launches"] == 2
+    assert rec["fetch_bytes_per_launch_corrected"] == 2.0 * 2000.0 * 1024 and rec["write_bytes_per_launch"] == 500.0 * 1024
+    assert rec["hbm_bytes_per_launch"] == (4000.0 + 500.0) * 1024 and doc["_meta"] == {"abi_version": ABI_VERSION}
+    monkeypatch.setattr(bench, "LIVE_TRAFFIC", doc)
+    assert bench.pmc_traffic("conv133_mm_kernel", "conv133_kernel") == (4000.0 + 500.0) * 1024
+    assert bench.traffic_source().startswith("live:")
+    stale = dict(doc, _meta={"abi_version": ABI_VERSION - 1})
+    monkeypatch.setattr(bench, "LIVE_TRAFFIC", stale)
+    assert bench.pmc_traffic("conv133_mm_kernel") is None          # counters of another library revision are never reported
+    # a counter pass that fails (no GPU here): nothing is reported as live, the committed summary stays in charge
+    monkeypatch.setattr(bench, "LIVE_TRAFFIC", None)
+
+    class R:
+        returncode, stderr = 1, "no device"
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: R())
+    bench.collect_live_traffic()
+    assert bench.LIVE_TRAFFIC is None and bench.traffic_source().startswith("profiles/")
