@@ -222,7 +222,7 @@ class _Lib:
 _lib = None
 
 
-ABI_VERSION = 18          # e2e_abi_version() of the library this binding was written against
+ABI_VERSION = 19          # e2e_abi_version() of the library this binding was written against
 
 
 def lib() -> _Lib:

@@ -21,7 +21,7 @@ void note_kernel(const char* fmt, ...) {
 
 extern "C" const char* e2e_last_error(void) { return e2e::g_err; }
 extern "C" const char* e2e_last_kernel(void) { return e2e::g_kernel; }
-extern "C" int e2e_abi_version(void) { return 18; }
+extern "C" int e2e_abi_version(void) { return 19; }
 
 extern "C" int e2e_diag_kernel_clock(int family, double* mhz, double* busy_ms, int reset) {
   E2E_REQUIRE(mhz != nullptr && (family == 0 || family == 1), "diag_kernel_clock: family 0 (conv133_mm) or 1 (conv133_wgrad v5)");

@@ -145,7 +145,8 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(float* __restrict__ d
                                                            const float* __restrict__ shift,
                                                            const float* __restrict__ gamma, float slope,
                                                            double* __restrict__ sums, const double* __restrict__ rec, int nrec,
-                                                           int B, int C, long long spatial, unsigned* __restrict__ absmax) {
+                                                           int B, int C, long long spatial, unsigned* __restrict__ absmax,
+                                                           double* __restrict__ rec3) {
   const int nc = blockIdx.y;
   const int c = nc % C;
   const float mu = mean[nc], rs = rstd[nc], g = gamma[c], sca = scale[nc], shf = shift[nc];
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(float* __restrict__ d
   if (lane == 0) { sh[wave] = acc; shm[wave] = amax; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    atomicAdd(&sums[(long long)nc * 3 + 2], sh[0] + sh[1] + sh[2] + sh[3]);
+    rec3[(long long)nc * gridDim.x + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];    // one record per block (no atomic: the bias gradient is bit-reproducible)
     if (absmax != nullptr) atomicMax(absmax, __builtin_bit_cast(unsigned, fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3]))));
   }
 }
@@ -254,16 +255,28 @@ __global__ __launch_bounds__(256) void in_bwd_apply_kernel(float* __restrict__ d
 // parameter gradients: sums over the batch (s3 was zeroed by the first pass of this call, accumulated by the apply pass).
 // (A "last block of the apply pass does this" variant was measured in round 6: the device-scope fence it needs in EVERY block
 //  writes the XCD's L2 back -- 16 k fences per launch took the apply pass from 3.4 to ~12 ms per step.  A separate 5 us launch it is.)
-__global__ void in_bwd_params_kernel(double* __restrict__ sums, float* __restrict__ dgamma,
-                                     float* __restrict__ dbeta, float* __restrict__ dbias, int B, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+__global__ __launch_bounds__(64) void in_bwd_params_kernel(const double* __restrict__ sums, const double* __restrict__ rec3, int nblocks,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           float* __restrict__ dbias, int B, int C) {
+  const int c = blockIdx.x;                                   // one wave per channel
+  double s3 = 0.0;
+  if (dbias != nullptr) {
+    // sum dy: the apply pass's per-block records of every batch item, lane t takes records t, t + 64, ... and the wave adds its
+    // lanes in a fixed tree -- the same order in every run.  (Until round 6 an fp64 atomic per block: the conv bias in front of an
+    // InstanceNorm has an analytically zero gradient, what is computed is the rounding residue of sum dy, and THAT depended on the
+    // order of the atomics in its last fp32 bit -- tests/test_gpu_net.py::test_full_size_128_training_properties caught it once.)
+    for (int n = 0; n < B; ++n) {
+      const double* q = rec3 + ((long long)n * C + c) * nblocks;
+      for (int b = threadIdx.x; b < nblocks; b += 64) s3 += q[b];
+    }
+    s3 = e2e::wave_sum_d(s3);
+  }
+  if (threadIdx.x != 0) return;
+  double s1 = 0.0, s2 = 0.0;
   for (int n = 0; n < B; ++n) {
-    double* r = sums + ((long long)n * C + c) * 3;
+    const double* r = sums + ((long long)n * C + c) * 3;
     s1 += r[0];
     s2 += r[1];
-    s3 += r[2];
   }
   dbeta[c] = (float)s1;
   dgamma[c] = (float)s2;
@@ -295,8 +308,9 @@ extern "C" int e2e_in_stats_finalize(const double* part, int np, const float* ga
   return e2e::check_launch("in_finalize_kernel");
 }
 
-// doubles of workspace e2e_in_lrelu_bwd needs for (B, C): sums [B*C*3] + pass-1 records [B*C*256*2]; no state survives a call
-extern "C" long long e2e_in_lrelu_bwd_ws_doubles(int B, int C) { return (long long)B * C * (3 + 2 * 256) + 2; }
+// doubles of workspace e2e_in_lrelu_bwd needs for (B, C): sums [B*C*3] + pass-1 records [B*C*256*2] + the apply pass's sum-dy records
+// [B*C*256]; no state survives a call
+extern "C" long long e2e_in_lrelu_bwd_ws_doubles(int B, int C) { return (long long)B * C * (3 + 3 * 256) + 2; }
 
 extern "C" int e2e_in_lrelu_bwd(float* dz_dy, const float* y, const float* mean, const float* rstd, const float* scale,
                                 const float* shift, const float* gamma, float slope, float* dgamma, float* dbeta,
@@ -307,6 +321,7 @@ extern "C" int e2e_in_lrelu_bwd(float* dz_dy, const float* y, const float* mean,
   hipStream_t st = (hipStream_t)stream;
   double* ds = reinterpret_cast<double*>(sums);
   double* recs = ds + (long long)B * C * 3;
+  double* rec3 = recs + (long long)B * C * 256 * 2;
   long long blocks = e2e::cdivll(spatial, 256 * 4 * 4);
   if (blocks > 256) blocks = 256;
   if (blocks < 1) blocks = 1;
@@ -317,13 +332,14 @@ extern "C" int e2e_in_lrelu_bwd(float* dz_dy, const float* y, const float* mean,
     hipLaunchKernelGGL(in_bwd_reduce_kernel, grid, dim3(256), 0, st, dz_dy, y, mean, rstd, scale, shift, slope, recs, C,
                        spatial, dy_absmax, ds);
     hipLaunchKernelGGL(in_bwd_apply_kernel, grid, dim3(256), 0, st, dz_dy, y, mean, rstd, scale, shift, gamma, slope, ds,
-                       (const double*)recs, (int)blocks, B, C, spatial, dy_absmax);
+                       (const double*)recs, (int)blocks, B, C, spatial, dy_absmax, rec3);
   } else {
     E2E_REQUIRE(np > 0, "in_lrelu_bwd: tile_sums without a record count");
     hipLaunchKernelGGL(in_bwd_tile_sums_kernel, dim3(B * C), dim3(64), 0, st, tile_sums, ds, np, dy_absmax);
     hipLaunchKernelGGL(in_bwd_apply_kernel, grid, dim3(256), 0, st, dz_dy, y, mean, rstd, scale, shift, gamma, slope, ds,
-                       (const double*)nullptr, 0, B, C, spatial, dy_absmax);
+                       (const double*)nullptr, 0, B, C, spatial, dy_absmax, rec3);
   }
-  hipLaunchKernelGGL(in_bwd_params_kernel, dim3(e2e::cdiv(C, 64)), dim3(64), 0, st, ds, dgamma, dbeta, dbias, B, C);
+  hipLaunchKernelGGL(in_bwd_params_kernel, dim3(C), dim3(64), 0, st, (const double*)ds, (const double*)rec3, (int)blocks,
+                     dgamma, dbeta, dbias, B, C);
   return e2e::check_launch("in_lrelu_bwd");
 }

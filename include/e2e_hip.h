@@ -264,9 +264,9 @@ int e2e_in_stats_finalize(const double* part, int np, const float* gamma, const 
 /* ---- K7: InstanceNorm + LeakyReLU backward -------------------------------------------
  * Given dz = dL/d(lrelu(IN(y))) and the saved pre-norm y, overwrite dz with dy = dL/dy and
  * produce dgamma, dbeta (accumulated over the batch) and dbias = sum(dy).
- *   sums  workspace of e2e_in_lrelu_bwd_ws_doubles(B, C) doubles (s1 = sum du, s2 = sum du*xhat, s3 = sum dy per (n, c); the
- *         per-block records of the first pass); no state survives a call (round 6: the first pass writes records instead of
- *         atomics -- deterministic, no zeroing launch)
+ *   sums  workspace of e2e_in_lrelu_bwd_ws_doubles(B, C) doubles (s1 = sum du, s2 = sum du*xhat per (n, c); the per-block
+ *         records of the first pass; the per-block sum dy records of the apply pass); no state survives a call (round 6: every
+ *         sum is formed from per-block records in a fixed order -- no atomics, no zeroing launch, bit-reproducible gradients)
  *   tile_sums  NULL: the first pass (s1, s2) runs here.  Otherwise the per-tile records [B][C][np][2] that the last writers of
  *              dz have produced (e2e_in_sum_chan_t): they are added up in a fixed order and only the apply pass runs
  *   dy_absmax  NULL, or one device word that receives the bit pattern of max |dy| over the tensor (consumed by e2e_conv133_wgrad)

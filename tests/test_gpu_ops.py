@@ -27,7 +27,7 @@ def _eng_stub(params):
     e.params = {k: v.to(e.device) for k, v in params.items()}
     e.grads = {k: torch.zeros_like(v) for k, v in e.params.items()}
     e.wgrad_ws = torch.empty(64 << 20, dtype=torch.float32, device=e.device)   # 256 MiB
-    e.in_sums = torch.zeros(1024 * (3 + 512) + 2, dtype=torch.float64, device=e.device)   # e2e_in_lrelu_bwd_ws_doubles for B * C <= 1024, zeroed once
+    e.in_sums = torch.zeros(1024 * (3 + 768) + 2, dtype=torch.float64, device=e.device)   # e2e_in_lrelu_bwd_ws_doubles for B * C <= 1024, zeroed once
     e.batch = 1
     return e
 
